@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def load_golden(name):
+    """npz -> {group: {key: torch tensor}} split on the first '/'."""
+    z = np.load(os.path.join(GOLDEN, name))
+    out = {}
+    for k in z.files:
+        grp, _, rest = k.partition("/")
+        t = torch.from_numpy(z[k])
+        if rest:
+            out.setdefault(grp, {})[rest] = t
+        else:
+            out[grp] = t
+    return out
+
+
+ENC_ORDER = ["I1", "C1", "C2", "I2", "C3", "I3", "C4", "C5"]
+VOCAB = {"C1": 7, "C2": 3, "C3": 50, "C4": 11, "C5": 2}
+
+
+def small_enc_dict():
+    """Same ordered enc_dict tests/golden/make_golden.py fed the reference."""
+    return {k: ({"min": 0.0, "max": 1.0} if k.startswith("I") else {"vocab_size": VOCAB[k]}) for k in ENC_ORDER}
+
+
+@pytest.fixture(scope="session")
+def enc_dict():
+    return small_enc_dict()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("this test is marked gpu and needs a visible MI355X")

@@ -1,0 +1,148 @@
+"""The oracle (oracle/ref_ops.py) against golden vectors produced by RUNNING the reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances: index work bit-exact; fp32 blocks 1e-6
+relative-ish (same ATen arithmetic, possibly different association); logits/loss 1e-5 abs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, small_enc_dict
+from oracle import ref_ops as R
+
+torch.set_num_threads(1)
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+def _grads(loss, sd, names):
+    gs = torch.autograd.grad(loss, [sd[n] for n in names], allow_unused=True)
+    return dict(zip(names, gs))
+
+
+def _model_case(name, fn):
+    g = load_golden(f"model_{name}.npz")
+    enc = small_enc_dict()
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in g["init"].items()}
+    out = fn(sd, enc, g["batch"], g)
+    for k, v in g["out"].items():
+        torch.testing.assert_close(out[k].detach(), v, rtol=1e-5, atol=1e-6, msg=lambda m: f"{name}:{k}: {m}")
+    names = [k for k in g["grad"].keys() if k in sd]
+    gr = _grads(out["loss"], sd, names)
+    for k in names:
+        got = gr[k] if gr[k] is not None else torch.zeros_like(sd[k])
+        torch.testing.assert_close(got, g["grad"][k], rtol=1e-4, atol=1e-6, msg=lambda m: f"{name}:grad {k}: {m}")
+    return g, sd
+
+
+def test_deepfm():
+    _model_case("deepfm", lambda sd, enc, b, g: R.deepfm(sd, enc, b))
+
+
+def test_fm():
+    _model_case("fm", lambda sd, enc, b, g: R.fm(sd, enc, b))
+
+
+def test_dcn():
+    _model_case("dcn", lambda sd, enc, b, g: R.dcn(sd, enc, b))
+
+
+def test_xdeepfm():
+    _model_case("xdeepfm", lambda sd, enc, b, g: R.xdeepfm(sd, enc, b))
+
+
+@pytest.mark.parametrize("tag,h,a", [("autoint_h2", 2, 4), ("autoint_h1", 1, 8), ("autoint_h3a5", 3, 5)])
+def test_autoint(tag, h, a):
+    _model_case(tag, lambda sd, enc, b, g: R.autoint(sd, enc, b, h, a))
+
+
+@pytest.mark.parametrize("tag,training", [("mmoe_eval", False), ("mmoe_train", True)])
+def test_mmoe(tag, training):
+    def run(sd, enc, b, g):
+        gates = [g["gates"][str(i)] for i in range(2)]
+        gb = [g["gates_bias"][str(i)] for i in range(2)]
+        return R.mmoe(sd, gates, gb, enc, b, num_task=2, training=training)
+    _model_case(tag, run)
+
+
+def test_deepfm_two_adam_steps():
+    """Dense Adam as RankTrainer builds it (trainer.py:75), two steps, against the reference's own run."""
+    g = load_golden("model_deepfm.npz")
+    enc = small_enc_dict()
+    p = {k: v.clone() for k, v in g["init"].items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p.items()}
+    for step in (1, 2):
+        sd = {k: t.clone().requires_grad_(True) for k, t in p.items()}
+        loss = R.deepfm(sd, enc, g["batch"])["loss"]
+        gr = torch.autograd.grad(loss, list(sd.values()))
+        for (k, _), gk in zip(sd.items(), gr):
+            p[k], m[k], v2[k] = R.adam_step(p[k], gk, m[k], v2[k], step, lr=1e-2)
+    for k, ref in g["adam2"].items():
+        torch.testing.assert_close(p[k], ref, rtol=1e-5, atol=1e-6, msg=lambda s: f"adam2 {k}: {s}")
+    out = R.deepfm(p, enc, g["batch"], is_training=False)
+    torch.testing.assert_close(out["pred"], g["adam2_out"]["pred"], rtol=1e-5, atol=1e-6)
+
+
+def test_layers():
+    g = load_golden("layers.npz")
+    enc = small_enc_dict()
+    b = g["batch"]
+    tables = {k.split(".")[1]: v for k, v in g["emb"].items() if k.startswith("w/")}
+    # index work: bit-exact
+    assert torch.equal(R.embedding_all(tables, enc, b), g["emb"]["all"])
+    assert torch.equal(R.embedding_by_name(tables, b, "C3"), g["emb"]["by_name_C3"])
+    d2 = dict(b)
+    d2["C3_seq"] = g["emb"]["seq_in"]
+    assert torch.equal(R.embedding_by_name(tables, d2, "C3_seq"), g["emb"]["by_name_C3_seq"])
+    with pytest.raises(IndexError):
+        bad = dict(b)
+        bad["C2"] = b["C2"].clone()
+        bad["C2"][3] = 4  # vocab 3 -> rows 0..3
+        R.embedding_all(tables, enc, bad)
+
+    torch.testing.assert_close(R.fm_second_order(g["ip"]["in"]), g["ip"]["product_sum_pooling"], **TOL)
+    torch.testing.assert_close(R.fm_bi_interaction(g["ip"]["in"]), g["ip"]["Bi_interaction_pooling"], **TOL)
+
+    c = g["cross"]
+    ws = [c[f"w/cross_net.{i}.weight.weight"] for i in range(3)]
+    bs = [c[f"w/cross_net.{i}.bias"] for i in range(3)]
+    torch.testing.assert_close(R.cross_net(c["in"], ws, bs), c["out"], rtol=1e-5, atol=1e-5)
+
+    c = g["cin"]
+    cw = [c[f"w/cin_layer.layer_{i}.weight"] for i in (1, 2)]
+    cb = [c[f"w/cin_layer.layer_{i}.bias"] for i in (1, 2)]
+    torch.testing.assert_close(R.cin(c["in"], cw, cb, c["w/fc.weight"], c["w/fc.bias"]), c["out"], rtol=1e-5, atol=1e-5)
+
+    for tag, (h, a) in {"a": (2, 4), "b": (2, 3), "c": (1, 8), "d": (3, 5)}.items():
+        c = g[f"attn_{tag}"]
+        y = R.mhsa(c["in"], c["w/W_q.weight"], c["w/W_k.weight"], c["w/W_v.weight"], c.get("w/W_res.weight"), h, a)
+        torch.testing.assert_close(y, c["out"], rtol=1e-5, atol=1e-5)
+
+    c = g["mlp"]
+    sd = {k[2:]: v for k, v in c.items() if k.startswith("w/")}
+    torch.testing.assert_close(R.mlp_relu(c["in"], sd, "net.", [0, 2, 4]), c["out"], **TOL)
+
+    c = g["lr"]
+    sd = {"lr." + k[2:]: v for k, v in c.items() if k.startswith("w/")}
+    torch.testing.assert_close(R.lr_layer(sd, "lr.", enc, b), c["out"], **TOL)
+
+
+def test_dataset_encode():
+    import json, os
+    from conftest import GOLDEN
+    import pandas as pd
+    meta = json.load(open(os.path.join(GOLDEN, "dataset.json")))
+    df = pd.read_json(os.path.join(GOLDEN, "dataset_frame.json"), orient="split")
+    g = load_golden("dataset.npz")
+    enc = meta["enc_dict"]
+    valid = df[100:130]
+    train = df[:100]
+    for col in meta["schema"]["sparse_cols"]:
+        ids = R.encode_sparse(train[col].astype(str).tolist(), enc[col])  # train split IS cast (base_dataset.py:58)
+        assert np.array_equal(np.asarray(ids, dtype=np.int64), g["train"][col].numpy())
+    for col in meta["schema"]["sparse_cols"]:
+        # reference quirk (B8): with a given enc_dict the column is NOT cast to str (the cast lives in
+        # get_enc_dict, base_dataset.py:58), so numeric-typed categorical columns all map to OOV here.
+        ids = R.encode_sparse(valid[col].tolist(), enc[col])
+        assert np.array_equal(np.asarray(ids, dtype=np.int64), g["valid"][col].numpy())
+    for col in meta["schema"]["dense_cols"]:
+        x = R.encode_dense(valid[col].values, enc[col]["min"], enc[col]["max"]).astype(np.float32)
+        np.testing.assert_allclose(x, g["valid"][col].numpy(), rtol=1e-6, atol=1e-7)
