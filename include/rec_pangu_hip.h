@@ -1,0 +1,133 @@
+/*
+ * rec_pangu_hip.h — C ABI of librecpangu_hip.so, the MI355X (gfx950) kernels behind the
+ * rec_pangu ranking hot path.
+ *
+ * The reference (HaSai666/rec_pangu v0.4.1) is pure Python over ATen and has NO native
+ * interface of its own.  Each entry point below therefore replaces one
+ * ATen op *site* of the reference; the site is cited as `file:line` relative to the reference
+ * root.  A maintainer binds these with ctypes (rec_pangu_amd/hip.py; INTEGRATION.md shows the
+ * stub that goes into the reference's own modules).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch / C++ types; `stream` is a hipStream_t
+ *     passed as void* (0 = the null stream).  All calls are asynchronous on `stream`, never
+ *     synchronise, never allocate: every buffer (outputs and workspaces) is owned by the caller.
+ *   - pointers named *_ptrs are HOST arrays of DEVICE pointers (copied into the launch packet).
+ *   - return 0 on success, <0 on failure (RP_ERR_*); rp_last_error() gives the message for the
+ *     calling thread.  Nothing throws or aborts.
+ *   - fp32 storage and arithmetic unless a name says otherwise; matrix products run on the
+ *     exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) so results are an fp32 FMA chain like ATen's.
+ *   - callable from any host thread (autograd's backward thread included).
+ */
+#ifndef REC_PANGU_HIP_H
+#define REC_PANGU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_OK 0
+#define RP_ERR_ARG (-1)         /* bad size / alignment / null pointer            */
+#define RP_ERR_LAUNCH (-2)      /* hipGetLastError() after a launch                */
+#define RP_ERR_UNSUPPORTED (-3) /* shape outside what the kernels were built for   */
+
+#define RP_MAX_FIELDS 64 /* sparse fields (and dense columns) per launch            */
+
+/* epilogue selectors for rp_linear_fwd */
+#define RP_ACT_NONE 0
+#define RP_ACT_RELU 1
+#define RP_ACT_MASK 2 /* out = acc * (aux > 0): ReLU backward fused into a dgrad GEMM */
+
+typedef void *rp_stream_t;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int rp_version(void);
+const char *rp_last_error(void);
+/* number of kernel launches issued through this library since load (tests use it to prove the
+ * HIP path, not a fallback, produced a result) */
+uint64_t rp_launch_count(void);
+
+/* ---- K1/K2/K3: fused multi-table gather + dense concat + FM second order -------------------
+ * replaces  layers/embedding.py:59-63 (F x nn.Embedding + stack),  models/utils.py:122-137
+ * (dense stack), ranking/deepfm.py:57-58 (flatten + cat) and layers/interaction.py:38-44 (FM).
+ *   arena      [R_total, D] all tables back to back (table f starts at row row_base[f])
+ *   row_base   device int64[F];  row_count device int64[F] (= vocab_size+1, bounds check)
+ *   idx_ptrs   F device pointers to int64[B] ids (one index per field per sample, bag size 1)
+ *   dense_ptrs ND device pointers to float[B]
+ *   x          [B, ldx] out: cols [f*D,(f+1)*D) = arena[row_base[f]+idx_f[b]], then ND dense
+ *              columns, then zeros up to ldx.  ldx >= F*D+ND.
+ *   fm_out     [B]    0.5*sum_d((sum_f v)^2 - sum_f v^2)          (NULL to skip)
+ *   sum_out    [B, D] sum_f v, kept for the FM backward           (NULL to skip)
+ *   keys_out   int32[F*B], keys_out[f*B+b] = global arena row     (NULL to skip)
+ *   err_flag   device int32, set to 1 if any id is outside [0,row_count[f]) (the id is then
+ *              clamped to 0; the Python side turns the flag into the reference's IndexError)
+ */
+int rp_embed_gather_fwd(const float *arena, const int64_t *row_base, const int64_t *row_count,
+                        const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                        int64_t B, int D, float *x, int64_t ldx, float *fm_out, float *sum_out,
+                        int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
+
+/* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
+ * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
+ * interaction.py:38-44.  rp_sort_pairs_i32 sorts (key, position) pairs by key (stable, so
+ * equal rows keep ascending sample order); workspace size from rp_sort_workspace_bytes. */
+int rp_sort_workspace_bytes(int64_t n, size_t *bytes);
+int rp_sort_pairs_i32(void *workspace, size_t workspace_bytes, const int32_t *keys_in, int32_t *keys_out,
+                      int32_t *pos_out, int64_t n, int end_bit, rp_stream_t stream);
+/*   grad_arena[key] (+)= sum over pairs p=(f,b) with that key of
+ *        dx[b, f*D:(f+1)*D]  +  (gfm ? gfm[b] * (sum_in[b,:] - arena[key,:]) : 0)
+ *   dx may be NULL (FM-only models), gfm may be NULL (no FM term), not both.
+ *   accumulate=0: rows must be zero on entry (rp_zero_rows), complete runs are stored;
+ *   accumulate=1: everything is added to what is there.                                     */
+int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
+                         const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
+                         const float *arena, float *grad_arena, int accumulate, rp_stream_t stream);
+/* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
+int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
+
+/* ---- K4: Linear (+bias +activation) on the fp32 MFMA ----------------------------------------
+ * replaces layers/deep.py:62-72 (nn.Linear + ReLU chain) and its autograd.
+ *   out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]);  bias may be NULL;
+ *   act = RP_ACT_MASK multiplies by (aux[m,n] > 0) (aux: [M, ldaux]).                        */
+int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, float *out,
+                  int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux,
+                  rp_stream_t stream);
+/* weight/bias gradient: dw[N,K] (+)= dy[M,N]^T . x[M,K];  db[N] (+)= column sums of dy.
+ * Deterministic two-stage reduction through `workspace` (rp_linear_wgrad_workspace_bytes).  */
+int rp_linear_wgrad_workspace_bytes(int64_t M, int N, int K, size_t *bytes);
+int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dw, int64_t lddw,
+                    float *db, int64_t M, int N, int K, int accumulate, void *workspace,
+                    size_t workspace_bytes, rp_stream_t stream);
+/* out[C,R] = in[R,C]^T (weights for the dgrad GEMM) */
+int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
+/* y = dy * (act_out > 0), elementwise over [M,N] */
+int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
+                int64_t M, int N, rp_stream_t stream);
+
+/* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
+ * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
+ *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)
+ *   pred[b] = sigmoid(z);  loss = weight * mean_b BCE(pred + p_eps, label), logs clamped at -100
+ *   partial: float[rp_loss_partials(B)] workspace;  loss: device float[1] (written unless NULL) */
+int rp_loss_partials(int64_t B);
+int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
+                       int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
+                       rp_stream_t stream);
+/* dz[b] = gloss[0] * weight/B * dBCE/dp * (apply_sigmoid ? p(1-p) : 1) */
+int rp_sigmoid_bce_bwd(const float *pred, const float *label, const float *gloss, int64_t B, float p_eps,
+                       float weight, int apply_sigmoid, float *dz, rp_stream_t stream);
+
+/* ---- K11: fused Adam (torch.optim.Adam single-tensor operation order) -----------------------
+ * replaces trainer.py:75 + model_pipeline.py:57-58 (optimizer.step(); model.zero_grad()).
+ * n_tensors <= RP_MAX_FIELDS per call; zero_grad=1 also clears g (the fused zero_grad).       */
+int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
+                 const int64_t *sizes, int n_tensors, float lr, float beta1, float beta2, float eps,
+                 int64_t step, int zero_grad, rp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REC_PANGU_HIP_H */

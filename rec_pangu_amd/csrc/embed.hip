@@ -1,0 +1,254 @@
+// Multi-table embedding gather (+ dense concat + FM second order) and its backward, gfx950.
+//
+// HBM layout: every table of a model lives back to back in ONE arena [R_total, D] (fp32,
+// row = D*4 bytes = 256 B at D=64 -> two 128-B lines, 16-B aligned), table f starting at row
+// row_base[f].  A lookup is therefore arena[row_base[f] + id].  The forward writes straight into
+// the MLP input buffer x[B, ldx] (embeddings first, then the dense columns, then zero padding up
+// to ldx, which the host keeps a multiple of 32 floats so every row starts on a 128-B line), so
+// the reference's stack / flatten / cat copies (embedding.py:63, deepfm.py:57-58) never exist.
+//
+// Work decomposition (wave64): TPR lanes own one sample; each lane moves VEC=4 floats (16 B) of
+// every row, so a 64-float row is one 256-B coalesced segment per 16 lanes and a wave issues
+// 4 rows per load instruction.  The F rows of a sample are F independent loads per lane (memory
+// level parallelism comes from the unrolled field loop); sum_f v and sum_f v^2 stay in registers,
+// so FM costs no extra HBM traffic.  HBM-bound: algorithmic bytes/sample =
+// F*(D*4 + 8) read + (F*D+ND)*4 written.
+#include "common.h"
+
+struct IdxPtrs {
+    const int64_t *p[RP_MAX_FIELDS];
+};
+struct DensePtrs {
+    const float *p[RP_MAX_FIELDS];
+};
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T load(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, T v) { *reinterpret_cast<f32x4 *>(p) = v; }
+    static __device__ __forceinline__ T zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ float hsum(T v) { return (v.x + v.y) + (v.z + v.w); }
+    static __device__ __forceinline__ void atomic_add(float *p, T v) {
+        atomicAdd(p + 0, v.x);
+        atomicAdd(p + 1, v.y);
+        atomicAdd(p + 2, v.z);
+        atomicAdd(p + 3, v.w);
+    }
+};
+template <>
+struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T load(const float *p) { return *p; }
+    static __device__ __forceinline__ void store(float *p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0.f; }
+    static __device__ __forceinline__ float hsum(T v) { return v; }
+    static __device__ __forceinline__ void atomic_add(float *p, T v) { atomicAdd(p, v); }
+};
+
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void embed_gather_fwd_kernel(
+    const float *__restrict__ arena, const int64_t *__restrict__ row_base, const int64_t *__restrict__ row_count,
+    IdxPtrs idx, int F, DensePtrs dense, int ND, int64_t B, int D, float *__restrict__ x, int64_t ldx,
+    float *__restrict__ fm_out, float *__restrict__ sum_out, int32_t *__restrict__ keys_out,
+    int32_t *__restrict__ err_flag) {
+    typedef Vec<VEC> V;
+    constexpr int SPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    const int64_t b = (int64_t)blockIdx.x * SPB + threadIdx.x / TPR;
+    if (b >= B) return;  // groups are TPR-aligned inside the wave: whole groups leave together
+    float *xrow = x + b * ldx;
+    float fm_acc = 0.f;
+    for (int c = t * VEC; c < D; c += TPR * VEC) {
+        typename V::T s = V::zero(), q = V::zero();
+#pragma unroll 4
+        for (int f = 0; f < F; ++f) {
+            int64_t id = idx.p[f][b];
+            if (id < 0 || id >= row_count[f]) {  // reference: IndexError from nn.Embedding on CPU
+                *err_flag = 1;
+                id = 0;
+            }
+            const int64_t key = row_base[f] + id;
+            const typename V::T v = V::load(arena + key * D + c);
+            V::store(xrow + (int64_t)f * D + c, v);
+            s += v;
+            q += v * v;
+            if (keys_out != nullptr && c == 0) keys_out[(int64_t)f * B + b] = (int32_t)key;  // t == 0 only
+        }
+        if (sum_out != nullptr) V::store(sum_out + b * D + c, s);
+        fm_acc += V::hsum(s * s - q);
+    }
+    const int64_t dense0 = (int64_t)F * D;
+    for (int j = t; j < ND; j += TPR) xrow[dense0 + j] = dense.p[j][b];
+    for (int64_t j = dense0 + ND + t; j < ldx; j += TPR) xrow[j] = 0.f;
+    if (fm_out != nullptr) {
+#pragma unroll
+        for (int o = TPR / 2; o > 0; o >>= 1) fm_acc += __shfl_xor(fm_acc, o, TPR);
+        if (t == 0) fm_out[b] = 0.5f * fm_acc;
+    }
+}
+
+// One TPR-lane group per sorted position; only run heads and 64-position chunk starts do work, so
+// a hot row of a tiny table (tens of thousands of hits at B=65536) is split over many groups.
+// Complete runs are stored, partial pieces are added with the L2 float atomic.
+#define RP_RUN_CHUNK 64
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
+    const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, int D,
+    const float *__restrict__ dx, int64_t ldx, const float *__restrict__ gfm, const float *__restrict__ sum_in,
+    const float *__restrict__ arena, float *__restrict__ G, int accumulate) {
+    typedef Vec<VEC> V;
+    constexpr int GPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
+    if (i >= n) return;
+    const int32_t key = sk[i];
+    const bool head = (i == 0) || (sk[i - 1] != key);
+    if (!head && (i % RP_RUN_CHUNK) != 0) return;
+    int64_t lim = (i / RP_RUN_CHUNK + 1) * RP_RUN_CHUNK;
+    if (lim > n) lim = n;
+    for (int c = t * VEC; c < D; c += TPR * VEC) {
+        typename V::T acc = V::zero();
+        float gs = 0.f;
+        int64_t j = i;
+        for (; j < lim; ++j) {
+            if (j > i && sk[j] != key) break;
+            const int32_t p = sp[j];
+            const int f = p / Bi;
+            const int b = p - f * Bi;
+            if (dx != nullptr) acc += V::load(dx + (int64_t)b * ldx + (int64_t)f * D + c);
+            if (gfm != nullptr) {
+                const float g = gfm[b];
+                acc += g * V::load(sum_in + (int64_t)b * D + c);
+                gs += g;
+            }
+        }
+        const bool ended = (j >= n) || (sk[j] != key);
+        if (gfm != nullptr) acc -= gs * V::load(arena + (int64_t)key * D + c);
+        float *dst = G + (int64_t)key * D + c;
+        if (head && ended && !accumulate)
+            V::store(dst, acc);
+        else
+            V::atomic_add(dst, acc);
+    }
+}
+
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void zero_rows_kernel(const int32_t *__restrict__ keys, int64_t n, int D,
+                                                        float *__restrict__ G) {
+    typedef Vec<VEC> V;
+    constexpr int GPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
+    if (i >= n) return;
+    float *dst = G + (int64_t)keys[i] * D;
+    for (int c = t * VEC; c < D; c += TPR * VEC) V::store(dst + c, V::zero());
+}
+
+static int pick_tpr(int D, int vec) {
+    int need = (D + vec - 1) / vec, tpr = 1;
+    while (tpr < need && tpr < 64) tpr <<= 1;
+    return tpr;
+}
+
+#define RP_DISPATCH_TPR(tpr, vec, CALL)                                 \
+    do {                                                                \
+        if (vec == 4) {                                                 \
+            switch (tpr) {                                              \
+                case 1: { CALL(1, 4); } break;                          \
+                case 2: { CALL(2, 4); } break;                          \
+                case 4: { CALL(4, 4); } break;                          \
+                case 8: { CALL(8, 4); } break;                          \
+                case 16: { CALL(16, 4); } break;                        \
+                case 32: { CALL(32, 4); } break;                        \
+                default: { CALL(64, 4); } break;                        \
+            }                                                           \
+        } else {                                                        \
+            switch (tpr) {                                              \
+                case 1: { CALL(1, 1); } break;                          \
+                case 2: { CALL(2, 1); } break;                          \
+                case 4: { CALL(4, 1); } break;                          \
+                case 8: { CALL(8, 1); } break;                          \
+                case 16: { CALL(16, 1); } break;                        \
+                case 32: { CALL(32, 1); } break;                        \
+                default: { CALL(64, 1); } break;                        \
+            }                                                           \
+        }                                                               \
+    } while (0)
+
+extern "C" int rp_embed_gather_fwd(const float *arena, const int64_t *row_base, const int64_t *row_count,
+                                   const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                                   int64_t B, int D, float *x, int64_t ldx, float *fm_out, float *sum_out,
+                                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(arena && row_base && row_count && idx_ptrs && x && err_flag, "embed_gather_fwd: null pointer");
+    RP_REQUIRE(F >= 1 && F <= RP_MAX_FIELDS, "embed_gather_fwd: F=%d outside [1,%d]", F, RP_MAX_FIELDS);
+    RP_REQUIRE(ND >= 0 && ND <= RP_MAX_FIELDS, "embed_gather_fwd: ND=%d outside [0,%d]", ND, RP_MAX_FIELDS);
+    RP_REQUIRE(ND == 0 || dense_ptrs, "embed_gather_fwd: dense_ptrs is null with ND=%d", ND);
+    RP_REQUIRE(D >= 1 && B >= 0, "embed_gather_fwd: bad D=%d B=%lld", D, (long long)B);
+    RP_REQUIRE(ldx >= (int64_t)F * D + ND, "embed_gather_fwd: ldx=%lld < F*D+ND", (long long)ldx);
+    RP_REQUIRE((int64_t)F * B < (int64_t)INT32_MAX, "embed_gather_fwd: F*B overflows int32 positions");
+    if (B == 0) return RP_OK;
+    IdxPtrs ip;
+    DensePtrs dp;
+    for (int f = 0; f < F; ++f) {
+        RP_REQUIRE(idx_ptrs[f], "embed_gather_fwd: idx_ptrs[%d] is null", f);
+        ip.p[f] = idx_ptrs[f];
+    }
+    for (int j = 0; j < ND; ++j) {
+        RP_REQUIRE(dense_ptrs[j], "embed_gather_fwd: dense_ptrs[%d] is null", j);
+        dp.p[j] = dense_ptrs[j];
+    }
+    const bool v4 = (D % 4 == 0) && (ldx % 4 == 0) && rp_aligned16(arena) && rp_aligned16(x) &&
+                    (sum_out == nullptr || rp_aligned16(sum_out));
+    const int vec = v4 ? 4 : 1;
+    const int tpr = pick_tpr(D, vec);
+    const unsigned grid = (unsigned)rp_cdiv(B, 256 / tpr);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(T, VV)                                                                                             \
+    hipLaunchKernelGGL((embed_gather_fwd_kernel<T, VV>), dim3(grid), dim3(256), 0, s, arena, row_base, row_count, \
+                       ip, F, dp, ND, B, D, x, ldx, fm_out, sum_out, keys_out, err_flag)
+    RP_DISPATCH_TPR(tpr, vec, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_gather_fwd");
+    return RP_OK;
+}
+
+extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
+                                    int D, const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
+                                    const float *arena, float *grad_arena, int accumulate, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && grad_arena, "embed_grad_reduce: null pointer");
+    RP_REQUIRE(dx != nullptr || gfm != nullptr, "embed_grad_reduce: neither dx nor gfm given");
+    RP_REQUIRE(gfm == nullptr || (sum_in && arena), "embed_grad_reduce: FM term needs sum_in and arena");
+    RP_REQUIRE(B >= 1 && B < INT32_MAX && D >= 1, "embed_grad_reduce: bad B/D");
+    if (n == 0) return RP_OK;
+    const bool v4 = (D % 4 == 0) && (dx == nullptr || ((ldx % 4 == 0) && rp_aligned16(dx))) &&
+                    rp_aligned16(grad_arena) && (gfm == nullptr || (rp_aligned16(sum_in) && rp_aligned16(arena)));
+    const int vec = v4 ? 4 : 1;
+    const int tpr = pick_tpr(D, vec);
+    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(T, VV)                                                                                            \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV>), dim3(grid), dim3(256), 0, s, sorted_keys, sorted_pos, \
+                       n, (int)B, D, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate)
+    RP_DISPATCH_TPR(tpr, vec, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_grad_reduce");
+    return RP_OK;
+}
+
+extern "C" int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream) {
+    RP_REQUIRE(keys && grad_arena && D >= 1, "zero_rows: bad argument");
+    if (n == 0) return RP_OK;
+    const int vec = (D % 4 == 0 && rp_aligned16(grad_arena)) ? 4 : 1;
+    const int tpr = pick_tpr(D, vec);
+    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(T, VV) \
+    hipLaunchKernelGGL((zero_rows_kernel<T, VV>), dim3(grid), dim3(256), 0, s, keys, n, D, grad_arena)
+    RP_DISPATCH_TPR(tpr, vec, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("zero_rows");
+    return RP_OK;
+}

@@ -1,0 +1,144 @@
+"""torch.autograd.Function wrappers that put the HIP kernels (rec_pangu_amd/hip.py) on the autograd tape.
+
+Everything here takes HIP-device fp32 tensors; nothing in this module computes on the CPU and
+nothing falls back: a missing librecpangu_hip.so raises from hip.lib().
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_RELU = hip.ACT_NONE, hip.ACT_RELU
+
+
+def _unit_inner(t: torch.Tensor) -> torch.Tensor:
+    """Kernels take row-major 2-D views with unit inner stride (any leading dimension)."""
+    if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
+        return t
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# K4  Linear (+bias, +ReLU)   — layers/deep.py:62-72
+# ----------------------------------------------------------------------------------------------
+class _LinearAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int):
+        x = _unit_inner(x)
+        K = weight.shape[1]
+        y = hip.linear_fwd(x, weight, bias, act, K=K)
+        ctx.act, ctx.K, ctx.has_bias = act, K, bias is not None
+        ctx.save_for_backward(x, weight, y if act == ACT_RELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _unit_inner(dy)
+        dpre = hip.relu_bwd(dy, y) if ctx.act == ACT_RELU else dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = hip.transpose(weight)  # [K, N]: the dgrad GEMM is the same NT kernel on W^T
+            dx = torch.empty_like(x)
+            if x.shape[1] > ctx.K:
+                dx[:, ctx.K:].zero_()
+            hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx[:, :ctx.K] if x.shape[1] > ctx.K else dx)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
+        return dx, dw, db, None
+
+
+def linear_act(x, weight, bias=None, act: int = ACT_NONE):
+    """act(x[:, :K] @ weight^T + bias) for 2-D x; x may carry zero padding columns beyond K."""
+    lead = None
+    if x.dim() != 2:
+        lead = x.shape[:-1]
+        x = x.reshape(-1, x.shape[-1])
+    y = _LinearAct.apply(x, weight, bias, act)
+    return y if lead is None else y.reshape(*lead, y.shape[-1])
+
+
+# ----------------------------------------------------------------------------------------------
+# K10  sum of logits -> sigmoid -> BCE(mean)   — ranking/deepfm.py:61-63, multi_task/mmoe.py:127
+# ----------------------------------------------------------------------------------------------
+class _SigmoidBCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, label, apply_sigmoid: bool, p_eps: float, weight: float, *addends):
+        adds = [a.contiguous() for a in addends]
+        label = label.contiguous()
+        pred, loss = hip.sigmoid_bce_fwd(adds, label, apply_sigmoid, p_eps, weight)
+        ctx.cfg = (apply_sigmoid, p_eps, weight, len(adds), [tuple(a.shape) for a in addends])
+        ctx.save_for_backward(pred, label)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, dpred, dloss):
+        pred, label = ctx.saved_tensors
+        apply_sigmoid, p_eps, weight, n, shapes = ctx.cfg
+        dz = None
+        if dloss is not None:
+            dz = hip.sigmoid_bce_bwd(pred, label, dloss, apply_sigmoid, p_eps, weight)
+        if dpred is not None:  # someone differentiated through `pred` itself (rare): torch ops on device
+            extra = dpred * (pred * (1 - pred) if apply_sigmoid else 1.0)
+            dz = extra if dz is None else dz + extra
+        outs = [None if dz is None else dz.reshape(s) for s in shapes]
+        return (None, None, None, None, *outs)
+
+
+def sigmoid_bce(addends: Sequence[torch.Tensor], label: torch.Tensor, apply_sigmoid=True, p_eps=0.0, weight=1.0):
+    """pred [B,1] = sigmoid(sum(addends)); loss = weight * mean BCE(pred + p_eps, label)."""
+    return _SigmoidBCE.apply(label, apply_sigmoid, p_eps, weight, *addends)
+
+
+class _SigmoidSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *addends):
+        pred, _ = hip.sigmoid_bce_fwd([a.contiguous() for a in addends], None, True)
+        ctx.shapes = [tuple(a.shape) for a in addends]
+        ctx.save_for_backward(pred)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        (pred,) = ctx.saved_tensors
+        dz = dpred * pred * (1 - pred)
+        return tuple(dz.reshape(s) for s in ctx.shapes)
+
+
+def sigmoid_sum(addends: Sequence[torch.Tensor]):
+    return _SigmoidSum.apply(*addends)
+
+
+# ----------------------------------------------------------------------------------------------
+# K1/K2/K3  multi-table gather (+dense concat, +FM)   — layers/embedding.py:59-63 etc.
+# `store` is the arena-backed EmbeddingLayer; its per-table Parameters are passed only so that the
+# node is connected to the graph: their gradients are written by the kernel straight into the
+# layer's dense gradient arena (exposed as each Parameter's .grad), not returned through autograd.
+# ----------------------------------------------------------------------------------------------
+class _EmbedGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, store, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, want_fm: bool, *tables):
+        need_grad = any(ctx.needs_input_grad[5:])
+        x, fm, ssum, keys = hip.embed_gather_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx,
+                                                 want_fm, want_fm and need_grad, need_grad, store.err_flag)
+        ctx.store, ctx.want_fm, ctx.B = store, want_fm, idx[0].shape[0]
+        ctx.save_for_backward(keys, ssum)
+        if want_fm:
+            return x, fm
+        return x
+
+    @staticmethod
+    def backward(ctx, dx, dfm=None):
+        keys, ssum = ctx.saved_tensors
+        store = ctx.store
+        if dx is not None:
+            dx = _unit_inner(dx)
+        gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
+        store.accumulate_grad(keys, ctx.B, dx, gfm, ssum)
+        return (None,) * (5 + len(store.emb_feature))
+
+
+def embed_gather(store, idx, dense, ldx: int, want_fm: bool):
+    tables = [store.embedding_layer[c].weight for c in store.emb_feature]
+    return _EmbedGather.apply(store, idx, dense, ldx, want_fm, *tables)

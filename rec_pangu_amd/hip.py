@@ -1,0 +1,250 @@
+"""ctypes binding of librecpangu_hip.so (C ABI: include/rec_pangu_hip.h).
+
+This is the only place Python touches the kernels.  PyTorch is plumbing here: it owns device
+memory (`tensor.data_ptr()`), and the current HIP stream (`torch.cuda.current_stream()`); no
+torch type crosses the ABI.  There is NO fallback: if the shared object is missing or a call
+fails, a RuntimeError is raised — a CUDA(HIP)-resident tensor never silently takes another path.
+"""
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librecpangu_hip.so")
+MAX_FIELDS = 64
+
+ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
+
+_lib = None
+
+_i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+_SIGNATURES = {
+    "rp_version": (C.c_int, []),
+    "rp_last_error": (C.c_char_p, []),
+    "rp_launch_count": (C.c_uint64, []),
+    "rp_embed_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "rp_sort_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
+    "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "rp_linear_wgrad_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
+    "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "rp_loss_partials": (C.c_int, [_i64]),
+    "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
+    "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def lib():
+    """Load the shared object once; raise loudly if it is not there (no CPU stand-in exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C rec_pangu_amd/csrc` "
+                "(or __graft_entry__.build()). The HIP path has no fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def launch_count() -> int:
+    return int(lib().rp_launch_count())
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().rp_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a HIP-device tensor, got {t.device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> int:
+    """2-D tensor with unit inner stride -> leading dimension."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"{name}: need a 2-D tensor with unit inner stride, got {tuple(t.shape)}/{t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+# ----------------------------------------------------------------------------------------------
+def embed_gather_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int,
+                     want_fm: bool, want_sum: bool, want_keys: bool, err_flag: torch.Tensor):
+    _req(arena, torch.float32, "arena")
+    F, ND = len(idx), len(dense)
+    B, D = idx[0].shape[0], arena.shape[1]
+    for t in idx:
+        _req(t, torch.int64, "index")
+        if t.dim() != 1 or t.shape[0] != B or not t.is_contiguous():
+            raise RuntimeError("index tensors must be contiguous int64 [B]")
+    for t in dense:
+        _req(t, torch.float32, "dense")
+        if t.dim() != 1 or t.shape[0] != B or not t.is_contiguous():
+            raise RuntimeError("dense tensors must be contiguous float32 [B]")
+    dev = arena.device
+    x = torch.empty((B, ldx), dtype=torch.float32, device=dev)
+    fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
+    ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_sum else None
+    keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
+    _check(lib().rp_embed_gather_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
+                                     _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, _ptr(fm), _ptr(ssum), _ptr(keys),
+                                     err_flag.data_ptr(), _stream()), "rp_embed_gather_fwd")
+    return x, fm, ssum, keys
+
+
+def sort_pairs(keys: torch.Tensor, end_bit: int = 32):
+    _req(keys, torch.int32, "keys")
+    n = keys.numel()
+    nbytes = _sz(0)
+    _check(lib().rp_sort_workspace_bytes(n, C.byref(nbytes)), "rp_sort_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
+    ko, po = torch.empty_like(keys), torch.empty_like(keys)
+    _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
+                                   end_bit, _stream()), "rp_sort_pairs_i32")
+    return ko, po
+
+
+def embed_grad_reduce(sorted_keys, sorted_pos, B: int, D: int, dx, gfm, sum_in, arena, grad_arena, accumulate: bool):
+    _req(grad_arena, torch.float32, "grad_arena")
+    ldx = 0
+    if dx is not None:
+        _req(dx, torch.float32, "dx")
+        ldx = _rowmajor(dx, "dx")
+    _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
+                                      _ptr(dx), ldx, _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(),
+                                      int(accumulate), _stream()), "rp_embed_grad_reduce")
+
+
+def zero_rows(keys, D: int, grad_arena):
+    _check(lib().rp_zero_rows(keys.data_ptr(), keys.numel(), D, grad_arena.data_ptr(), _stream()), "rp_zero_rows")
+
+
+def linear_fwd(a, w, bias, act: int = ACT_NONE, aux=None, K: Optional[int] = None, out=None):
+    """out[M,N] = act(a[:, :K] @ w[N,K]^T + bias). `a` may be wider than K (padded rows)."""
+    _req(a, torch.float32, "a")
+    _req(w, torch.float32, "w")
+    lda, ldw = _rowmajor(a, "a"), _rowmajor(w, "w")
+    M, N = a.shape[0], w.shape[0]
+    K = w.shape[1] if K is None else K
+    if a.shape[1] < K:
+        raise RuntimeError(f"linear_fwd: a has {a.shape[1]} columns, need {K}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ldo = _rowmajor(out, "out")
+    ldaux = _rowmajor(aux, "aux") if aux is not None else 0
+    _check(lib().rp_linear_fwd(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldo, M, N, K, act,
+                               _ptr(aux), ldaux, _stream()), "rp_linear_fwd")
+    return out
+
+
+def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want_bias: bool = True):
+    """dw[N,K] = dy[M,N]^T @ x[:, :K]; db[N] = colsum(dy)."""
+    _req(dy, torch.float32, "dy")
+    _req(x, torch.float32, "x")
+    M, N = dy.shape
+    lddy, ldx = _rowmajor(dy, "dy"), _rowmajor(x, "x")
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    if db is None and want_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    nbytes = _sz(0)
+    _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
+    _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
+                                 M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
+    return dw, db
+
+
+def transpose(w):
+    _req(w, torch.float32, "w")
+    R, Cc = w.shape
+    out = torch.empty((Cc, R), dtype=torch.float32, device=w.device)
+    _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R, R, Cc, _stream()), "rp_transpose")
+    return out
+
+
+def relu_bwd(dy, act_out):
+    M, N = dy.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    _check(lib().rp_relu_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
+                             out.data_ptr(), N, M, N, _stream()), "rp_relu_bwd")
+    return out
+
+
+def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tensor], apply_sigmoid: bool = True,
+                    p_eps: float = 0.0, weight: float = 1.0):
+    B = addends[0].numel()
+    for z in addends:
+        _req(z, torch.float32, "logit")
+        if z.numel() != B or not z.is_contiguous():
+            raise RuntimeError("logit addends must be contiguous with B elements")
+    dev = addends[0].device
+    pred = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    loss = partial = None
+    if label is not None:
+        _req(label, torch.float32, "label")
+        if label.numel() != B or not label.is_contiguous():
+            raise RuntimeError("label must be contiguous float32 with B elements")
+        partial = torch.empty((lib().rp_loss_partials(B),), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+    _check(lib().rp_sigmoid_bce_fwd(_ptr_array(addends), len(addends), int(apply_sigmoid), _ptr(label), B, p_eps,
+                                    weight, pred.data_ptr(), _ptr(partial), _ptr(loss), _stream()),
+           "rp_sigmoid_bce_fwd")
+    return pred, loss
+
+
+def sigmoid_bce_bwd(pred, label, gloss, apply_sigmoid: bool = True, p_eps: float = 0.0, weight: float = 1.0):
+    B = pred.numel()
+    dz = torch.empty((B, 1), dtype=torch.float32, device=pred.device)
+    gloss = gloss.reshape(1).contiguous()
+    _check(lib().rp_sigmoid_bce_bwd(pred.data_ptr(), label.data_ptr(), gloss.data_ptr(), B, p_eps, weight,
+                                    int(apply_sigmoid), dz.data_ptr(), _stream()), "rp_sigmoid_bce_bwd")
+    return dz
+
+
+def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad: bool):
+    """One fused launch per <=64 tensors; tensors must be contiguous fp32 on the same device."""
+    for i in range(0, len(params), MAX_FIELDS):
+        ps, gs = params[i:i + MAX_FIELDS], grads[i:i + MAX_FIELDS]
+        mm, vv = ms[i:i + MAX_FIELDS], vs[i:i + MAX_FIELDS]
+        for t in (*ps, *gs, *mm, *vv):
+            _req(t, torch.float32, "adam tensor")
+            if not t.is_contiguous():
+                raise RuntimeError("adam tensors must be contiguous")
+        sizes = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
+        _check(lib().rp_adam_step(_ptr_array(ps), _ptr_array(gs), _ptr_array(mm), _ptr_array(vv), sizes, len(ps), lr,
+                                  beta1, beta2, eps, step, int(zero_grad), _stream()), "rp_adam_step")

@@ -1,0 +1,11 @@
+from .activation import get_activation
+from .embedding import EmbeddingLayer
+from .deep import MLP
+from .shallow import LR_Layer
+from .interaction import (InnerProductLayer, FM_Layer, CrossInteractionLayer, CrossNet,
+                          CompressedInteractionNet)
+from .attention import ScaledDotProductAttention, MultiHeadAttention, MultiHeadSelfAttention
+
+__all__ = ["get_activation", "EmbeddingLayer", "MLP", "LR_Layer", "InnerProductLayer", "FM_Layer",
+           "CrossInteractionLayer", "CrossNet", "CompressedInteractionNet", "ScaledDotProductAttention",
+           "MultiHeadAttention", "MultiHeadSelfAttention"]

@@ -1,0 +1,72 @@
+"""MLP — drop-in for rec_pangu/models/layers/deep.py:11-84.
+
+The module tree is the reference's (`net` = nn.Sequential of Linear/BatchNorm1d/activation/Dropout
+in the same order, so state_dict keys `net.<i>.{weight,bias}` and the init RNG draws are identical).
+On a HIP device forward() walks `net` and runs every Linear (+ a directly following ReLU) as one
+fp32-MFMA launch with fused bias/ReLU epilogue (rp_linear_fwd); its backward is rp_linear_fwd on the
+transposed weight + rp_linear_wgrad.  Other modules in the chain (Dropout, BatchNorm1d, non-ReLU
+activations — none of which the reference's DeepFM uses) are applied as they are.
+"""
+from typing import List, Union
+
+import torch.nn as nn
+
+from ... import functional as Fh
+from .activation import get_activation
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim: int, output_dim: Union[int, None] = None, hidden_units: List[int] = [],
+                 hidden_activations: Union[str, List[str]] = "ReLU", output_activation: Union[str, None] = None,
+                 dropout_rates: Union[float, List[float]] = 0.1, batch_norm: bool = False, use_bias: bool = True):
+        super(MLP, self).__init__()
+        if output_dim is not None:
+            assert isinstance(output_dim, int) and output_dim > 0, "output_dim must be an integer"
+        assert isinstance(input_dim, int) and input_dim > 0, "input_dim must be an integer"
+        assert isinstance(hidden_units, list) and all(isinstance(i, int) for i in hidden_units) and len(
+            hidden_units) >= 1, "hidden_units must be a list of integers and with at least one element"
+        if isinstance(hidden_activations, str):
+            hidden_activations = [hidden_activations] * len(hidden_units)
+        elif isinstance(hidden_activations, list):
+            assert len(hidden_activations) == len(hidden_units), \
+                "hidden_activations must have one element per hidden unit"
+        else:
+            raise TypeError("hidden_activations must be a string or a list of strings")
+        if not isinstance(dropout_rates, list):
+            dropout_rates = [dropout_rates] * len(hidden_units)
+        else:
+            assert len(dropout_rates) == len(hidden_units), "dropout_rates must have one element per hidden unit"
+
+        dims = [input_dim] + hidden_units
+        chain = []
+        for i in range(len(dims) - 1):
+            chain.append(nn.Linear(dims[i], dims[i + 1], bias=use_bias))
+            if batch_norm:
+                chain.append(nn.BatchNorm1d(dims[i + 1]))
+            if hidden_activations[i]:
+                chain.append(get_activation(hidden_activations[i]))
+            if dropout_rates[i] > 0:
+                chain.append(nn.Dropout(p=dropout_rates[i]))
+        if output_dim is not None:
+            chain.append(nn.Linear(dims[-1], output_dim, bias=use_bias))
+        if output_activation is not None:
+            chain.append(get_activation(output_activation))
+        self.net = nn.Sequential(*chain)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return self.net(x)  # BASELINE config 0 (CPU plumbing)
+        mods = list(self.net)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE)
+                i += 2 if fuse_relu else 1
+            elif isinstance(m, nn.Dropout) and not (self.training and m.p > 0):
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x

@@ -1,0 +1,204 @@
+"""EmbeddingLayer — drop-in for rec_pangu/models/layers/embedding.py:11-71, MI355X-first.
+
+Same constructor, same `emb_feature` order (enc_dict key order of entries with 'vocab_size'),
+same ModuleDict of nn.Embedding(vocab_size+1, D) and therefore the same state_dict keys
+(`embedding_layer.<col>.weight`) and the same RNG draws at construction.
+
+What is different is where the rows live: all tables of the layer are views into ONE contiguous
+arena [sum(vocab+1), D] (HBM layout for the fused gather: a lookup is arena[row_base[f]+id]), and
+their gradients are views into one dense gradient arena that the HIP backward writes in place.
+`module.to()/cuda()/float()` move the arena once and re-point the per-table Parameters; anything
+that replaces a table tensor behind our back (set_weights, external .data assignment) is detected
+at the next forward and the arena is re-packed.
+
+Device dispatch is by where the arena lives: a HIP-resident layer ALWAYS runs the HIP kernels
+(rec_pangu_amd/hip.py raises if the library is missing — no fallback); a CPU-resident layer is
+BASELINE.json config 0 ("plumbing, no GPU") and uses plain torch ops.
+"""
+from typing import Dict, List, Optional, Union
+
+import torch
+from torch import nn
+
+from ... import functional as Fh
+
+
+class EmbeddingLayer(nn.Module):
+    def __init__(self, enc_dict: Dict[str, Dict[str, Union[int, str]]], embedding_dim: int) -> None:
+        super().__init__()
+        self.enc_dict = enc_dict
+        self.embedding_dim = embedding_dim
+        self.embedding_layer = nn.ModuleDict()
+        self.emb_feature: List[str] = []
+        # "sync": raise IndexError right after the gather (one 4-byte D2H per forward, what the
+        # reference's CPU nn.Embedding does); "deferred": only when raise_if_bad_index() is called.
+        self.check_indices = "sync"
+
+        rows = [enc_dict[c]["vocab_size"] + 1 for c in enc_dict.keys() if "vocab_size" in enc_dict[c].keys()]
+        arena = torch.empty((sum(rows), embedding_dim))
+        off = 0
+        for col in self.enc_dict.keys():
+            if "vocab_size" in self.enc_dict[col].keys():
+                r = self.enc_dict[col]["vocab_size"] + 1
+                self.emb_feature.append(col)
+                emb = nn.Embedding(r, embedding_dim, _weight=arena[off:off + r])
+                with torch.no_grad():
+                    nn.init.normal_(emb.weight)  # the draw nn.Embedding.reset_parameters() would make
+                self.embedding_layer.update({col: emb})
+                off += r
+        self._arena = arena
+        self._grad_arena: Optional[torch.Tensor] = None
+        self._touched: Optional[torch.Tensor] = None  # sorted keys written by the last backward
+        self._dev_meta = None
+
+    # ------------------------------------------------------------------ arena bookkeeping
+    def _tables(self):
+        return [self.embedding_layer[c].weight for c in self.emb_feature]
+
+    def _point_at(self, arena: torch.Tensor):
+        off = 0
+        for p in self._tables():
+            r = p.shape[0]
+            p.data = arena[off:off + r]
+            off += r
+        self._arena = arena
+        self._dev_meta = None
+
+    def _apply(self, fn, recurse=True):
+        # one move for the whole arena instead of one per table (module.to / .cuda / .float ...)
+        self._ensure_packed()
+        self._point_at(fn(self._arena))
+        if self._grad_arena is not None:
+            self._grad_arena = fn(self._grad_arena)
+            self._attach_grads()
+        self._touched = None if self._touched is None else fn(self._touched)
+        return self
+
+    def _ensure_packed(self):
+        a, D = self._arena, self.embedding_dim
+        off, ok = 0, True
+        for p in self._tables():
+            r = p.shape[0]
+            if (p.device != a.device or p.dtype != a.dtype or p.dim() != 2 or p.shape[1] != D
+                    or not p.is_contiguous() or off + r > a.shape[0]
+                    or p.data_ptr() != a.data_ptr() + off * D * a.element_size()):
+                ok = False
+                break
+            off += r
+        if ok and off == a.shape[0]:
+            return
+        with torch.no_grad():
+            tabs = self._tables()
+            arena = torch.cat([p.detach().reshape(p.shape[0], -1) for p in tabs], dim=0).contiguous()
+        self.embedding_dim = arena.shape[1]
+        self._point_at(arena)
+        self._grad_arena, self._touched = None, None
+
+    @property
+    def arena(self) -> torch.Tensor:
+        return self._arena
+
+    def _meta(self):
+        dev = self._arena.device
+        if self._dev_meta is None or self._dev_meta[0].device != dev:
+            rows = [p.shape[0] for p in self._tables()]
+            base = [0]
+            for r in rows[:-1]:
+                base.append(base[-1] + r)
+            self._dev_meta = (torch.tensor(base, dtype=torch.int64, device=dev),
+                              torch.tensor(rows, dtype=torch.int64, device=dev),
+                              torch.zeros((1,), dtype=torch.int32, device=dev),
+                              max(1, int(sum(rows) - 1).bit_length()))
+        return self._dev_meta
+
+    row_base = property(lambda self: self._meta()[0])
+    row_count = property(lambda self: self._meta()[1])
+    err_flag = property(lambda self: self._meta()[2])
+
+    def raise_if_bad_index(self):
+        """Turn the device-side out-of-range flag into the reference's IndexError (synchronises)."""
+        if self._dev_meta is not None and self._arena.is_cuda and int(self._dev_meta[2].item()) != 0:
+            self._dev_meta[2].zero_()
+            raise IndexError("index out of range in self")
+
+    # ------------------------------------------------------------------ gradients (HIP path)
+    def _attach_grads(self):
+        off = 0
+        for p in self._tables():
+            r = p.shape[0]
+            p.grad = self._grad_arena[off:off + r]
+            off += r
+
+    def _grads_are_ours(self) -> bool:
+        g, D = self._grad_arena, self.embedding_dim
+        if g is None:
+            return False
+        off = 0
+        for p in self._tables():
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr() + off * D * 4 or p.grad.shape != p.shape:
+                return False
+            off += p.shape[0]
+        return True
+
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum):
+        """Called from the autograd node of the gather: dense table gradients, reference semantics
+        (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
+        sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
+        the rows listed in `_touched`, so a fresh gradient costs a sparse re-zero, not an 8.6 GB fill."""
+        from ... import hip
+        D = self.embedding_dim
+        fresh = not self._grads_are_ours()
+        if self._grad_arena is None or self._grad_arena.shape != self._arena.shape \
+                or self._grad_arena.device != self._arena.device:
+            self._grad_arena = torch.zeros_like(self._arena)
+            self._touched = None
+        elif fresh and self._touched is not None:
+            hip.zero_rows(self._touched, D, self._grad_arena)  # zero_grad() happened: drop the old rows
+            self._touched = None
+        sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena, accumulate=not fresh)
+        self._touched = sk if (fresh or self._touched is None) else torch.cat([self._touched, sk])
+        if fresh:
+            self._attach_grads()
+
+    # ------------------------------------------------------------------ reference API
+    def set_weights(self, col_name: str, embedding_matrix: torch.Tensor, trainable: Optional[bool] = True) -> None:
+        """embedding.py:36-47 — replace one table (re-packed into the arena at the next forward)."""
+        self.embedding_layer[col_name].weight = nn.Parameter(embedding_matrix)
+        if not trainable:
+            self.embedding_layer[col_name].weight.requires_grad = False
+
+    def _idx_list(self, X):
+        return [X[c].long().reshape(-1).contiguous() for c in self.emb_feature]
+
+    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 32):
+        """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
+        self._ensure_packed()
+        F, D = len(self.emb_feature), self.embedding_dim
+        d = F * D + len(dense)
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        dense = [t.float().reshape(-1).contiguous() for t in dense]
+        out = Fh.embed_gather(self, self._idx_list(X), dense, ldx, want_fm)
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return out if want_fm else (out, None)
+
+    def forward(self, X: Dict[str, torch.Tensor], name: Optional[str] = None) -> torch.Tensor:
+        self._ensure_packed()
+        if name is None:
+            if self._arena.is_cuda:
+                x, _ = self.gather_concat(X, [], want_fm=False, pad_to=1)
+                return x.view(x.shape[0], len(self.emb_feature), self.embedding_dim)
+            feature_emb_list = []
+            for col in self.emb_feature:
+                inp = X[col].long().view(-1, 1)
+                feature_emb_list.append(self.embedding_layer[col](inp))
+            return torch.stack(feature_emb_list, dim=1).squeeze(2)
+        # single-field / sequence lookups (embedding.py:64-71) are off the ranking hot path: torch op
+        if "seq" in name:
+            inp = X[name].long()
+            fea = self.embedding_layer[name.replace("_seq", "")](inp)
+        else:
+            inp = X[name].long().view(-1, 1)
+            fea = self.embedding_layer[name](inp)
+        return fea

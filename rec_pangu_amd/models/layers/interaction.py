@@ -1,0 +1,99 @@
+"""Feature-interaction blocks of the hot path — drop-ins for rec_pangu/models/layers/interaction.py:
+InnerProductLayer (:12-52, the two pooling outputs the ranking models use), FM_Layer (:225-235),
+CrossInteractionLayer / CrossNet (:119-141), CompressedInteractionNet (:144-171).
+Parameter names/shapes follow the reference so its checkpoints load.
+"""
+import torch
+from torch import nn
+
+
+class InnerProductLayer(nn.Module):
+    """product_sum_pooling -> [B,1];  Bi_interaction_pooling -> [B,D]  (interaction.py:36-44).
+
+    In DeepFM/FM on a HIP device the second-order term is produced inside the gather kernel
+    (EmbeddingLayer.gather_concat(want_fm=True)), so this module is only reached with an explicit
+    [B,F,D] tensor."""
+    _SUPPORTED = ("product_sum_pooling", "Bi_interaction_pooling")
+
+    def __init__(self, num_fields=None, output="product_sum_pooling"):
+        super(InnerProductLayer, self).__init__()
+        if output not in self._SUPPORTED:
+            raise ValueError("InnerProductLayer output={} is not supported.".format(output))
+        self._output_type = output
+
+    def forward(self, feature_emb):
+        field_sum = feature_emb.sum(dim=1)
+        bi = 0.5 * (field_sum * field_sum - (feature_emb * feature_emb).sum(dim=1))
+        if self._output_type == "Bi_interaction_pooling":
+            return bi
+        return bi.sum(dim=-1, keepdim=True)
+
+
+class FM_Layer(nn.Module):
+    def __init__(self, final_activation=None, use_bias=True):
+        super(FM_Layer, self).__init__()
+        self.inner_product_layer = InnerProductLayer(output="product_sum_pooling")
+        self.final_activation = final_activation
+
+    def forward(self, feature_emb_list):
+        out = self.inner_product_layer(feature_emb_list)
+        return out if self.final_activation is None else self.final_activation(out)
+
+
+class CrossInteractionLayer(nn.Module):
+    """one DCN-v1 cross layer: (X_i . w) * X_0 + b   (interaction.py:119-127)"""
+
+    def __init__(self, input_dim):
+        super(CrossInteractionLayer, self).__init__()
+        self.weight = nn.Linear(input_dim, 1, bias=False)
+        self.bias = nn.Parameter(torch.zeros(input_dim))
+
+    def forward(self, X_0, X_i):
+        return self.weight(X_i) * X_0 + self.bias
+
+
+class CrossNet(nn.Module):
+    """X_{l+1} = X_l + (X_l . w_l) X_0 + b_l   (interaction.py:130-141)"""
+
+    def __init__(self, input_dim, num_layers):
+        super(CrossNet, self).__init__()
+        self.num_layers = num_layers
+        self.input_dim = input_dim
+        self.cross_net = nn.ModuleList(CrossInteractionLayer(input_dim) for _ in range(num_layers))
+
+    def forward(self, X_0):
+        X_i = X_0
+        for layer in self.cross_net:
+            X_i = X_i + layer(X_0, X_i)
+        return X_i
+
+
+class CompressedInteractionNet(nn.Module):
+    """CIN (interaction.py:144-171): X_k[b,o,:] = sum_{h,m} W_k[o, h*M+m] X_0[b,h,:] X_{k-1}[b,m,:] + bias_k[o];
+    no activation, no split-half; sum-pool over the embedding axis, concat, fc -> [B, output_dim].
+    Weights are kept as Conv1d(kernel_size=1) modules for state_dict compatibility
+    (`cin_layer.layer_k.weight` is [O, H*M, 1])."""
+
+    def __init__(self, num_fields, cin_layer_units, output_dim=1):
+        super(CompressedInteractionNet, self).__init__()
+        self.cin_layer_units = cin_layer_units
+        self.num_fields = num_fields
+        self.fc = nn.Linear(sum(cin_layer_units), output_dim)
+        self.cin_layer = nn.ModuleDict()
+        prev = num_fields
+        for i, unit in enumerate(cin_layer_units):
+            self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(num_fields * prev, unit, kernel_size=1)
+            prev = unit
+
+    def forward(self, feature_emb):
+        B, H, D = feature_emb.shape
+        X_0, X_i, pooled = feature_emb, feature_emb, []
+        for i in range(len(self.cin_layer_units)):
+            conv = self.cin_layer["layer_" + str(i + 1)]
+            M = X_i.shape[1]
+            W = conv.weight.view(conv.weight.shape[0], H, M)
+            # contract (h, m) without materialising the [B, H*M, D] outer product the reference builds
+            t = torch.einsum("ohm,bmd->bohd", W, X_i)
+            X_i = (t * X_0.unsqueeze(1)).sum(dim=2) + conv.bias.view(1, -1, 1)
+            pooled.append(X_i.sum(dim=-1))
+        return self.fc(torch.cat(pooled, dim=-1))

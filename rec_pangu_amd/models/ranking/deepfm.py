@@ -1,0 +1,35 @@
+"""DeepFM — drop-in for rec_pangu/models/ranking/deepfm.py:13-67.
+
+logit = FM second order + MLP(cat(flatten(emb), dense)); there is NO first-order term in the
+reference and none here.  HIP forward = 1 gather launch (embeddings + dense columns + FM) ->
+MLP GEMMs -> 1 loss launch; the [B,F,D] tensor, the flatten and the cat never exist.
+"""
+from typing import Dict, List
+
+import torch
+
+from ..base_model import BaseModel, build_loss
+from ..layers import FM_Layer, MLP
+from ..utils import get_dnn_input_dim, get_linear_input
+
+
+class DeepFM(BaseModel):
+    def __init__(self, embedding_dim: int = 32, hidden_units: List[int] = [64, 64, 64],
+                 loss_fun: str = 'torch.nn.BCELoss()', enc_dict: Dict[str, dict] = None):
+        super(DeepFM, self).__init__(enc_dict, embedding_dim)
+        self.hidden_units = hidden_units
+        self.loss_fun = build_loss(loss_fun)
+        self.enc_dict = enc_dict
+        self.fm = FM_Layer()
+        self.dnn_input_dim = get_dnn_input_dim(self.enc_dict, self.embedding_dim)
+        self.dnn = MLP(input_dim=self.dnn_input_dim, output_dim=1, hidden_units=self.hidden_units,
+                       hidden_activations='relu', dropout_rates=0)
+        self.reset_parameters()
+
+    def forward(self, data, is_training=True):
+        if self.on_hip:
+            x, fm_out = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=True)
+            return self._finish([fm_out, self.dnn(x)], data, is_training, self.loss_fun)
+        sparse_embedding = self.embedding_layer(data)
+        dnn_input = torch.cat((sparse_embedding.flatten(start_dim=1), get_linear_input(self.enc_dict, data)), dim=1)
+        return self._finish([self.fm(sparse_embedding), self.dnn(dnn_input)], data, is_training, self.loss_fun)

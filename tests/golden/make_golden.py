@@ -77,7 +77,7 @@ def small_batch(seed=7):
 
 
 def to_np(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()
 
 
 def dump_model_case(name, build, seed=1234, train_mode=False, extra=None):
