@@ -1,0 +1,219 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on its config: samples/s of a DeepFM train step
+(forward + backward + the reference's dense Adam + zero_grad) on synthetic Criteo-shaped batches,
+global batch 65536, 26 sparse fields (Criteo-Kaggle cardinalities, 33.76 M rows) x D=64 + 13 dense,
+MLP [64,64,64], fp32, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One JSON line on stdout (rank 0).  Inputs are resident in HBM before the timed region.  Besides the
+contract's fields it carries `roofline` (dominant kernel, HIP events on the launch stream inside the
+timed region), `kernels` (every C-ABI entry point: calls/step, mean ms, algorithmic GB/s where defined)
+and `cpu_baseline` (the CPU oracle port timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CRITEO_CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
+               10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def criteo_enc_dict(scale=1):
+    enc = {f"I{i + 1}": {"min": 0.0, "max": 1.0} for i in range(13)}
+    enc.update({f"C{i + 1}": {"vocab_size": max(2, c // scale)} for i, c in enumerate(CRITEO_CARD)})
+    return enc
+
+
+def synth_batch(enc, B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    b = {}
+    for k, v in enc.items():
+        if "min" in v:
+            b[k] = torch.rand(B, generator=g)
+        else:
+            b[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g)  # uniform: worst case for caches
+    b["label"] = (torch.rand(B, generator=g) < 0.25).float()
+    return {k: t.to(device) for k, t in b.items()}
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle port (oracle/ref_ops.py: the reference's algorithm in ATen fp32 ops + autograd, dense
+    torch.optim.Adam as trainer.py:75) on this box's host cores.  Bounded sample: B=65536, vocabulary / 16
+    (dense Adam then touches 2.1 M rows instead of 33.8 M), 1 warm-up + up to 2 timed steps."""
+    from oracle import ref_ops as R  # checker/baseline only
+    from rec_pangu_amd.models.ranking import DeepFM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    enc = criteo_enc_dict(scale=16)
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in model.state_dict().items()}
+    del model
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    B = 65536
+    batch = synth_batch(enc, B, 1, "cpu")
+
+    def step():
+        out = R.deepfm(params, enc, batch)
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+
+    step()
+    t0, n = time.perf_counter(), 0
+    while n < 2 and (n == 0 or time.perf_counter() - t0 < seconds_budget):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train step(s) of B=65536 (fwd+bwd+dense Adam), vocabulary/16 = "
+                      f"{sum(v['vocab_size'] + 1 for v in enc.values() if 'vocab_size' in v)} rows, "
+                      f"{dt:.2f} s/step, torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="global batch")
+    ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.optim import make_adam
+    hip.lib()
+
+    enc = criteo_enc_dict(args.vocab_scale)
+    B = args.batch
+    if world > 1:
+        from rec_pangu_amd.sharded import shard_model_tables  # row-sharded tables + RCCL all-to-all
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+    if world > 1:
+        model = shard_model_tables(model, world, rank)
+    model.embedding_layer.check_indices = "deferred"  # no per-step host sync; checked once after the run
+    model.train()
+    opt = make_adam(model, 1e-3)
+    n_params = sum(p.numel() for p in model.parameters())
+    n_table_rows = model.embedding_layer.arena.shape[0]
+
+    local_B = B // world
+    batches = [synth_batch(enc, B, 100 + i, dev) for i in range(4)]
+    if world > 1:
+        batches = [{k: v[rank * local_B:(rank + 1) * local_B].contiguous() for k, v in b.items()} for b in batches]
+
+    def step(i):
+        data = batches[i % len(batches)]
+        if args.mode == "forward":
+            with torch.no_grad():
+                model(data, is_training=False)
+            return
+        out = model(data)
+        out["loss"].backward()
+        opt.step()
+        model.zero_grad()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    hip.enable_timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = hip.timing_summary()
+    hip.enable_timing(False)
+    model.embedding_layer.raise_if_bad_index()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * args.steps / dt
+
+    # ---- per-kernel numbers (algorithmic bytes from SURVEY.md §8d) --------------------------------
+    F, D, ND = 26, 64, 13
+    alg_bytes = {
+        # table rows read + int64 ids read + [B, F*D+ND] fp32 output written
+        "embed_gather_fwd": local_B * (F * (D * 4 + 8) + (F * D + ND) * 4),
+        # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
+        "adam_step": 7 * 4 * (n_params),
+    }
+    kernels = {}
+    for name, (calls, mean_ms) in sorted(timing.items()):
+        k = {"calls_per_step": round(calls / args.steps, 2), "mean_ms": round(mean_ms, 4)}
+        if name in alg_bytes:
+            k["algorithmic_GBps"] = round(alg_bytes[name] / (mean_ms * 1e-3) / 1e9, 1)
+        kernels[name] = k
+    total = {n: c * m for n, (c, m) in timing.items()}
+    dominant = max(total, key=total.get) if total else None
+    roofline = None
+    if dominant in alg_bytes:
+        a = alg_bytes[dominant] / (timing[dominant][1] * 1e-3) / 1e9
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg_bytes[dominant]}
+    gather = None
+    if "embed_gather_fwd" in timing:
+        a = alg_bytes["embed_gather_fwd"] / (timing["embed_gather_fwd"][1] * 1e-3) / 1e9
+        gather = {"kernel": "embed_gather_fwd", "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                  "algorithmic_bytes_per_launch": alg_bytes["embed_gather_fwd"]}
+
+    if rank == 0:
+        res = {
+            "metric": "samples/sec DeepFM Criteo-shape bsz=65536 (train step: fwd+bwd+dense Adam+zero_grad)"
+                      if args.mode == "train" else "samples/sec DeepFM Criteo-shape bsz=65536 (forward only)",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeepFM, 26 sparse fields (Criteo-Kaggle cardinalities/{args.vocab_scale}, "
+                                   f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D=64 + 13 dense, "
+                                   f"MLP [64,64,64], global batch {B}, uniform ids",
+                       "global_batch": B, "optimizer": "dense Adam (reference semantics, fused zero_grad)",
+                       "parallelism": "single GPU" if world == 1 else f"tables row-sharded x{world}, all-to-all lookup"},
+            "roofline": roofline, "roofline_gather": gather, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

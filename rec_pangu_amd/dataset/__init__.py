@@ -1,0 +1,5 @@
+from .base_dataset import BaseDataset
+from .multi_task_dataset import MultiTaskDataset
+from .process_data import get_dataloader, get_single_dataloader
+
+__all__ = ["BaseDataset", "MultiTaskDataset", "get_dataloader", "get_single_dataloader"]

@@ -94,6 +94,45 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+# ---- optional per-entry-point timing with HIP events on the launch stream (bench.py's roofline) ----
+_timing = None
+
+
+def enable_timing(on: bool = True):
+    """Start/stop recording a (start, end) HIP-event pair around every C-ABI call, on the stream the
+    kernels are launched on.  Read with timing_summary() after a torch.cuda.synchronize()."""
+    global _timing
+    _timing = {} if on else None
+
+
+class _Timed:
+    __slots__ = ("name", "ev")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timing is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.ev[1].record()
+            _timing.setdefault(self.name, []).append(self.ev)
+        return False
+
+
+def timing_summary():
+    """{entry point: (calls, mean milliseconds)} for the calls recorded since enable_timing(True)."""
+    out = {}
+    for name, evs in (_timing or {}).items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out
+
+
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * max(len(tensors), 1))()
     for i, t in enumerate(tensors):
@@ -120,7 +159,8 @@ def embed_gather_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense:
     fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
     ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_sum else None
     keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
-    _check(lib().rp_embed_gather_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
+    with _Timed("embed_gather_fwd"):
+        _check(lib().rp_embed_gather_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
                                      _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, _ptr(fm), _ptr(ssum), _ptr(keys),
                                      err_flag.data_ptr(), _stream()), "rp_embed_gather_fwd")
     return x, fm, ssum, keys
@@ -133,7 +173,8 @@ def sort_pairs(keys: torch.Tensor, end_bit: int = 32):
     _check(lib().rp_sort_workspace_bytes(n, C.byref(nbytes)), "rp_sort_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
     ko, po = torch.empty_like(keys), torch.empty_like(keys)
-    _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
+    with _Timed("sort_pairs_i32"):
+        _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
                                    end_bit, _stream()), "rp_sort_pairs_i32")
     return ko, po
 
@@ -144,13 +185,15 @@ def embed_grad_reduce(sorted_keys, sorted_pos, B: int, D: int, dx, gfm, sum_in, 
     if dx is not None:
         _req(dx, torch.float32, "dx")
         ldx = _rowmajor(dx, "dx")
-    _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
+    with _Timed("embed_grad_reduce"):
+        _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
                                       _ptr(dx), ldx, _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(),
                                       int(accumulate), _stream()), "rp_embed_grad_reduce")
 
 
 def zero_rows(keys, D: int, grad_arena):
-    _check(lib().rp_zero_rows(keys.data_ptr(), keys.numel(), D, grad_arena.data_ptr(), _stream()), "rp_zero_rows")
+    with _Timed("zero_rows"):
+        _check(lib().rp_zero_rows(keys.data_ptr(), keys.numel(), D, grad_arena.data_ptr(), _stream()), "rp_zero_rows")
 
 
 def linear_fwd(a, w, bias, act: int = ACT_NONE, aux=None, K: Optional[int] = None, out=None):
@@ -166,7 +209,8 @@ def linear_fwd(a, w, bias, act: int = ACT_NONE, aux=None, K: Optional[int] = Non
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldo = _rowmajor(out, "out")
     ldaux = _rowmajor(aux, "aux") if aux is not None else 0
-    _check(lib().rp_linear_fwd(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldo, M, N, K, act,
+    with _Timed("linear_fwd"):
+        _check(lib().rp_linear_fwd(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldo, M, N, K, act,
                                _ptr(aux), ldaux, _stream()), "rp_linear_fwd")
     return out
 
@@ -184,7 +228,8 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     nbytes = _sz(0)
     _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
-    _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
+    with _Timed("linear_wgrad"):
+        _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
                                  M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
     return dw, db
 
@@ -193,14 +238,16 @@ def transpose(w):
     _req(w, torch.float32, "w")
     R, Cc = w.shape
     out = torch.empty((Cc, R), dtype=torch.float32, device=w.device)
-    _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R, R, Cc, _stream()), "rp_transpose")
+    with _Timed("transpose"):
+        _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R, R, Cc, _stream()), "rp_transpose")
     return out
 
 
 def relu_bwd(dy, act_out):
     M, N = dy.shape
     out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
-    _check(lib().rp_relu_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
+    with _Timed("relu_bwd"):
+        _check(lib().rp_relu_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
                              out.data_ptr(), N, M, N, _stream()), "rp_relu_bwd")
     return out
 
@@ -221,7 +268,8 @@ def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tenso
             raise RuntimeError("label must be contiguous float32 with B elements")
         partial = torch.empty((lib().rp_loss_partials(B),), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
-    _check(lib().rp_sigmoid_bce_fwd(_ptr_array(addends), len(addends), int(apply_sigmoid), _ptr(label), B, p_eps,
+    with _Timed("sigmoid_bce_fwd"):
+        _check(lib().rp_sigmoid_bce_fwd(_ptr_array(addends), len(addends), int(apply_sigmoid), _ptr(label), B, p_eps,
                                     weight, pred.data_ptr(), _ptr(partial), _ptr(loss), _stream()),
            "rp_sigmoid_bce_fwd")
     return pred, loss
@@ -231,7 +279,8 @@ def sigmoid_bce_bwd(pred, label, gloss, apply_sigmoid: bool = True, p_eps: float
     B = pred.numel()
     dz = torch.empty((B, 1), dtype=torch.float32, device=pred.device)
     gloss = gloss.reshape(1).contiguous()
-    _check(lib().rp_sigmoid_bce_bwd(pred.data_ptr(), label.data_ptr(), gloss.data_ptr(), B, p_eps, weight,
+    with _Timed("sigmoid_bce_bwd"):
+        _check(lib().rp_sigmoid_bce_bwd(pred.data_ptr(), label.data_ptr(), gloss.data_ptr(), B, p_eps, weight,
                                     int(apply_sigmoid), dz.data_ptr(), _stream()), "rp_sigmoid_bce_bwd")
     return dz
 
@@ -246,5 +295,6 @@ def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad
             if not t.is_contiguous():
                 raise RuntimeError("adam tensors must be contiguous")
         sizes = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
-        _check(lib().rp_adam_step(_ptr_array(ps), _ptr_array(gs), _ptr_array(mm), _ptr_array(vv), sizes, len(ps), lr,
+        with _Timed("adam_step"):
+            _check(lib().rp_adam_step(_ptr_array(ps), _ptr_array(gs), _ptr_array(mm), _ptr_array(vv), sizes, len(ps), lr,
                                   beta1, beta2, eps, step, int(zero_grad), _stream()), "rp_adam_step")

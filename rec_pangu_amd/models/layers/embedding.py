@@ -15,6 +15,7 @@ Device dispatch is by where the arena lives: a HIP-resident layer ALWAYS runs th
 (rec_pangu_amd/hip.py raises if the library is missing — no fallback); a CPU-resident layer is
 BASELINE.json config 0 ("plumbing, no GPU") and uses plain torch ops.
 """
+import weakref
 from typing import Dict, List, Optional, Union
 
 import torch
@@ -49,11 +50,21 @@ class EmbeddingLayer(nn.Module):
         self._arena = arena
         self._grad_arena: Optional[torch.Tensor] = None
         self._touched: Optional[torch.Tensor] = None  # sorted keys written by the last backward
+        self._grad_clean = True  # gradient arena known to be all zero
         self._dev_meta = None
+        self._tag_tables()
 
     # ------------------------------------------------------------------ arena bookkeeping
     def _tables(self):
         return [self.embedding_layer[c].weight for c in self.emb_feature]
+
+    def table_parameters(self):
+        return self._tables()
+
+    def _tag_tables(self):
+        ref = weakref.ref(self)
+        for p in self._tables():
+            p._rp_store = ref  # lets FusedAdam find the arena behind a table Parameter
 
     def _point_at(self, arena: torch.Tensor):
         off = 0
@@ -63,6 +74,7 @@ class EmbeddingLayer(nn.Module):
             off += r
         self._arena = arena
         self._dev_meta = None
+        self._tag_tables()
 
     def _apply(self, fn, recurse=True):
         # one move for the whole arena instead of one per table (module.to / .cuda / .float ...)
@@ -92,7 +104,7 @@ class EmbeddingLayer(nn.Module):
             arena = torch.cat([p.detach().reshape(p.shape[0], -1) for p in tabs], dim=0).contiguous()
         self.embedding_dim = arena.shape[1]
         self._point_at(arena)
-        self._grad_arena, self._touched = None, None
+        self._grad_arena, self._touched, self._grad_clean = None, None, True
 
     @property
     def arena(self) -> torch.Tensor:
@@ -126,8 +138,21 @@ class EmbeddingLayer(nn.Module):
         off = 0
         for p in self._tables():
             r = p.shape[0]
-            p.grad = self._grad_arena[off:off + r]
+            if p.requires_grad:  # a frozen table (set_weights(trainable=False)) never shows a gradient
+                p.grad = self._grad_arena[off:off + r]
             off += r
+
+    @property
+    def grad_arena(self):
+        return self._grad_arena
+
+    def grads_are_arena(self) -> bool:
+        """True when every table's .grad is the matching view of the gradient arena."""
+        return self._grads_are_ours() and all(p.requires_grad for p in self._tables())
+
+    def grads_were_zeroed(self):
+        """FusedAdam(fuse_zero_grad) cleared the whole gradient arena."""
+        self._touched, self._grad_clean = None, True
 
     def _grads_are_ours(self) -> bool:
         g, D = self._grad_arena, self.embedding_dim
@@ -135,7 +160,8 @@ class EmbeddingLayer(nn.Module):
             return False
         off = 0
         for p in self._tables():
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr() + off * D * 4 or p.grad.shape != p.shape:
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != g.data_ptr() + off * D * 4
+                                    or p.grad.shape != p.shape):
                 return False
             off += p.shape[0]
         return True
@@ -151,13 +177,19 @@ class EmbeddingLayer(nn.Module):
         if self._grad_arena is None or self._grad_arena.shape != self._arena.shape \
                 or self._grad_arena.device != self._arena.device:
             self._grad_arena = torch.zeros_like(self._arena)
-            self._touched = None
-        elif fresh and self._touched is not None:
-            hip.zero_rows(self._touched, D, self._grad_arena)  # zero_grad() happened: drop the old rows
-            self._touched = None
+            self._touched, self._grad_clean = None, True
+        elif fresh and not self._grad_clean:
+            # zero_grad() dropped the .grad views: clear the rows the previous backward wrote
+            if self._touched is not None:
+                hip.zero_rows(self._touched, D, self._grad_arena)
+            else:
+                self._grad_arena.zero_()
+            self._touched, self._grad_clean = None, True
         sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
-        hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena, accumulate=not fresh)
-        self._touched = sk if (fresh or self._touched is None) else torch.cat([self._touched, sk])
+        hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
+                              accumulate=not self._grad_clean)
+        self._touched = sk if self._touched is None else torch.cat([self._touched, sk])
+        self._grad_clean = False
         if fresh:
             self._attach_grads()
 

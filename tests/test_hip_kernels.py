@@ -1,0 +1,288 @@
+"""GPU parity tests: every C-ABI entry point (through rec_pangu_amd.hip = ctypes over
+include/rec_pangu_hip.h) against the CPU oracle (oracle/ref_ops.py) on the same seeded inputs.
+
+Bars (BASELINE.json north_star): index work bit-exact; floating point within 1e-4 of the fp32
+reference on logits/loss — block-level checks here are held tighter (1e-5 relative to the operand
+scale) because the kernels are fp32 FMA chains like ATen's.
+"""
+import pytest
+import torch
+
+from conftest import require_gpu
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    require_gpu()
+    from rec_pangu_amd import hip as h
+    h.lib()
+    return h
+
+
+DEV = "cuda"
+
+
+def _tables(rows, D, gen):
+    arena = torch.randn(sum(rows), D, generator=gen)
+    base, off = [], 0
+    for r in rows:
+        base.append(off)
+        off += r
+    return arena, base
+
+
+def _gather_case(hip, rows, D, ND, B, seed, pad_to=32, want_fm=True):
+    g = torch.Generator().manual_seed(seed)
+    F = len(rows)
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    dense = [torch.rand(B, generator=g) for _ in range(ND)]
+    d = F * D + ND
+    ldx = (d + pad_to - 1) // pad_to * pad_to
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x, fm, ssum, keys = hip.embed_gather_fwd(
+        arena.to(DEV), torch.tensor(base, device=DEV), torch.tensor(rows, device=DEV), [i.to(DEV) for i in idx],
+        [t.to(DEV) for t in dense], ldx, want_fm, want_fm, True, err)
+    torch.cuda.synchronize()
+    # oracle
+    emb = torch.stack([arena[base[f] + idx[f]] for f in range(F)], dim=1)  # == R.embedding_all on per-table views
+    assert int(err.item()) == 0
+    x = x.cpu()
+    assert torch.equal(x[:, :F * D], emb.flatten(1)), "gathered rows must be bit-exact copies"
+    if ND:
+        assert torch.equal(x[:, F * D:d], torch.stack(dense, dim=1)), "dense columns must be exact copies"
+    assert torch.count_nonzero(x[:, d:]) == 0, "padding columns must be zero"
+    exp_keys = torch.cat([base[f] + idx[f] for f in range(F)]).to(torch.int32)
+    assert torch.equal(keys.cpu(), exp_keys), "arena row keys (index work) must be bit-exact"
+    if want_fm:
+        ref_fm = R.fm_second_order(emb)
+        scale = (emb.abs().sum(dim=(1, 2)) ** 2).clamp(min=1.0).unsqueeze(1) * 1e-6
+        assert ((fm.cpu() - ref_fm).abs() <= scale + 1e-5).all(), (fm.cpu() - ref_fm).abs().max()
+        torch.testing.assert_close(ssum.cpu(), emb.sum(dim=1), rtol=1e-5, atol=1e-5)
+    return arena, base, idx, x, keys
+
+
+@pytest.mark.parametrize("rows,D,ND,B", [
+    ([8, 4, 51, 12, 3], 8, 3, 24),               # the golden-fixture shape
+    ([1000] * 26, 64, 13, 1000),                 # Criteo field/dim shape, ragged batch
+    ([3, 4, 10, 100000, 27], 64, 13, 4099),      # tiny hot tables next to a big one
+    ([17, 5], 40, 9, 333),                       # D=40 (MMOE default): 10 of 16 lanes active
+    ([50, 7, 9], 1, 2, 777),                     # D=1: the LR_Layer scalar path
+    ([50, 7], 6, 0, 65),                         # D not a multiple of 4 -> scalar lanes
+    ([9], 256, 1, 130),                          # one wave per row
+    ([9, 5], 320, 0, 70),                        # D > 256: lanes loop over chunks
+])
+def test_embed_gather_fwd(hip, rows, D, ND, B):
+    _gather_case(hip, rows, D, ND, B, seed=D * 7 + B)
+
+
+def test_embed_gather_flags_out_of_range(hip):
+    g = torch.Generator().manual_seed(0)
+    rows, D, B = [5, 6], 8, 40
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    idx[1][7] = 6  # == row_count -> out of range
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    hip.embed_gather_fwd(arena.to(DEV), torch.tensor(base, device=DEV), torch.tensor(rows, device=DEV),
+                         [i.to(DEV) for i in idx], [], 16, False, False, False, err)
+    assert int(err.item()) == 1
+    idx[1][7] = -1
+    err.zero_()
+    hip.embed_gather_fwd(arena.to(DEV), torch.tensor(base, device=DEV), torch.tensor(rows, device=DEV),
+                         [i.to(DEV) for i in idx], [], 16, False, False, False, err)
+    assert int(err.item()) == 1
+
+
+@pytest.mark.parametrize("n,hi", [(1, 5), (1000, 7), (100001, 1 << 20), (1703936, 33762603)])
+def test_sort_pairs(hip, n, hi):
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int32)
+    ko, po = hip.sort_pairs(keys.to(DEV), end_bit=max(1, (hi - 1).bit_length()))
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    assert torch.equal(ko.cpu(), ref_k)
+    assert torch.equal(po.cpu(), ref_p.to(torch.int32)), "sort must be stable (ascending position among equal rows)"
+
+
+@pytest.mark.parametrize("rows,D,B,with_fm,with_dx", [
+    ([8, 4, 51, 12, 3], 8, 24, True, True),
+    ([3, 4, 10, 5000, 27], 64, 4099, True, True),     # runs of >1000 equal rows: chunked + atomic pieces
+    ([3, 4, 10, 5000, 27], 64, 4099, False, True),    # DCN-like: no FM term
+    ([17, 5], 40, 333, True, False),                  # FM-only model: dx absent
+    ([50, 7, 9], 1, 777, False, True),                # LR tables
+])
+def test_embed_grad_reduce_vs_autograd(hip, rows, D, B, with_fm, with_dx):
+    g = torch.Generator().manual_seed(B + D)
+    F = len(rows)
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    ldx = (F * D + 3 + 31) // 32 * 32
+    dx = torch.randn(B, ldx, generator=g)
+    gfm = torch.randn(B, 1, generator=g)
+    # oracle: autograd through gather (+FM) on CPU
+    w = arena.clone().requires_grad_(True)
+    emb = torch.stack([w[base[f] + idx[f]] for f in range(F)], dim=1)
+    obj = 0
+    if with_dx:
+        obj = obj + (emb.flatten(1) * dx[:, :F * D]).sum()
+    if with_fm:
+        obj = obj + (R.fm_second_order(emb) * gfm).sum()
+    obj.backward()
+    ref = w.grad
+    keys = torch.cat([base[f] + idx[f] for f in range(F)]).to(torch.int32).to(DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=max(1, (sum(rows) - 1).bit_length()))
+    G = torch.zeros_like(arena, device=DEV)
+    ssum = emb.detach().sum(dim=1).to(DEV)
+    hip.embed_grad_reduce(sk, sp, B, D, dx.to(DEV) if with_dx else None, gfm.to(DEV) if with_fm else None,
+                          ssum if with_fm else None, arena.to(DEV), G, accumulate=False)
+    tol = 1e-5 * max(1.0, float(ref.abs().max()))
+    assert (G.cpu() - ref).abs().max() <= 20 * tol, (G.cpu() - ref).abs().max()
+    untouched = torch.ones(sum(rows), dtype=torch.bool)
+    untouched[keys.cpu().long()] = False
+    assert torch.count_nonzero(G.cpu()[untouched]) == 0, "rows nobody looked up must stay exactly zero"
+    # accumulate mode adds a second copy; zero_rows restores the all-zero invariant
+    hip.embed_grad_reduce(sk, sp, B, D, dx.to(DEV) if with_dx else None, gfm.to(DEV) if with_fm else None,
+                          ssum if with_fm else None, arena.to(DEV), G, accumulate=True)
+    assert (G.cpu() - 2 * ref).abs().max() <= 40 * tol
+    hip.zero_rows(sk, D, G)
+    assert torch.count_nonzero(G) == 0
+
+
+@pytest.mark.parametrize("M,N,K,lda_pad,act", [
+    (24, 16, 43, 64, "relu"),
+    (1000, 64, 1677, 1696, "relu"),     # DeepFM first layer, padded A rows, unaligned W rows
+    (777, 64, 64, 64, "relu"),
+    (513, 1, 64, 64, "none"),           # the 64 -> 1 head
+    (300, 1677, 64, 64, "none"),        # dgrad shape: wide N, short K
+    (129, 100, 37, 37, "none"),         # nothing aligned
+    (256, 512, 649, 672, "none"),       # MMOE expert GEMM shape
+])
+def test_linear_fwd(hip, M, N, K, lda_pad, act):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.zeros(M, lda_pad)
+    a[:, :K] = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = a[:, :K].double() @ w.double().t() + b.double()
+    if act == "relu":
+        ref = ref.relu()
+    out = hip.linear_fwd(a.to(DEV), w.to(DEV), b.to(DEV), hip.ACT_RELU if act == "relu" else hip.ACT_NONE, K=K)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+    # transpose-detecting mask epilogue (asymmetric aux)
+    aux = torch.randn(M, N, generator=g)
+    out2 = hip.linear_fwd(a.to(DEV), w.to(DEV), None, hip.ACT_MASK, aux=aux.to(DEV), K=K)
+    ref2 = (a[:, :K].double() @ w.double().t()) * (aux > 0)
+    torch.testing.assert_close(out2.cpu().double(), ref2, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,ldx_pad", [
+    (24, 16, 43, 64), (4099, 64, 1677, 1696), (65536, 64, 64, 64), (1000, 1, 64, 64), (513, 100, 37, 37),
+    (2048, 512, 649, 672),
+])
+def test_linear_wgrad(hip, M, N, K, ldx_pad):
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    x = torch.zeros(M, ldx_pad)
+    x[:, :K] = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    dw, db = hip.linear_wgrad(dy.to(DEV), x.to(DEV), K)
+    ref_w = dy.double().t() @ x[:, :K].double()
+    ref_b = dy.double().sum(dim=0)
+    tol = 2e-6 * M ** 0.5 * 4  # fp32 accumulation over M terms
+    torch.testing.assert_close(dw.cpu().double(), ref_w, rtol=1e-4, atol=tol * 10)
+    torch.testing.assert_close(db.cpu().double(), ref_b, rtol=1e-4, atol=tol * 10)
+    # accumulate=True adds on top
+    dw2, db2 = hip.linear_wgrad(dy.to(DEV), x.to(DEV), K, dw=dw.clone(), db=db.clone(), accumulate=True)
+    torch.testing.assert_close(dw2.cpu().double(), 2 * ref_w, rtol=1e-4, atol=tol * 20)
+    torch.testing.assert_close(db2.cpu().double(), 2 * ref_b, rtol=1e-4, atol=tol * 20)
+
+
+def test_transpose_and_relu_bwd(hip):
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 1677, generator=g)
+    assert torch.equal(hip.transpose(w.to(DEV)).cpu(), w.t().contiguous())
+    w = torch.randn(37, 5, generator=g)
+    assert torch.equal(hip.transpose(w.to(DEV)).cpu(), w.t().contiguous())
+    dy, y = torch.randn(1001, 64, generator=g), torch.randn(1001, 64, generator=g).relu()
+    assert torch.equal(hip.relu_bwd(dy.to(DEV), y.to(DEV)).cpu(), dy * (y > 0))
+
+
+@pytest.mark.parametrize("B,n_add,apply_sigmoid,p_eps,weight", [
+    (24, 2, True, 0.0, 1.0), (65536, 3, True, 0.0, 1.0), (1000, 1, False, 1e-6, 0.5), (300001, 1, True, 0.0, 1.0)])
+def test_sigmoid_bce(hip, B, n_add, apply_sigmoid, p_eps, weight):
+    g = torch.Generator().manual_seed(B)
+    adds = [torch.randn(B, 1, generator=g) * 2 for _ in range(n_add)]
+    if not apply_sigmoid:
+        adds = [torch.rand(B, 1, generator=g) * 0.98 + 0.01]
+    adds[0][0] = 40.0 if apply_sigmoid else adds[0][0]  # saturated logit: log clamp path
+    y = (torch.rand(B, generator=g) < 0.3).float()
+    zs = [a.clone().requires_grad_(True) for a in adds]
+    z = sum(zs)
+    p = torch.sigmoid(z) if apply_sigmoid else z
+    ref_loss = weight * torch.nn.functional.binary_cross_entropy(p.squeeze(-1) + p_eps, y)
+    ref_loss.backward()
+    pred, loss = hip.sigmoid_bce_fwd([a.to(DEV) for a in adds], y.to(DEV), apply_sigmoid, p_eps, weight)
+    torch.testing.assert_close(pred.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(loss.cpu(), ref_loss.detach(), rtol=2e-6, atol=1e-7)
+    dz = hip.sigmoid_bce_bwd(pred, y.to(DEV), torch.ones((), device=DEV), apply_sigmoid, p_eps, weight)
+    torch.testing.assert_close(dz.cpu(), zs[0].grad, rtol=1e-4, atol=1e-9)
+    pred_only, none = hip.sigmoid_bce_fwd([a.to(DEV) for a in adds], None, apply_sigmoid)
+    assert none is None and torch.equal(pred_only, pred)
+
+
+def test_adam_matches_reference_order(hip):
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1000, 64), (64,), (7, 13), (1,), (33762 * 64 + 3,)]
+    p = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (0.0 if i == 2 else 1.0) for s in shapes] for i in range(3)]
+    ref = [t.clone() for t in p]
+    opt = torch.optim.Adam([torch.nn.Parameter(t) for t in ref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    dp = [t.to(DEV) for t in p]
+    dm = [torch.zeros_like(t) for t in dp]
+    dv = [torch.zeros_like(t) for t in dp]
+    for step in range(1, 4):
+        for q, gr in zip(opt.param_groups[0]["params"], grads[step - 1]):
+            q.grad = gr.clone()
+        opt.step()
+        dg = [t.to(DEV) for t in grads[step - 1]]
+        hip.adam_step(dp, dg, dm, dv, 1e-2, 0.9, 0.999, 1e-8, step, zero_grad=(step == 2))
+        if step == 2:
+            assert all(torch.count_nonzero(t) == 0 for t in dg), "fused zero_grad must clear g"
+    for q, d in zip(opt.param_groups[0]["params"], dp):
+        torch.testing.assert_close(d.cpu(), q.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_gather_properties(hip):
+    """BASELINE config 1 shape (B=65536, 26 fields, D=64) on a 1/16-vocabulary arena: size-independent
+    properties instead of a CPU oracle — every gathered row is a bit-exact copy of its arena row and the
+    backward is linear: column sums of the gradient arena equal column sums of dx."""
+    g = torch.Generator().manual_seed(1)
+    card = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
+            10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+    rows = [max(2, c // 16) + 1 for c in card]
+    F, D, B, ND = 26, 64, 65536, 13
+    arena = torch.randn(sum(rows), D, device=DEV)
+    base = [0]
+    for r in rows[:-1]:
+        base.append(base[-1] + r)
+    idx = [torch.randint(0, r, (B,), generator=g).to(DEV) for r in rows]
+    dense = [torch.rand(B, generator=g).to(DEV) for _ in range(ND)]
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n0 = hip.launch_count()
+    x, fm, ssum, keys = hip.embed_gather_fwd(arena, torch.tensor(base, device=DEV), torch.tensor(rows, device=DEV),
+                                             idx, dense, 1696, True, True, True, err)
+    assert hip.launch_count() == n0 + 1
+    emb = x[:, :F * D].view(B, F, D)
+    for f in (0, 2, 8, 25):
+        assert torch.equal(emb[:, f], arena[base[f] + idx[f]])
+    torch.testing.assert_close(fm, 0.5 * ((emb.sum(1) ** 2) - (emb ** 2).sum(1)).sum(-1, keepdim=True), rtol=1e-4,
+                               atol=1e-2)
+    dx = torch.randn(B, 1696, device=DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=(sum(rows) - 1).bit_length())
+    assert bool((sk[1:] >= sk[:-1]).all())
+    G = torch.zeros_like(arena)
+    hip.embed_grad_reduce(sk, sp, B, D, dx, None, None, None, G, accumulate=False)
+    lhs = G.double().sum(dim=0)
+    rhs = dx[:, :F * D].double().view(B, F, D).sum(dim=(0, 1))
+    torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=1e-3)

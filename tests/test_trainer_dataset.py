@@ -1,0 +1,137 @@
+"""Host logic on the CPU (BASELINE config 0): dataset encode, RankTrainer.fit / evaluate / predict,
+checkpoint layout and BenchmarkTrainer CSV schema against the fixtures captured from a run of the
+reference (tests/golden/{dataset,trainer,benchmark}.*)."""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from rec_pangu_amd.benchmark_trainer import BenchmarkTrainer
+from rec_pangu_amd.dataset import BaseDataset, MultiTaskDataset, get_dataloader
+from rec_pangu_amd.models.ranking import DeepFM
+from rec_pangu_amd.trainer import RankTrainer
+
+torch.set_num_threads(1)
+
+
+def _frames():
+    meta = json.load(open(os.path.join(GOLDEN, "dataset.json")))
+    df = pd.read_json(os.path.join(GOLDEN, "dataset_frame.json"), orient="split")
+    return meta, df[:100].copy(), df[100:130].copy(), df[130:].copy()
+
+
+def test_dataset_encode_matches_reference():
+    meta, train_df, valid_df, test_df = _frames()
+    g = load_golden("dataset.npz")
+    train_loader, valid_loader, test_loader, enc_dict = get_dataloader(train_df, valid_df, test_df, meta["schema"],
+                                                                       batch_size=32)
+    # enc_dict content equals the reference's (key ORDER is schema order here, hash order there: B4)
+    assert set(enc_dict) == set(meta["enc_dict"])
+    for col, ref in meta["enc_dict"].items():
+        got = {str(k): (int(v) if isinstance(v, (int, np.integer)) else float(v)) for k, v in enc_dict[col].items()}
+        assert got == ref, col
+    for split, loader in (("train", train_loader), ("valid", valid_loader), ("test", test_loader)):
+        for col, ref in g[split].items():
+            got = loader.dataset.data_dict[col]
+            assert got.dtype == ref.dtype
+            if ref.dtype == torch.int64:
+                assert torch.equal(got, ref), f"{split}/{col}: ids must be bit-exact"
+            else:
+                torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+    b0 = next(iter(valid_loader))
+    assert set(b0) == set(g["valid_batch0"])
+    for k, ref in g["valid_batch0"].items():
+        assert b0[k].dtype == ref.dtype and b0[k].shape == ref.shape
+        torch.testing.assert_close(b0[k], ref, rtol=1e-6, atol=1e-7)
+
+
+def _loaders_in_reference_order():
+    meta, train_df, valid_df, test_df = _frames()
+    train_loader, valid_loader, test_loader, enc = get_dataloader(train_df, valid_df, test_df, meta["schema"],
+                                                                  batch_size=32)
+    enc_ref_order = {k: enc[k] for k in meta["enc_order"]}  # the field order the reference run had
+    return meta, train_loader, valid_loader, test_loader, enc_ref_order, test_df
+
+
+def test_rank_trainer_fit_matches_reference_run(tmp_path):
+    meta, train_loader, valid_loader, test_loader, enc, test_df = _loaders_in_reference_order()
+    ref = json.load(open(os.path.join(GOLDEN, "trainer.json")))
+    g = load_golden("trainer.npz")
+    torch.manual_seed(ref["seed"])
+    model = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc)
+    for k, v in g["init"].items():
+        assert torch.equal(model.state_dict()[k], v), k
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    valid_metric = trainer.fit(model, train_loader, valid_loader, epoch=ref["epoch"], lr=ref["lr"],
+                               device=torch.device("cpu"))
+    assert sorted(os.listdir(tmp_path)) == ref["ckpt_files"]
+    assert valid_metric == ref["valid_metric"]
+    for k, v in g["final"].items():
+        torch.testing.assert_close(model.state_dict()[k], v, rtol=1e-4, atol=1e-6)
+    assert trainer.evaluate_model(model, test_loader, device=torch.device("cpu")) == ref["test_metric"]
+    p_df = trainer.predict_dataframe(model, test_df, enc, meta["schema"], batch_size=16)
+    p_dl = trainer.predict_dataloader(model, test_loader)
+    np.testing.assert_allclose(np.asarray(p_df), g["pred_dataframe"].numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(p_dl), g["pred_dataloader"].numpy(), rtol=1e-4, atol=1e-6)
+    trainer.save_all(model, enc, str(tmp_path))
+    saved = torch.load(os.path.join(tmp_path, "model.pth"), weights_only=False)
+    assert sorted(saved.keys()) == ref["save_all_keys"]
+    reloaded = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=saved["enc_dict"])
+    reloaded.load_state_dict(saved["model"])
+    assert trainer.predict_dataloader(reloaded, test_loader) == p_dl
+
+
+def test_early_stopping_and_scheduler(tmp_path):
+    _, train_loader, valid_loader, _, enc, _ = _loaders_in_reference_order()
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=4, hidden_units=[8], enc_dict=enc)
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    m = trainer.fit(model, train_loader, valid_loader, epoch=6, lr=1e-2, use_earlystopping=True, max_patience=1,
+                    monitor_metric="roc_auc_score", lr_scheduler_type="StepLR",
+                    scheduler_params={"step_size": 1, "gamma": 0.5})
+    assert set(m) == {"roc_auc_score", "log_loss"}
+    assert "model_best.pth" in os.listdir(tmp_path)
+    with pytest.raises(ValueError):
+        trainer.fit(model, train_loader, valid_loader, epoch=1, lr_scheduler_type="nope")
+    with pytest.raises(AssertionError):
+        trainer.fit(model, train_loader, valid_loader, epoch=1, use_earlystopping=True, monitor_metric="f1")
+
+
+def test_benchmark_trainer_csv_schema(tmp_path):
+    _, train_loader, valid_loader, test_loader, enc, _ = _loaders_in_reference_order()
+    ref = json.load(open(os.path.join(GOLDEN, "benchmark.json")))
+    csv = os.path.join(tmp_path, "bench.csv")
+    torch.manual_seed(1)
+    bt = BenchmarkTrainer(num_task=1, model_list=["DeepFM", "FM"], benchmark_res_path=csv,
+                          ckpt_root=os.path.join(tmp_path, "ck"))
+    bt.run(train_loader, enc, valid_loader, test_loader, epoch=1, lr=1e-3, device=torch.device("cpu"))
+    res = pd.read_csv(csv)
+    assert list(res.columns) == ref["columns"]
+    assert list(res["model_name"]) == ref["model_name"]
+    assert sorted(os.listdir(os.path.join(tmp_path, "ck"))) == ref["ckpt_dirs"]
+    assert sorted(os.listdir(os.path.join(tmp_path, "ck", "DeepFM"))) == ref["ckpt_files"]
+    with pytest.raises(NameError):
+        BenchmarkTrainer(model_list=["NoSuchModel"], benchmark_res_path=csv).run(train_loader, enc)
+
+
+def test_multitask_dataset_and_trainer(tmp_path):
+    """The reference's MultiTaskDataset is dead at v0.4.1 (B1); ours implements its documented output."""
+    from rec_pangu_amd.models.multi_task import MMOE
+    meta, train_df, valid_df, test_df = _frames()
+    schema = dict(meta["schema"], label_col=["click", "scroll"], task_type="multitask")
+    train_loader, valid_loader, test_loader, enc = get_dataloader(train_df, valid_df, test_df, schema, batch_size=50)
+    b = next(iter(valid_loader))
+    assert {"task1_label", "task2_label"} <= set(b) and "label" not in b
+    assert isinstance(train_loader.dataset, MultiTaskDataset)
+    torch.manual_seed(0)
+    model = MMOE(num_task=2, n_expert=2, embedding_dim=4, mmoe_hidden_dim=8, hidden_dim=[8, 4], enc_dict=enc)
+    trainer = RankTrainer(num_task=2, model_ckpt_dir=str(tmp_path))
+    m = trainer.fit(model, train_loader, valid_loader, epoch=1, lr=1e-3)
+    assert set(m) == {"test_task1_roc_auc_score", "test_task1_log_loss", "test_task2_roc_auc_score",
+                      "test_task2_log_loss"}
+    preds = trainer.predict_dataloader(model, test_loader)
+    assert len(preds) == 2 and len(preds[0]) == len(test_df)
