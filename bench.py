@@ -113,7 +113,7 @@ def main():
     enc = criteo_enc_dict(args.vocab_scale)
     B = args.batch
     if world > 1:
-        from rec_pangu_amd.sharded import shard_model_tables  # row-sharded tables + RCCL all-to-all
+        from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads  # row-sharded tables + RCCL
     torch.manual_seed(0)
     with torch.device(dev):
         model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
@@ -138,6 +138,8 @@ def main():
             return
         out = model(data)
         out["loss"].backward()
+        if world > 1:
+            allreduce_dense_grads(model)  # one flat bucket; embedding-row grads already travelled in backward
         opt.step()
         model.zero_grad()
 

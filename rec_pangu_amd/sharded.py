@@ -1,0 +1,279 @@
+"""Row-sharded embedding tables across the GPUs of one node (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Nothing like this exists in the reference (single process, single device: SURVEY.md §2.2); its only
+contract is "same numbers as the 1-GPU path" (§8e), which tests/test_sharded_gloo.py checks.
+
+Partition.  Global batch B is split into contiguous local batches of b = B/G samples.  Every arena row r
+(all tables of the layer back to back, as in EmbeddingLayer) lives on rank r % G at local row r // G:
+mod-sharding spreads both capacity and traffic (Criteo's three 5-10 M-row tables hold 76 % of the rows,
+its 3..30-row tables are the hottest), without per-table placement decisions.
+
+One exchange each way per step (the only data-path collectives):
+  forward   ids  : all_to_all_single of int64 local-row ids, bucketed by owner (sizes via a G-int all-to-all)
+            rows : owner gathers its rows -> all_to_all_single back ([n, D] fp32, ~b*F/G rows per peer:
+                   26 624 x 256 B = 6.8 MB per xGMI link at B=65536, G=8 — every peer pair has its own link)
+  backward  grads: the same route reversed, then a local sort + segmented reduce into the local dense gradient
+Dense parameters are replicated; `allreduce_dense_grads` averages their gradients in ONE flat bucket
+(0.46 MB for the default MLP: latency-bound, so one collective, not one per tensor).
+Embedding-row gradients are scaled by 1/G before they travel, so the update equals the 1-GPU update on
+the global batch (loss = mean over B).
+
+On a HIP device the local work runs on the HIP kernels (fused gather + FM from the received rows,
+sort + segmented reduce for the gradients); on CPU (gloo tests, BASELINE config 0 style) plain torch ops.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import functional as Fh
+
+
+def _a2a(out, inp, out_splits, in_splits, group):
+    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+class _Route:
+    """Bucketing of n row requests by owner rank + the split sizes of the exchange."""
+
+    def __init__(self, keys: torch.Tensor, world: int, group):
+        dest = keys % world
+        self.order = torch.argsort(dest, stable=True)  # positions (pair ids) in send order
+        send_counts = torch.bincount(dest, minlength=world)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        self.send = send_counts.tolist()  # one host sync per exchange: RCCL wants sizes on the host
+        self.recv = recv_counts.tolist()
+        self.local_rows = torch.div(keys, world, rounding_mode="floor")[self.order].contiguous()
+        self.n_recv = sum(self.recv)
+
+
+class _ShardedRows(torch.autograd.Function):
+    """rows_in_send_order[j] = global_arena[keys[order[j]]]; backward routes the row gradients back to the
+    owners and reduces them into the owner's local dense gradient."""
+
+    @staticmethod
+    def forward(ctx, layer, keys, local_arena):
+        route = _Route(keys, layer.world, layer.group)
+        recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=keys.device)
+        _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
+        served = layer._local_gather(recv_rows)  # [n_recv, D]
+        rows = torch.empty((keys.numel(), local_arena.shape[1]), dtype=local_arena.dtype, device=keys.device)
+        _a2a(rows, served, route.send, route.recv, layer.group)
+        ctx.layer, ctx.route = layer, route
+        ctx.save_for_backward(recv_rows)
+        ctx.mark_non_differentiable(route.order)
+        return rows, route.order
+
+    @staticmethod
+    def backward(ctx, g_rows, _g_order):
+        (recv_rows,) = ctx.saved_tensors
+        layer, route = ctx.layer, ctx.route
+        g_rows = (g_rows * (1.0 / layer.world)).contiguous()
+        recv_g = torch.empty((route.n_recv, g_rows.shape[1]), dtype=g_rows.dtype, device=g_rows.device)
+        _a2a(recv_g, g_rows, route.recv, route.send, layer.group)
+        layer._local_scatter_add(recv_rows, recv_g)
+        return None, None, None
+
+
+class _RowsToX(torch.autograd.Function):
+    """HIP: x[b, ldx] (+ FM) from the rows received in send order (bag size 1: row j serves pair order[j])."""
+
+    @staticmethod
+    def forward(ctx, rows, inv, dense: List[torch.Tensor], order, b: int, F: int, ldx: int, want_fm: bool,
+                err_flag):
+        from . import hip
+        n, D = rows.shape
+        dev = rows.device
+        zero = torch.zeros((1,), dtype=torch.int64, device=dev)
+        cnt = torch.full((1,), n, dtype=torch.int64, device=dev)
+        idx = [inv[f * b:(f + 1) * b] for f in range(F)]
+        x, fm, ssum, _ = hip.embed_gather_fwd(rows, zero.expand(F).contiguous(), cnt.expand(F).contiguous(), idx, dense,
+                                              ldx, want_fm, want_fm, False, err_flag)
+        ctx.cfg = (b, F, D, want_fm)
+        ctx.save_for_backward(rows, order, ssum)
+        return (x, fm) if want_fm else x
+
+    @staticmethod
+    def backward(ctx, dx, dfm=None):
+        from . import hip
+        rows, order, ssum = ctx.saved_tensors
+        b, F, D, want_fm = ctx.cfg
+        n = rows.shape[0]
+        g_rows = torch.empty_like(rows)
+        ident = torch.arange(n, dtype=torch.int32, device=rows.device)
+        gfm = dfm.contiguous() if (want_fm and dfm is not None) else None
+        dx = None if dx is None else Fh._unit_inner(dx)
+        # run length 1 everywhere: "key" j = position in send order, its single pair is order[j]
+        hip.embed_grad_reduce(ident, order.to(torch.int32), b, D, dx, gfm, ssum if gfm is not None else None,
+                              rows if gfm is not None else None, g_rows, accumulate=False)
+        return g_rows, None, None, None, None, None, None, None, None
+
+
+class ShardedEmbeddingLayer(nn.Module):
+    """Drop-in for EmbeddingLayer inside a model whose tables are row-sharded over `world` ranks."""
+
+    def __init__(self, full_layer, world: int, rank: int, group=None):
+        super().__init__()
+        full_layer._ensure_packed()
+        self.enc_dict = full_layer.enc_dict
+        self.embedding_dim = full_layer.embedding_dim
+        self.emb_feature = list(full_layer.emb_feature)
+        self.world, self.rank, self.group = world, rank, group
+        self.check_indices = full_layer.check_indices
+        rows = [p.shape[0] for p in full_layer.table_parameters()]
+        base = [0]
+        for r in rows[:-1]:
+            base.append(base[-1] + r)
+        self.total_rows = sum(rows)
+        self.register_buffer("_row_base", torch.tensor(base, dtype=torch.int64, device=full_layer.arena.device),
+                             persistent=False)
+        self.register_buffer("_row_count", torch.tensor(rows, dtype=torch.int64, device=full_layer.arena.device),
+                             persistent=False)
+        # rows r with r % world == rank, in order: local row = r // world
+        self.local_arena = nn.Parameter(full_layer.arena.detach()[rank::world].clone())
+        self._touched = None
+        self._err = None
+
+    # ---- EmbeddingLayer-compatible surface ------------------------------------------------------
+    @property
+    def arena(self):
+        return self.local_arena
+
+    def raise_if_bad_index(self):
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise IndexError("index out of range in self")
+
+    def _keys(self, X):
+        idx = torch.stack([X[c].long().reshape(-1) for c in self.emb_feature])  # [F, b]
+        bad = (idx < 0) | (idx >= self._row_count[:, None])
+        if self._err is None or self._err.device != idx.device:
+            self._err = torch.zeros((1,), dtype=torch.int32, device=idx.device)
+        self._err |= bad.any().to(torch.int32)
+        # like the kernel: flag, then use row 0 so the exchange itself stays well-formed on every rank
+        idx = torch.where(bad, torch.zeros_like(idx), idx)
+        return (idx + self._row_base[:, None]).reshape(-1)  # p = f*b + i
+
+    # ---- local primitives: HIP kernels on a HIP device, torch ops on CPU ---------------------------
+    def _local_gather(self, rows_idx):
+        if self.local_arena.is_cuda:
+            from . import hip
+            n = rows_idx.numel()
+            if n == 0:
+                return torch.empty((0, self.embedding_dim), device=rows_idx.device)
+            zero = torch.zeros((1,), dtype=torch.int64, device=rows_idx.device)
+            cnt = torch.full((1,), self.local_arena.shape[0], dtype=torch.int64, device=rows_idx.device)
+            x, _, _, _ = hip.embed_gather_fwd(self.local_arena.detach(), zero, cnt, [rows_idx], [], self.embedding_dim,
+                                              False, False, False, self._err)
+            return x
+        return self.local_arena.detach()[rows_idx]
+
+    def _local_scatter_add(self, rows_idx, g):
+        p = self.local_arena
+        if p.is_cuda:
+            from . import hip
+            fresh = p.grad is None
+            if fresh:
+                if getattr(self, "_grad_buf", None) is None or self._grad_buf.shape != p.shape:
+                    self._grad_buf = torch.zeros_like(p)
+                elif self._touched is not None:
+                    hip.zero_rows(self._touched, self.embedding_dim, self._grad_buf)
+                else:
+                    self._grad_buf.zero_()
+                self._touched = None
+            if rows_idx.numel():
+                bits = max(1, int(p.shape[0] - 1).bit_length())
+                sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=bits)
+                hip.embed_grad_reduce(sk, sp, rows_idx.numel(), self.embedding_dim, g, None, None, None,
+                                      self._grad_buf, accumulate=not fresh)
+                self._touched = sk if self._touched is None else torch.cat([self._touched, sk])
+            if fresh:
+                p.grad = self._grad_buf
+        else:
+            upd = torch.zeros_like(p).index_add_(0, rows_idx, g)
+            p.grad = upd if p.grad is None else p.grad + upd
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 32):
+        keys = self._keys(X)
+        F, D = len(self.emb_feature), self.embedding_dim
+        b = keys.numel() // F
+        rows, order = _ShardedRows.apply(self, keys, self.local_arena)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        d = F * D + len(dense)
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        dense = [t.float().reshape(-1).contiguous() for t in dense]
+        out = _RowsToX.apply(rows, inv, dense, order, b, F, ldx, want_fm, self._err)
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return out if want_fm else (out, None)
+
+    def forward(self, X: Dict[str, torch.Tensor], name: Optional[str] = None) -> torch.Tensor:
+        if name is not None:
+            raise NotImplementedError("by-name lookups are not sharded (off the ranking hot path)")
+        F, D = len(self.emb_feature), self.embedding_dim
+        if self.local_arena.is_cuda:
+            x, _ = self.gather_concat(X, [], want_fm=False, pad_to=1)
+            return x.view(x.shape[0], F, D)
+        keys = self._keys(X)
+        rows, order = _ShardedRows.apply(self, keys, self.local_arena)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return rows[inv].view(F, -1, D).permute(1, 0, 2)
+
+    # ---- checkpoints in the reference layout ------------------------------------------------------------
+    def full_tables(self) -> Dict[str, torch.Tensor]:
+        """All-gather the shards and cut them back into the reference's per-table tensors
+        (`embedding_layer.<col>.weight`), e.g. for RankTrainer.save_all on rank 0."""
+        per = (self.total_rows + self.world - 1) // self.world
+        mine = torch.zeros((per, self.embedding_dim), dtype=self.local_arena.dtype, device=self.local_arena.device)
+        mine[:self.local_arena.shape[0]] = self.local_arena.detach()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine, group=self.group)
+        full = torch.stack(parts, dim=1).reshape(per * self.world, self.embedding_dim)[:self.total_rows]
+        out, off = {}, 0
+        for col, r in zip(self.emb_feature, self._row_count.tolist()):
+            out[col] = full[off:off + r].clone()
+            off += r
+        return out
+
+
+def shard_model_tables(model: nn.Module, world: int, rank: int, group=None) -> nn.Module:
+    """Replace every EmbeddingLayer of `model` by its row-sharded counterpart (in place).  Build the model
+    identically on every rank first (same seed): the shards are cut from that common initialisation."""
+    from .models.layers.embedding import EmbeddingLayer
+
+    def swap(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, EmbeddingLayer):
+                setattr(mod, name, ShardedEmbeddingLayer(child, world, rank, group))
+            else:
+                swap(child)
+    swap(model)
+    return model
+
+
+def dense_parameters(model: nn.Module):
+    sharded = {id(m.local_arena) for m in model.modules() if isinstance(m, ShardedEmbeddingLayer)}
+    return [p for p in model.parameters() if id(p) not in sharded]
+
+
+def allreduce_dense_grads(model: nn.Module, group=None):
+    """Average the replicated parameters' gradients over the ranks in one flat bucket."""
+    ps = [p for p in dense_parameters(model) if p.grad is not None]
+    if not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
