@@ -107,6 +107,35 @@ int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R
 int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
                 int64_t M, int N, rp_stream_t stream);
 
+/* ---- K5: DCN-v1 CrossNet, all L layers in one pass ------------------------------------------
+ * replaces layers/interaction.py:119-141 (CrossInteractionLayer/CrossNet) and, when wfc is given,
+ * the `fc` that follows it in ranking/dcn.py:64.
+ *   X_{l+1} = X_l + (X_l . W[l]) * X_0 + Bv[l];   W, Bv: [L, d] (the L Linear(d,1) weights / biases stacked)
+ *   xout [B, ldo] = X_L (NULL to skip);  logit[B] = X_L . wfc + bfc[0] (NULL to skip)
+ *   s_out [B, L] = the per-layer scalars X_l . W[l], all the backward needs besides X_0.
+ * backward: g_x [B, ldg] = dL/dX_L and/or g_logit [B] = dL/dlogit  ->  dx0 [B, lddx], dW [L,d], dB [L,d],
+ * dwfc [d] (per-block partial sums in `workspace`, reduced in fixed order).  d <= 2048, L <= 6.        */
+int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv, const float *wfc,
+                    const float *bfc, float *xout, int64_t ldo, float *logit, float *s_out, int64_t B,
+                    rp_stream_t stream);
+int rp_crossnet_bwd_workspace_bytes(int64_t B, int d, int L, size_t *bytes);
+int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv, const float *wfc,
+                    const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
+                    int64_t lddx, float *dW, float *dB, float *dwfc, int64_t B, void *workspace,
+                    size_t workspace_bytes, rp_stream_t stream);
+
+/* ---- K8: MMOE gate softmax + gate-weighted expert combine -----------------------------------
+ * replaces multi_task/mmoe.py:92-104.  The expert einsum (mmoe.py:86) and the T gate products (:94)
+ * are ONE rp_linear_fwd over the concatenated [experts | gates] matrix; its output z [B, ldz] has the
+ * expert outputs at columns k*E+e (k < K) and the gate logits at K*E + t*E + e.
+ *   gate [B, T*E] = per-task softmax over experts (kept for the backward)
+ *   out  [T, B, K] : out[t,b,k] = sum_e z[b,k*E+e] * gate[b,t,e]
+ * backward: dout [T,B,K] -> dz [B, lddz] (expert columns and gate-logit columns).  T, E <= 8, T*E <= 32. */
+int rp_mmoe_combine_fwd(const float *z, int64_t ldz, int K, int E, int T, float *out, float *gate, int64_t B,
+                        rp_stream_t stream);
+int rp_mmoe_combine_bwd(const float *z, int64_t ldz, int K, int E, int T, const float *gate, const float *dout,
+                        float *dz, int64_t lddz, int64_t B, rp_stream_t stream);
+
 /* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
  * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
  *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)

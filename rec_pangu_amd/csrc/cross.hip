@@ -1,0 +1,258 @@
+// DCN-v1 CrossNet, all layers in one pass per direction, gfx950.
+//   X_{l+1} = X_l + (X_l . w_l) * X_0 + b_l          (reference: layers/interaction.py:119-141)
+// HBM-bound: the forward reads each [d]-row of X_0 once and keeps it in registers through all L layers
+// (the reference re-reads and re-writes [B,d] about 5 times per layer); it writes X_L only if asked, and
+// can finish with the fc dot product (DCN's `fc(cross_out)`, dcn.py:64) so only a logit leaves the chip.
+// The backward recomputes X_l from X_0 and the saved per-layer scalars s_l = X_l . w_l (no [B,d]
+// activations are stored), writes dX_0 once and accumulates the parameter gradients per block in
+// registers; a second kernel sums the per-block partials in fixed order (deterministic).
+//
+// One 256-thread workgroup per row, element e of the row on thread e % 256 (coalesced 1-KiB segments);
+// a row of up to 256*CROSS_J floats lives in CROSS_J registers per thread.  Dot products are a wave
+// shuffle reduction + one LDS exchange between the 4 waves.
+#include "common.h"
+
+#define CROSS_J 8  // d <= 2048
+#define CROSS_MAXL 6
+
+__device__ __forceinline__ float block_allsum_256(float v, float *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // sh may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
+                                                           const float *__restrict__ W, const float *__restrict__ Bv,
+                                                           const float *__restrict__ wfc, const float *__restrict__ bfc,
+                                                           float *__restrict__ xout, int64_t ldo,
+                                                           float *__restrict__ logit, float *__restrict__ s_out,
+                                                           int64_t B) {
+    __shared__ float sh[4];
+    const int t = threadIdx.x;
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        float r0[CROSS_J], r[CROSS_J];
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            const int e = t + 256 * j;
+            r0[j] = (e < d) ? x0[b * ldx + e] : 0.f;
+            r[j] = r0[j];
+        }
+        for (int l = 0; l < L; ++l) {
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) {
+                const int e = t + 256 * j;
+                if (e < d) part += r[j] * W[(int64_t)l * d + e];
+            }
+            const float s = block_allsum_256(part, sh);
+            if (t == 0 && s_out != nullptr) s_out[b * L + l] = s;
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) {
+                const int e = t + 256 * j;
+                if (e < d) r[j] = r[j] + (s * r0[j] + Bv[(int64_t)l * d + e]);
+            }
+        }
+        if (xout != nullptr) {
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) {
+                const int e = t + 256 * j;
+                if (e < d) xout[b * ldo + e] = r[j];
+            }
+        }
+        if (logit != nullptr) {
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) {
+                const int e = t + 256 * j;
+                if (e < d) part += r[j] * wfc[e];
+            }
+            const float z = block_allsum_256(part, sh);
+            if (t == 0) logit[b] = z + (bfc != nullptr ? bfc[0] : 0.f);
+        }
+    }
+}
+
+// partial layout per block: [ dW (L*d) | dB (L*d) | dwfc (d) ]
+__global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
+                                                           const float *__restrict__ W, const float *__restrict__ Bv,
+                                                           const float *__restrict__ wfc,
+                                                           const float *__restrict__ s_in,
+                                                           const float *__restrict__ g_x, int64_t ldg,
+                                                           const float *__restrict__ g_logit,
+                                                           float *__restrict__ dx0, int64_t lddx,
+                                                           float *__restrict__ partial, int64_t B) {
+    __shared__ float sh[4];
+    const int t = threadIdx.x;
+    float aW[CROSS_MAXL][CROSS_J], aB[CROSS_MAXL][CROSS_J], aF[CROSS_J];
+#pragma unroll
+    for (int l = 0; l < CROSS_MAXL; ++l)
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            aW[l][j] = 0.f;
+            aB[l][j] = 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < CROSS_J; ++j) aF[j] = 0.f;
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        float r0[CROSS_J], g[CROSS_J], gx0[CROSS_J], xl[CROSS_J];
+        const float gl = (g_logit != nullptr) ? g_logit[b] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            const int e = t + 256 * j;
+            r0[j] = (e < d) ? x0[b * ldx + e] : 0.f;
+            gx0[j] = 0.f;
+        }
+        // X_L (for the fc weight gradient) and dL/dX_L
+        if (g_logit != nullptr) {
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) xl[j] = r0[j];
+            for (int l = 0; l < L; ++l) {
+                const float s = s_in[b * L + l];
+#pragma unroll
+                for (int j = 0; j < CROSS_J; ++j) {
+                    const int e = t + 256 * j;
+                    if (e < d) xl[j] = xl[j] + (s * r0[j] + Bv[(int64_t)l * d + e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            const int e = t + 256 * j;
+            float v = 0.f;
+            if (e < d) {
+                if (g_x != nullptr) v += g_x[b * ldg + e];
+                if (g_logit != nullptr) {
+                    v += gl * wfc[e];
+                    aF[j] += gl * xl[j];
+                }
+            }
+            g[j] = v;
+        }
+#pragma unroll
+        for (int l = CROSS_MAXL - 1; l >= 0; --l) {
+            if (l >= L) continue;
+            // recompute X_l from X_0 with the saved scalars
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) xl[j] = r0[j];
+            for (int k = 0; k < l; ++k) {
+                const float s = s_in[b * L + k];
+#pragma unroll
+                for (int j = 0; j < CROSS_J; ++j) {
+                    const int e = t + 256 * j;
+                    if (e < d) xl[j] = xl[j] + (s * r0[j] + Bv[(int64_t)k * d + e]);
+                }
+            }
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) part += g[j] * r0[j];
+            const float tl = block_allsum_256(part, sh);  // dL/ds_l
+            const float s = s_in[b * L + l];
+#pragma unroll
+            for (int j = 0; j < CROSS_J; ++j) {
+                const int e = t + 256 * j;
+                if (e < d) {
+                    aB[l][j] += g[j];
+                    aW[l][j] += tl * xl[j];
+                    gx0[j] += s * g[j];
+                    g[j] = g[j] + tl * W[(int64_t)l * d + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            const int e = t + 256 * j;
+            if (e < d && dx0 != nullptr) dx0[b * lddx + e] = gx0[j] + g[j];
+        }
+    }
+    float *P = partial + (int64_t)blockIdx.x * (2 * L + 1) * d;
+#pragma unroll
+    for (int l = 0; l < CROSS_MAXL; ++l) {
+        if (l >= L) continue;
+#pragma unroll
+        for (int j = 0; j < CROSS_J; ++j) {
+            const int e = t + 256 * j;
+            if (e < d) {
+                P[(int64_t)l * d + e] = aW[l][j];
+                P[(int64_t)(L + l) * d + e] = aB[l][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CROSS_J; ++j) {
+        const int e = t + 256 * j;
+        if (e < d) P[(int64_t)2 * L * d + e] = aF[j];
+    }
+}
+
+// out[e] = sum_k partial[k*stride + e], e < count (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblk, int64_t stride,
+                                                          int64_t count, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * stride + e];
+    out[e] = s;
+}
+
+static int cross_blocks(int64_t B) {
+    int64_t nb = B < 1024 ? B : 1024;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv,
+                               const float *wfc, const float *bfc, float *xout, int64_t ldo, float *logit,
+                               float *s_out, int64_t B, rp_stream_t stream) {
+    RP_REQUIRE(x0 && W && Bv && B >= 0 && ldx >= d, "crossnet_fwd: bad argument");
+    RP_REQUIRE(xout != nullptr || logit != nullptr, "crossnet_fwd: nothing to produce");
+    RP_REQUIRE(logit == nullptr || wfc != nullptr, "crossnet_fwd: logit needs wfc");
+    if (d < 1 || d > 256 * CROSS_J || L < 1 || L > CROSS_MAXL)
+        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) / L=%d (max %d) unsupported", d, 256 * CROSS_J, L,
+                       CROSS_MAXL);
+    if (B == 0) return RP_OK;
+    hipLaunchKernelGGL(crossnet_fwd_kernel, dim3(B < 65536 * 4 ? (unsigned)B : 65536u * 4), dim3(256), 0,
+                       (hipStream_t)stream, x0, ldx, d, L, W, Bv, wfc, bfc, xout, ldo, logit, s_out, B);
+    RP_LAUNCH_CHECK("crossnet_fwd");
+    return RP_OK;
+}
+
+extern "C" int rp_crossnet_bwd_workspace_bytes(int64_t B, int d, int L, size_t *bytes) {
+    RP_REQUIRE(bytes && d >= 1 && L >= 1, "crossnet_bwd_workspace_bytes: bad argument");
+    *bytes = (size_t)cross_blocks(B) * (2 * L + 1) * d * sizeof(float) + 256;
+    return RP_OK;
+}
+
+extern "C" int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv,
+                               const float *wfc, const float *s_in, const float *g_x, int64_t ldg,
+                               const float *g_logit, float *dx0, int64_t lddx, float *dW, float *dB, float *dwfc,
+                               int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(x0 && W && Bv && s_in && dW && dB && workspace && B >= 1, "crossnet_bwd: bad argument");
+    RP_REQUIRE(g_x != nullptr || g_logit != nullptr, "crossnet_bwd: no incoming gradient");
+    RP_REQUIRE(g_logit == nullptr || (wfc && dwfc), "crossnet_bwd: logit gradient needs wfc and dwfc");
+    if (d < 1 || d > 256 * CROSS_J || L < 1 || L > CROSS_MAXL)
+        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d / L=%d unsupported", d, L);
+    size_t need = 0;
+    rp_crossnet_bwd_workspace_bytes(B, d, L, &need);
+    RP_REQUIRE(workspace_bytes >= need, "crossnet_bwd: workspace %zu < %zu", workspace_bytes, need);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int nb = cross_blocks(B);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(crossnet_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in, g_x, ldg,
+                       g_logit, dx0, lddx, P, B);
+    RP_LAUNCH_CHECK("crossnet_bwd");
+    const int64_t n = (int64_t)(2 * L + 1) * d;
+    const int64_t ld = (int64_t)L * d;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv(ld, 256)), dim3(256), 0, s, P, nb, n, ld, dW);
+    RP_LAUNCH_CHECK("crossnet_bwd reduce dW");
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv(ld, 256)), dim3(256), 0, s, P + ld, nb, n, ld, dB);
+    RP_LAUNCH_CHECK("crossnet_bwd reduce dB");
+    if (g_logit != nullptr) {
+        hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv((int64_t)d, 256)), dim3(256), 0, s, P + 2 * ld, nb,
+                           n, (int64_t)d, dwfc);
+        RP_LAUNCH_CHECK("crossnet_bwd reduce dwfc");
+    }
+    return RP_OK;
+}

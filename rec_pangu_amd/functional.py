@@ -60,6 +60,102 @@ def linear_act(x, weight, bias=None, act: int = ACT_NONE):
 
 
 # ----------------------------------------------------------------------------------------------
+# K5  CrossNet (+ the fc that follows it in DCN)   — layers/interaction.py:119-141, ranking/dcn.py:64
+# ----------------------------------------------------------------------------------------------
+class _CrossNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, W, Bv, wfc, bfc):
+        x0 = _unit_inner(x0)
+        d = W.shape[1]
+        W, Bv = W.contiguous(), Bv.contiguous()
+        wfc_c = None if wfc is None else wfc.contiguous()
+        xout, logit, s = hip.crossnet_fwd(x0, d, W, Bv, wfc_c, bfc, want_x=wfc is None)
+        ctx.d, ctx.fused_fc = d, wfc is not None
+        ctx.save_for_backward(x0, W, Bv, wfc_c, s)
+        return logit if wfc is not None else xout
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, W, Bv, wfc, s = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.fused_fc:
+            dx0, dW, dB, dwfc = hip.crossnet_bwd(x0, ctx.d, W, Bv, wfc, s, None, g)
+            return dx0, dW, dB, dwfc.view_as(wfc), g.sum().reshape(1)
+        dx0, dW, dB, _ = hip.crossnet_bwd(x0, ctx.d, W, Bv, None, s, g, None)
+        return dx0, dW, dB, None, None
+
+
+def crossnet(x0, W, Bv, wfc=None, bfc=None):
+    """x0 [B, >=d] -> X_L [B, d], or the fc logit [B,1] when (wfc [1,d], bfc [1]) are given."""
+    return _CrossNet.apply(x0, W, Bv, wfc, bfc)
+
+
+# ----------------------------------------------------------------------------------------------
+# K8  MMOE: one GEMM over [experts | gates] stored input-major ([h, N], as the reference keeps them),
+#     then gate softmax + gate-weighted combine   — multi_task/mmoe.py:86-104
+# ----------------------------------------------------------------------------------------------
+class _LinearInputMajor(torch.autograd.Function):
+    """z = x[:, :h] @ Wm + bias with Wm [h, N] (einsum 'ij,jk->ik' layout)."""
+
+    @staticmethod
+    def forward(ctx, x, Wm, bias):
+        x = _unit_inner(x)
+        Wm = Wm.contiguous()
+        h = Wm.shape[0]
+        z = hip.linear_fwd(x, hip.transpose(Wm), bias, ACT_NONE, K=h)
+        ctx.h = h
+        ctx.save_for_backward(x, Wm)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, Wm = ctx.saved_tensors
+        dz = _unit_inner(dz)
+        h, N = Wm.shape
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if x.shape[1] > h:
+                dx[:, h:].zero_()
+            hip.linear_fwd(dz, Wm, None, ACT_NONE, out=dx[:, :h] if x.shape[1] > h else dx)  # dz @ Wm^T
+        if ctx.needs_input_grad[1]:
+            dW, _ = hip.linear_wgrad(x[:, :h], dz, N, want_bias=False)  # roles swapped: x^T @ dz -> [h, N]
+        if ctx.needs_input_grad[2]:
+            _, db = hip.linear_wgrad(dz, dz, 1)  # column sums of dz ride on the wgrad kernel (K=1)
+        return dx, dW, db
+
+
+def linear_input_major(x, Wm, bias):
+    return _LinearInputMajor.apply(x, Wm, bias)
+
+
+class _MMOECombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, K: int, E: int, T: int):
+        z = _unit_inner(z)
+        out, gate = hip.mmoe_combine_fwd(z, K, E, T)
+        ctx.cfg = (K, E, T)
+        ctx.save_for_backward(z, gate)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, gate = ctx.saved_tensors
+        K, E, T = ctx.cfg
+        dz = hip.mmoe_combine_bwd(z, K, E, T, gate, dout.contiguous())
+        if z.shape[1] != dz.shape[1]:
+            full = torch.zeros_like(z)
+            full[:, :dz.shape[1]] = dz
+            dz = full
+        return dz, None, None, None
+
+
+def mmoe_combine(z, K: int, E: int, T: int):
+    """z [B, K*E + T*E] (experts | gate logits) -> [T, B, K] gate-weighted expert mixtures."""
+    return _MMOECombine.apply(z, K, E, T)
+
+
+# ----------------------------------------------------------------------------------------------
 # K10  sum of logits -> sigmoid -> BCE(mean)   — ranking/deepfm.py:61-63, multi_task/mmoe.py:127
 # ----------------------------------------------------------------------------------------------
 class _SigmoidBCE(torch.autograd.Function):

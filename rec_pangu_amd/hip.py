@@ -34,6 +34,12 @@ _SIGNATURES = {
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
+    "rp_crossnet_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
+                                  _i64, _vp, _sz, _vp]),
+    "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
@@ -250,6 +256,65 @@ def relu_bwd(dy, act_out):
         _check(lib().rp_relu_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
                              out.data_ptr(), N, M, N, _stream()), "rp_relu_bwd")
     return out
+
+
+def crossnet_fwd(x0, d: int, W, Bv, wfc=None, bfc=None, want_x: bool = True):
+    """X_L (and/or logit = X_L . wfc + bfc) of the L-layer CrossNet; returns (xout, logit, s)."""
+    _req(x0, torch.float32, "x0")
+    B, L = x0.shape[0], W.shape[0]
+    dev = x0.device
+    xout = torch.empty((B, d), dtype=torch.float32, device=dev) if want_x else None
+    logit = torch.empty((B, 1), dtype=torch.float32, device=dev) if wfc is not None else None
+    s = torch.empty((B, L), dtype=torch.float32, device=dev)
+    with _Timed("crossnet_fwd"):
+        _check(lib().rp_crossnet_fwd(x0.data_ptr(), _rowmajor(x0, "x0"), d, L, W.data_ptr(), Bv.data_ptr(), _ptr(wfc),
+                                     _ptr(bfc), _ptr(xout), d, _ptr(logit), s.data_ptr(), B, _stream()),
+               "rp_crossnet_fwd")
+    return xout, logit, s
+
+
+def crossnet_bwd(x0, d: int, W, Bv, wfc, s, g_x, g_logit):
+    """-> dx0 [B, x0.shape[1]] (columns >= d zeroed), dW [L,d], dB [L,d], dwfc [d] or None."""
+    B, L = x0.shape[0], W.shape[0]
+    dev = x0.device
+    dx0 = torch.empty_like(x0)
+    if x0.shape[1] > d:
+        dx0[:, d:].zero_()
+    dW = torch.empty((L, d), dtype=torch.float32, device=dev)
+    dB = torch.empty((L, d), dtype=torch.float32, device=dev)
+    dwfc = torch.empty((d,), dtype=torch.float32, device=dev) if g_logit is not None else None
+    nbytes = _sz(0)
+    _check(lib().rp_crossnet_bwd_workspace_bytes(B, d, L, C.byref(nbytes)), "rp_crossnet_bwd_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    ldg = _rowmajor(g_x, "g_x") if g_x is not None else 0
+    with _Timed("crossnet_bwd"):
+        _check(lib().rp_crossnet_bwd(x0.data_ptr(), _rowmajor(x0, "x0"), d, L, W.data_ptr(), Bv.data_ptr(), _ptr(wfc),
+                                     s.data_ptr(), _ptr(g_x), ldg, _ptr(g_logit), dx0.data_ptr(),
+                                     _rowmajor(dx0, "dx0"), dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), B, ws.data_ptr(),
+                                     nbytes.value, _stream()), "rp_crossnet_bwd")
+    return dx0, dW, dB, dwfc
+
+
+def mmoe_combine_fwd(z, K: int, E: int, T: int):
+    """z [B, >=K*E+T*E] -> (out [T,B,K], gate [B,T*E])."""
+    _req(z, torch.float32, "z")
+    B = z.shape[0]
+    out = torch.empty((T, B, K), dtype=torch.float32, device=z.device)
+    gate = torch.empty((B, T * E), dtype=torch.float32, device=z.device)
+    with _Timed("mmoe_combine_fwd"):
+        _check(lib().rp_mmoe_combine_fwd(z.data_ptr(), _rowmajor(z, "z"), K, E, T, out.data_ptr(), gate.data_ptr(), B,
+                                         _stream()), "rp_mmoe_combine_fwd")
+    return out, gate
+
+
+def mmoe_combine_bwd(z, K: int, E: int, T: int, gate, dout):
+    """dout [T,B,K] -> dz [B, K*E+T*E]."""
+    B = z.shape[0]
+    dz = torch.empty((B, K * E + T * E), dtype=torch.float32, device=z.device)
+    with _Timed("mmoe_combine_bwd"):
+        _check(lib().rp_mmoe_combine_bwd(z.data_ptr(), _rowmajor(z, "z"), K, E, T, gate.data_ptr(), dout.data_ptr(),
+                                         dz.data_ptr(), K * E + T * E, B, _stream()), "rp_mmoe_combine_bwd")
+    return dz
 
 
 def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tensor], apply_sigmoid: bool = True,

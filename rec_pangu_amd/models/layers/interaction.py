@@ -61,11 +61,25 @@ class CrossNet(nn.Module):
         self.input_dim = input_dim
         self.cross_net = nn.ModuleList(CrossInteractionLayer(input_dim) for _ in range(num_layers))
 
-    def forward(self, X_0):
+    def stacked(self):
+        """([L,d] weights, [L,d] biases): the per-layer parameters stacked for the one-pass HIP kernel
+        (torch.stack keeps them on the autograd tape, so the gradients flow back to each layer)."""
+        W = torch.stack([layer.weight.weight.reshape(-1) for layer in self.cross_net])
+        Bv = torch.stack([layer.bias for layer in self.cross_net])
+        return W, Bv
+
+    def forward(self, X_0, fc: nn.Linear = None):
+        """X_L [B,d]; with `fc` (a Linear(d,1), as in DCN) the fused kernel returns fc(X_L) [B,1] instead."""
+        if X_0.is_cuda:
+            from ... import functional as Fh
+            W, Bv = self.stacked()
+            if fc is not None:
+                return Fh.crossnet(X_0, W, Bv, fc.weight, fc.bias)
+            return Fh.crossnet(X_0, W, Bv)
         X_i = X_0
         for layer in self.cross_net:
             X_i = X_i + layer(X_0, X_i)
-        return X_i
+        return X_i if fc is None else fc(X_i)
 
 
 class CompressedInteractionNet(nn.Module):

