@@ -124,6 +124,21 @@ int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, 
                     int64_t lddx, float *dW, float *dB, float *dwfc, int64_t B, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
 
+/* ---- K7: AutoInt field self-attention layer ----------------------------------------------------
+ * replaces layers/attention.py:63-101 (MultiHeadSelfAttention, align_to="output", no dropout/LayerNorm):
+ * QKV(+residual) projections, RAW-view head split (:73-75), scores [/scale], softmax, PV, +residual, ReLU.
+ *   x   [B, ldx]: T tokens of Din floats, contiguous per sample (x[b, t*Din + k])
+ *   W   [(3|4)*H*a, Din]: Wq, Wk, Wv (and Wres when has_res) stacked; without Wres Din must equal H*a
+ *   scale: attention_dim**0.5 when use_scale, 0 for none
+ *   out [B, T*H*a];   backward: gout [B, T*H*a] -> dx [B, lddx] (NULL to skip), dW like W.          */
+int rp_field_attention_fits(int T, int Din, int H, int a, int has_res); /* 1 if fwd+bwd fit the 160 KB LDS */
+int rp_field_attention_fwd(const float *x, int64_t ldx, const float *W, int T, int Din, int H, int a, int has_res,
+                           float scale, float *out, int64_t B, rp_stream_t stream);
+int rp_field_attention_bwd_workspace_bytes(int64_t B, int T, int Din, int H, int a, int has_res, size_t *bytes);
+int rp_field_attention_bwd(const float *x, int64_t ldx, const float *W, int T, int Din, int H, int a, int has_res,
+                           float scale, const float *gout, float *dx, int64_t lddx, float *dW, int64_t B,
+                           void *workspace, size_t workspace_bytes, rp_stream_t stream);
+
 /* ---- K8: MMOE gate softmax + gate-weighted expert combine -----------------------------------
  * replaces multi_task/mmoe.py:92-104.  The expert einsum (mmoe.py:86) and the T gate products (:94)
  * are ONE rp_linear_fwd over the concatenated [experts | gates] matrix; its output z [B, ldz] has the

@@ -91,6 +91,33 @@ def crossnet(x0, W, Bv, wfc=None, bfc=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# K7  AutoInt field self-attention layer   — layers/attention.py:63-101
+# ----------------------------------------------------------------------------------------------
+class _FieldAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float):
+        x = _unit_inner(x)
+        W = W.contiguous()
+        out = hip.field_attention_fwd(x, W, T, Din, H, a, has_res, scale)
+        ctx.cfg = (T, Din, H, a, has_res, scale)
+        ctx.save_for_backward(x, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, W = ctx.saved_tensors
+        T, Din, H, a, has_res, scale = ctx.cfg
+        dx, dW = hip.field_attention_bwd(x, W, T, Din, H, a, has_res, scale, gout.contiguous(),
+                                         ctx.needs_input_grad[0])
+        return dx, dW, None, None, None, None, None, None
+
+
+def field_attention(x, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float = 0.0):
+    """x [B, >=T*Din] -> relu(attention + residual) [B, T, H*a];  W = cat(Wq, Wk, Wv[, Wres]) [(3|4)*H*a, Din]."""
+    return _FieldAttention.apply(x, W, T, Din, H, a, has_res, scale)
+
+
+# ----------------------------------------------------------------------------------------------
 # K8  MMOE: one GEMM over [experts | gates] stored input-major ([h, N], as the reference keeps them),
 #     then gate softmax + gate-weighted combine   — multi_task/mmoe.py:86-104
 # ----------------------------------------------------------------------------------------------

@@ -38,6 +38,11 @@ _SIGNATURES = {
     "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_crossnet_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
                                   _i64, _vp, _sz, _vp]),
+    "rp_field_attention_fits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "rp_field_attention_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp]),
+    "rp_field_attention_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)]),
+    "rp_field_attention_bwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp, _i64,
+                                         _vp, _sz, _vp]),
     "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
@@ -293,6 +298,42 @@ def crossnet_bwd(x0, d: int, W, Bv, wfc, s, g_x, g_logit):
                                      _rowmajor(dx0, "dx0"), dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), B, ws.data_ptr(),
                                      nbytes.value, _stream()), "rp_crossnet_bwd")
     return dx0, dW, dB, dwfc
+
+
+def field_attention_fits(T: int, Din: int, H: int, a: int, has_res: bool) -> bool:
+    return bool(lib().rp_field_attention_fits(T, Din, H, a, int(has_res)))
+
+
+def field_attention_fwd(x, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float):
+    """x [B, >=T*Din] (tokens contiguous per sample) -> out [B, T, H*a]."""
+    _req(x, torch.float32, "x")
+    _req(W, torch.float32, "W")
+    B = x.shape[0]
+    out = torch.empty((B, T, H * a), dtype=torch.float32, device=x.device)
+    with _Timed("field_attention_fwd"):
+        _check(lib().rp_field_attention_fwd(x.data_ptr(), _rowmajor(x, "x"), W.data_ptr(), T, Din, H, a, int(has_res),
+                                            scale, out.data_ptr(), B, _stream()), "rp_field_attention_fwd")
+    return out
+
+
+def field_attention_bwd(x, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float, gout, want_dx: bool):
+    B = x.shape[0]
+    dx = None
+    if want_dx:
+        dx = torch.empty_like(x)
+        if x.shape[1] > T * Din:
+            dx[:, T * Din:].zero_()
+    dW = torch.empty_like(W)
+    nbytes = _sz(0)
+    _check(lib().rp_field_attention_bwd_workspace_bytes(B, T, Din, H, a, int(has_res), C.byref(nbytes)),
+           "rp_field_attention_bwd_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x.device)
+    with _Timed("field_attention_bwd"):
+        _check(lib().rp_field_attention_bwd(x.data_ptr(), _rowmajor(x, "x"), W.data_ptr(), T, Din, H, a, int(has_res),
+                                            scale, gout.data_ptr(), _ptr(dx), _rowmajor(dx, "dx") if want_dx else 0,
+                                            dW.data_ptr(), B, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_field_attention_bwd")
+    return dx, dW
 
 
 def mmoe_combine_fwd(z, K: int, E: int, T: int):

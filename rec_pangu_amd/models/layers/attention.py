@@ -1,12 +1,21 @@
 """Field self-attention of AutoInt — drop-in for rec_pangu/models/layers/attention.py:12-101.
 
-Quirks of the reference that are kept on purpose: heads are split by a RAW
-.view(B*H, -1, a) of the [B,T,H*a] projections (:73-75), there is no 1/sqrt(d) scale unless
-use_scale, the residual uses W_res only when input_dim != H*a, and ReLU is always applied (:94).
+Same classes, constructor arguments, sub-module names (W_q, W_k, W_v, W_res, dot_product_attention,
+layer_norm, dropout -> same state_dict keys) and the reference's quirks, kept on purpose:
+heads are split by a RAW .view(B*H, -1, a) of the [B,T,H*a] projections (attention.py:73-75), there is no
+1/sqrt(d) scale unless use_scale, the residual goes through W_res only when input_dim != H*a, and ReLU is
+always applied last (:94).
+
+On a HIP device the AutoInt configuration (self-attention, align_to="output", no mask / dropout / LayerNorm,
+residual on) runs as ONE launch per layer (rp_field_attention_fwd): projections, raw-view head split, scores,
+softmax, PV, residual and ReLU for a sample all stay in LDS.  Any other configuration of the general
+MultiHeadAttention module is composed from device ops as written in `_compose`.
 """
 import numpy as np
 import torch
 from torch import nn
+
+from ... import functional as Fh
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -31,14 +40,13 @@ class MultiHeadAttention(nn.Module):
     def __init__(self, input_dim, attention_dim=None, num_heads=1, dropout_rate=0., use_residual=True,
                  use_scale=False, layer_norm=False, align_to="input"):
         super(MultiHeadAttention, self).__init__()
-        if attention_dim is None:
-            attention_dim = input_dim // num_heads
-        self.attention_dim = attention_dim
-        self.output_dim = num_heads * attention_dim
+        self.input_dim = input_dim
+        self.attention_dim = input_dim // num_heads if attention_dim is None else attention_dim
         self.num_heads = num_heads
+        self.output_dim = num_heads * self.attention_dim
         self.use_residual = use_residual
         self.align_to = align_to
-        self.scale = attention_dim ** 0.5 if use_scale else None
+        self.scale = self.attention_dim ** 0.5 if use_scale else None
         self.W_q = nn.Linear(input_dim, self.output_dim, bias=False)
         self.W_k = nn.Linear(input_dim, self.output_dim, bias=False)
         self.W_v = nn.Linear(input_dim, self.output_dim, bias=False)
@@ -52,14 +60,40 @@ class MultiHeadAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(self.output_dim) if layer_norm else None
         self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0 else None
 
-    def forward(self, query, key, value, mask=None):
+    # -- which calls the one-launch HIP layer covers
+    def _fused_ok(self, query, key, value, mask) -> bool:
+        return (query.is_cuda and key is query and value is query and mask is None and self.use_residual
+                and self.layer_norm is None and (self.dropout is None or not self.training)
+                and (self.dot_product_attention.dropout is None or not self.training)
+                and (self.W_res is None or self.align_to == "output") and query.dim() == 3
+                and self._fits_lds(query.shape[1]))
+
+    def _fits_lds(self, T) -> bool:
+        """The one-launch layer keeps a sample's Q/K/V/P and the stacked weights in the CU's 160 KB LDS; very
+        wide configurations (H*a*Din of the order of 64x64 and up) do not fit and are composed from device ops."""
+        from ... import hip
+        key = (T, self.input_dim, self.num_heads, self.attention_dim, self.W_res is not None)
+        if getattr(self, "_fit_key", None) != key:
+            self._fit_key, self._fit = key, hip.field_attention_fits(*key)
+        return self._fit
+
+    def _fused(self, X):
+        B, T, Din = X.shape
+        ws = [self.W_q.weight, self.W_k.weight, self.W_v.weight]
+        if self.W_res is not None:
+            ws.append(self.W_res.weight)
+        out = Fh.field_attention(X.reshape(B, T * Din), torch.cat(ws, dim=0), T, Din, self.num_heads,
+                                 self.attention_dim, self.W_res is not None, float(self.scale or 0.0))
+        return out  # [B, T, H*a]
+
+    def _compose(self, query, key, value, mask):
         residual = query
-        B = query.size(0)
-        q = self.W_q(query).view(B * self.num_heads, -1, self.attention_dim)
-        k = self.W_k(key).view(B * self.num_heads, -1, self.attention_dim)
-        v = self.W_v(value).view(B * self.num_heads, -1, self.attention_dim)
+        B, H, a = query.size(0), self.num_heads, self.attention_dim
+        q = self.W_q(query).view(B * H, -1, a)  # raw view, not a per-head transpose
+        k = self.W_k(key).view(B * H, -1, a)
+        v = self.W_v(value).view(B * H, -1, a)
         if mask:
-            mask = mask.repeat(self.num_heads, 1, 1)
+            mask = mask.repeat(H, 1, 1)
         output, attention = self.dot_product_attention(q, k, v, self.scale, mask)
         output = output.view(B, -1, self.output_dim)
         if self.W_res is not None:
@@ -74,6 +108,11 @@ class MultiHeadAttention(nn.Module):
         if self.layer_norm is not None:
             output = self.layer_norm(output)
         return output.relu(), attention
+
+    def forward(self, query, key, value, mask=None):
+        if self._fused_ok(query, key, value, mask):
+            return self._fused(query), None  # attention weights are not materialised by the fused layer
+        return self._compose(query, key, value, mask)
 
 
 class MultiHeadSelfAttention(MultiHeadAttention):

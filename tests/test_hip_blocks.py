@@ -68,6 +68,67 @@ def test_crossnet_fused_fc_vs_oracle(B, d, ld, L):
     _close(xl_dev.cpu(), xl.detach(), what="X_L")
 
 
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("tag,din,heads,adim", [("a", 8, 2, 4), ("b", 8, 2, 3), ("c", 8, 1, 8), ("d", 6, 3, 5)])
+def test_field_attention_vs_reference_fixture(tag, din, heads, adim):
+    """MultiHeadSelfAttention (raw-view head split, no scale, W_res only when Din != H*a, ReLU) forward and
+    all gradients against what the reference produced (tests/golden/layers.npz attn_*)."""
+    from rec_pangu_amd.models.layers import MultiHeadSelfAttention
+    c = load_golden("layers.npz")[f"attn_{tag}"]
+    att = MultiHeadSelfAttention(din, attention_dim=adim, num_heads=heads, align_to="output")
+    att.load_state_dict({k[2:]: v for k, v in c.items() if k.startswith("w/")})
+    att = att.to(DEV)
+    x = c["in"].to(DEV).requires_grad_(True)
+    y = att(x)
+    _close(y.detach().cpu(), c["out"], what="attention out")
+    (y * y).sum().backward()
+    _close(x.grad.cpu(), c["grad_in"], rel=2e-4, what="attention dX")
+    for k, p in att.named_parameters():
+        _close(p.grad.cpu(), c["gw/" + k], rel=2e-4, what=f"attention d{k}")
+
+
+def test_field_attention_oversize_config_is_composed_not_crashed():
+    """H*a = 64 at Din = 64 needs > 160 KB of LDS in the backward: the layer reports it and the module composes
+    the same arithmetic from device ops instead (still on the GPU, still correct)."""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.layers import MultiHeadSelfAttention
+    assert hip.field_attention_fits(26, 64, 1, 8, True) and hip.field_attention_fits(26, 64, 2, 16, True)
+    assert not hip.field_attention_fits(26, 64, 2, 32, False)
+    g = torch.Generator().manual_seed(0)
+    att = MultiHeadSelfAttention(64, attention_dim=32, num_heads=2, align_to="output")
+    x = torch.randn(50, 26, 64, generator=g)
+    ref = R.mhsa(x, att.W_q.weight, att.W_k.weight, att.W_v.weight, None, 2, 32)
+    n0 = hip.launch_count()
+    out = att.to(DEV)(x.to(DEV))
+    assert hip.launch_count() == n0
+    _close(out.detach().cpu(), ref.detach(), what="composed attention")
+
+
+@pytest.mark.parametrize("B,T,din,heads,adim,scale", [(1000, 26, 64, 1, 8, False), (513, 26, 64, 2, 16, True),
+                                                       (300, 16, 40, 4, 10, False), (70, 39, 16, 4, 8, False)])
+def test_field_attention_vs_oracle(B, T, din, heads, adim, scale):
+    from rec_pangu_amd import functional as Fh
+    g = torch.Generator().manual_seed(B + T)
+    ld = T * din + 13
+    x = torch.randn(B, ld, generator=g)
+    HA = heads * adim
+    has_res = din != HA
+    ws = [torch.randn(HA, din, generator=g) / din ** 0.5 for _ in range(4 if has_res else 3)]
+    coef = torch.randn(B, T, HA, generator=g)
+    rx = x[:, :T * din].reshape(B, T, din).clone().requires_grad_(True)
+    rw = [w.clone().requires_grad_(True) for w in ws]
+    ref = R.mhsa(rx, rw[0], rw[1], rw[2], rw[3] if has_res else None, heads, adim, use_scale=scale)
+    (ref * coef).sum().backward()
+    dx = x.to(DEV).requires_grad_(True)
+    dw = torch.cat(ws).to(DEV).requires_grad_(True)
+    out = Fh.field_attention(dx, dw, T, din, heads, adim, has_res, adim ** 0.5 if scale else 0.0)
+    _close(out.detach().cpu(), ref.detach(), what="out")
+    (out * coef.to(DEV)).sum().backward()
+    _close(dx.grad[:, :T * din].cpu().reshape(B, T, din), rx.grad, rel=2e-4, what="dX")
+    assert torch.count_nonzero(dx.grad[:, T * din:]) == 0
+    _close(dw.grad.cpu(), torch.cat([w.grad for w in rw]), rel=3e-4, what="dW")
+
+
 # ------------------------------------------------------------------------------------------------ MMOE
 @pytest.mark.parametrize("B,h,ld,K,E,T", [(24, 43, 64, 16, 3, 2), (2048, 649, 672, 128, 4, 2), (333, 100, 100, 20, 8, 4),
                                            (100, 30, 32, 300, 2, 1)])
