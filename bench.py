@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--optimizer", default="lazy", choices=["lazy", "dense"],
+                    help="how the reference's dense Adam is executed on the embedding arena: 'lazy' = exact lazy "
+                         "replay (bit-identical results, flushed inside the timed region), 'dense' = stream every row")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +124,7 @@ def main():
         model = shard_model_tables(model, world, rank)
     model.embedding_layer.check_indices = "deferred"  # no per-step host sync; checked once after the run
     model.train()
-    opt = make_adam(model, 1e-3)
+    opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"))
     n_params = sum(p.numel() for p in model.parameters())
     n_table_rows = model.embedding_layer.arena.shape[0]
 
@@ -155,6 +158,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if args.mode == "train" and hasattr(opt, "flush"):
+        opt.flush()  # lazy Adam: every row is brought to step K INSIDE the timed region (dense-equivalent state)
     barrier()
     dt = time.perf_counter() - t0
     timing = hip.timing_summary()
@@ -169,7 +174,17 @@ def main():
 
     # ---- per-kernel numbers (algorithmic bytes from SURVEY.md §8d) --------------------------------
     F, D, ND = 26, 64, 13
+    keys0 = torch.cat([batches[0][f"C{i + 1}"] + 0 for i in range(F)])  # unique (field, id) pairs of one batch
+    n_unique = int(sum(torch.unique(batches[0][f"C{i + 1}"]).numel() for i in range(F)))
+    n_pairs = F * local_B
+    row_b = D * 4
     alg_bytes = {
+        # dX row + sum_f v row per pair, table row read + gradient row written per unique row
+        "embed_grad_reduce": (2 * n_pairs + 2 * n_unique) * row_b,
+        # p,m,v read+written, g read + cleared, per unique touched row
+        "lazy_adam_rows_step": 8 * n_unique * row_b,
+        # p,m,v read+written per unique row that skipped at least one step (upper bound: all of them)
+        "lazy_adam_rows_replay": 6 * n_unique * row_b,
         # table rows read + int64 ids read + [B, F*D+ND] fp32 output written
         "embed_gather_fwd": local_B * (F * (D * 4 + 8) + (F * D + ND) * 4),
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
@@ -206,7 +221,11 @@ def main():
             "config": {"workload": f"DeepFM, 26 sparse fields (Criteo-Kaggle cardinalities/{args.vocab_scale}, "
                                    f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D=64 + 13 dense, "
                                    f"MLP [64,64,64], global batch {B}, uniform ids",
-                       "global_batch": B, "optimizer": "dense Adam (reference semantics, fused zero_grad)",
+                       "global_batch": B,
+                       "optimizer": ("dense Adam, reference semantics, executed lazily (bit-identical; all rows flushed "
+                                     "to the last step inside the timed region)" if args.optimizer == "lazy"
+                                     else "dense Adam (reference semantics, every row streamed each step, fused zero_grad)"),
+                       "unique_rows_per_batch": n_unique,
                        "parallelism": "single GPU" if world == 1 else f"tables row-sharded x{world}, all-to-all lookup"},
             "roofline": roofline, "roofline_gather": gather, "kernels": kernels,
         }

@@ -171,6 +171,26 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
                  const int64_t *sizes, int n_tensors, float lr, float beta1, float beta2, float eps,
                  int64_t step, int zero_grad, rp_stream_t stream);
 
+/* ---- exact LAZY dense Adam for arena rows -----------------------------------------------------
+ * Same semantics as rp_adam_step over the whole arena (trainer.py:75: DENSE Adam, every row every step), but a
+ * row's zero-gradient steps are replayed in registers when the row is next needed instead of being streamed
+ * through HBM every step.  last[row] (int32, 0 = never updated) is the step the stored (p,m,v) are current at;
+ * step_scalars is a device float2 table indexed by step: {lr_t/(1-b1^t), sqrt(1-b2^t)} from
+ * rp_adam_step_scalars.  The replay runs the dense kernel's update function with g = 0: bit-identical results.
+ *   rp_embed_keys       arena-row keys of a batch (same check/flag/clamp as the gather) — needed before the gather
+ *   rp_lazy_adam_rows   for every UNIQUE row of `sorted_keys` (sorted; duplicates skipped): replay steps
+ *                       last+1 .. t_target(-1); if real_step also apply step t_target with g = grad row
+ *                       (and clear it if zero_grad); last[row] = t_target
+ *   rp_lazy_adam_flush  replay every row up to t_target (before a checkpoint / state_dict / eval of raw tables) */
+int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
+                  int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
+int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size, float *bc2_sqrt);
+int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
+                      int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
+                      float beta1, float beta2, float eps, rp_stream_t stream);
+int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last, const float *step_scalars,
+                       int64_t t_target, float beta1, float beta2, float eps, rp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,37 @@ extern "C" int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_a
     RP_LAUNCH_CHECK("zero_rows");
     return RP_OK;
 }
+
+// keys_out[f*B + b] = row_base[f] + id_f[b] (int32 arena rows), with the same range check / flag / clamp as the
+// gather.  Used when the rows must be known BEFORE the gather (lazy Adam replays the rows a batch is about to read).
+__global__ __launch_bounds__(256) void embed_keys_kernel(const int64_t *__restrict__ row_base,
+                                                         const int64_t *__restrict__ row_count, IdxPtrs idx, int F,
+                                                         int64_t B, int32_t *__restrict__ keys_out,
+                                                         int32_t *__restrict__ err_flag) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (b >= B || f >= F) return;
+    int64_t id = idx.p[f][b];
+    if (id < 0 || id >= row_count[f]) {
+        *err_flag = 1;
+        id = 0;
+    }
+    keys_out[(int64_t)f * B + b] = (int32_t)(row_base[f] + id);
+}
+
+extern "C" int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F,
+                             int64_t B, int32_t *keys_out, int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(row_base && row_count && idx_ptrs && keys_out && err_flag, "embed_keys: null pointer");
+    RP_REQUIRE(F >= 1 && F <= RP_MAX_FIELDS && B >= 0, "embed_keys: bad F/B");
+    RP_REQUIRE((int64_t)F * B < (int64_t)INT32_MAX, "embed_keys: F*B overflows int32 positions");
+    if (B == 0) return RP_OK;
+    IdxPtrs ip;
+    for (int f = 0; f < F; ++f) {
+        RP_REQUIRE(idx_ptrs[f], "embed_keys: idx_ptrs[%d] is null", f);
+        ip.p[f] = idx_ptrs[f];
+    }
+    hipLaunchKernelGGL(embed_keys_kernel, dim3((unsigned)rp_cdiv(B, 256), (unsigned)F), dim3(256), 0,
+                       (hipStream_t)stream, row_base, row_count, ip, F, B, keys_out, err_flag);
+    RP_LAUNCH_CHECK("embed_keys");
+    return RP_OK;
+}

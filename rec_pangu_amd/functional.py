@@ -243,9 +243,15 @@ class _EmbedGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, store, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, want_fm: bool, *tables):
         need_grad = any(ctx.needs_input_grad[5:])
+        pre = store._presorted  # set by the lazy-Adam replay: keys already computed and sorted for this batch
+        store._presorted = None
         x, fm, ssum, keys = hip.embed_gather_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx,
-                                                 want_fm, want_fm and need_grad, need_grad, store.err_flag)
+                                                 want_fm, want_fm and need_grad, need_grad and pre is None,
+                                                 store.err_flag)
         ctx.store, ctx.want_fm, ctx.B = store, want_fm, idx[0].shape[0]
+        ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
+        if pre is not None:
+            keys = pre[0] if need_grad else None
         ctx.save_for_backward(keys, ssum)
         if want_fm:
             return x, fm
@@ -258,7 +264,7 @@ class _EmbedGather(torch.autograd.Function):
         if dx is not None:
             dx = _unit_inner(dx)
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
-        store.accumulate_grad(keys, ctx.B, dx, gfm, ssum)
+        store.accumulate_grad(keys, ctx.B, dx, gfm, ssum, presorted=ctx.presorted)
         return (None,) * (5 + len(store.emb_feature))
 
 

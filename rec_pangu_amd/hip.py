@@ -49,6 +49,11 @@ _SIGNATURES = {
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
     "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
+    "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
+                                    _vp]),
+    "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -404,3 +409,35 @@ def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad
         with _Timed("adam_step"):
             _check(lib().rp_adam_step(_ptr_array(ps), _ptr_array(gs), _ptr_array(mm), _ptr_array(vv), sizes, len(ps), lr,
                                   beta1, beta2, eps, step, int(zero_grad), _stream()), "rp_adam_step")
+
+
+# ---- exact lazy dense Adam (arena rows) ---------------------------------------------------------------
+def embed_keys(row_base, row_count, idx: List[torch.Tensor], err_flag):
+    F, B = len(idx), idx[0].shape[0]
+    keys = torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
+    with _Timed("embed_keys"):
+        _check(lib().rp_embed_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, keys.data_ptr(),
+                                   err_flag.data_ptr(), _stream()), "rp_embed_keys")
+    return keys
+
+
+def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int):
+    a, b = C.c_float(0), C.c_float(0)
+    _check(lib().rp_adam_step_scalars(lr, beta1, beta2, step, C.byref(a), C.byref(b)), "rp_adam_step_scalars")
+    return a.value, b.value
+
+
+def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int, real_step: bool, zero_grad: bool,
+                   beta1: float, beta2: float, eps: float):
+    with _Timed("lazy_adam_rows_step" if real_step else "lazy_adam_rows_replay"):
+        _check(lib().rp_lazy_adam_rows(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
+                                       m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_target,
+                                       int(real_step), int(zero_grad), beta1, beta2, eps, _stream()),
+               "rp_lazy_adam_rows")
+
+
+def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, beta1: float, beta2: float, eps: float):
+    with _Timed("lazy_adam_flush"):
+        _check(lib().rp_lazy_adam_flush(rows, D, p.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(),
+                                        scalars.data_ptr(), t_target, beta1, beta2, eps, _stream()),
+               "rp_lazy_adam_flush")

@@ -52,7 +52,10 @@ class EmbeddingLayer(nn.Module):
         self._touched: Optional[torch.Tensor] = None  # sorted keys written by the last backward
         self._grad_clean = True  # gradient arena known to be all zero
         self._dev_meta = None
+        self._lazy = None        # optim.LazyAdamRows when the optimiser runs the exact lazy dense Adam
+        self._presorted = None   # (keys, sorted keys, sorted positions) of the batch being looked up
         self._tag_tables()
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 
     # ------------------------------------------------------------------ arena bookkeeping
     def _tables(self):
@@ -79,7 +82,10 @@ class EmbeddingLayer(nn.Module):
     def _apply(self, fn, recurse=True):
         # one move for the whole arena instead of one per table (module.to / .cuda / .float ...)
         self._ensure_packed()
+        self.flush_lazy()
         self._point_at(fn(self._arena))
+        if self._lazy is not None:
+            self._lazy.apply(fn)
         if self._grad_arena is not None:
             self._grad_arena = fn(self._grad_arena)
             self._attach_grads()
@@ -166,7 +172,13 @@ class EmbeddingLayer(nn.Module):
             off += p.shape[0]
         return True
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum):
+    def flush_lazy(self):
+        """Bring every row to the optimiser's current step (no-op unless the lazy Adam is active).  Called before
+        anything reads the raw tables: state_dict(), .to(), checkpoints."""
+        if self._lazy is not None:
+            self._lazy.flush(self)
+
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -185,10 +197,16 @@ class EmbeddingLayer(nn.Module):
             else:
                 self._grad_arena.zero_()
             self._touched, self._grad_clean = None, True
-        sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        if presorted is not None:
+            sk, sp = presorted
+        else:
+            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
         hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
                               accumulate=not self._grad_clean)
-        self._touched = sk if self._touched is None else torch.cat([self._touched, sk])
+        if self._touched is None:
+            self._touched, self._touched_unsorted = sk, False
+        else:  # several backward passes before one optimiser step: the union is no longer sorted
+            self._touched, self._touched_unsorted = torch.cat([self._touched, sk]), True
         self._grad_clean = False
         if fresh:
             self._attach_grads()
@@ -210,7 +228,17 @@ class EmbeddingLayer(nn.Module):
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
-        out = Fh.embed_gather(self, self._idx_list(X), dense, ldx, want_fm)
+        idx = self._idx_list(X)
+        self._presorted = None
+        if self._lazy is not None and self._lazy.t > 0:
+            # exact lazy dense Adam: the rows this batch reads must first replay the zero-gradient steps they
+            # skipped.  The (row, position) sort the backward needs anyway is done here and reused there.
+            from ... import hip
+            keys = hip.embed_keys(self.row_base, self.row_count, idx, self.err_flag)
+            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            self._lazy.replay(self, sk)
+            self._presorted = (keys, sk, sp)
+        out = Fh.embed_gather(self, idx, dense, ldx, want_fm)
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)

@@ -1,13 +1,21 @@
 """FusedAdam — the optimiser RankTrainer.fit builds (reference: rec_pangu/trainer.py:75,
 torch.optim.Adam(lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)), as fused HIP launches.
 
-Semantics are the reference's: DENSE Adam over every parameter, embedding tables included — rows
-nobody looked up still decay their moments and move.  Arena-backed embedding tables
-(rec_pangu_amd.models.layers.EmbeddingLayer) are updated as ONE flat tensor per layer
-(p/g/m/v arenas), all other parameters in one multi-tensor launch.  `fuse_zero_grad=True` clears
-the gradients inside the same pass (the model.zero_grad() that follows optimizer.step() in the
-reference loop, model_pipeline.py:57-58) so the 8.6 GB gradient arena is not streamed twice.
-CPU parameters are not handled here: build torch.optim.Adam for a CPU model (make_adam does).
+Semantics are the reference's: DENSE Adam over every parameter, embedding tables included — rows nobody
+looked up still decay their moments and move.  Two ways to execute exactly that for the
+arena-backed embedding tables (rec_pangu_amd.models.layers.EmbeddingLayer):
+
+  lazy_tables=False  one flat dense launch over the p/g/m/v arenas per step (69 GB of HBM traffic per step at
+                     Criteo shape — the optimiser then is 80 % of the train step);
+  lazy_tables=True   exact lazy dense Adam (LazyAdamRows): a row's zero-gradient steps are replayed in
+                     registers, with the dense kernel's own update function, when the row is next looked up or
+                     flushed.  Bit-identical parameters and moments (tests/test_hip_lazy_adam.py), ~1/10 of
+                     the traffic.  Anything that reads the raw tables (state_dict, .to, checkpoints) flushes
+                     first; direct reads of `embedding.weight` need `optimizer.flush()`.
+
+All other parameters go through one multi-tensor dense launch.  `fuse_zero_grad=True` clears gradients inside
+the same pass (the model.zero_grad() that follows optimizer.step() in the reference loop,
+model_pipeline.py:57-58).  CPU parameters are not handled here: make_adam builds torch.optim.Adam for those.
 """
 from typing import Dict, List
 
@@ -16,18 +24,92 @@ import torch
 from . import hip
 
 
+class LazyAdamRows:
+    """Per-EmbeddingLayer state of the exact lazy dense Adam: moment arenas, per-row `last` step stamps and the
+    device table of per-step scalars {lr_t/(1-b1^t), sqrt(1-b2^t)} (computed by the C library, like the dense
+    kernel does)."""
+    TABLE_CHUNK = 1024
+
+    def __init__(self, store, betas, eps):
+        a = store.arena
+        self.m, self.v = torch.zeros_like(a), torch.zeros_like(a)
+        self.last = torch.zeros((a.shape[0],), dtype=torch.int32, device=a.device)
+        self.betas, self.eps = betas, eps
+        self.t = 0
+        self.flushed_t = 0
+        self._table = torch.zeros((1, 2), dtype=torch.float32, device=a.device)
+        self._table_lr = None
+        self._table_from = 1
+
+    def apply(self, fn):
+        self.m, self.v, self.last, self._table = fn(self.m), fn(self.v), fn(self.last), fn(self._table)
+
+    def _ensure_table(self, t_new, lr):
+        """rows [.., t_new] of the scalar table must exist and row t_new must have been built with `lr`."""
+        cap = self._table.shape[0] - 1
+        if t_new <= cap and (self._table_lr == lr or t_new < self._table_from):
+            return
+        hi = t_new + self.TABLE_CHUNK
+        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s) for s in range(t_new, hi + 1)]
+        new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
+        self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
+        self._table_lr, self._table_from = lr, t_new
+
+    def _sorted_touched(self, store):
+        sk = store._touched
+        if sk is None:
+            return None
+        if getattr(store, "_touched_unsorted", False):
+            sk, _ = hip.sort_pairs(sk, end_bit=store._meta()[3])
+        return sk
+
+    def replay(self, store, sorted_keys):
+        if self.t > 0:
+            hip.lazy_adam_rows(sorted_keys, store.embedding_dim, store.arena, None, self.m, self.v, self.last,
+                               self._table, self.t, False, False, self.betas[0], self.betas[1], self.eps)
+
+    def step(self, store, lr):
+        t_new = self.t + 1
+        self._ensure_table(t_new, lr)
+        sk = self._sorted_touched(store)
+        if sk is not None and sk.numel():
+            hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
+                               self._table, t_new, True, True, self.betas[0], self.betas[1], self.eps)
+        self.t = t_new
+        store.grads_were_zeroed()
+
+    def flush(self, store):
+        if self.flushed_t == self.t:
+            return
+        hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
+                            self._table, self.t, self.betas[0], self.betas[1], self.eps)
+        self.flushed_t = self.t
+
+
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, fuse_zero_grad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, fuse_zero_grad=False,
+                 lazy_tables=False):
         if weight_decay != 0:
             raise ValueError("FusedAdam mirrors the reference's optimiser: weight_decay must be 0")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0))
         self.fuse_zero_grad = fuse_zero_grad
+        self.lazy_tables = lazy_tables
         self._arena_state: Dict[int, dict] = {}
+        self._stores = {}
 
     @staticmethod
     def _store_of(p):
         ref = getattr(p, "_rp_store", None)
         return None if ref is None else ref()
+
+    def flush(self):
+        """Lazy mode: bring every embedding row to the current step (dense-equivalent state)."""
+        for store in self._stores.values():
+            store.flush_lazy()
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -64,32 +146,47 @@ class FusedAdam(torch.optim.Optimizer):
                 ms.append(st["exp_avg"])
                 vs.append(st["exp_avg_sq"])
             for sid, store in stores.items():
+                self._stores[sid] = store
+                use_lazy = self.lazy_tables and store.embedding_dim % 4 == 0
+                if use_lazy:
+                    lz = store._lazy
+                    if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
+                        lz = store._lazy = LazyAdamRows(store, (b1, b2), eps)
+                        lz.t = lz.flushed_t = step - 1
+                        self._expose_state(store, lz.m, lz.v)
+                    lz.step(store, lr)
+                    continue
                 st = self._arena_state.get(sid)
                 if st is None or st["m"].shape != store.arena.shape or st["m"].device != store.arena.device:
                     st = {"m": torch.zeros_like(store.arena), "v": torch.zeros_like(store.arena)}
                     self._arena_state[sid] = st
-                    off = 0
-                    for p in store.table_parameters():  # per-table views, for state_dict()/inspection
-                        r = p.shape[0]
-                        self.state[p]["exp_avg"] = st["m"][off:off + r]
-                        self.state[p]["exp_avg_sq"] = st["v"][off:off + r]
-                        off += r
+                    self._expose_state(store, st["m"], st["v"])
                 ps.append(store.arena.view(-1))
                 gs.append(store.grad_arena.view(-1))
                 ms.append(st["m"].view(-1))
                 vs.append(st["v"].view(-1))
+                if self.fuse_zero_grad:
+                    store.grads_were_zeroed()
             if ps:
                 hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
-            if self.fuse_zero_grad:
-                for store in stores.values():
-                    store.grads_were_zeroed()
         return loss
 
+    def _expose_state(self, store, m, v):
+        """per-table views of the moment arenas, so optimizer.state / state_dict() look like torch.optim.Adam's"""
+        off = 0
+        for p in store.table_parameters():
+            r = p.shape[0]
+            self.state[p]["exp_avg"] = m[off:off + r]
+            self.state[p]["exp_avg_sq"] = v[off:off + r]
+            off += r
 
-def make_adam(model, lr):
-    """What RankTrainer.fit uses: fused HIP Adam for a HIP-resident model, torch.optim.Adam on CPU
-    (BASELINE config 0).  Hyper-parameters are the reference's (trainer.py:75)."""
+
+def make_adam(model, lr, lazy_tables=True):
+    """What RankTrainer.fit uses: fused HIP Adam for a HIP-resident model (exact lazy dense Adam on the embedding
+    arenas by default), torch.optim.Adam on CPU (BASELINE config 0).  Hyper-parameters are the reference's
+    (trainer.py:75)."""
     params = list(model.parameters())
     if params and params[0].is_cuda:
-        return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, fuse_zero_grad=True)
+        return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, fuse_zero_grad=True,
+                         lazy_tables=lazy_tables)
     return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
