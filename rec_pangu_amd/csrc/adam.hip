@@ -17,13 +17,22 @@ struct AdamPtrs {
     int64_t n[RP_MAX_FIELDS];
 };
 
+// Every multiply-add is spelled out as an explicit fma so that the dense kernel and the lazy replay (which
+// must reproduce it bit for bit) cannot be contracted differently by the compiler.
+__device__ __forceinline__ float rp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x4 rp_fma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float rp_splat(float x, float) { return x; }
+__device__ __forceinline__ f32x4 rp_splat(float x, f32x4) { return f32x4{x, x, x, x}; }
+
 template <typename T>
 __device__ __forceinline__ void adam1(T &p, const T g, T &m, T &v, float one_m_b1, float b2, float one_m_b2,
                                       float step_size, float bc2_sqrt, float eps) {
-    m = m + (g - m) * one_m_b1;
-    v = v * b2 + one_m_b2 * g * g;
+    const T c1 = rp_splat(one_m_b1, p), c2 = rp_splat(one_m_b2, p), ns = rp_splat(-step_size, p);
+    m = rp_fma(g - m, c1, m);                      // m + (g - m)(1 - b1)
+    const T vb = v * b2;                           // rounded once
+    v = rp_fma(c2 * g, g, vb);                     // b2 v + ((1 - b2) g) g
     const T denom = __builtin_elementwise_sqrt(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
+    p = rp_fma(ns, m / denom, p);                  // p - step_size * (m / denom)
 }
 
 template <bool ZERO_G>
