@@ -90,10 +90,16 @@ __global__ __launch_bounds__(256) void embed_gather_fwd_kernel(
     }
 }
 
-// One TPR-lane group per sorted position; only run heads and 64-position chunk starts do work, so
-// a hot row of a tiny table (tens of thousands of hits at B=65536) is split over many groups.
-// Complete runs are stored, partial pieces are added with the L2 float atomic.
-#define RP_RUN_CHUNK 64
+// Segmented reduction of the per-pair gradient rows into the dense gradient arena.
+// One TPR-lane group owns RP_SEG consecutive SORTED positions: it loads all their keys/positions, issues all
+// their row loads at once (RP_SEG independent 256-B loads per group keep the memory pipe full; a per-run serial
+// walk was latency-bound at 0.8 TB/s) and then folds equal keys together in registers.
+//   * a run that starts and ends inside the segment is stored (or atomically added when accumulating);
+//   * the piece of a run that crosses a segment border goes to LDS; after a barrier the first group of the
+//     workgroup merges neighbouring pieces with equal keys (a hot row of a tiny table fills whole workgroups
+//     with one key: 16 segments x 8 positions collapse into ONE fp32-atomic row add instead of 16, which is what
+//     keeps the few L2 channels holding the tiny tables from serialising the kernel).
+#define RP_SEG 8
 template <int TPR, int VEC>
 __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, int D,
@@ -101,37 +107,100 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     const float *__restrict__ arena, float *__restrict__ G, int accumulate) {
     typedef Vec<VEC> V;
     constexpr int GPB = 256 / TPR;
-    const int t = threadIdx.x % TPR;
-    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
-    if (i >= n) return;
-    const int32_t key = sk[i];
-    const bool head = (i == 0) || (sk[i - 1] != key);
-    if (!head && (i % RP_RUN_CHUNK) != 0) return;
-    int64_t lim = (i / RP_RUN_CHUNK + 1) * RP_RUN_CHUNK;
-    if (lim > n) lim = n;
-    for (int c = t * VEC; c < D; c += TPR * VEC) {
-        typename V::T acc = V::zero();
-        float gs = 0.f;
-        int64_t j = i;
-        for (; j < lim; ++j) {
-            if (j > i && sk[j] != key) break;
-            const int32_t p = sp[j];
-            const int f = p / Bi;
-            const int b = p - f * Bi;
-            if (dx != nullptr) acc += V::load(dx + (int64_t)b * ldx + (int64_t)f * D + c);
-            if (gfm != nullptr) {
-                const float g = gfm[b];
-                acc += g * V::load(sum_in + (int64_t)b * D + c);
-                gs += g;
+    constexpr int W = TPR * VEC;  // columns handled per pass
+    __shared__ __attribute__((aligned(16))) float piece[GPB][2][W];
+    __shared__ int32_t pkey[GPB][2];  // -1: no piece
+    const int t = threadIdx.x % TPR, grp = threadIdx.x / TPR;
+    const int64_t start = ((int64_t)blockIdx.x * GPB + grp) * RP_SEG;
+    const bool active = start < n;
+    const int cnt = active ? (int)((n - start) < RP_SEG ? (n - start) : RP_SEG) : 0;
+    int32_t k[RP_SEG];
+    int bb[RP_SEG], ff[RP_SEG];
+#pragma unroll
+    for (int j = 0; j < RP_SEG; ++j) {
+        const bool ok = j < cnt;
+        k[j] = ok ? sk[start + j] : -1;
+        const int32_t p = ok ? sp[start + j] : 0;
+        ff[j] = p / Bi;
+        bb[j] = p - ff[j] * Bi;
+    }
+    const int32_t kprev = (active && start > 0) ? sk[start - 1] : -1;
+    const int32_t knext = (active && start + cnt < n) ? sk[start + cnt] : -1;
+    for (int c0 = 0; c0 < D; c0 += W) {
+        const int c = c0 + t * VEC;
+        const bool col_ok = c < D;
+        typename V::T r[RP_SEG], w[RP_SEG];
+        float gf[RP_SEG];
+#pragma unroll
+        for (int j = 0; j < RP_SEG; ++j) {
+            r[j] = V::zero();
+            w[j] = V::zero();
+            gf[j] = 0.f;
+            if (j < cnt && col_ok) {
+                if (dx != nullptr) r[j] = V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
+                if (gfm != nullptr) {
+                    gf[j] = gfm[bb[j]];
+                    r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);
+                    w[j] = V::load(arena + (int64_t)k[j] * D + c);  // the looked-up row itself (FM: -g * v)
+                }
             }
         }
-        const bool ended = (j >= n) || (sk[j] != key);
-        if (gfm != nullptr) acc -= gs * V::load(arena + (int64_t)key * D + c);
-        float *dst = G + (int64_t)key * D + c;
-        if (head && ended && !accumulate)
-            V::store(dst, acc);
-        else
-            V::atomic_add(dst, acc);
+        if (t == 0) {
+            pkey[grp][0] = -1;
+            pkey[grp][1] = -1;
+        }
+        typename V::T acc = V::zero();
+        float gs = 0.f;
+        bool run_head = (k[0] != kprev);
+#pragma unroll
+        for (int j = 0; j < RP_SEG; ++j) {
+            if (j < cnt) {
+                acc += r[j];
+                gs += gf[j];
+                const bool last_of_run = (j + 1 < cnt) ? (k[j + 1] != k[j]) : true;
+                if (last_of_run) {
+                    const bool run_ends_here = (j + 1 < cnt) ? true : (k[j] != knext);
+                    if (gfm != nullptr) acc -= gs * w[j];
+                    if (run_head && run_ends_here) {
+                        if (col_ok) {
+                            float *dst = G + (int64_t)k[j] * D + c;
+                            if (!accumulate) V::store(dst, acc);
+                            else V::atomic_add(dst, acc);
+                        }
+                    } else {
+                        // border piece: slot 0 if the run came in from the previous segment, else slot 1
+                        const int slot = run_head ? 1 : 0;
+                        V::store(&piece[grp][slot][t * VEC], acc);
+                        if (t == 0) pkey[grp][slot] = k[j];
+                    }
+                    acc = V::zero();
+                    gs = 0.f;
+                    run_head = true;
+                }
+            }
+        }
+        __syncthreads();
+        if (grp == 0 && col_ok) {
+            int32_t cur = -1;
+            typename V::T cacc = V::zero();
+            for (int g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int32_t key = pkey[g2][slot];
+                    if (key < 0) continue;
+                    const typename V::T pv = V::load(&piece[g2][slot][t * VEC]);
+                    if (key == cur) {
+                        cacc += pv;
+                    } else {
+                        if (cur >= 0) V::atomic_add(G + (int64_t)cur * D + c, cacc);
+                        cur = key;
+                        cacc = pv;
+                    }
+                }
+            }
+            if (cur >= 0) V::atomic_add(G + (int64_t)cur * D + c, cacc);
+        }
+        __syncthreads();
     }
 }
 
@@ -227,7 +296,7 @@ extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *s
                     rp_aligned16(grad_arena) && (gfm == nullptr || (rp_aligned16(sum_in) && rp_aligned16(arena)));
     const int vec = v4 ? 4 : 1;
     const int tpr = pick_tpr(D, vec);
-    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
+    const unsigned grid = (unsigned)rp_cdiv(rp_cdiv(n, RP_SEG), 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
 #define CALL(T, VV)                                                                                            \
     hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV>), dim3(grid), dim3(256), 0, s, sorted_keys, sorted_pos, \

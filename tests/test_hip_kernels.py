@@ -285,4 +285,4 @@ def test_full_size_gather_properties(hip):
     hip.embed_grad_reduce(sk, sp, B, D, dx, None, None, None, G, accumulate=False)
     lhs = G.double().sum(dim=0)
     rhs = dx[:, :F * D].double().view(B, F, D).sum(dim=(0, 1))
-    torch.testing.assert_close(lhs, rhs, rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(lhs, rhs, rtol=2e-4, atol=5e-3)  # fp32 row sums of up to 20k addends per hot row
