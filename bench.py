@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--sharded", action="store_true",
+                    help="take the row-sharded all-to-all path even with one rank (validates the N>1 code on 1 GPU)")
     ap.add_argument("--optimizer", default="lazy", choices=["lazy", "dense"],
                     help="how the reference's dense Adam is executed on the embedding arena: 'lazy' = exact lazy "
                          "replay (bit-identical results, flushed inside the timed region), 'dense' = stream every row")
@@ -104,8 +106,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:  # single process, --sharded
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from rec_pangu_amd import hip
@@ -115,12 +120,12 @@ def main():
 
     enc = criteo_enc_dict(args.vocab_scale)
     B = args.batch
-    if world > 1:
+    if sharded:
         from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads  # row-sharded tables + RCCL
     torch.manual_seed(0)
     with torch.device(dev):
         model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
-    if world > 1:
+    if sharded:
         model = shard_model_tables(model, world, rank)
     model.embedding_layer.check_indices = "deferred"  # no per-step host sync; checked once after the run
     model.train()
@@ -141,7 +146,7 @@ def main():
             return
         out = model(data)
         out["loss"].backward()
-        if world > 1:
+        if sharded:
             allreduce_dense_grads(model)  # one flat bucket; embedding-row grads already travelled in backward
         opt.step()
         model.zero_grad()
@@ -226,13 +231,13 @@ def main():
                                      "to the last step inside the timed region)" if args.optimizer == "lazy"
                                      else "dense Adam (reference semantics, every row streamed each step, fused zero_grad)"),
                        "unique_rows_per_batch": n_unique,
-                       "parallelism": "single GPU" if world == 1 else f"tables row-sharded x{world}, all-to-all lookup"},
+                       "parallelism": "single GPU" if not sharded else f"tables row-sharded x{world}, all-to-all lookup"},
             "roofline": roofline, "roofline_gather": gather, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -22,6 +22,7 @@ the global batch (loss = mean over B).
 On a HIP device the local work runs on the HIP kernels (fused gather + FM from the received rows,
 sort + segmented reduce for the gradients); on CPU (gloo tests, BASELINE config 0 style) plain torch ops.
 """
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -60,6 +61,8 @@ class _ShardedRows(torch.autograd.Function):
         recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=keys.device)
         _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
         served = layer._local_gather(recv_rows)  # [n_recv, D]
+        ctx.presorted = getattr(layer, "_served_sorted", None)
+        layer._served_sorted = None
         rows = torch.empty((keys.numel(), local_arena.shape[1]), dtype=local_arena.dtype, device=keys.device)
         _a2a(rows, served, route.send, route.recv, layer.group)
         ctx.layer, ctx.route = layer, route
@@ -74,7 +77,7 @@ class _ShardedRows(torch.autograd.Function):
         g_rows = (g_rows * (1.0 / layer.world)).contiguous()
         recv_g = torch.empty((route.n_recv, g_rows.shape[1]), dtype=g_rows.dtype, device=g_rows.device)
         _a2a(recv_g, g_rows, route.recv, route.send, layer.group)
-        layer._local_scatter_add(recv_rows, recv_g)
+        layer._local_scatter_add(recv_rows, recv_g, presorted=ctx.presorted)
         return None, None, None
 
 
@@ -134,13 +137,40 @@ class ShardedEmbeddingLayer(nn.Module):
                              persistent=False)
         # rows r with r % world == rank, in order: local row = r // world
         self.local_arena = nn.Parameter(full_layer.arena.detach()[rank::world].clone())
-        self._touched = None
+        self.local_arena._rp_store = weakref.ref(self)  # FusedAdam finds the arena (and its lazy state) through this
+        self._touched, self._touched_unsorted = None, False
+        self._grad_buf = None
+        self._lazy = None
+        self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 
     # ---- EmbeddingLayer-compatible surface ------------------------------------------------------
     @property
     def arena(self):
         return self.local_arena
+
+    # ---- the "store" protocol FusedAdam / LazyAdamRows use (same as EmbeddingLayer) ------------------------
+    @property
+    def grad_arena(self):
+        return self._grad_buf
+
+    def table_parameters(self):
+        return [self.local_arena]
+
+    def _meta(self):
+        return (None, None, None, max(1, int(self.local_arena.shape[0] - 1).bit_length()))
+
+    def grads_are_arena(self) -> bool:
+        g = self.local_arena.grad
+        return g is not None and self._grad_buf is not None and g.data_ptr() == self._grad_buf.data_ptr()
+
+    def grads_were_zeroed(self):
+        self._touched, self._touched_unsorted = None, False
+
+    def flush_lazy(self):
+        if self._lazy is not None:
+            self._lazy.flush(self)
 
     def raise_if_bad_index(self):
         if self._err is not None and int(self._err.item()) != 0:
@@ -164,6 +194,12 @@ class ShardedEmbeddingLayer(nn.Module):
             n = rows_idx.numel()
             if n == 0:
                 return torch.empty((0, self.embedding_dim), device=rows_idx.device)
+            self._served_sorted = None
+            if self._lazy is not None and self._lazy.t > 0:
+                # exact lazy dense Adam: rows about to be served first replay the steps they skipped
+                sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
+                self._lazy.replay(self, sk)
+                self._served_sorted = (sk, sp)
             zero = torch.zeros((1,), dtype=torch.int64, device=rows_idx.device)
             cnt = torch.full((1,), self.local_arena.shape[0], dtype=torch.int64, device=rows_idx.device)
             x, _, _, _ = hip.embed_gather_fwd(self.local_arena.detach(), zero, cnt, [rows_idx], [], self.embedding_dim,
@@ -171,25 +207,29 @@ class ShardedEmbeddingLayer(nn.Module):
             return x
         return self.local_arena.detach()[rows_idx]
 
-    def _local_scatter_add(self, rows_idx, g):
+    def _local_scatter_add(self, rows_idx, g, presorted=None):
         p = self.local_arena
         if p.is_cuda:
             from . import hip
-            fresh = p.grad is None
-            if fresh:
-                if getattr(self, "_grad_buf", None) is None or self._grad_buf.shape != p.shape:
-                    self._grad_buf = torch.zeros_like(p)
-                elif self._touched is not None:
-                    hip.zero_rows(self._touched, self.embedding_dim, self._grad_buf)
-                else:
-                    self._grad_buf.zero_()
-                self._touched = None
+            fresh = not self.grads_are_arena()
+            if self._grad_buf is None or self._grad_buf.shape != p.shape or self._grad_buf.device != p.device:
+                self._grad_buf = torch.zeros_like(p)
+                self._touched, self._touched_unsorted = None, False
+            elif fresh and self._touched is not None:
+                hip.zero_rows(self._touched, self.embedding_dim, self._grad_buf)  # zero_grad() dropped the old rows
+                self._touched, self._touched_unsorted = None, False
+            clean = self._touched is None
             if rows_idx.numel():
-                bits = max(1, int(p.shape[0] - 1).bit_length())
-                sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=bits)
+                if presorted is not None:
+                    sk, sp = presorted
+                else:
+                    sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
                 hip.embed_grad_reduce(sk, sp, rows_idx.numel(), self.embedding_dim, g, None, None, None,
-                                      self._grad_buf, accumulate=not fresh)
-                self._touched = sk if self._touched is None else torch.cat([self._touched, sk])
+                                      self._grad_buf, accumulate=not clean)
+                if self._touched is None:
+                    self._touched, self._touched_unsorted = sk, False
+                else:
+                    self._touched, self._touched_unsorted = torch.cat([self._touched, sk]), True
             if fresh:
                 p.grad = self._grad_buf
         else:
@@ -231,6 +271,7 @@ class ShardedEmbeddingLayer(nn.Module):
     def full_tables(self) -> Dict[str, torch.Tensor]:
         """All-gather the shards and cut them back into the reference's per-table tensors
         (`embedding_layer.<col>.weight`), e.g. for RankTrainer.save_all on rank 0."""
+        self.flush_lazy()
         per = (self.total_rows + self.world - 1) // self.world
         mine = torch.zeros((per, self.embedding_dim), dtype=self.local_arena.dtype, device=self.local_arena.device)
         mine[:self.local_arena.shape[0]] = self.local_arena.detach()
