@@ -124,6 +124,29 @@ int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, 
                     int64_t lddx, float *dW, float *dB, float *dwfc, int64_t B, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
 
+/* ---- K6: xDeepFM CIN layer on the fp32 MFMA ------------------------------------------------------
+ * replaces layers/interaction.py:164-168 (einsum "bhd,bmd->bhmd" + view + Conv1d(k=1) + sum over d).
+ *   x0 [B, ld0]: X_0[b] as H rows of D floats;  xp [B, ldp]: X_{k-1}[b] as M rows of D floats (xp == x0 for layer 1)
+ *   W  [O, H*M] (Conv1d weight, channel c = h*M + m), bias [O] or NULL
+ *   out [B, O, D] = X_k (NULL to skip: the collapsed last layer only needs the pooling)
+ *   pooled [B, ldpool]: pooled[b, o] = sum_d X_k[b,o,d]  (NULL to skip)
+ * The outer product [B, H*M, D] is never materialised.  H <= 32 fields; must fit the 160 KB LDS.
+ * backward (g_out [B,O,D] = dL/dX_k and/or g_pool [B, ldgp] = dL/dpooled, broadcast over d):
+ *   rp_cin_layer_bwd_x: dx0 [B, lddx0] (+)= , dxp [B, lddxp] = gradients of both factors
+ *   rp_cin_layer_bwd_w: dW [O, H*M], dbias [O] (batch-reduced through `workspace`)                           */
+int rp_cin_layer_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *W, const float *bias,
+                     float *out, float *pooled, int64_t ldpool, int H, int M, int O, int D, int64_t B,
+                     rp_stream_t stream);
+/* add_dx0 != 0: dx0 += (several layers share X_0), else dx0 = ; for the first layer (xp == x0) both factor
+ * gradients land in dx0 and dxp is ignored.  Middle layers with O >= 4 need M <= 32 (register-tiled). */
+int rp_cin_layer_bwd_x(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *W, const float *g_out,
+                       const float *g_pool, int64_t ldgp, float *dx0, int64_t lddx0, int add_dx0, float *dxp,
+                       int64_t lddxp, int H, int M, int O, int D, int64_t B, rp_stream_t stream);
+int rp_cin_layer_bwd_w_workspace_bytes(int64_t B, int H, int M, int O, size_t *bytes);
+int rp_cin_layer_bwd_w(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *g_out,
+                       const float *g_pool, int64_t ldgp, float *dW, float *dbias, int H, int M, int O, int D,
+                       int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+
 /* ---- K7: AutoInt field self-attention layer ----------------------------------------------------
  * replaces layers/attention.py:63-101 (MultiHeadSelfAttention, align_to="output", no dropout/LayerNorm):
  * QKV(+residual) projections, RAW-view head split (:73-75), scores [/scale], softmax, PV, +residual, ReLU.

@@ -91,6 +91,40 @@ def crossnet(x0, W, Bv, wfc=None, bfc=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# K6  xDeepFM CIN layer   — layers/interaction.py:164-168
+# ----------------------------------------------------------------------------------------------
+class _CINLayer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, xp, W, bias, H: int, M: int, D: int, want_out: bool):
+        x0 = _unit_inner(x0)
+        same = xp is None
+        xp_t = x0 if same else _unit_inner(xp)
+        W = W.contiguous()
+        out, pooled = hip.cin_layer_fwd(x0, xp_t, W, bias, H, M, D, want_out, True)
+        ctx.cfg = (H, M, D, same, bias is not None, want_out)
+        ctx.save_for_backward(x0, None if same else xp_t, W)
+        if want_out:
+            return out, pooled
+        return pooled
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x0, xp, W = ctx.saved_tensors
+        H, M, D, same, has_bias, want_out = ctx.cfg
+        g_out, g_pool = (grads if want_out else (None, grads[0]))
+        g_out = None if g_out is None else g_out.contiguous()
+        g_pool = None if g_pool is None else _unit_inner(g_pool)
+        dx0, dxp, dW, db = hip.cin_layer_bwd(x0, x0 if same else xp, W, H, M, D, g_out, g_pool, has_bias)
+        return dx0, dxp, dW, db, None, None, None, None
+
+
+def cin_layer(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool = True):
+    """One CIN layer on [B, >=H*D] / [B, M*D] row buffers (xp=None: first layer, X_{k-1} = X_0).
+    -> (X_k [B,O,D], pooled [B,O]) or pooled alone when want_out is False."""
+    return _CINLayer.apply(x0, xp, W, bias, H, M, D, want_out)
+
+
+# ----------------------------------------------------------------------------------------------
 # K7  AutoInt field self-attention layer   — layers/attention.py:63-101
 # ----------------------------------------------------------------------------------------------
 class _FieldAttention(torch.autograd.Function):

@@ -38,6 +38,12 @@ _SIGNATURES = {
     "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_crossnet_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
                                   _i64, _vp, _sz, _vp]),
+    "rp_cin_layer_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
+    "rp_cin_layer_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
+                                     _i32, _i32, _i64, _vp]),
+    "rp_cin_layer_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, _i32, C.POINTER(_sz)]),
+    "rp_cin_layer_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _vp,
+                                     _sz, _vp]),
     "rp_field_attention_fits": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "rp_field_attention_fwd": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _vp]),
     "rp_field_attention_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, _i32, _i32, _i32, C.POINTER(_sz)]),
@@ -303,6 +309,47 @@ def crossnet_bwd(x0, d: int, W, Bv, wfc, s, g_x, g_logit):
                                      _rowmajor(dx0, "dx0"), dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), B, ws.data_ptr(),
                                      nbytes.value, _stream()), "rp_crossnet_bwd")
     return dx0, dW, dB, dwfc
+
+
+def cin_layer_fwd(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool, want_pool: bool):
+    """One CIN layer.  x0 [B, >=H*D], xp [B, >=M*D] (pass the same tensor for the first layer), W [O, H*M].
+    -> (out [B,O,D] or None, pooled [B,O] or None)."""
+    _req(x0, torch.float32, "x0")
+    _req(xp, torch.float32, "xp")
+    B, O = x0.shape[0], W.shape[0]
+    out = torch.empty((B, O, D), dtype=torch.float32, device=x0.device) if want_out else None
+    pooled = torch.empty((B, O), dtype=torch.float32, device=x0.device) if want_pool else None
+    with _Timed("cin_layer_fwd"):
+        _check(lib().rp_cin_layer_fwd(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"),
+                                      W.data_ptr(), _ptr(bias), _ptr(out), _ptr(pooled), O, H, M, O, D, B, _stream()),
+               "rp_cin_layer_fwd")
+    return out, pooled
+
+
+def cin_layer_bwd(x0, xp, W, H: int, M: int, D: int, g_out, g_pool, want_bias: bool):
+    """Gradients of one CIN layer: -> (dx0 like x0, dxp [B, M*D] or None when xp is x0, dW like W, dbias [O] or None)."""
+    B, O = x0.shape[0], W.shape[0]
+    same = xp is x0
+    dx0 = torch.empty_like(x0)
+    if x0.shape[1] > H * D:
+        dx0[:, H * D:].zero_()
+    dxp = None if same else torch.empty((B, M * D), dtype=torch.float32, device=x0.device)
+    ldgp = _rowmajor(g_pool, "g_pool") if g_pool is not None else 0
+    with _Timed("cin_layer_bwd_x"):
+        _check(lib().rp_cin_layer_bwd_x(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"),
+                                        W.data_ptr(), _ptr(g_out), _ptr(g_pool), ldgp, dx0.data_ptr(),
+                                        _rowmajor(dx0, "dx0"), 0, _ptr(dxp), M * D, H, M, O, D, B, _stream()),
+               "rp_cin_layer_bwd_x")
+    dW = torch.empty_like(W)
+    db = torch.empty((O,), dtype=torch.float32, device=x0.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_cin_layer_bwd_w_workspace_bytes(B, H, M, O, C.byref(nbytes)), "rp_cin_layer_bwd_w_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x0.device)
+    with _Timed("cin_layer_bwd_w"):
+        _check(lib().rp_cin_layer_bwd_w(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"),
+                                        _ptr(g_out), _ptr(g_pool), ldgp, dW.data_ptr(), _ptr(db), H, M, O, D, B,
+                                        ws.data_ptr(), nbytes.value, _stream()), "rp_cin_layer_bwd_w")
+    return dx0, dxp, dW, db
 
 
 def field_attention_fits(T: int, Din: int, H: int, a: int, has_res: bool) -> bool:

@@ -99,8 +99,45 @@ class CompressedInteractionNet(nn.Module):
             self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(num_fields * prev, unit, kernel_size=1)
             prev = unit
 
+    def _forward_hip(self, feature_emb):
+        """fp32-MFMA CIN kernels (rp_cin_layer_*).  Every layer but the last runs at full width and keeps X_k for
+        the next one; the LAST layer only feeds sum-pooling and `fc`, both linear, and the CIN has no activation, so
+            sum_o c[o] * sum_d X_L[b,o,d] = sum_d sum_{h,m} V[h,m] X_0[b,h,d] X_{L-1}[b,m,d] + D * (c . bias_L),
+            V = sum_o c[o] W_L[o]            (c = the slice of fc.weight that multiplies the last layer's pooling)
+        and it is evaluated as a single-output-channel layer with weights V: 1/O_L of the work, same algebra."""
+        from ... import functional as Fh
+        B, H, D = feature_emb.shape
+        x0 = feature_emb.reshape(B, H * D)
+        L = len(self.cin_layer_units)
+        xp, M, pooled, n_prev = None, H, [], 0
+        for i in range(L - 1):
+            conv = self.cin_layer["layer_" + str(i + 1)]
+            O = conv.weight.shape[0]
+            X_i, p_i = Fh.cin_layer(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D, want_out=True)
+            pooled.append(p_i)
+            xp, M, n_prev = X_i.view(B, O * D), O, n_prev + O
+        conv = self.cin_layer["layer_" + str(L)]
+        O = conv.weight.shape[0]
+        c_last = self.fc.weight[:, n_prev:]                                  # [out_dim, O_L]
+        if self.fc.weight.shape[0] != 1:
+            raise NotImplementedError("CIN on HIP collapses the last layer into fc: output_dim must be 1")
+        V = c_last @ conv.weight.view(O, H * M)                              # [1, H*M]   (weight-space, tiny)
+        vb = (c_last @ conv.bias.view(O, 1)).view(1)                         # c . bias_L
+        logit = Fh.cin_layer(x0, xp, V, vb, H, M, D, want_out=False)         # [B,1] = sum_o c[o] pooled_L[b,o]
+        if pooled:
+            logit = logit + Fh.linear_act(torch.cat(pooled, dim=-1), self.fc.weight[:, :n_prev].contiguous(), None)
+        return logit + self.fc.bias
+
+    def hip_supported(self, H) -> bool:
+        """What the register-tiled backward covers: <= 32 fields, and every middle layer (not first, not last)
+        fed by at most 32 maps; anything else is composed from device ops in forward()."""
+        units = self.cin_layer_units
+        return H <= 32 and self.fc.weight.shape[0] == 1 and all(u <= 32 for u in units[:-2])
+
     def forward(self, feature_emb):
         B, H, D = feature_emb.shape
+        if feature_emb.is_cuda and self.hip_supported(H):
+            return self._forward_hip(feature_emb)
         X_0, X_i, pooled = feature_emb, feature_emb, []
         for i in range(len(self.cin_layer_units)):
             conv = self.cin_layer["layer_" + str(i + 1)]

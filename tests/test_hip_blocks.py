@@ -68,6 +68,54 @@ def test_crossnet_fused_fc_vs_oracle(B, d, ld, L):
     _close(xl_dev.cpu(), xl.detach(), what="X_L")
 
 
+# ------------------------------------------------------------------------------------------------ CIN
+def test_cin_vs_reference_fixture():
+    """CompressedInteractionNet (two layers, the last one collapsed into fc) against the reference's own output and
+    gradients (tests/golden/layers.npz cin/*)."""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.layers import CompressedInteractionNet
+    c = load_golden("layers.npz")["cin"]
+    cin = CompressedInteractionNet(5, [6, 4], output_dim=1)
+    cin.load_state_dict({k[2:]: v for k, v in c.items() if k.startswith("w/")})
+    cin = cin.to(DEV)
+    x = c["in"].to(DEV).requires_grad_(True)
+    n0 = hip.launch_count()
+    y = cin(x)
+    assert hip.launch_count() > n0
+    _close(y.detach().cpu(), c["out"], what="cin out")
+    (y.squeeze(-1) * torch.linspace(-1, 1, x.shape[0], device=DEV)).sum().backward()
+    _close(x.grad.cpu(), c["grad_in"], rel=2e-4, what="cin dX0")
+    for k, p in cin.named_parameters():
+        # the fixture's output weights sum to zero, so the bias gradients are pure cancellation: absolute floor
+        _close(p.grad.cpu(), c["gw/" + k], rel=2e-4, floor=1e-2, what=f"cin d{k}")
+
+
+@pytest.mark.parametrize("B,H,D,units", [(300, 26, 64, [128, 128]), (257, 26, 64, [16, 16, 16]), (130, 16, 40, [8, 8]),
+                                          (64, 5, 8, [7]), (100, 26, 32, [32, 24, 9])])
+def test_cin_vs_oracle(B, H, D, units):
+    from rec_pangu_amd.models.layers import CompressedInteractionNet
+    g = torch.Generator().manual_seed(B + H)
+    torch.manual_seed(B)
+    cin = CompressedInteractionNet(H, units, output_dim=1)
+    ld = H * D + 13
+    xbuf = torch.randn(B, ld, generator=g) * 0.5
+    coef = torch.randn(B, 1, generator=g)
+    rx = xbuf[:, :H * D].reshape(B, H, D).clone().requires_grad_(True)
+    rw = {k: v.detach().clone().requires_grad_(True) for k, v in cin.named_parameters()}
+    n = len(units)
+    ref = R.cin(rx, [rw[f"cin_layer.layer_{i + 1}.weight"] for i in range(n)],
+                [rw[f"cin_layer.layer_{i + 1}.bias"] for i in range(n)], rw["fc.weight"], rw["fc.bias"])
+    (ref * coef).sum().backward()
+    cin = cin.to(DEV)
+    dxbuf = xbuf.to(DEV).requires_grad_(True)
+    out = cin(dxbuf[:, :H * D].unflatten(1, (H, D)))  # strided view, as the models pass it
+    _close(out.detach().cpu(), ref.detach(), rel=2e-4, what="cin out")
+    (out * coef.to(DEV)).sum().backward()
+    _close(dxbuf.grad[:, :H * D].cpu().reshape(B, H, D), rx.grad, rel=3e-4, what="cin dX0")
+    for k, p in cin.named_parameters():
+        _close(p.grad.cpu(), rw[k].grad, rel=3e-4, what=f"cin d{k}")
+
+
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("tag,din,heads,adim", [("a", 8, 2, 4), ("b", 8, 2, 3), ("c", 8, 1, 8), ("d", 6, 3, 5)])
 def test_field_attention_vs_reference_fixture(tag, din, heads, adim):
