@@ -44,7 +44,36 @@ def synth_batch(enc, B, seed, device):
         else:
             b[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g)  # uniform: worst case for caches
     b["label"] = (torch.rand(B, generator=g) < 0.25).float()
+    b["task1_label"] = b["label"]
+    b["task2_label"] = (torch.rand(B, generator=g) < 0.1).float()
     return {k: t.to(device) for k, t in b.items()}
+
+
+def mmoe_enc_dict(scale=1):
+    """BASELINE config 3: the multi-task example schema shape (16 sparse + 9 dense); cardinalities = the first 16
+    Criteo ones (the reference's 100-row sample has no meaningful cardinalities of its own)."""
+    enc = {f"I{i + 1}": {"min": 0.0, "max": 1.0} for i in range(9)}
+    enc.update({f"C{i + 1}": {"vocab_size": max(2, c // scale)} for i, c in enumerate(CRITEO_CARD[:16])})
+    return enc
+
+
+def build_model(name, enc):
+    """The BASELINE.json configs: 1 = DeepFM (headline), 2 = xDeepFM CIN [128,128], 3 = MMOE 4 experts, towers
+    [256,128]; DCN / AutoInt with their reference defaults at D=64 for completeness."""
+    from rec_pangu_amd.models.ranking import DeepFM, xDeepFM, DCN, AutoInt
+    from rec_pangu_amd.models.multi_task import MMOE
+    if name == "deepfm":
+        return DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+    if name == "xdeepfm":
+        return xDeepFM(embedding_dim=64, dnn_hidden_units=[64, 64, 64], cin_layer_units=[128, 128], enc_dict=enc)
+    if name == "dcn":
+        return DCN(embedding_dim=64, crossing_layers=3, enc_dict=enc)
+    if name == "autoint":
+        return AutoInt(embedding_dim=64, dnn_hidden_units=[64, 64, 64], attention_layers=1, num_heads=1,
+                       attention_dim=8, enc_dict=enc)
+    if name == "mmoe":
+        return MMOE(num_task=2, n_expert=4, embedding_dim=40, mmoe_hidden_dim=128, hidden_dim=[256, 128], enc_dict=enc)
+    raise ValueError(name)
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -91,6 +120,8 @@ def main():
     ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--model", default="deepfm", choices=["deepfm", "xdeepfm", "dcn", "autoint", "mmoe"],
+                    help="deepfm = BASELINE headline config; the others are BASELINE configs 2-3 / siblings")
     ap.add_argument("--sharded", action="store_true",
                     help="take the row-sharded all-to-all path even with one rank (validates the N>1 code on 1 GPU)")
     ap.add_argument("--optimizer", default="lazy", choices=["lazy", "dense"],
@@ -118,16 +149,18 @@ def main():
     from rec_pangu_amd.optim import make_adam
     hip.lib()
 
-    enc = criteo_enc_dict(args.vocab_scale)
+    enc = mmoe_enc_dict(args.vocab_scale) if args.model == "mmoe" else criteo_enc_dict(args.vocab_scale)
     B = args.batch
     if sharded:
         from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads  # row-sharded tables + RCCL
     torch.manual_seed(0)
     with torch.device(dev):
-        model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+        model = build_model(args.model, enc)
     if sharded:
         model = shard_model_tables(model, world, rank)
-    model.embedding_layer.check_indices = "deferred"  # no per-step host sync; checked once after the run
+    for m in model.modules():
+        if hasattr(m, "check_indices"):
+            m.check_indices = "deferred"  # no per-step host sync; checked once after the run
     model.train()
     opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"))
     n_params = sum(p.numel() for p in model.parameters())
@@ -169,7 +202,9 @@ def main():
     dt = time.perf_counter() - t0
     timing = hip.timing_summary()
     hip.enable_timing(False)
-    model.embedding_layer.raise_if_bad_index()
+    for m in model.modules():
+        if hasattr(m, "raise_if_bad_index"):
+            m.raise_if_bad_index()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -178,8 +213,9 @@ def main():
     value = B * args.steps / dt
 
     # ---- per-kernel numbers (algorithmic bytes from SURVEY.md §8d) --------------------------------
-    F, D, ND = 26, 64, 13
-    keys0 = torch.cat([batches[0][f"C{i + 1}"] + 0 for i in range(F)])  # unique (field, id) pairs of one batch
+    F = sum(1 for v in enc.values() if "vocab_size" in v)
+    ND = sum(1 for v in enc.values() if "min" in v)
+    D = model.embedding_dim
     n_unique = int(sum(torch.unique(batches[0][f"C{i + 1}"]).numel() for i in range(F)))
     n_pairs = F * local_B
     row_b = D * 4
@@ -218,14 +254,17 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "samples/sec DeepFM Criteo-shape bsz=65536 (train step: fwd+bwd+dense Adam+zero_grad)"
-                      if args.mode == "train" else "samples/sec DeepFM Criteo-shape bsz=65536 (forward only)",
+            "metric": f"samples/sec {type(model).__name__} Criteo-shape bsz={B} (train step: fwd+bwd+dense Adam+zero_grad)"
+                      if args.mode == "train" else f"samples/sec {type(model).__name__} Criteo-shape bsz={B} (forward only)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DeepFM, 26 sparse fields (Criteo-Kaggle cardinalities/{args.vocab_scale}, "
-                                   f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D=64 + 13 dense, "
-                                   f"MLP [64,64,64], global batch {B}, uniform ids",
+            "config": {"workload": f"{type(model).__name__} ({args.model}), {F} sparse fields (Criteo-Kaggle "
+                                   f"cardinalities/{args.vocab_scale}, "
+                                   f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D={D} + {ND} dense, "
+                                   f"global batch {B}, uniform ids"
+                                   + (", MLP [64,64,64]" if args.model != "mmoe" else ", 4 experts x 128, towers [256,128]")
+                                   + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
                        "global_batch": B,
                        "optimizer": ("dense Adam, reference semantics, executed lazily (bit-identical; all rows flushed "
                                      "to the last step inside the timed region)" if args.optimizer == "lazy"
