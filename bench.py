@@ -76,9 +76,27 @@ def build_model(name, enc):
     raise ValueError(name)
 
 
+def pmc_traffic(entry):
+    """HBM bytes per launch of the kernel behind a C-ABI entry point, from the committed rocprofv3 PMC summary of
+    this same workload (profiles/r*_pmc.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes).
+    bench.py cannot run the profiler on itself, so this is a recorded figure; null when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    try:
+        pmc = json.load(open(files[-1]))
+    except Exception:
+        return None
+    for k, v in pmc.items():
+        if k.startswith(entry + "_kernel") and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The CPU oracle port (oracle/ref_ops.py: the reference's algorithm in ATen fp32 ops + autograd, dense
-    torch.optim.Adam as trainer.py:75) on this box's host cores.  Bounded sample: B=16384, vocabulary / 16
+    torch.optim.Adam as trainer.py:75) on this box's host cores.  Bounded sample: B=65536, vocabulary / 16
     (dense Adam then touches 2.1 M rows instead of 33.8 M), 1 warm-up + up to 2 timed steps."""
     from oracle import ref_ops as R  # checker/baseline only
     from rec_pangu_amd.models.ranking import DeepFM
@@ -90,7 +108,7 @@ def cpu_baseline(seconds_budget=25.0):
     params = {k: torch.nn.Parameter(v.clone()) for k, v in model.state_dict().items()}
     del model
     opt = torch.optim.Adam(list(params.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
-    B = 16384
+    B = 65536
     batch = synth_batch(enc, B, 1, "cpu")
 
     def step():
@@ -226,30 +244,40 @@ def main():
         "lazy_adam_rows_step": 8 * n_unique * row_b,
         # p,m,v read+written per unique row that skipped at least one step (upper bound: all of them)
         "lazy_adam_rows_replay": 6 * n_unique * row_b,
+        # (key, position) pairs read + written once per radix pass (26 key bits -> 4 passes of <= 8 bits)
+        "sort_pairs_i32": 4 * 2 * 8 * n_pairs,
         # table rows read + int64 ids read + [B, F*D+ND] fp32 output written
         "embed_gather_fwd": local_B * (F * (D * 4 + 8) + (F * D + ND) * 4),
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
         "adam_step": 7 * 4 * (n_params),
     }
+    if args.model == "deepfm":
+        # mean algorithmic bytes per launch over the launches of one step (activations in + out, fp32);
+        # forward 1677->64->64->64->1 plus the four dgrad launches on the transposed weights / four wgrad launches
+        d_in = F * D + ND
+        alg_bytes["linear_fwd"] = local_B * 4 * 2 * ((d_in + 64) + 2 * (64 + 64) + (64 + 1)) // 8
+        alg_bytes["linear_wgrad"] = local_B * 4 * ((d_in + 64) + 2 * (64 + 64) + (64 + 1)) // 4
     kernels = {}
     for name, (calls, mean_ms) in sorted(timing.items()):
         k = {"calls_per_step": round(calls / args.steps, 2), "mean_ms": round(mean_ms, 4)}
         if name in alg_bytes:
             k["algorithmic_GBps"] = round(alg_bytes[name] / (mean_ms * 1e-3) / 1e9, 1)
         kernels[name] = k
-    total = {n: c * m for n, (c, m) in timing.items()}
+    total = {n: c * m for n, (c, m) in timing.items() if n in alg_bytes}
     dominant = max(total, key=total.get) if total else None
     roofline = None
     if dominant in alg_bytes:
         a = alg_bytes[dominant] / (timing[dominant][1] * 1e-3) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(a / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic(dominant) if (args.model == "deepfm" and world == 1) else None,
                     "algorithmic_bytes_per_launch": alg_bytes[dominant]}
     gather = None
     if "embed_gather_fwd" in timing:
         a = alg_bytes["embed_gather_fwd"] / (timing["embed_gather_fwd"][1] * 1e-3) / 1e9
         gather = {"kernel": "embed_gather_fwd", "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS,
-                  "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                  "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                  "traffic": pmc_traffic("embed_gather_fwd") if (args.model == "deepfm" and world == 1) else None,
                   "algorithmic_bytes_per_launch": alg_bytes["embed_gather_fwd"]}
 
     if rank == 0:
