@@ -57,13 +57,13 @@ def mmoe_enc_dict(scale=1):
     return enc
 
 
-def build_model(name, enc):
+def build_model(name, enc, hidden=(64, 64, 64)):
     """The BASELINE.json configs: 1 = DeepFM (headline), 2 = xDeepFM CIN [128,128], 3 = MMOE 4 experts, towers
     [256,128]; DCN / AutoInt with their reference defaults at D=64 for completeness."""
     from rec_pangu_amd.models.ranking import DeepFM, xDeepFM, DCN, AutoInt
     from rec_pangu_amd.models.multi_task import MMOE
     if name == "deepfm":
-        return DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+        return DeepFM(embedding_dim=64, hidden_units=list(hidden), enc_dict=enc)
     if name == "xdeepfm":
         return xDeepFM(embedding_dim=64, dnn_hidden_units=[64, 64, 64], cin_layer_units=[128, 128], enc_dict=enc)
     if name == "dcn":
@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "xdeepfm", "dcn", "autoint", "mmoe"],
                     help="deepfm = BASELINE headline config; the others are BASELINE configs 2-3 / siblings")
+    ap.add_argument("--hidden", default="64,64,64",
+                    help="DeepFM hidden_units; the reference default 64,64,64 is HBM-bound (SURVEY D5), "
+                         "1024,512,256 is the MFMA-bound variant BASELINE's MLP-utilisation target refers to")
     ap.add_argument("--sharded", action="store_true",
                     help="take the row-sharded all-to-all path even with one rank (validates the N>1 code on 1 GPU)")
     ap.add_argument("--optimizer", default="lazy", choices=["lazy", "dense"],
@@ -173,7 +176,8 @@ def main():
         from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads  # row-sharded tables + RCCL
     torch.manual_seed(0)
     with torch.device(dev):
-        model = build_model(args.model, enc)
+        hidden = tuple(int(h) for h in args.hidden.split(","))
+        model = build_model(args.model, enc, hidden)
     if sharded:
         model = shard_model_tables(model, world, rank)
     for m in model.modules():
@@ -251,7 +255,13 @@ def main():
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
         "adam_step": 7 * 4 * (n_params),
     }
-    if args.model == "deepfm":
+    mlp_flops = None
+    if args.model == "deepfm" and hidden != (64, 64, 64):
+        dims = [F * D + ND] + list(hidden) + [1]
+        # forward + dgrad launches go through linear_fwd (2 flop per MAC), wgrad through linear_wgrad
+        mlp_flops = {"linear_fwd": 2 * 2 * local_B * sum(a * b for a, b in zip(dims[:-1], dims[1:])),
+                     "linear_wgrad": 2 * local_B * sum(a * b for a, b in zip(dims[:-1], dims[1:]))}
+    if args.model == "deepfm" and hidden == (64, 64, 64):
         # mean algorithmic bytes per launch over the launches of one step (activations in + out, fp32);
         # forward 1677->64->64->64->1 plus the four dgrad launches on the transposed weights / four wgrad launches
         d_in = F * D + ND
@@ -272,6 +282,15 @@ def main():
                     "frac": round(a / HBM_PEAK_GBS, 4),
                     "traffic": pmc_traffic(dominant) if (args.model == "deepfm" and world == 1) else None,
                     "algorithmic_bytes_per_launch": alg_bytes[dominant]}
+    if mlp_flops is not None:
+        # MFMA-bound variant: report the GEMM launches against the exact-fp32 matrix-core peak (157.3 TFLOP/s)
+        tot_ms = {n: timing[n][0] * timing[n][1] / args.steps for n in mlp_flops if n in timing}
+        if tot_ms:
+            n = max(tot_ms, key=tot_ms.get)
+            tf = mlp_flops[n] / (tot_ms[n] * 1e-3) / 1e12
+            roofline = {"kernel": n, "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": round(tf / 157.3, 4), "traffic": None,
+                        "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; flops = all launches of this entry per step"}
     gather = None
     if "embed_gather_fwd" in timing:
         a = alg_bytes["embed_gather_fwd"] / (timing["embed_gather_fwd"][1] * 1e-3) / 1e9
@@ -291,7 +310,8 @@ def main():
                                    f"cardinalities/{args.vocab_scale}, "
                                    f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D={D} + {ND} dense, "
                                    f"global batch {B}, uniform ids"
-                                   + (", MLP [64,64,64]" if args.model != "mmoe" else ", 4 experts x 128, towers [256,128]")
+                                   + (f", MLP {list(hidden)}" if args.model == "deepfm" else
+                                      (", MLP [64,64,64]" if args.model != "mmoe" else ", 4 experts x 128, towers [256,128]"))
                                    + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
                        "global_batch": B,
                        "optimizer": ("dense Adam, reference semantics, executed lazily (bit-identical; all rows flushed "

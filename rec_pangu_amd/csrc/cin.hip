@@ -20,6 +20,90 @@
 #define CIN_MAXH 32
 #define CIN_LDS_BUDGET (156 * 1024)
 
+// One MFMA accumulation chain of n2 steps: acc += sum_k A[.,k] B[k,.] with both operands read from LDS at
+// pa + k*sa / pb + k*sb (float strides).  Operands are fetched four steps ahead of the MFMAs that consume them and
+// the addresses are walked, not recomputed: the first version spent ~15 VALU instructions per MFMA on index
+// arithmetic (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA), which capped the matrix pipe at ~34 %.
+__device__ __forceinline__ void cin_chain(f32x16 &acc, const float *pa, int sa, const float *pb, int sb, int n2,
+                                          float bscale) {
+    int k = 0;
+    for (; k + 4 <= n2; k += 4) {
+        const float a0 = pa[0], a1 = pa[sa], a2 = pa[2 * sa], a3 = pa[3 * sa];
+        const float b0 = pb[0], b1 = pb[sb], b2 = pb[2 * sb], b3 = pb[3 * sb];
+        pa += 4 * sa;
+        pb += 4 * sb;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bscale * b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bscale * b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, bscale * b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, bscale * b3, acc, 0, 0, 0);
+    }
+    for (; k < n2; ++k) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[0], bscale * pb[0], acc, 0, 0, 0);
+        pa += sa;
+        pb += sb;
+    }
+}
+
+// Two column tiles at once: they share the A operand (one LDS read feeds two MFMAs) and give the matrix pipe two
+// independent accumulators to alternate between.
+__device__ __forceinline__ void cin_chain2(f32x16 &acc0, f32x16 &acc1, const float *pa, int sa, const float *pb,
+                                           int sb, int n2) {
+    int k = 0;
+    for (; k + 4 <= n2; k += 4) {
+        const float a0 = pa[0], a1 = pa[sa], a2 = pa[2 * sa], a3 = pa[3 * sa];
+        const float b0 = pb[0], b1 = pb[sb], b2 = pb[2 * sb], b3 = pb[3 * sb];
+        const float c0 = pb[32], c1 = pb[sb + 32], c2 = pb[2 * sb + 32], c3 = pb[3 * sb + 32];
+        pa += 4 * sa;
+        pb += 4 * sb;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, c0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, c1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, c2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, c3, acc1, 0, 0, 0);
+    }
+    for (; k < n2; ++k) {
+        const float a = pa[0];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[32], acc1, 0, 0, 0);
+        pa += sa;
+        pb += sb;
+    }
+}
+
+// W[o] ([H][M] contiguous in global memory) -> registers -> this wave's padded LDS tile [32][Ms].  The global
+// loads for channel o+4 are issued before the MFMA work of channel o and only consumed (stored to LDS) after it,
+// so their ~1 us L2 latency is hidden; without this the staging was ~2/3 of the kernel time.
+#define CIN_WREGS 16  // H*M <= 1024 floats per channel (M <= 32 layers); larger tiles stage synchronously
+struct CinWRegs {
+    float r[CIN_WREGS];
+};
+__device__ __forceinline__ void cin_w_load(CinWRegs &w, const float *__restrict__ Wo, int HM, int lane) {
+#pragma unroll
+    for (int u = 0; u < CIN_WREGS; ++u) {
+        const int i = lane + 64 * u;
+        w.r[u] = (i < HM) ? Wo[i] : 0.f;
+    }
+}
+struct CinWOff {
+    int off[CIN_WREGS];  // LDS offset of element lane + 64u of a [H][M] tile inside the padded [32][Ms] tile, or -1
+};
+__device__ __forceinline__ void cin_w_offsets(CinWOff &o, int HM, int M, int Ms, int lane) {
+#pragma unroll
+    for (int u = 0; u < CIN_WREGS; ++u) {
+        const int i = lane + 64 * u;
+        const int h = i / M;
+        o.off[u] = (i < HM) ? h * Ms + (i - h * M) : -1;
+    }
+}
+__device__ __forceinline__ void cin_w_store(const CinWRegs &w, const CinWOff &o, float *Wl) {
+#pragma unroll
+    for (int u = 0; u < CIN_WREGS; ++u)
+        if (o.off[u] >= 0) Wl[o.off[u]] = w.r[u];
+}
+
 // LDS plan shared by host and device.  All tiles are zero-padded so the MFMA loop carries no predicates:
 //   X0s [S][32][Dpp]       rows >= H and columns >= D are zero            (Dpp = 32*ceil(D/32) + 1, odd)
 //   Xps [S][Mr][Dpp]       Mr = M rounded up to even (pad row zero); aliases X0s for the first layer (X_{k-1} = X_0)
@@ -82,24 +166,69 @@ __global__ __launch_bounds__(256) void cin_layer_fwd_kernel(const float *__restr
     // over all S*ND tiles); with fewer (the collapsed last layer) the (sample, column tile) items are dealt out
     const bool by_channel = (O >= 4);
     const int nitems = S * ND;
-    for (int o = by_channel ? wave : 0; o < O; o += by_channel ? 4 : 1) {
-        // stage W[o] ([H][M] contiguous in global) into this wave's padded [32][Ms] tile: coalesced reads
-        for (int i = lane; i < H * M; i += 64) {
-            const int h = i / M, m = i - h * M;
-            Wl[h * Ms + m] = W[(int64_t)o * H * M + i];
+    const int HM = H * M, ostep = by_channel ? 4 : 1;
+    const bool pre = HM <= 64 * CIN_WREGS;
+    CinWRegs wr;
+    CinWOff wo;
+    if (pre) cin_w_offsets(wo, HM, M, Ms, lane);
+    if (pre && (by_channel ? wave : 0) < O) cin_w_load(wr, W + (int64_t)(by_channel ? wave : 0) * HM, HM, lane);
+    for (int o = by_channel ? wave : 0; o < O; o += ostep) {
+        if (pre) {
+            cin_w_store(wr, wo, Wl);
+            if (o + ostep < O) cin_w_load(wr, W + (int64_t)(o + ostep) * HM, HM, lane);  // in flight during the MFMAs
+        } else {
+            for (int i = lane; i < HM; i += 64) {
+                const int h = i / M, m = i - h * M;
+                Wl[h * Ms + m] = W[(int64_t)o * HM + i];
+            }
         }
         __builtin_amdgcn_wave_barrier();
         const float bo = (bias != nullptr) ? bias[o] : 0.f;
+        if (by_channel && (ND % 2) == 0) {
+            // two 32-column tiles of a sample per chain
+            for (int s = 0; s < S; ++s)
+                for (int dp = 0; dp < ND; dp += 2) {
+                    const int d = dp * 32 + li;
+                    f32x16 acc0, acc1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc0[r] = 0.f;
+                        acc1[r] = 0.f;
+                    }
+                    cin_chain2(acc0, acc1, Wl + li * Ms + half, 2, Xps + (s * xrows + half) * Dpp + d, 2 * Dpp, M2);
+                    const float *x0c = X0s + (s * 32 + 4 * half) * Dpp + d;
+                    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = ((r & 3) + 8 * (r >> 2)) * Dpp;
+                        v0 += acc0[r] * x0c[ro];
+                        v1 += acc1[r] * x0c[ro + 32];
+                    }
+                    v0 += __shfl_xor(v0, 32, 64);
+                    v1 += __shfl_xor(v1, 32, 64);
+                    v0 += bo;
+                    v1 += bo;
+                    const bool bok = (b0 + s) < B;
+                    const bool k0 = (half == 0) && (d < D), k1 = (half == 0) && (d + 32 < D);
+                    if (out != nullptr && bok) {
+                        if (k0) out[((b0 + s) * O + o) * D + d] = v0;
+                        if (k1) out[((b0 + s) * O + o) * D + d + 32] = v1;
+                    }
+                    float pv = (k0 ? v0 : 0.f) + (k1 ? v1 : 0.f);
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) pv += __shfl_xor(pv, off, 64);
+                    if (lane == 0) atomicAdd(&poolL[s * O + o], pv);
+                }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         for (int it = by_channel ? 0 : wave; it < nitems; it += by_channel ? 1 : 4) {
             const int s = it / ND, dh = it - s * ND;
             const int d = dh * 32 + li;
-            const float *xb = Xps + (s * xrows) * Dpp + d;
-            const float *wa = Wl + li * Ms + half;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int s2 = 0; s2 < M2; ++s2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s2], xb[(2 * s2 + half) * Dpp], acc, 0, 0, 0);
+            cin_chain(acc, Wl + li * Ms + half, 2, Xps + (s * xrows + half) * Dpp + d, 2 * Dpp, M2, 1.f);
             const float *x0c = X0s + (s * 32 + 4 * half) * Dpp + d;
             float v = 0.f;
 #pragma unroll
@@ -232,11 +361,14 @@ __global__ __launch_bounds__(256) void cin_layer_bwd_x_kernel(
                 a0[it][r] = 0.f;
                 ap[it][r] = 0.f;
             }
+        const int HM = H * M;  // M <= 32 here, so H*M <= 1024 always fits the prefetch registers
+        CinWRegs wr;
+        CinWOff wo;
+        cin_w_offsets(wo, HM, M, Ms, lane);
+        if (wave < O) cin_w_load(wr, W + (int64_t)wave * HM, HM, lane);
         for (int o = wave; o < O; o += 4) {
-            for (int i = lane; i < H * M; i += 64) {
-                const int h = i / M, m = i - h * M;
-                Wl[h * Ms + m] = W[(int64_t)o * H * M + i];
-            }
+            cin_w_store(wr, wo, Wl);
+            if (o + 4 < O) cin_w_load(wr, W + (int64_t)(o + 4) * HM, HM, lane);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < CIN_BX_MAXT; ++it) {
@@ -250,21 +382,14 @@ __global__ __launch_bounds__(256) void cin_layer_bwd_x_kernel(
                         if (g_pool != nullptr) g += g_pool[(b0 + s) * ldgp + o];
                     }
                     // (i) forward chain T_o, then dX0 += G * T_o
-                    const float *xb = Xps + (s * xrows) * Dpp + d;
-                    const float *wa = Wl + li * Ms + half;
                     f32x16 t;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t[r] = 0.f;
-                    for (int s2 = 0; s2 < M2; ++s2)
-                        t = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s2], xb[(2 * s2 + half) * Dpp], t, 0, 0, 0);
+                    cin_chain(t, Wl + li * Ms + half, 2, Xps + (s * xrows + half) * Dpp + d, 2 * Dpp, M2, 1.f);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a0[it][r] += g * t[r];
                     // (ii) dXp tile (m = li, single m tile): A[m][h] = W[o][h][m], B[h][d] = G * X0[h][d]
-                    const float *x0b = X0s + (s * 32) * Dpp + d;
-                    const float *wt = Wl + half * Ms + li;
-                    for (int s2 = 0; s2 < H2; ++s2)
-                        ap[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[2 * s2 * Ms], g * x0b[(2 * s2 + half) * Dpp],
-                                                                      ap[it], 0, 0, 0);
+                    cin_chain(ap[it], Wl + half * Ms + li, 2 * Ms, X0s + (s * 32 + half) * Dpp + d, 2 * Dpp, H2, g);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -323,23 +448,16 @@ __global__ __launch_bounds__(256) void cin_layer_bwd_x_kernel(
                         if (g_pool != nullptr) g += g_pool[(b0 + s) * ldgp + o];
                     }
                     if (mt < 0) {
-                        const float *xb = Xps + (s * xrows) * Dpp + d;
-                        const float *wa = Wl + li * Ms + half;
                         f32x16 t;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) t[r] = 0.f;
-                        for (int s2 = 0; s2 < M2; ++s2)
-                            t = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * s2], xb[(2 * s2 + half) * Dpp], t, 0, 0, 0);
+                        cin_chain(t, Wl + li * Ms + half, 2, Xps + (s * xrows + half) * Dpp + d, 2 * Dpp, M2, 1.f);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) a0[r] += g * t[r];
                     } else {
-                        const float *x0b = X0s + (s * 32) * Dpp + d;
-                        const int mcol = mt * 32 + li;  // Wl has Ms >= M+1 columns; columns >= M are zero... up to Ms
+                        const int mcol = mt * 32 + li;  // tile rows beyond M read a clamped column and are never stored
                         const float *wt = Wl + half * Ms + (mcol < Ms ? mcol : Ms - 1);
-                        const float msk = (mcol < M) ? 1.f : 0.f;
-                        for (int s2 = 0; s2 < H2; ++s2)
-                            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(msk * wt[2 * s2 * Ms],
-                                                                      g * x0b[(2 * s2 + half) * Dpp], ap, 0, 0, 0);
+                        cin_chain(ap, wt, 2 * Ms, X0s + (s * 32 + half) * Dpp + d, 2 * Dpp, H2, g);
                     }
                 }
                 if (!bok) continue;
@@ -431,29 +549,28 @@ __global__ __launch_bounds__(256) void cin_layer_bwd_w_kernel(const float *__res
     const int64_t bbeg = (int64_t)blockIdx.y * chunk;
     int64_t bend = bbeg + chunk;
     if (bend > B) bend = B;
+    for (int i = tid; i < total; i += 256) smem[i] = 0.f;  // padding rows/columns stay zero for the whole chunk
     for (int64_t b0 = bbeg; b0 < bend; b0 += S) {
-        __syncthreads();
-        for (int i = tid; i < total; i += 256) smem[i] = 0.f;
         __syncthreads();
         for (int i = tid; i < S * H * D; i += 256) {
             const int s = i / (H * D), r = i - s * H * D, h = r / D, d = r - h * D;
-            if (b0 + s < bend) X0s[(s * 32 + h) * Dpp + d] = x0[(b0 + s) * ld0 + r];
+            X0s[(s * 32 + h) * Dpp + d] = (b0 + s < bend) ? x0[(b0 + s) * ld0 + r] : 0.f;
         }
         if (!same)
             for (int i = tid; i < S * M * D; i += 256) {
                 const int s = i / (M * D), r = i - s * M * D, m = r / D, d = r - m * D;
-                if (b0 + s < bend) Xps[(s * MR + m) * Dpp + d] = xp[(b0 + s) * ldp + r];
+                Xps[(s * MR + m) * Dpp + d] = (b0 + s < bend) ? xp[(b0 + s) * ldp + r] : 0.f;
             }
         if (o_ok)
             for (int i = lane; i < S * D; i += 64) {
                 const int s = i / D, d = i - s * D;
+                float g = 0.f;
                 if (b0 + s < bend) {
-                    float g = 0.f;
                     if (g_out != nullptr) g += g_out[((b0 + s) * O + o) * D + d];
                     if (g_pool != nullptr) g += g_pool[(b0 + s) * ldgp + o];
-                    Gs[(wave * S + s) * Dpp + d] = g;
-                    bsum += g;
                 }
+                Gs[(wave * S + s) * Dpp + d] = g;
+                bsum += g;
             }
         __syncthreads();
         if (o_ok) {
@@ -461,7 +578,23 @@ __global__ __launch_bounds__(256) void cin_layer_bwd_w_kernel(const float *__res
                 const float *gs = Gs + (wave * S + s) * Dpp;
                 const float *xa = X0s + (s * 32 + li) * Dpp;
                 const float *xb = Xps + (s * (same ? 32 : MR) + li) * Dpp;
-                for (int s2 = 0; s2 < D2; ++s2) {
+                int s2 = 0;
+                for (; s2 + 4 <= D2; s2 += 4) {  // operands four steps ahead of their MFMAs (see cin_chain)
+                    float a4[4], b4[4][MT];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int d = 2 * (s2 + u) + half;
+                        a4[u] = gs[d] * xa[d];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) b4[u][mt] = (same && mt > 0) ? 0.f : xb[(mt * 32) * Dpp + d];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u], b4[u][mt], acc[mt], 0, 0, 0);
+                }
+                for (; s2 < D2; ++s2) {
                     const int d = 2 * s2 + half;
                     const float a = gs[d] * xa[d];
 #pragma unroll
@@ -515,7 +648,7 @@ extern "C" int rp_cin_layer_bwd_w_workspace_bytes(int64_t B, int H, int M, int O
     RP_REQUIRE(bytes && B >= 1 && H >= 1 && M >= 1 && O >= 1, "cin_layer_bwd_w_workspace_bytes: bad argument");
     int64_t chunk;
     int nchunk;
-    cin_bw_plan(B, O, &chunk, &nchunk, 4);
+    cin_bw_plan(B, O, &chunk, &nchunk, 8);
     *bytes = ((size_t)nchunk * O * H * M + (size_t)nchunk * O) * sizeof(float) + 256;
     return RP_OK;
 }
@@ -535,7 +668,7 @@ extern "C" int rp_cin_layer_bwd_w(const float *x0, int64_t ld0, const float *xp,
     const int same = (xp == x0) && (ldp == ld0) && (M == H);
     const int MT = (M + 31) / 32, MTt = MT <= 1 ? 1 : (MT <= 4 ? 4 : 8);
     const int ND = (D + 31) / 32, Dpp = ND * 32 + 1;
-    int S = 4;
+    int S = 8;  // samples staged per barrier pair: more of them amortise the staging latency
     size_t lds = 0;
     for (; S >= 1; S >>= 1) {
         lds = ((size_t)S * 32 * Dpp + (same ? 0 : (size_t)S * MTt * 32 * Dpp) + (size_t)4 * S * Dpp) * sizeof(float);
@@ -544,7 +677,7 @@ extern "C" int rp_cin_layer_bwd_w(const float *x0, int64_t ld0, const float *xp,
     if (lds > CIN_LDS_BUDGET) return rp_fail(RP_ERR_UNSUPPORTED, "cin backward-w: M=%d D=%d does not fit in LDS", M, D);
     int64_t chunk;
     int nchunk;
-    cin_bw_plan(B, O, &chunk, &nchunk, 4);
+    cin_bw_plan(B, O, &chunk, &nchunk, 8);
     float *Pw = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     float *Pb = Pw + (size_t)nchunk * O * H * M;
     dim3 grid((unsigned)((O + 3) / 4), (unsigned)nchunk);

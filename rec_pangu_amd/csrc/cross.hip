@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restri
 }
 
 // partial layout per block: [ dW (L*d) | dB (L*d) | dwfc (d) ]
+template <int MAXL>
 __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
                                                            const float *__restrict__ W, const float *__restrict__ Bv,
                                                            const float *__restrict__ wfc,
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restri
                                                            float *__restrict__ partial, int64_t B) {
     __shared__ float sh[4];
     const int t = threadIdx.x;
-    float aW[CROSS_MAXL][CROSS_J], aB[CROSS_MAXL][CROSS_J], aF[CROSS_J];
+    float aW[MAXL][CROSS_J], aB[MAXL][CROSS_J], aF[CROSS_J];
 #pragma unroll
-    for (int l = 0; l < CROSS_MAXL; ++l)
+    for (int l = 0; l < MAXL; ++l)
 #pragma unroll
         for (int j = 0; j < CROSS_J; ++j) {
             aW[l][j] = 0.f;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restri
             g[j] = v;
         }
 #pragma unroll
-        for (int l = CROSS_MAXL - 1; l >= 0; --l) {
+        for (int l = MAXL - 1; l >= 0; --l) {
             if (l >= L) continue;
             // recompute X_l from X_0 with the saved scalars
 #pragma unroll
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restri
     }
     float *P = partial + (int64_t)blockIdx.x * (2 * L + 1) * d;
 #pragma unroll
-    for (int l = 0; l < CROSS_MAXL; ++l) {
+    for (int l = 0; l < MAXL; ++l) {
         if (l >= L) continue;
 #pragma unroll
         for (int j = 0; j < CROSS_J; ++j) {
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restric
 }
 
 static int cross_blocks(int64_t B) {
-    int64_t nb = B < 1024 ? B : 1024;
+    int64_t nb = B < 2048 ? B : 2048;
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -240,8 +241,12 @@ extern "C" int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const
     float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const int nb = cross_blocks(B);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(crossnet_bwd_kernel, dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in, g_x, ldg,
-                       g_logit, dx0, lddx, P, B);
+    if (L <= 3)
+        hipLaunchKernelGGL((crossnet_bwd_kernel<3>), dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in, g_x, ldg,
+                           g_logit, dx0, lddx, P, B);
+    else
+        hipLaunchKernelGGL((crossnet_bwd_kernel<CROSS_MAXL>), dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in,
+                           g_x, ldg, g_logit, dx0, lddx, P, B);
     RP_LAUNCH_CHECK("crossnet_bwd");
     const int64_t n = (int64_t)(2 * L + 1) * d;
     const int64_t ld = (int64_t)L * d;

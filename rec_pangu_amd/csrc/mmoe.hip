@@ -87,10 +87,12 @@ __global__ __launch_bounds__(256) void mmoe_combine_bwd_kernel(const float *__re
         for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float v = dg[tt][e];
+                if (tt < T && e < E) {  // uniform: only the T*E live accumulators are reduced
+                    float v = dg[tt][e];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if ((t & 63) == 0) red[t >> 6][tt * 8 + e] = v;
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if ((t & 63) == 0) red[t >> 6][tt * 8 + e] = v;
+                }
             }
         __syncthreads();
         if (t < T) {
