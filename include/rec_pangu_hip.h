@@ -174,6 +174,15 @@ int rp_mmoe_combine_fwd(const float *z, int64_t ldz, int K, int E, int T, float 
 int rp_mmoe_combine_bwd(const float *z, int64_t ldz, int K, int E, int T, const float *gate, const float *dout,
                         float *dz, int64_t lddz, int64_t B, rp_stream_t stream);
 
+/* Streaming CrossNet backward (what rec_pangu_amd uses; rp_crossnet_bwd above is the single-kernel variant that
+ * keeps the parameter-gradient partials in registers).  X_l = A_l X_0 + C_l (A_l = 1 + sum_{k<l} s_k per sample,
+ * C_l = sum_{k<l} b_k per feature), so one wave per row produces dx0 and V[B, 2L+2] =
+ * [t_l A_l (l<L) | g_logit A_L | t_l (l<L) | g_logit]; then dW_l = (V^T X_0)[l] + C_l colsum(V)[L+1+l] etc. are one
+ * rp_linear_wgrad(V, X_0) plus [L,d]-sized weight-space arithmetic.  d <= 2048.                            */
+int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float *W, const float *wfc,
+                         const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
+                         int64_t lddx, float *V, int64_t B, rp_stream_t stream);
+
 /* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
  * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
  *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)

@@ -189,6 +189,92 @@ __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, streaming form.  CrossNet is low-rank in disguise: by induction X_l = A_l X_0 + C_l with the per-sample
+// scalar A_l = 1 + sum_{k<l} s_k and the per-feature vector C_l = sum_{k<l} b_k.  Hence
+//   t_l := dL/ds_l = g_{l+1} . X_0            g_l = g_{l+1} + t_l w_l            dX_0 = g_0 + sum_l s_l g_{l+1}
+//   dW_l = sum_b t_l X_l = X_0^T (t_l A_l) + C_l sum_b t_l        (a [B,L]^T x [B,d] product: rp_linear_wgrad)
+// so the per-row kernel needs NO parameter-gradient accumulators: one wave per row, the row (d <= 2048 -> 32
+// floats per lane) in registers, dots by wave shuffles, no barriers; it writes dX_0 and the 2L+2 scalars
+// V[b] = [t_l A_l (l<L) | gl A_L | t_l (l<L) | gl] whose product with X_0 (and column sums) give every parameter
+// gradient.  HBM traffic: X_0 read once, dX_0 written once (+ the incoming gradient row when it is not the fc).
+// ------------------------------------------------------------------------------------------------
+#define CROSS_WJ 32  // floats per lane: d <= 2048
+__global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
+                                                                const float *__restrict__ W,
+                                                                const float *__restrict__ wfc,
+                                                                const float *__restrict__ s_in,
+                                                                const float *__restrict__ g_x, int64_t ldg,
+                                                                const float *__restrict__ g_logit,
+                                                                float *__restrict__ dx0, int64_t lddx,
+                                                                float *__restrict__ V, int64_t B) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float r0[CROSS_WJ], g[CROSS_WJ], gx0[CROSS_WJ];
+    const float gl = (g_logit != nullptr) ? g_logit[b] : 0.f;
+#pragma unroll
+    for (int j = 0; j < CROSS_WJ; ++j) {
+        const int e = lane + 64 * j;
+        const bool ok = e < d;
+        r0[j] = ok ? x0[b * ldx + e] : 0.f;
+        float v = 0.f;
+        if (ok && g_x != nullptr) v += g_x[b * ldg + e];
+        if (ok && g_logit != nullptr) v += gl * wfc[e];
+        g[j] = v;
+        gx0[j] = 0.f;
+    }
+    float a_run = 1.f;  // A_L = 1 + sum_k s_k, then peeled back layer by layer
+    for (int l = 0; l < L; ++l) a_run += s_in[b * L + l];
+    float *Vb = V + b * (2 * L + 2);
+    if (lane == 0) {
+        Vb[L] = gl * a_run;
+        Vb[2 * L + 1] = gl;
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const float sl = s_in[b * L + l];
+        a_run -= sl;  // A_l
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < CROSS_WJ; ++j) part += g[j] * r0[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        const float tl = part;
+        if (lane == 0) {
+            Vb[l] = tl * a_run;
+            Vb[L + 1 + l] = tl;
+        }
+#pragma unroll
+        for (int j = 0; j < CROSS_WJ; ++j) {
+            const int e = lane + 64 * j;
+            if (e < d) {
+                gx0[j] += sl * g[j];
+                g[j] += tl * W[(int64_t)l * d + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CROSS_WJ; ++j) {
+        const int e = lane + 64 * j;
+        if (e < d) dx0[b * lddx + e] = gx0[j] + g[j];
+    }
+}
+
+extern "C" int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float *W, const float *wfc,
+                                    const float *s_in, const float *g_x, int64_t ldg, const float *g_logit,
+                                    float *dx0, int64_t lddx, float *V, int64_t B, rp_stream_t stream) {
+    RP_REQUIRE(x0 && W && s_in && dx0 && V && B >= 0, "crossnet_bwd_rows: bad argument");
+    RP_REQUIRE(g_x != nullptr || g_logit != nullptr, "crossnet_bwd_rows: no incoming gradient");
+    RP_REQUIRE(g_logit == nullptr || wfc != nullptr, "crossnet_bwd_rows: logit gradient needs wfc");
+    if (d < 1 || d > 64 * CROSS_WJ || L < 1)
+        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) unsupported", d, 64 * CROSS_WJ);
+    if (B == 0) return RP_OK;
+    hipLaunchKernelGGL(crossnet_bwd_rows_kernel, dim3((unsigned)rp_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x0,
+                       ldx, d, L, W, wfc, s_in, g_x, ldg, g_logit, dx0, lddx, V, B);
+    RP_LAUNCH_CHECK("crossnet_bwd_rows");
+    return RP_OK;
+}
+
 // out[e] = sum_k partial[k*stride + e], e < count (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblk, int64_t stride,
                                                           int64_t count, float *__restrict__ out) {

@@ -76,13 +76,25 @@ class _CrossNet(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """Streaming backward (rp_crossnet_bwd_rows): X_l = A_l X_0 + C_l, so the per-row kernel only emits dX_0 and
+        2L+2 scalars per sample; the parameter gradients are one skinny wgrad GEMM V^T X_0 plus [L,d] arithmetic."""
         x0, W, Bv, wfc, s = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.fused_fc:
-            dx0, dW, dB, dwfc = hip.crossnet_bwd(x0, ctx.d, W, Bv, wfc, s, None, g)
-            return dx0, dW, dB, dwfc.view_as(wfc), g.sum().reshape(1)
-        dx0, dW, dB, _ = hip.crossnet_bwd(x0, ctx.d, W, Bv, None, s, g, None)
-        return dx0, dW, dB, None, None
+        L, d = W.shape
+        fused = ctx.fused_fc
+        dx0, V = hip.crossnet_bwd_rows(x0, d, W, wfc if fused else None, s, None if fused else g, g if fused else None)
+        P, cs = hip.linear_wgrad(V, x0, d)                      # [2L+2, d], column sums of V
+        st, sgl = cs[L + 1:2 * L + 1], cs[2 * L + 1]             # sum_b t_l, sum_b g_logit
+        C = torch.cat([torch.zeros_like(Bv[:1]), Bv.cumsum(0)])  # C_l = sum_{k<l} b_k, l = 0..L
+        dW = P[:L] + C[:L] * st[:, None]
+        tw = W * st[:, None]                                     # w_k * sum_b t_k
+        dB = tw.flip(0).cumsum(0).flip(0) - tw                   # sum_{k>l} w_k sum_b t_k
+        if fused:
+            dB = dB + wfc.reshape(1, d) * sgl
+            dwfc = (P[L] + C[L] * sgl).view_as(wfc)
+            return dx0, dW, dB, dwfc, sgl.reshape(1)
+        _, colg = hip.linear_wgrad(g, g, 1)                      # column sums of the incoming gradient
+        return dx0, dW, dB + colg[None, :], None, None
 
 
 def crossnet(x0, W, Bv, wfc=None, bfc=None):

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_crossnet_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
                                   _i64, _vp, _sz, _vp]),
+    "rp_crossnet_bwd_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "rp_cin_layer_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
     "rp_cin_layer_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                      _i32, _i32, _i64, _vp]),
@@ -309,6 +310,21 @@ def crossnet_bwd(x0, d: int, W, Bv, wfc, s, g_x, g_logit):
                                      _rowmajor(dx0, "dx0"), dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), B, ws.data_ptr(),
                                      nbytes.value, _stream()), "rp_crossnet_bwd")
     return dx0, dW, dB, dwfc
+
+
+def crossnet_bwd_rows(x0, d: int, W, wfc, s, g_x, g_logit):
+    """-> dx0 [B, x0.shape[1]] (columns >= d zeroed), V [B, 2L+2] (see rp_crossnet_bwd_rows)."""
+    B, L = x0.shape[0], W.shape[0]
+    dx0 = torch.empty_like(x0)
+    if x0.shape[1] > d:
+        dx0[:, d:].zero_()
+    V = torch.empty((B, 2 * L + 2), dtype=torch.float32, device=x0.device)
+    ldg = _rowmajor(g_x, "g_x") if g_x is not None else 0
+    with _Timed("crossnet_bwd_rows"):
+        _check(lib().rp_crossnet_bwd_rows(x0.data_ptr(), _rowmajor(x0, "x0"), d, L, W.data_ptr(), _ptr(wfc),
+                                          s.data_ptr(), _ptr(g_x), ldg, _ptr(g_logit), dx0.data_ptr(),
+                                          _rowmajor(dx0, "dx0"), V.data_ptr(), B, _stream()), "rp_crossnet_bwd_rows")
+    return dx0, V
 
 
 def cin_layer_fwd(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool, want_pool: bool):
