@@ -25,7 +25,7 @@ __host__ __device__ static inline AttnLds attn_layout(const AttnDims &d, bool bw
     AttnLds L;
     int o = 0;
     const int TH = d.T * d.HA, PP = d.H * d.T * d.T;
-    L.X = o; o += d.T * d.Din;
+    L.X = o; o += d.T * (d.Din | 1);  // odd row stride: lanes reading different rows hit different banks
     L.Q = o; o += TH;
     L.K = o; o += TH;
     L.V = o; o += TH;
@@ -47,20 +47,26 @@ __host__ __device__ static inline AttnLds attn_layout(const AttnDims &d, bool bw
 // forward of one sample into the wave's LDS region; every lane of the block calls this (barriers inside)
 __device__ __forceinline__ void attn_forward_lds(const AttnDims &d, const AttnLds &L, float *S, const float *Ws,
                                                  const float *__restrict__ xg, bool valid, int lane) {
-    const int T = d.T, Din = d.Din, HA = d.HA, a = d.a, H = d.H, TH = T * HA;
-    for (int i = lane; i < T * Din; i += 64) S[L.X + i] = valid ? xg[i] : 0.f;
+    const int T = d.T, Din = d.Din, HA = d.HA, a = d.a, H = d.H, TH = T * HA, Dx = Din | 1;
+    for (int i = lane; i < T * Din; i += 64) {
+        const int t = i / Din, k = i - t * Din;
+        S[L.X + t * Dx + k] = valid ? xg[i] : 0.f;
+    }
     __syncthreads();
     const int nproj = d.has_res ? 4 : 3;
     for (int o = lane; o < nproj * TH; o += 64) {
         const int p = o / TH, r = o - p * TH, t = r / HA, c = r - t * HA;
-        const float *w = Ws + ((int64_t)p * HA + c) * Din;
-        const float *x = S + L.X + t * Din;
+        const float *w = Ws + (p * HA + c) * Dx;
+        const float *x = S + L.X + t * Dx;
         float acc = 0.f;
         for (int k = 0; k < Din; ++k) acc += x[k] * w[k];
         S[(p == 0 ? L.Q : p == 1 ? L.K : p == 2 ? L.V : L.R) + r] = acc;
     }
     if (!d.has_res)
-        for (int i = lane; i < TH; i += 64) S[L.R + i] = S[L.X + i];  // Din == HA: residual is X itself
+        for (int i = lane; i < TH; i += 64) {  // Din == HA: residual is X itself
+            const int t = i / HA, c = i - t * HA;
+            S[L.R + i] = S[L.X + t * Dx + c];
+        }
     __syncthreads();
     for (int o = lane; o < H * T * T; o += 64) {
         const int g = o / (T * T), r = o - g * T * T, tq = r / T, tk = r - tq * T;
@@ -102,11 +108,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnDims d, const float *
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttnLds L = attn_layout(d, false);
     const int nproj = d.has_res ? 4 : 3;
-    const int wsz = nproj * d.HA * d.Din;
-    float *Ws = smem;
+    const int wsz = nproj * d.HA * d.Din, Dx = d.Din | 1, wlds = (nproj * d.HA * Dx + 3) & ~3;
+    float *Ws = smem;  // [nproj*HA][Dx]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *S = smem + ((wsz + 3) & ~3) + wave * L.total;
-    for (int i = threadIdx.x; i < wsz; i += blockDim.x) Ws[i] = W[i];
+    float *S = smem + wlds + wave * L.total;
+    for (int i = threadIdx.x; i < wsz; i += blockDim.x) {
+        const int row = i / d.Din, k = i - row * d.Din;
+        Ws[row * Dx + k] = W[i];
+    }
     __syncthreads();
     const int TH = d.T * d.HA;
     for (int64_t base = (int64_t)blockIdx.x * NW; base < B; base += (int64_t)gridDim.x * NW) {
@@ -127,13 +136,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnDims d, const float *
     const AttnLds L = attn_layout(d, true);
     const int T = d.T, Din = d.Din, HA = d.HA, a = d.a, H = d.H, TH = T * HA;
     const int nproj = d.has_res ? 4 : 3;
-    const int wsz = nproj * HA * Din, wpad = (wsz + 3) & ~3;
-    float *Ws = smem;
-    float *Acc = smem + wpad;  // [NW][wsz] per-wave weight-gradient accumulators
+    const int wsz = nproj * HA * Din, wpad = (wsz + 3) & ~3, Dx = Din | 1, wlds = (nproj * HA * Dx + 3) & ~3;
+    float *Ws = smem;          // [nproj*HA][Dx]
+    float *Acc = smem + wlds;  // [NW][wsz] per-wave weight-gradient accumulators (dense)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *S = smem + wpad + NW * wpad + wave * L.total;
+    float *S = smem + wlds + NW * wpad + wave * L.total;
     float *A = Acc + wave * wpad;
-    for (int i = threadIdx.x; i < wsz; i += blockDim.x) Ws[i] = W[i];
+    for (int i = threadIdx.x; i < wsz; i += blockDim.x) {
+        const int row = i / Din, k = i - row * Din;
+        Ws[row * Dx + k] = W[i];
+    }
     for (int i = threadIdx.x; i < NW * wpad; i += blockDim.x) Acc[i] = 0.f;
     __syncthreads();
     for (int64_t base = (int64_t)blockIdx.x * NW; base < B; base += (int64_t)gridDim.x * NW) {
@@ -186,10 +198,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnDims d, const float *
                 const int t = o / Din, k = o - t * Din;
                 float acc = 0.f;
                 for (int c = 0; c < HA; ++c) {
-                    acc += S[L.dQ + t * HA + c] * Ws[(0 * HA + c) * Din + k];
-                    acc += S[L.dK + t * HA + c] * Ws[(1 * HA + c) * Din + k];
-                    acc += S[L.dV + t * HA + c] * Ws[(2 * HA + c) * Din + k];
-                    if (d.has_res) acc += S[L.dZ + t * HA + c] * Ws[(3 * HA + c) * Din + k];
+                    acc += S[L.dQ + t * HA + c] * Ws[(0 * HA + c) * Dx + k];
+                    acc += S[L.dK + t * HA + c] * Ws[(1 * HA + c) * Dx + k];
+                    acc += S[L.dV + t * HA + c] * Ws[(2 * HA + c) * Dx + k];
+                    if (d.has_res) acc += S[L.dZ + t * HA + c] * Ws[(3 * HA + c) * Dx + k];
                 }
                 if (!d.has_res) acc += S[L.dZ + o];  // Din == HA
                 dx[b * lddx + o] = acc;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnDims d, const float *
             const int p = o / (HA * Din), r = o - p * HA * Din, c = r / Din, k = r - c * Din;
             const float *gsrc = S + (p == 0 ? L.dQ : p == 1 ? L.dK : p == 2 ? L.dV : L.dZ);
             float acc = 0.f;
-            for (int t = 0; t < T; ++t) acc += gsrc[t * HA + c] * S[L.X + t * Din + k];
+            for (int t = 0; t < T; ++t) acc += gsrc[t * HA + c] * S[L.X + t * Dx + k];
             A[o] += acc;  // invalid samples contribute exact zeros (X = 0, dZ = 0)
         }
         __syncthreads();
@@ -228,8 +240,9 @@ static int attn_plan(const AttnDims &d, bool bwd, int *NW, size_t *lds) {
     const AttnLds L = attn_layout(d, bwd);
     const int nproj = d.has_res ? 4 : 3;
     const size_t wpad = ((size_t)nproj * d.HA * d.Din + 3) & ~(size_t)3;
+    const size_t wlds = ((size_t)nproj * d.HA * (d.Din | 1) + 3) & ~(size_t)3;
     for (int nw = 4; nw >= 1; --nw) {
-        const size_t need = (wpad + (bwd ? nw * wpad : 0) + (size_t)nw * L.total) * sizeof(float);
+        const size_t need = (wlds + (bwd ? nw * wpad : 0) + (size_t)nw * L.total) * sizeof(float);
         if (need <= ATTN_LDS_BUDGET) {
             *NW = nw;
             *lds = need;
@@ -259,7 +272,8 @@ extern "C" int rp_field_attention_fits(int T, int Din, int H, int a, int has_res
     d.T = T; d.Din = Din; d.H = H; d.a = a; d.HA = H * a; d.has_res = has_res ? 1 : 0; d.inv_scale = 1.f;
     const AttnLds L = attn_layout(d, true);
     const size_t wpad = ((size_t)(has_res ? 4 : 3) * d.HA * Din + 3) & ~(size_t)3;
-    return ((2 * wpad + (size_t)L.total) * sizeof(float) <= ATTN_LDS_BUDGET) ? 1 : 0;
+    const size_t wlds = ((size_t)(has_res ? 4 : 3) * d.HA * (Din | 1) + 3) & ~(size_t)3;
+    return ((wlds + wpad + (size_t)L.total) * sizeof(float) <= ATTN_LDS_BUDGET) ? 1 : 0;
 }
 
 extern "C" int rp_field_attention_fwd(const float *x, int64_t ldx, const float *W, int T, int Din, int H, int a,
