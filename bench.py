@@ -88,10 +88,9 @@ def pmc_traffic(entry):
         pmc = json.load(open(files[-1]))
     except Exception:
         return None
-    for k, v in pmc.items():
-        if k.startswith(entry + "_kernel") and "hbm_bytes_per_launch" in v:
-            return v["hbm_bytes_per_launch"]
-    return None
+    hits = [v["hbm_bytes_per_launch"] for k, v in pmc.items()
+            if k.startswith(entry + "_kernel") and "hbm_bytes_per_launch" in v]
+    return hits[0] if len(hits) == 1 else None  # several template variants behind one entry point: ambiguous
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -255,6 +254,26 @@ def main():
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
         "adam_step": 7 * 4 * (n_params),
     }
+    d_in = F * D + ND
+    alg_bytes["crossnet_fwd"] = local_B * d_in * 4                      # X_0 read once, only a logit leaves
+    alg_bytes["crossnet_bwd_rows"] = 2 * local_B * d_in * 4             # X_0 read, dX_0 written
+    if args.model == "mmoe":
+        K_, E_, T_ = model.mmoe_hidden_dim, model.n_expert, model.num_task
+        alg_bytes["mmoe_combine_fwd"] = local_B * 4 * (K_ * E_ + T_ * E_ + T_ * K_)
+        alg_bytes["mmoe_combine_bwd"] = local_B * 4 * (2 * (K_ * E_ + T_ * E_) + T_ * K_)
+    if args.model == "autoint":
+        att = model.self_attention[0]
+        alg_bytes["field_attention_fwd"] = local_B * 4 * F * (D + att.output_dim)
+        alg_bytes["field_attention_bwd"] = local_B * 4 * F * (2 * D + att.output_dim)
+    mfma_flops = {}
+    if args.model == "xdeepfm":
+        units, Mi, per = list(model.cin.cin_layer_units), F, 0
+        for i, O_ in enumerate(units):
+            per += 2 * F * Mi * (O_ if i + 1 < len(units) else 1) * D   # the last layer runs collapsed to O = 1
+            Mi = O_
+        # flop per launch averaged over the launches of a step (fwd: one chain; bwd_x: two chains; bwd_w: one)
+        mfma_flops = {"cin_layer_fwd": local_B * per / len(units), "cin_layer_bwd_x": 2 * local_B * per / len(units),
+                      "cin_layer_bwd_w": local_B * per / len(units)}
     mlp_flops = None
     if args.model == "deepfm" and hidden != (64, 64, 64):
         dims = [F * D + ND] + list(hidden) + [1]
@@ -264,7 +283,6 @@ def main():
     if args.model == "deepfm" and hidden == (64, 64, 64):
         # mean algorithmic bytes per launch over the launches of one step (activations in + out, fp32);
         # forward 1677->64->64->64->1 plus the four dgrad launches on the transposed weights / four wgrad launches
-        d_in = F * D + ND
         alg_bytes["linear_fwd"] = local_B * 4 * 2 * ((d_in + 64) + 2 * (64 + 64) + (64 + 1)) // 8
         alg_bytes["linear_wgrad"] = local_B * 4 * ((d_in + 64) + 2 * (64 + 64) + (64 + 1)) // 4
     kernels = {}
@@ -273,10 +291,15 @@ def main():
         if name in alg_bytes:
             k["algorithmic_GBps"] = round(alg_bytes[name] / (mean_ms * 1e-3) / 1e9, 1)
         kernels[name] = k
-    total = {n: c * m for n, (c, m) in timing.items() if n in alg_bytes}
+    total = {n: c * m for n, (c, m) in timing.items() if n in alg_bytes or n in mfma_flops}
     dominant = max(total, key=total.get) if total else None
     roofline = None
-    if dominant in alg_bytes:
+    if dominant in mfma_flops:
+        tf = mfma_flops[dominant] / (timing[dominant][1] * 1e-3) / 1e12
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": round(tf / 157.3, 4), "traffic": None,
+                    "note": "exact-fp32 MFMA peak; flops per launch = mean over this entry's launches in a step"}
+    elif dominant in alg_bytes:
         a = alg_bytes[dominant] / (timing[dominant][1] * 1e-3) / 1e9
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(a / HBM_PEAK_GBS, 4),
