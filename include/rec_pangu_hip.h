@@ -183,6 +183,34 @@ int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float
                          const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
                          int64_t lddx, float *V, int64_t B, rp_stream_t stream);
 
+/* ---- stand-alone FM pooling on a [B,F,D] tensor -------------------------------------------------------
+ * replaces layers/interaction.py:36-44 when the caller already holds the stacked embeddings (in DeepFM/FM the
+ * gather kernel produces the term itself).  x[b] = F rows of D floats at x + b*ldb.
+ *   out_sum [B] = product_sum_pooling, out_bi [B,D] = Bi_interaction_pooling (either may be NULL)
+ *   backward: dx[b,f,:] = (g_sum[b] + g_bi[b,:]) * (sum_f x[b,f,:] - x[b,f,:])                             */
+int rp_fm_pool_fwd(const float *x, int64_t ldb, int F, int D, float *out_sum, float *out_bi, int64_t B,
+                   rp_stream_t stream);
+int rp_fm_pool_bwd(const float *x, int64_t ldb, int F, int D, const float *g_sum, const float *g_bi, float *dx,
+                   int64_t lddx, int64_t B, rp_stream_t stream);
+
+/* ---- K9: BatchNorm1d of the MMOE towers ---------------------------------------------------------------
+ * replaces nn.BatchNorm1d at multi_task/mmoe.py:54.  Training: batch mean / biased variance per column
+ * (deterministic two-stage reductions, variance taken around the mean), y = (x-mean)*rstd*gamma+beta; the caller
+ * updates the running statistics from mean/var.  Backward: dgamma = sum dy*xhat, dbeta = sum dy,
+ * dx = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)).  rp_batchnorm_apply(_bwd): given statistics (eval mode). */
+int rp_batchnorm_workspace_bytes(int64_t M, int N, size_t *bytes);
+int rp_batchnorm_train_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta, float eps, float *y,
+                           int64_t ldy, float *mean, float *var, float *rstd, int64_t M, int N, void *workspace,
+                           size_t workspace_bytes, rp_stream_t stream);
+int rp_batchnorm_train_bwd(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
+                           const float *rstd, const float *gamma, float *dx, int64_t lddx, float *dgamma,
+                           float *dbeta, int64_t M, int N, void *workspace, size_t workspace_bytes,
+                           rp_stream_t stream);
+int rp_batchnorm_apply(const float *x, int64_t ldx, const float *mean, const float *rstd, const float *gamma,
+                       const float *beta, float *y, int64_t ldy, int64_t M, int N, rp_stream_t stream);
+int rp_batchnorm_apply_bwd(const float *dy, int64_t lddy, const float *rstd, const float *gamma, float *dx,
+                           int64_t lddx, int64_t M, int N, rp_stream_t stream);
+
 /* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
  * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
  *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)

@@ -229,6 +229,88 @@ def mmoe_combine(z, K: int, E: int, T: int):
 
 
 # ----------------------------------------------------------------------------------------------
+# stand-alone FM pooling ([B,F,D] already materialised)   — layers/interaction.py:36-44
+# ----------------------------------------------------------------------------------------------
+class _FMPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, F: int, D: int, bi: bool):
+        x2d = _unit_inner(x2d)
+        out_sum, out_bi = hip.fm_pool_fwd(x2d, F, D, not bi, bi)
+        ctx.cfg = (F, D, bi)
+        ctx.save_for_backward(x2d)
+        return out_bi if bi else out_sum
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2d,) = ctx.saved_tensors
+        F, D, bi = ctx.cfg
+        g = g.contiguous()
+        return hip.fm_pool_bwd(x2d, F, D, None if bi else g, g if bi else None), None, None, None
+
+
+def fm_pool(feature_emb, bi_interaction: bool = False):
+    """feature_emb [B,F,D] (any row stride) -> product_sum_pooling [B,1] or Bi_interaction_pooling [B,D]."""
+    B, F, D = feature_emb.shape
+    return _FMPool.apply(feature_emb.reshape(B, F * D), F, D, bi_interaction)
+
+
+# ----------------------------------------------------------------------------------------------
+# K9  BatchNorm1d (MMOE towers)   — multi_task/mmoe.py:54
+# ----------------------------------------------------------------------------------------------
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        x = _unit_inner(x)
+        y, mean, var, rstd = hip.batchnorm_train_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _gm, _gv):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta = hip.batchnorm_train_bwd(x, _unit_inner(dy), mean, rstd, gamma)
+        return dx, (dgamma if gamma is not None else None), dbeta, None
+
+
+class _BatchNormApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, rstd, gamma, beta):
+        x = _unit_inner(x)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return hip.batchnorm_apply(x, mean, rstd, gamma, beta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dy = _unit_inner(dy)
+        dx = hip.batchnorm_apply_bwd(dy, rstd, gamma)
+        dgamma = dbeta = None
+        if gamma is not None and ctx.needs_input_grad[3]:
+            dgamma = (dy * ((x - mean) * rstd)).sum(dim=0)  # eval-mode fine-tuning is off the hot path
+        if ctx.needs_input_grad[4]:
+            dbeta = dy.sum(dim=0)
+        return dx, None, None, dgamma, dbeta
+
+
+def batch_norm(x, bn: torch.nn.BatchNorm1d):
+    """nn.BatchNorm1d semantics on the HIP kernels, including the running-statistics update in training mode."""
+    use_batch = bn.training or not bn.track_running_stats or bn.running_mean is None
+    if use_batch:
+        y, mean, var = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps)
+        if bn.training and bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                M = x.shape[0]
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+        return y
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    return _BatchNormApply.apply(x, bn.running_mean, rstd, bn.weight, bn.bias)
+
+
+# ----------------------------------------------------------------------------------------------
 # K10  sum of logits -> sigmoid -> BCE(mean)   — ranking/deepfm.py:61-63, multi_task/mmoe.py:127
 # ----------------------------------------------------------------------------------------------
 class _SigmoidBCE(torch.autograd.Function):

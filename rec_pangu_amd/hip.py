@@ -52,6 +52,14 @@ _SIGNATURES = {
                                          _vp, _sz, _vp]),
     "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "rp_fm_pool_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "rp_fm_pool_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "rp_batchnorm_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_batchnorm_train_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "rp_batchnorm_train_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz,
+                                         _vp]),
+    "rp_batchnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_batchnorm_apply_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
@@ -424,6 +432,81 @@ def mmoe_combine_bwd(z, K: int, E: int, T: int, gate, dout):
         _check(lib().rp_mmoe_combine_bwd(z.data_ptr(), _rowmajor(z, "z"), K, E, T, gate.data_ptr(), dout.data_ptr(),
                                          dz.data_ptr(), K * E + T * E, B, _stream()), "rp_mmoe_combine_bwd")
     return dz
+
+
+def fm_pool_fwd(x2d, F: int, D: int, want_sum: bool, want_bi: bool):
+    """x2d [B, >=F*D] -> (sum [B,1] or None, bi [B,D] or None)."""
+    _req(x2d, torch.float32, "x")
+    B = x2d.shape[0]
+    out_sum = torch.empty((B, 1), dtype=torch.float32, device=x2d.device) if want_sum else None
+    out_bi = torch.empty((B, D), dtype=torch.float32, device=x2d.device) if want_bi else None
+    with _Timed("fm_pool_fwd"):
+        _check(lib().rp_fm_pool_fwd(x2d.data_ptr(), _rowmajor(x2d, "x"), F, D, _ptr(out_sum), _ptr(out_bi), B,
+                                    _stream()), "rp_fm_pool_fwd")
+    return out_sum, out_bi
+
+
+def fm_pool_bwd(x2d, F: int, D: int, g_sum, g_bi):
+    dx = torch.empty_like(x2d)
+    if x2d.shape[1] > F * D:
+        dx[:, F * D:].zero_()
+    with _Timed("fm_pool_bwd"):
+        _check(lib().rp_fm_pool_bwd(x2d.data_ptr(), _rowmajor(x2d, "x"), F, D, _ptr(g_sum), _ptr(g_bi), dx.data_ptr(),
+                                    _rowmajor(dx, "dx"), x2d.shape[0], _stream()), "rp_fm_pool_bwd")
+    return dx
+
+
+def _bn_ws(M, N, dev):
+    nbytes = _sz(0)
+    _check(lib().rp_batchnorm_workspace_bytes(M, N, C.byref(nbytes)), "rp_batchnorm_workspace_bytes")
+    return torch.empty((nbytes.value,), dtype=torch.uint8, device=dev), nbytes.value
+
+
+def batchnorm_train_fwd(x, gamma, beta, eps: float):
+    """-> y, mean [N], var [N] (biased), rstd [N]"""
+    _req(x, torch.float32, "x")
+    M, N = x.shape
+    dev = x.device
+    y = torch.empty((M, N), dtype=torch.float32, device=dev)
+    mean, var, rstd = (torch.empty((N,), dtype=torch.float32, device=dev) for _ in range(3))
+    ws, nb = _bn_ws(M, N, dev)
+    with _Timed("batchnorm_train_fwd"):
+        _check(lib().rp_batchnorm_train_fwd(x.data_ptr(), _rowmajor(x, "x"), _ptr(gamma), _ptr(beta), eps, y.data_ptr(),
+                                            N, mean.data_ptr(), var.data_ptr(), rstd.data_ptr(), M, N, ws.data_ptr(),
+                                            nb, _stream()), "rp_batchnorm_train_fwd")
+    return y, mean, var, rstd
+
+
+def batchnorm_train_bwd(x, dy, mean, rstd, gamma):
+    M, N = x.shape
+    dev = x.device
+    dx = torch.empty((M, N), dtype=torch.float32, device=dev)
+    dgamma, dbeta = (torch.empty((N,), dtype=torch.float32, device=dev) for _ in range(2))
+    ws, nb = _bn_ws(M, N, dev)
+    with _Timed("batchnorm_train_bwd"):
+        _check(lib().rp_batchnorm_train_bwd(x.data_ptr(), _rowmajor(x, "x"), dy.data_ptr(), _rowmajor(dy, "dy"),
+                                            mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), dx.data_ptr(), N,
+                                            dgamma.data_ptr(), dbeta.data_ptr(), M, N, ws.data_ptr(), nb, _stream()),
+               "rp_batchnorm_train_bwd")
+    return dx, dgamma, dbeta
+
+
+def batchnorm_apply(x, mean, rstd, gamma, beta):
+    M, N = x.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _Timed("batchnorm_apply"):
+        _check(lib().rp_batchnorm_apply(x.data_ptr(), _rowmajor(x, "x"), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+                                        _ptr(beta), y.data_ptr(), N, M, N, _stream()), "rp_batchnorm_apply")
+    return y
+
+
+def batchnorm_apply_bwd(dy, rstd, gamma):
+    M, N = dy.shape
+    dx = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    with _Timed("batchnorm_apply_bwd"):
+        _check(lib().rp_batchnorm_apply_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), rstd.data_ptr(), _ptr(gamma),
+                                            dx.data_ptr(), N, M, N, _stream()), "rp_batchnorm_apply_bwd")
+    return dx
 
 
 def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tensor], apply_sigmoid: bool = True,

@@ -64,6 +64,9 @@ class MLP(nn.Module):
                 fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE)
                 i += 2 if fuse_relu else 1
+            elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2:
+                x = Fh.batch_norm(x, m)
+                i += 1
             elif isinstance(m, nn.Dropout) and not (self.training and m.p > 0):
                 i += 1
             else:

@@ -22,6 +22,9 @@ class InnerProductLayer(nn.Module):
         self._output_type = output
 
     def forward(self, feature_emb):
+        if feature_emb.is_cuda and feature_emb.dtype == torch.float32 and feature_emb.shape[-1] % 4 == 0:
+            from ... import functional as Fh
+            return Fh.fm_pool(feature_emb, self._output_type == "Bi_interaction_pooling")
         field_sum = feature_emb.sum(dim=1)
         bi = 0.5 * (field_sum * field_sum - (feature_emb * feature_emb).sum(dim=1))
         if self._output_type == "Bi_interaction_pooling":

@@ -101,7 +101,7 @@ class MMOE(BaseModel):
 
     def _forward_hip(self, data, is_training):
         """HIP path: gather+concat -> ONE fp32-MFMA GEMM over [experts | gates] -> gate softmax + combine kernel
-        -> towers (Linear on the MFMA kernel; BatchNorm1d/Dropout as they are) -> sigmoid+BCE(p+1e-6) kernel."""
+        -> towers (Linear on the MFMA kernel, BatchNorm1d on rp_batchnorm_*; Dropout as it is) -> sigmoid+BCE(p+1e-6) kernel."""
         x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
         h, K, E, T = self.experts.shape[0], self.mmoe_hidden_dim, self.n_expert, self.num_task
         w_cat = torch.cat([self.experts.reshape(h, K * E)] + self.gates, dim=1)
@@ -115,6 +115,8 @@ class MMOE(BaseModel):
                     x_t = Fh.linear_act(x_t, mod.weight, mod.bias, Fh.ACT_NONE)
                 elif isinstance(mod, nn.Sigmoid):
                     break  # fused into the loss / prediction kernel below
+                elif isinstance(mod, nn.BatchNorm1d):
+                    x_t = Fh.batch_norm(x_t, mod)
                 elif isinstance(mod, nn.Dropout) and not (self.training and mod.p > 0):
                     continue
                 else:

@@ -206,3 +206,73 @@ def test_mmoe_expert_gemm_and_combine_vs_oracle(B, h, ld, K, E, T):
     _close(dx.grad[:, :h].cpu(), rx.grad, rel=2e-4, what="d hidden")
     _close(de.grad.cpu(), re.grad, rel=2e-4, what="d experts")
     _close(db.grad.cpu(), rb.grad, rel=2e-4, what="d experts_bias")
+
+
+# ------------------------------------------------------------------------------------------------ FM pooling
+def test_fm_pool_vs_reference_fixture():
+    from rec_pangu_amd.models.layers import InnerProductLayer
+    ip = load_golden("layers.npz")["ip"]
+    x = ip["in"].to(DEV)
+    for mode in ("product_sum_pooling", "Bi_interaction_pooling"):
+        from rec_pangu_amd import hip
+        n0 = hip.launch_count()
+        y = InnerProductLayer(output=mode)(x)
+        assert hip.launch_count() > n0
+        _close(y.cpu(), ip[mode], rel=1e-5, what=mode)
+
+
+@pytest.mark.parametrize("B,F,D", [(1000, 26, 16), (65, 3, 4), (7, 39, 40), (300, 10, 256), (1, 1, 8)])
+def test_fm_pool_fwd_bwd_vs_torch(B, F, D):
+    from rec_pangu_amd import functional as Fh
+    g = torch.Generator().manual_seed(B + F)
+    x = torch.randn(B, F, D, generator=g)
+    for bi in (False, True):
+        xr = x.clone().requires_grad_(True)
+        s = xr.sum(1)
+        ref = 0.5 * (s * s - (xr * xr).sum(1))
+        ref = ref if bi else ref.sum(-1, keepdim=True)
+        w = torch.randn(ref.shape, generator=g)
+        (ref * w).sum().backward()
+        xd = x.to(DEV).requires_grad_(True)
+        y = Fh.fm_pool(xd, bi)
+        (y * w.to(DEV)).sum().backward()
+        _close(y.detach().cpu(), ref.detach(), rel=2e-5, floor=1e-2, what="fm out")
+        _close(xd.grad.cpu(), xr.grad, rel=2e-5, what="fm dx")
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm1d
+@pytest.mark.parametrize("M,N", [(4096, 64), (1000, 128), (257, 7), (2, 300), (70000, 32)])
+def test_batchnorm_train_and_eval_vs_torch(M, N):
+    from rec_pangu_amd import functional as Fh, hip
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g) * 3 + 5
+    w = torch.randn(M, N, generator=g)
+    ref_bn = torch.nn.BatchNorm1d(N)
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.rand(N, generator=g) + 0.5)
+        ref_bn.bias.copy_(torch.randn(N, generator=g))
+    import copy
+    bn = copy.deepcopy(ref_bn).to(DEV)
+    for step in range(2):  # two steps: running statistics and num_batches_tracked follow nn.BatchNorm1d
+        xr = x.clone().requires_grad_(True)
+        yr = ref_bn(xr)
+        (yr * w).sum().backward()
+        xd = x.to(DEV).requires_grad_(True)
+        n0 = hip.launch_count()
+        y = Fh.batch_norm(xd, bn)
+        (y * w.to(DEV)).sum().backward()
+        assert hip.launch_count() > n0
+        _close(y.detach().cpu(), yr.detach(), rel=2e-5, what="bn y")
+        _close(xd.grad.cpu(), xr.grad, rel=1e-4, floor=1e-2, what="bn dx")
+        _close(bn.weight.grad.cpu(), ref_bn.weight.grad, rel=1e-4, floor=1.0, what="bn dgamma")
+        _close(bn.bias.grad.cpu(), ref_bn.bias.grad, rel=1e-4, floor=1.0, what="bn dbeta")
+        _close(bn.running_mean.cpu(), ref_bn.running_mean, rel=1e-4, what="bn running_mean")
+        _close(bn.running_var.cpu(), ref_bn.running_var, rel=1e-4, what="bn running_var")
+        assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == step + 1
+    ref_bn.eval(); bn.eval()
+    xr = x.clone().requires_grad_(True)
+    yr = ref_bn(xr); (yr * w).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    y = Fh.batch_norm(xd, bn); (y * w.to(DEV)).sum().backward()
+    _close(y.detach().cpu(), yr.detach(), rel=2e-5, what="bn eval y")
+    _close(xd.grad.cpu(), xr.grad, rel=2e-5, what="bn eval dx")
