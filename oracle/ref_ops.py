@@ -190,6 +190,21 @@ def fm(sd, enc_dict, data, is_training=True):
     return _finish(fm_second_order(emb), data, is_training)
 
 
+def wdl(sd, enc_dict, data, is_training=True):
+    """ranking/wdl.py:57-66: logit = LR_Layer(data) + MLP(cat(emb_flat, dense))."""
+    _, x = _dnn_input(sd, enc_dict, data)
+    logit = lr_layer(sd, "lr.", enc_dict, data) + mlp_relu(x, sd, "dnn.net.", _linear_ids(sd, "dnn.net."))
+    return _finish(logit, data, is_training)
+
+
+def nfm(sd, enc_dict, data, is_training=True):
+    """ranking/nfm.py:55-68: logit = LR_Layer(data) + MLP(Bi_interaction_pooling(emb)) — MLP input is [B, D]."""
+    emb = embedding_all(_tables(sd, _EMB, enc_dict), enc_dict, data)
+    logit = lr_layer(sd, "lr.", enc_dict, data) + mlp_relu(fm_bi_interaction(emb), sd, "dnn.net.",
+                                                           _linear_ids(sd, "dnn.net."))
+    return _finish(logit, data, is_training)
+
+
 def dcn(sd, enc_dict, data, is_training=True):
     """ranking/dcn.py:57-67: sigmoid(fc(CrossNet(cat(emb_flat, dense)))) — no deep branch."""
     _, x = _dnn_input(sd, enc_dict, data)

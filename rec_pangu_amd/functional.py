@@ -369,11 +369,13 @@ def sigmoid_sum(addends: Sequence[torch.Tensor]):
 # ----------------------------------------------------------------------------------------------
 class _EmbedGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, store, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, want_fm: bool, *tables):
-        need_grad = any(ctx.needs_input_grad[5:])
+    def forward(ctx, store, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, want_fm: bool, meta,
+                *tables):
+        need_grad = any(ctx.needs_input_grad[6:])
         pre = store._presorted  # set by the lazy-Adam replay: keys already computed and sorted for this batch
         store._presorted = None
-        x, fm, ssum, keys = hip.embed_gather_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx,
+        row_base, row_count = meta if meta is not None else (store.row_base, store.row_count)
+        x, fm, ssum, keys = hip.embed_gather_fwd(store.arena, row_base, row_count, idx, dense, ldx,
                                                  want_fm, want_fm and need_grad, need_grad and pre is None,
                                                  store.err_flag)
         ctx.store, ctx.want_fm, ctx.B = store, want_fm, idx[0].shape[0]
@@ -393,9 +395,11 @@ class _EmbedGather(torch.autograd.Function):
             dx = _unit_inner(dx)
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
         store.accumulate_grad(keys, ctx.B, dx, gfm, ssum, presorted=ctx.presorted)
-        return (None,) * (5 + len(store.emb_feature))
+        return (None,) * (6 + len(store.emb_feature))
 
 
-def embed_gather(store, idx, dense, ldx: int, want_fm: bool):
+def embed_gather(store, idx, dense, ldx: int, want_fm: bool, meta=None):
+    """`meta` = (row_base, row_count) of the tables `idx` addresses when that is a subset of the store's fields
+    (single-field / sequence lookups); None = all fields in order."""
     tables = [store.embedding_layer[c].weight for c in store.emb_feature]
-    return _EmbedGather.apply(store, idx, dense, ldx, want_fm, *tables)
+    return _EmbedGather.apply(store, idx, dense, ldx, want_fm, meta, *tables)

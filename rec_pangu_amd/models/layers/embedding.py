@@ -224,21 +224,26 @@ class EmbeddingLayer(nn.Module):
     def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 32):
         """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
         self._ensure_packed()
-        F, D = len(self.emb_feature), self.embedding_dim
+        return self._gather(self._idx_list(X), None, dense, want_fm, pad_to)
+
+    def _gather(self, idx, meta, dense, want_fm: bool, pad_to: int):
+        """idx: one contiguous int64 [n] per addressed table; meta = (row_base, row_count) of those tables or None
+        for all fields in order."""
+        F, D = len(idx), self.embedding_dim
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
-        idx = self._idx_list(X)
+        row_base, row_count = meta if meta is not None else (self.row_base, self.row_count)
         self._presorted = None
         if self._lazy is not None and self._lazy.t > 0:
             # exact lazy dense Adam: the rows this batch reads must first replay the zero-gradient steps they
             # skipped.  The (row, position) sort the backward needs anyway is done here and reused there.
             from ... import hip
-            keys = hip.embed_keys(self.row_base, self.row_count, idx, self.err_flag)
+            keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
             self._lazy.replay(self, sk)
             self._presorted = (keys, sk, sp)
-        out = Fh.embed_gather(self, idx, dense, ldx, want_fm)
+        out = Fh.embed_gather(self, idx, dense, ldx, want_fm, meta)
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)
@@ -254,7 +259,16 @@ class EmbeddingLayer(nn.Module):
                 inp = X[col].long().view(-1, 1)
                 feature_emb_list.append(self.embedding_layer[col](inp))
             return torch.stack(feature_emb_list, dim=1).squeeze(2)
-        # single-field / sequence lookups (embedding.py:64-71) are off the ranking hot path: torch op
+        # single-field / sequence lookups (embedding.py:64-71): the same gather kernel over ONE table, every
+        # (sample, position) of a `_seq` column being one row of the batch it sees
+        base_name = name.replace("_seq", "") if "seq" in name else name
+        if self._arena.is_cuda:
+            i = self.emb_feature.index(base_name)
+            ids = X[name].long()
+            shape = tuple(ids.shape) if "seq" in name else (ids.numel(), 1)
+            meta = (self.row_base[i:i + 1], self.row_count[i:i + 1])
+            x, _ = self._gather([ids.reshape(-1).contiguous()], meta, [], False, 1)
+            return x.view(*shape, self.embedding_dim)
         if "seq" in name:
             inp = X[name].long()
             fea = self.embedding_layer[name.replace("_seq", "")](inp)

@@ -33,7 +33,7 @@ _ref_import.install()
 
 import pandas as pd  # noqa: E402
 import torch  # noqa: E402
-from rec_pangu.models.ranking import DeepFM, xDeepFM, DCN, AutoInt, FM  # noqa: E402
+from rec_pangu.models.ranking import DeepFM, xDeepFM, DCN, AutoInt, FM, WDL, NFM  # noqa: E402
 from rec_pangu.models.multi_task import MMOE  # noqa: E402
 from rec_pangu.models.layers import (EmbeddingLayer, InnerProductLayer, CrossNet,  # noqa: E402
                                      CompressedInteractionNet, MultiHeadSelfAttention, MLP, LR_Layer)
@@ -80,7 +80,12 @@ def to_np(t):
     return t.detach().cpu().numpy().copy()
 
 
+ONLY = None  # set from the command line: regenerate just these model cases
+
+
 def dump_model_case(name, build, seed=1234, train_mode=False, extra=None):
+    if ONLY is not None and name not in ONLY:
+        return
     out = {}
     torch.manual_seed(seed)
     model = build()
@@ -138,6 +143,8 @@ def make_models():
     enc = small_enc_dict()
     dump_model_case("deepfm", lambda: DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), train_mode=True)
     dump_model_case("fm", lambda: FM(embedding_dim=8, enc_dict=enc), train_mode=True)
+    dump_model_case("wdl", lambda: WDL(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), train_mode=True)
+    dump_model_case("nfm", lambda: NFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), train_mode=True)
     dump_model_case("dcn", lambda: DCN(embedding_dim=8, crossing_layers=3, enc_dict=enc), train_mode=True)
     # default MLP dropout 0.1 in xDeepFM/AutoInt -> compare in eval()
     dump_model_case("xdeepfm", lambda: xDeepFM(embedding_dim=8, dnn_hidden_units=[16, 8],
@@ -355,6 +362,10 @@ def make_dataset_and_trainer():
 
 
 if __name__ == "__main__":
-    make_models()
-    make_layers()
-    make_dataset_and_trainer()
+    if len(sys.argv) > 1:  # e.g. `make_golden.py wdl nfm`: only those model_<name>.npz files
+        ONLY = set(sys.argv[1:])
+        make_models()
+    else:
+        make_models()
+        make_layers()
+        make_dataset_and_trainer()

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import load_golden, small_enc_dict
-from rec_pangu_amd.models.ranking import DeepFM, xDeepFM, DCN, AutoInt, FM
+from rec_pangu_amd.models.ranking import DeepFM, xDeepFM, DCN, AutoInt, FM, WDL, NFM, LR
 from rec_pangu_amd.models.multi_task import MMOE
 
 torch.set_num_threads(1)
@@ -15,6 +15,8 @@ torch.set_num_threads(1)
 CASES = {
     "deepfm": (lambda enc: DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), True),
     "fm": (lambda enc: FM(embedding_dim=8, enc_dict=enc), True),
+    "wdl": (lambda enc: WDL(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), True),
+    "nfm": (lambda enc: NFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), True),
     "dcn": (lambda enc: DCN(embedding_dim=8, crossing_layers=3, enc_dict=enc), True),
     "xdeepfm": (lambda enc: xDeepFM(embedding_dim=8, dnn_hidden_units=[16, 8], cin_layer_units=[6, 4], enc_dict=enc), False),
     "autoint_h2": (lambda enc: AutoInt(embedding_dim=8, dnn_hidden_units=[16, 8], attention_layers=2, num_heads=2,
@@ -104,6 +106,8 @@ def test_constructor_signatures():
     assert sig(AutoInt) == dict(embedding_dim=32, dnn_hidden_units=[64, 64, 64], attention_layers=1, num_heads=1,
                                 attention_dim=8, loss_fun='torch.nn.BCELoss()', enc_dict=None)
     assert sig(FM) == dict(embedding_dim=32, loss_fun='torch.nn.BCELoss()', enc_dict=None)
+    assert sig(WDL) == sig(NFM) == sig(DeepFM)
+    assert sig(LR) == dict(loss_fun='torch.nn.BCELoss()', enc_dict=None)
     assert sig(MMOE) == dict(num_task=2, n_expert=3, embedding_dim=40, mmoe_hidden_dim=128, expert_activation=None,
                              hidden_dim=[128, 64], dropouts=[0.2, 0.2], enc_dict=None, device=None)
 

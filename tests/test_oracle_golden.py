@@ -40,6 +40,14 @@ def test_fm():
     _model_case("fm", lambda sd, enc, b, g: R.fm(sd, enc, b))
 
 
+def test_wdl():
+    _model_case("wdl", lambda sd, enc, b, g: R.wdl(sd, enc, b))
+
+
+def test_nfm():
+    _model_case("nfm", lambda sd, enc, b, g: R.nfm(sd, enc, b))
+
+
 def test_dcn():
     _model_case("dcn", lambda sd, enc, b, g: R.dcn(sd, enc, b))
 
