@@ -241,18 +241,13 @@ def autoint(sd, enc_dict, data, num_heads, attention_dim, is_training=True):
     return _finish(logit, data, is_training)
 
 
-def mmoe(sd, gates, gates_bias, enc_dict, data, num_task, training=False, is_training=True, bn_eps=1e-5):
-    """multi_task/mmoe.py:81-130.  experts einsum 'ij,jkl->ikl' + bias; per-task softmax gate (gates are
-    the UNREGISTERED N(0,1) tensors of mmoe.py:43-47, passed separately); gate-weighted sum over experts;
-    tower = [Linear -> BatchNorm1d -> Dropout]* -> Linear -> Sigmoid with NO activation in between;
-    loss = sum_t (1/T) BCE(p_t + 1e-6, y_t).  `training` selects BatchNorm batch statistics
-    (dropout must be 0 for a deterministic comparison)."""
-    _, hidden = _dnn_input(sd, enc_dict, data)
-    eo = torch.einsum("ij,jkl->ikl", hidden, sd["experts"]) + sd["experts_bias"]
+def task_towers(sd, inputs, data, num_task, training, is_training, p_eps=0.0, bn_eps=1e-5):
+    """The tower stack every multi-task model builds (mmoe.py:44-56 etc.): [Linear -> BatchNorm1d -> Dropout]* ->
+    Linear -> Sigmoid with NO activation in between; loss = sum_t (1/T) BCE(p_t + p_eps, y_t).  `training` selects
+    BatchNorm batch statistics (dropout must be 0 for a deterministic comparison)."""
     out, task_outputs = {}, []
     for t in range(num_task):
-        g = torch.softmax(hidden @ gates[t] + gates_bias[t], dim=-1)
-        x = (eo * g.unsqueeze(1)).sum(dim=2)
+        x = inputs[t]
         p, j = f"task_{t + 1}_dnn.", 0
         while f"{p}ctr_hidden_{j}.weight" in sd:
             x = x @ sd[f"{p}ctr_hidden_{j}.weight"].t() + sd[f"{p}ctr_hidden_{j}.bias"]
@@ -269,9 +264,49 @@ def mmoe(sd, gates, gates_bias, enc_dict, data, num_task, training=False, is_tra
     if is_training:
         loss = 0
         for t, x in enumerate(task_outputs):
-            loss = loss + (1.0 / num_task) * F.binary_cross_entropy(x.squeeze(-1) + 1e-6, data[f"task{t + 1}_label"])
+            loss = loss + (1.0 / num_task) * F.binary_cross_entropy(x.squeeze(-1) + p_eps, data[f"task{t + 1}_label"])
         out["loss"] = loss
     return out
+
+
+def mmoe(sd, gates, gates_bias, enc_dict, data, num_task, training=False, is_training=True):
+    """multi_task/mmoe.py:81-130.  experts einsum 'ij,jkl->ikl' + bias; per-task softmax gate (gates are
+    the UNREGISTERED N(0,1) tensors of mmoe.py:43-47, passed separately); gate-weighted sum over experts;
+    towers; loss with p + 1e-6."""
+    _, hidden = _dnn_input(sd, enc_dict, data)
+    eo = torch.einsum("ij,jkl->ikl", hidden, sd["experts"]) + sd["experts_bias"]
+    xs = []
+    for t in range(num_task):
+        g = torch.softmax(hidden @ gates[t] + gates_bias[t], dim=-1)
+        xs.append((eo * g.unsqueeze(1)).sum(dim=2))
+    return task_towers(sd, xs, data, num_task, training, is_training, p_eps=1e-6)
+
+
+def omoe(sd, enc_dict, data, num_task, training=False, is_training=True):
+    """multi_task/omoe.py:71-95: ONE input-independent gate softmax(gate[E,1], dim=0) shared by all tasks."""
+    _, hidden = _dnn_input(sd, enc_dict, data)
+    eo = torch.einsum("ij,jkl->ikl", hidden, sd["experts"]) + sd["experts_bias"]
+    x = (eo @ torch.softmax(sd["gate"], dim=0)).squeeze(-1)
+    return task_towers(sd, [x] * num_task, data, num_task, training, is_training)
+
+
+def mlmmoe(sd, level_gates, gates, gates_bias, enc_dict, data, num_task, training=False, is_training=True):
+    """multi_task/mlmmoe.py:88-130: level_out[..., j] = experts_out . softmax(level_gates[j], dim=0), then the MMOE
+    per-task gating over the level outputs (all three gate lists are unregistered tensors, passed separately)."""
+    _, hidden = _dnn_input(sd, enc_dict, data)
+    eo = torch.einsum("ij,jkl->ikl", hidden, sd["experts"]) + sd["experts_bias"]
+    lv = torch.cat([eo @ torch.softmax(lg, dim=0) for lg in level_gates], dim=-1)
+    xs = []
+    for t in range(num_task):
+        g = torch.softmax(hidden @ gates[t] + gates_bias[t], dim=-1)
+        xs.append((lv * g.unsqueeze(1)).sum(dim=2))
+    return task_towers(sd, xs, data, num_task, training, is_training)
+
+
+def sharebottom(sd, enc_dict, data, num_task, training=False, is_training=True):
+    """multi_task/sharebottom.py:64-85: every tower reads cat(emb_flat, dense) directly."""
+    _, hidden = _dnn_input(sd, enc_dict, data)
+    return task_towers(sd, [hidden] * num_task, data, num_task, training, is_training)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ Trains each named model with RankTrainer.fit, times fit/evaluate with the wall c
 `model_name, train_model_time, test_model_time, <valid metrics>, <test metrics>` (milliseconds).
 Model names resolve through an explicit registry of the hot-path models instead of eval().
 """
+import inspect
 import logging
 import os
 import time
@@ -40,7 +41,11 @@ class BenchmarkTrainer:
             if model_name not in MODEL_REGISTRY:
                 raise NameError(f"name '{model_name}' is not defined")  # what the reference's eval() raises
             model_class = MODEL_REGISTRY[model_name]
-            model = model_class(enc_dict=enc_dict, device=device) if self.num_task > 1 else model_class(enc_dict=enc_dict)
+            # benchmark_trainer.py:67-68 passes device= to every multi-task model although ShareBottom's constructor
+            # has no such argument (TypeError in the reference): pass it only where it is accepted
+            kw = {"device": device} if (self.num_task > 1 and "device" in
+                                        inspect.signature(model_class.__init__).parameters) else {}
+            model = model_class(enc_dict=enc_dict, **kw)
             ckpt_dir = os.path.join(self.ckpt_root, model_name)
             trainer = RankTrainer(num_task=self.num_task, model_ckpt_dir=ckpt_dir)
 

@@ -7,13 +7,13 @@ not in state_dict(), not in parameters() and never trained.  Here they are non-p
 Towers are Linear -> BatchNorm1d -> Dropout with no activation in between, then Linear -> Sigmoid;
 loss = sum_t (1/T) * BCE(p_t + 1e-6, y_t).
 """
-import numpy as np
 import torch
 from torch import nn
 
 from ... import functional as Fh
 from ..base_model import BaseModel
 from ..utils import get_feature_num, get_linear_input
+from .towers import build_towers, run_towers, weighted_bce
 
 
 class MMOE(BaseModel):
@@ -41,16 +41,7 @@ class MMOE(BaseModel):
             self.register_buffer(f"_gate_{t}", gates[t], persistent=False)
             self.register_buffer(f"_gate_bias_{t}", gates_bias[t], persistent=False)
 
-        for i in range(self.num_task):
-            tower = nn.ModuleList()
-            setattr(self, 'task_{}_dnn'.format(i + 1), tower)
-            hid_dim = [mmoe_hidden_dim] + hidden_dim
-            for j in range(len(hid_dim) - 1):
-                tower.add_module('ctr_hidden_{}'.format(j), nn.Linear(hid_dim[j], hid_dim[j + 1]))
-                tower.add_module('ctr_batchnorm_{}'.format(j), nn.BatchNorm1d(hid_dim[j + 1]))
-                tower.add_module('ctr_dropout_{}'.format(j), nn.Dropout(dropouts[j]))
-            tower.add_module('task_last_layer', nn.Linear(hid_dim[-1], 1))
-            tower.add_module('task_sigmoid', nn.Sigmoid())
+        build_towers(self, num_task, mmoe_hidden_dim, hidden_dim, dropouts)
         self.set_device(device)
         self.apply(self._init_weights)
 
@@ -88,16 +79,7 @@ class MMOE(BaseModel):
             gate_out = torch.softmax(hidden @ gate + gate_bias, dim=-1)
             outs.append((experts_out * gate_out.unsqueeze(1)).sum(dim=2))
 
-        output_dict, task_outputs = dict(), []
-        for i in range(self.num_task):
-            x_t = outs[i]
-            for mod in getattr(self, 'task_{}_dnn'.format(i + 1)):
-                x_t = mod(x_t)
-            task_outputs.append(x_t)
-            output_dict[f'task{i + 1}_pred'] = x_t
-        if is_training:
-            output_dict['loss'] = self.loss(task_outputs, data)
-        return output_dict
+        return run_towers(self, outs, data, is_training, p_eps=1e-6)
 
     def _forward_hip(self, data, is_training):
         """HIP path: gather+concat -> ONE fp32-MFMA GEMM over [experts | gates] -> gate softmax + combine kernel
@@ -107,40 +89,7 @@ class MMOE(BaseModel):
         w_cat = torch.cat([self.experts.reshape(h, K * E)] + self.gates, dim=1)
         b_cat = torch.cat([self.experts_bias.reshape(-1)] + self.gates_bias)
         mix = Fh.mmoe_combine(Fh.linear_input_major(x, w_cat, b_cat), K, E, T)  # [T, B, K]
-        output_dict, total = dict(), 0
-        for i in range(T):
-            x_t = mix[i]
-            for mod in getattr(self, 'task_{}_dnn'.format(i + 1)):
-                if isinstance(mod, nn.Linear):
-                    x_t = Fh.linear_act(x_t, mod.weight, mod.bias, Fh.ACT_NONE)
-                elif isinstance(mod, nn.Sigmoid):
-                    break  # fused into the loss / prediction kernel below
-                elif isinstance(mod, nn.BatchNorm1d):
-                    x_t = Fh.batch_norm(x_t, mod)
-                elif isinstance(mod, nn.Dropout) and not (self.training and mod.p > 0):
-                    continue
-                else:
-                    x_t = mod(x_t)
-            if is_training:
-                pred, l_i = Fh.sigmoid_bce([x_t], data[f'task{i + 1}_label'].float(), apply_sigmoid=True, p_eps=1e-6,
-                                           weight=1.0 / T)
-                total = total + l_i
-            else:
-                pred = Fh.sigmoid_sum([x_t])
-            output_dict[f'task{i + 1}_pred'] = pred
-        if is_training:
-            output_dict['loss'] = total
-        return output_dict
+        return run_towers(self, [mix[i] for i in range(T)], data, is_training, p_eps=1e-6)
 
     def loss(self, task_outputs, data, weight=None):
-        if weight is None:
-            weight = np.ones(self.num_task) / self.num_task
-        total = 0
-        for i, p in enumerate(task_outputs):
-            y = data[f'task{i + 1}_label']
-            if p.is_cuda:
-                _, l_i = Fh.sigmoid_bce([p], y.float(), apply_sigmoid=False, p_eps=1e-6, weight=float(weight[i]))
-                total = total + l_i
-            else:
-                total = total + weight[i] * nn.functional.binary_cross_entropy(p.squeeze(-1) + 1e-6, y)
-        return total
+        return weighted_bce(task_outputs, data, self.num_task, p_eps=1e-6, weight=weight)

@@ -34,7 +34,7 @@ _ref_import.install()
 import pandas as pd  # noqa: E402
 import torch  # noqa: E402
 from rec_pangu.models.ranking import DeepFM, xDeepFM, DCN, AutoInt, FM, WDL, NFM  # noqa: E402
-from rec_pangu.models.multi_task import MMOE  # noqa: E402
+from rec_pangu.models.multi_task import MMOE, OMOE, MLMMOE, ShareBottom  # noqa: E402
 from rec_pangu.models.layers import (EmbeddingLayer, InnerProductLayer, CrossNet,  # noqa: E402
                                      CompressedInteractionNet, MultiHeadSelfAttention, MLP, LR_Layer)
 from rec_pangu.trainer import RankTrainer  # noqa: E402
@@ -139,6 +139,12 @@ def mmoe_extra(model, out):
         out[f"gates_bias/{i}"] = to_np(g)
 
 
+def mlmmoe_extra(model, out):
+    mmoe_extra(model, out)
+    for i, g in enumerate(model.level_gates):
+        out[f"level_gates/{i}"] = to_np(g)
+
+
 def make_models():
     enc = small_enc_dict()
     dump_model_case("deepfm", lambda: DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc), train_mode=True)
@@ -162,6 +168,19 @@ def make_models():
     dump_model_case("mmoe_train", lambda: MMOE(num_task=2, n_expert=4, embedding_dim=8, mmoe_hidden_dim=16,
                                                hidden_dim=[8, 4], dropouts=[0.0, 0.0], enc_dict=enc,
                                                device=torch.device("cpu")), train_mode=True, extra=mmoe_extra)
+
+
+    # the sibling multi-task models on the same expert-GEMM / tower kernels
+    for tag, tm, dp in (("eval", False, [0.2, 0.2]), ("train", True, [0.0, 0.0])):
+        dump_model_case(f"omoe_{tag}", lambda: OMOE(num_task=2, n_expert=3, embedding_dim=8, omoe_hidden_dim=16,
+                                                    hidden_dim=[8, 4], dropouts=dp, enc_dict=enc,
+                                                    device=torch.device("cpu")), train_mode=tm)
+        dump_model_case(f"mlmmoe_{tag}", lambda: MLMMOE(num_task=2, n_expert=3, embedding_dim=8, mmoe_hidden_dim=16,
+                                                        hidden_dim=[8, 4], dropouts=dp, enc_dict=enc,
+                                                        device=torch.device("cpu")), train_mode=tm,
+                        extra=mlmmoe_extra)
+        dump_model_case(f"sharebottom_{tag}", lambda: ShareBottom(num_task=2, embedding_dim=8, hidden_units=[8, 4],
+                                                                  dropouts=dp, enc_dict=enc), train_mode=tm)
 
 
 def make_layers():

@@ -70,6 +70,19 @@ def test_mmoe(tag, training):
     _model_case(tag, run)
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_omoe_mlmmoe_sharebottom(training):
+    tag = "train" if training else "eval"
+    _model_case(f"omoe_{tag}", lambda sd, enc, b, g: R.omoe(sd, enc, b, num_task=2, training=training))
+    _model_case(f"sharebottom_{tag}", lambda sd, enc, b, g: R.sharebottom(sd, enc, b, num_task=2, training=training))
+
+    def run(sd, enc, b, g):
+        lst = lambda grp: [g[grp][str(i)] for i in range(len(g[grp]))]  # noqa: E731
+        return R.mlmmoe(sd, lst("level_gates"), lst("gates"), lst("gates_bias"), enc, b, num_task=2,
+                        training=training)
+    _model_case(f"mlmmoe_{tag}", run)
+
+
 def test_deepfm_two_adam_steps():
     """Dense Adam as RankTrainer builds it (trainer.py:75), two steps, against the reference's own run."""
     g = load_golden("model_deepfm.npz")

@@ -135,3 +135,18 @@ def test_multitask_dataset_and_trainer(tmp_path):
                       "test_task2_log_loss"}
     preds = trainer.predict_dataloader(model, test_loader)
     assert len(preds) == 2 and len(preds[0]) == len(test_df)
+
+
+def test_benchmark_trainer_multitask_list(tmp_path):
+    """BenchmarkTrainer(num_task=2) over the multi-task models, ShareBottom included (its
+    constructor takes no `device`, which the reference passes anyway — B2)."""
+    meta, train_df, valid_df, test_df = _frames()
+    schema = dict(meta["schema"], label_col=["click", "scroll"], task_type="multitask")
+    train_loader, valid_loader, test_loader, enc = get_dataloader(train_df, valid_df, test_df, schema, batch_size=50)
+    csv = os.path.join(tmp_path, "mt.csv")
+    names = ["MMOE", "OMOE", "MLMMOE", "ShareBottom"]
+    bt = BenchmarkTrainer(num_task=2, model_list=names, benchmark_res_path=csv, ckpt_root=os.path.join(tmp_path, "ck"))
+    bt.run(train_loader, enc, valid_loader, test_loader, epoch=1, lr=1e-3, device=torch.device("cpu"))
+    res = pd.read_csv(csv)
+    assert list(res["model_name"]) == names
+    assert {"test_task1_roc_auc_score", "test_task2_log_loss", "train_model_time"} <= set(res.columns)
