@@ -41,6 +41,17 @@ extern "C" {
 #define RP_ACT_RELU 1
 #define RP_ACT_MASK 2 /* out = acc * (aux > 0): ReLU backward fused into a dgrad GEMM */
 
+/* Matrix-core precision of the GEMM entry points (process-wide; fp32 operands and fp32 accumulation in every mode).
+ * The reference computes torch.nn.Linear in fp32 (ATen); BF16X6 reproduces fp32 products to ~2^-23 on the bf16
+ * matrix core by splitting each operand into three bf16 pieces (6 MFMA products), BF16X3 to ~2^-16 with two pieces,
+ * BF16 rounds the operands to bf16 (outside the 1e-4 parity gate: opt-in only), FP32 uses v_mfma_f32_32x32x2_f32. */
+#define RP_MATMUL_FP32 0
+#define RP_MATMUL_BF16 1
+#define RP_MATMUL_BF16X3 3
+#define RP_MATMUL_BF16X6 6
+int rp_set_matmul_precision(int mode); /* default RP_MATMUL_BF16X6 */
+int rp_get_matmul_precision(void);
+
 typedef void *rp_stream_t;
 
 /* ---- library ------------------------------------------------------------------------------ */

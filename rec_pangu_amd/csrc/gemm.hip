@@ -202,21 +202,540 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float *
     if (do_bias && n0 + t < N) Pb[(int64_t)blockIdx.z * N + n0 + t] = bsum;
 }
 
+// ================================================================================================
+// Split-bf16 GEMMs on the CDNA4 bf16 matrix core (v_mfma_f32_32x32x16_bf16, 16x the rate of the f32-input MFMA).
+//
+// An fp32 operand x is split on the fly, while it is staged into LDS, into bf16 pieces
+//     x = hi + mid + lo (+ r),   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)      (the subtractions are exact)
+// and a product a*b is evaluated as a sum of bf16 x bf16 MFMA products accumulated in fp32:
+//     NPROD = 6 : hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi      relative error ~2^-23  (fp32-faithful; default)
+//     NPROD = 3 : hi*hi + hi*mid + mid*hi                                  relative error ~2^-16
+//     NPROD = 1 : hi*hi                                                    plain bf16 inputs, ~2^-9
+// Even at NPROD = 6 the matrix-core work is 6/16 of the f32 MFMA's, which turns the first DeepFM layer
+// ([B,1677] x [1677,64]: 32 flop per streamed byte, above the f32-MFMA ridge of ~20) back into an HBM-bound kernel.
+// Fragment layout: lane l carries row/col (l & 31) and the 8 consecutive k = 8*(l >> 5) .. +7 of a 16-deep k step
+// for A and B alike (the contraction is a sum, so any k pairing shared by both operands is valid).
+// LDS rows hold 32 bf16 + 8 pad (80 B = 5 x 16 B, odd) so the ds_read_b128 fragment reads are conflict-free.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+#define BF_LD 40
+
+template <int NPROD>
+struct BfProd {
+    static constexpr int NP = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);
+    // smallest terms first
+    __device__ static constexpr int pa(int i) { return NPROD == 6 ? (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : i == 4 ? 1 : 0)
+                                                     : NPROD == 3 ? (i == 0 ? 0 : i == 1 ? 1 : 0) : 0; }
+    __device__ static constexpr int pb(int i) { return NPROD == 6 ? (i == 0 ? 2 : i == 1 ? 0 : i == 2 ? 1 : i == 3 ? 1 : i == 4 ? 0 : 0)
+                                                     : NPROD == 3 ? (i == 0 ? 1 : i == 1 ? 0 : 0) : 0; }
+};
+
+template <int NP>
+__device__ __forceinline__ void bf_split4(f32x4 v, bf16x4 (&p)[NP]) {
+    p[0] = __builtin_convertvector(v, bf16x4);
+    if (NP > 1) {
+        v -= __builtin_convertvector(p[0], f32x4);
+        p[1] = __builtin_convertvector(v, bf16x4);
+    }
+    if (NP > 2) {
+        v -= __builtin_convertvector(p[1], f32x4);
+        p[2] = __builtin_convertvector(v, bf16x4);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void bf_split8(f32x8 v, bf16x8 (&p)[NP]) {
+    p[0] = __builtin_convertvector(v, bf16x8);
+    if (NP > 1) {
+        v -= __builtin_convertvector(p[0], f32x8);
+        p[1] = __builtin_convertvector(v, bf16x8);
+    }
+    if (NP > 2) {
+        v -= __builtin_convertvector(p[1], f32x8);
+        p[2] = __builtin_convertvector(v, bf16x8);
+    }
+}
+
+// NT:  out[M,N] = act(A[M,K] . W[N,K]^T + bias).  Block tile (32*WM) x 64 x 32, 4 waves:
+//   WM = 4: wave w owns rows 32w.. and both 32-column halves;   WM = 2: waves are 2 (rows) x 2 (column halves) — used
+//   when the 128-row grid would leave the chip under-filled (skinny N).
+template <int NPROD, int WM, int PF, bool VEC_A, bool VEC_W>
+__global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__restrict__ A, int64_t lda,
+                                                              const float *__restrict__ W, int64_t ldw,
+                                                              const float *__restrict__ bias, float *__restrict__ C,
+                                                              int64_t ldc, int64_t M, int N, int K, int act,
+                                                              const float *__restrict__ aux, int64_t ldaux) {
+    constexpr int NP = BfProd<NPROD>::NP;
+    constexpr int BMT = 32 * WM;
+    constexpr int NACC = (WM == 4) ? 2 : 1;
+    constexpr int RA = BMT / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 As[NP][BMT][BF_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][BN][BF_LD];
+    const int t = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * BMT;
+    const int n0 = blockIdx.y * BN;
+    const int lr = t >> 3, lc = (t & 7) * 4;
+    const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
+    const int wm = (WM == 4) ? w : (w & 1);
+    const int wn = (WM == 4) ? 0 : (w >> 1);
+
+    // PF tiles of global loads are kept in flight per workgroup (a register ring): one tile per workgroup is a few
+    // KB, and at 2-4 resident workgroups per CU that is far too little to cover HBM latency at full bandwidth.
+    f32x4 ra[PF][RA], rw[PF][2];
+    auto load_tile = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[2]) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int64_t m = m0 + lr + 32 * j;
+            da[j] = (m < M) ? load4_guard(A + m * lda + k0 + lc, K - (k0 + lc), VEC_A) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + lr + 32 * j;
+            dw[j] = (n < N) ? load4_guard(W + (int64_t)n * ldw + k0 + lc, K - (k0 + lc), VEC_W)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < nk) load_tile(p * BK, ra[p], rw[p]);
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kt = kt0 + p;
+            if (kt >= nk) break;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                bf16x4 pc[NP];
+                bf_split4<NP>(ra[p][j], pc);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + 32 * j][lc]) = pc[q];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x4 pc[NP];
+                bf_split4<NP>(rw[p][j], pc);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[q][lr + 32 * j][lc]) = pc[q];
+            }
+            __syncthreads();
+            if (kt + PF < nk) load_tile((kt + PF) * BK, ra[p], rw[p]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    a[q] = *reinterpret_cast<const bf16x8 *>(&As[q][32 * wm + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int nt = 0; nt < NACC; ++nt) {
+                    const int col0 = (WM == 4) ? nt * 32 : wn * 32;
+                    if (n0 + col0 >= N) continue;  // wave-uniform
+                    bf16x8 b[NP];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        b[q] = *reinterpret_cast<const bf16x8 *>(&Ws[q][col0 + i][ks * 16 + 8 * h]);
+#pragma unroll
+                    for (int pr = 0; pr < NPROD; ++pr)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)],
+                                                                          b[BfProd<NPROD>::pb(pr)], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < NACC; ++nt) {
+        const int col0 = (WM == 4) ? nt * 32 : wn * 32;
+        const int n = n0 + col0 + i;
+        if (n >= N) continue;
+        const float bv = (bias != nullptr) ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= M) continue;
+            float v = acc[nt][r] + bv;
+            if (act == RP_ACT_RELU)
+                v = v > 0.f ? v : 0.f;
+            else if (act == RP_ACT_MASK)
+                v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+            C[m * ldc + n] = v;
+        }
+    }
+}
+
+// NT with a short contraction (K <= 64: the dgrad of a wide layer, the 64 -> 64 hidden layers, the 64 -> 1 head).
+// The [128, K] A tile is read ONCE, split, and kept in registers as MFMA fragments (4 k-steps x NP pieces); the
+// workgroup then walks over `ntiles` 64-column tiles of W, double-buffered through LDS with one barrier per tile
+// and the next W tile's global loads in flight, writing a 128 x 64 block of the output per step.  For the dgrad
+// dX[B,1677] = dH[B,64] . W this makes the kernel a pure stream of output writes.
+//
+// FULL = every tile is interior (M % 128 == 0, N % 64 == 0, 16-byte aligned rows, K % 4 == 0): the loop body is
+// straight-line code.  That matters: gfx950 counts loads and stores on ONE in-order counter (vmcnt), the W prefetch
+// of tile t+1 is issued before the stores of tile t, and the compiler only emits the counted wait vmcnt(#stores)
+// for it when no branch separates them — any guarded load/store in the loop turns it into vmcnt(0), a full store
+// round trip (microseconds under a saturated write stream) per tile.  Edges run the guarded instantiation.
+#define SK_LD 72
+template <int NPROD, int ACT, bool FULL>
+__global__ __launch_bounds__(256) void linear_fwd_bf16_smallk_kernel(const float *__restrict__ A, int64_t lda,
+                                                                     const float *__restrict__ W, int64_t ldw,
+                                                                     const float *__restrict__ bias,
+                                                                     float *__restrict__ C, int64_t ldc, int64_t M,
+                                                                     int N, int K, const float *__restrict__ aux,
+                                                                     int64_t ldaux, int ntiles) {
+    constexpr int NP = BfProd<NPROD>::NP;
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NP][BN][SK_LD];
+    const int t = threadIdx.x;
+    const int64_t m0 = (int64_t)blockIdx.x * 128;
+    const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
+    const int lr = t >> 4, lc = (t & 15) * 4;
+    const int tile0 = blockIdx.y * ntiles;
+    int tile1 = tile0 + ntiles;
+    const int tiles_all = (N + BN - 1) / BN;
+    if (tile1 > tiles_all) tile1 = tiles_all;
+
+    // A fragments: lane (i, h) holds row 32w+i, k = 16*ks + 8h .. +7
+    bf16x8 af[4][NP];
+    {
+        const int64_t m = m0 + 32 * w + i;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = ks * 16 + 8 * h;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (FULL) {
+                // unguarded: clamp the column into range and zero by select (no branch)
+                const int ka = (k + 4 <= K) ? k : 0, kb = (k + 8 <= K) ? k + 4 : 0;
+                const f32x4 t0 = *reinterpret_cast<const f32x4 *>(A + m * lda + ka);
+                const f32x4 t1 = *reinterpret_cast<const f32x4 *>(A + m * lda + kb);
+                const float s0 = (k + 4 <= K) ? 1.f : 0.f, s1 = (k + 8 <= K) ? 1.f : 0.f;
+                v0 = t0 * s0;
+                v1 = t1 * s1;
+            } else if (m < M) {
+                v0 = load4_guard(A + m * lda + k, K - k, false);
+                v1 = load4_guard(A + m * lda + k + 4, K - (k + 4), false);
+            }
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = v0[e];
+                v[4 + e] = v1[e];
+            }
+            bf_split8<NP>(v, af[ks]);
+        }
+    }
+    f32x4 rw[4];
+    const int lcc = (lc + 4 <= K) ? lc : 0;
+    const float lcs = (lc + 4 <= K) ? 1.f : 0.f;
+    // FULL: the bias of the NEXT tile is fetched together with its W tile (i.e. before this tile's stores) so that no
+    // load younger than the stores has to be waited for; a null bias reads W instead and is zeroed by a select.
+    const float *bp = (bias != nullptr) ? bias : W;
+    const float bsel = (bias != nullptr) ? 1.f : 0.f;
+    float bnx[2] = {0.f, 0.f};
+    auto load_w = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tile * BN + lr + 16 * j;
+            if (FULL)
+                rw[j] = *reinterpret_cast<const f32x4 *>(W + (int64_t)n * ldw + lcc);  // (* lcs at the point of use)
+            else
+                rw[j] = (n < N) ? load4_guard(W + (int64_t)n * ldw + lc, K - lc, false) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (FULL) {
+            bnx[0] = bp[tile * BN + i];
+            bnx[1] = bp[tile * BN + 32 + i];
+        }
+    };
+    if (tile0 < tile1) load_w(tile0);
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int buf = (tile - tile0) & 1;
+        const float bcur[2] = {bnx[0] * bsel, bnx[1] * bsel};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 pc[NP];
+            bf_split4<NP>(FULL ? rw[j] * lcs : rw[j], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[buf][q][lr + 16 * j][lc]) = pc[q];
+        }
+        // LDS-only barrier (no release fence -> no vmcnt drain).  Tile `tile` is visible after it; everyone is also
+        // past the reads of this buffer two tiles ago.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (FULL) {
+            load_w(tile + 1 < tile1 ? tile + 1 : tile);  // unconditional (the last one is a harmless re-read)
+        } else if (tile + 1 < tile1) {
+            load_w(tile + 1);
+        }
+        const int n0 = tile * BN;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (!FULL && n0 + nt * 32 >= N) continue;  // wave-uniform
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    b[q] = *reinterpret_cast<const bf16x8 *>(&Ws[buf][q][nt * 32 + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int pr = 0; pr < NPROD; ++pr)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][BfProd<NPROD>::pa(pr)], b[BfProd<NPROD>::pb(pr)],
+                                                                  acc, 0, 0, 0);
+            }
+            const int n = n0 + nt * 32 + i;
+            if (FULL) {
+                const float bv = bcur[nt];
+                float *cp = C + (m0 + 32 * w + 4 * h) * ldc + n;
+                if (ACT == RP_ACT_MASK) {
+                    const float *ap = aux + (m0 + 32 * w + 4 * h) * ldaux + n;
+                    float mk[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = ap[((r & 3) + 8 * (r >> 2)) * ldaux];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * ldc] = (mk[r] > 0.f) ? acc[r] + bv : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[r] + bv;
+                        cp[((r & 3) + 8 * (r >> 2)) * ldc] = (ACT == RP_ACT_RELU) ? fmaxf(v, 0.f) : v;
+                    }
+                }
+            } else if (n < N) {
+                const float bv = (bias != nullptr) ? bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m >= M) continue;
+                    float v = acc[r] + bv;
+                    if (ACT == RP_ACT_RELU)
+                        v = v > 0.f ? v : 0.f;
+                    else if (ACT == RP_ACT_MASK)
+                        v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+                    C[m * ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int NPROD>
+static void launch_smallk(bool full, const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                          float *out, int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux,
+                          hipStream_t s) {
+    // split the column tiles over gridDim.y only as far as needed to fill the chip (each split re-reads the A tile)
+    const int64_t mb = rp_cdiv(M, 128);
+    const int tiles = (int)rp_cdiv(N, BN);
+    int64_t ysplit = rp_cdiv(768, mb);
+    if (ysplit > tiles) ysplit = tiles;
+    if (ysplit < 1) ysplit = 1;
+    const int per = (int)rp_cdiv(tiles, ysplit);
+    dim3 grid((unsigned)mb, (unsigned)rp_cdiv(tiles, per));
+#define SK(ACT, FULL)                                                                                                  \
+    hipLaunchKernelGGL((linear_fwd_bf16_smallk_kernel<NPROD, ACT, FULL>), grid, dim3(256), 0, s, a, lda, w, ldw, bias, \
+                       out, ldo, M, N, K, aux, ldaux, per)
+    if (full) {
+        if (act == RP_ACT_RELU) SK(RP_ACT_RELU, true);
+        else if (act == RP_ACT_MASK) SK(RP_ACT_MASK, true);
+        else SK(RP_ACT_NONE, true);
+    } else {
+        if (act == RP_ACT_RELU) SK(RP_ACT_RELU, false);
+        else if (act == RP_ACT_MASK) SK(RP_ACT_MASK, false);
+        else SK(RP_ACT_NONE, false);
+    }
+#undef SK
+}
+
+// interior region with the straight-line kernel, the right / bottom edges with the guarded one
+template <int NPROD>
+static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, float *out,
+                       int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux, hipStream_t s) {
+    const bool aligned = (lda % 4 == 0) && (ldw % 4 == 0) && rp_aligned16(a) && rp_aligned16(w) && (K % 4 == 0);
+    const int64_t Mf = aligned ? (M / 128) * 128 : 0;
+    const int Nf = aligned ? (N / BN) * BN : 0;
+    if (Mf > 0 && Nf > 0)
+        launch_smallk<NPROD>(true, a, lda, w, ldw, bias, out, ldo, Mf, Nf, K, act, aux, ldaux, s);
+    else {
+        launch_smallk<NPROD>(false, a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
+        return;
+    }
+    if (N > Nf)  // right edge: all rows, the last (partial) column tile
+        launch_smallk<NPROD>(false, a, lda, w + (int64_t)Nf * ldw, ldw, bias ? bias + Nf : nullptr, out + Nf, ldo, M,
+                             N - Nf, K, act, aux ? aux + Nf : nullptr, ldaux, s);
+    if (M > Mf)  // bottom edge: the last rows over the interior columns
+        launch_smallk<NPROD>(false, a + Mf * lda, lda, w, ldw, bias, out + Mf * ldo, ldo, M - Mf, Nf, K, act,
+                             aux ? aux + Mf * ldaux : nullptr, ldaux, s);
+}
+
+// TN:  dW[N,K] = dY[M,N]^T . X[M,K].  Output tile 64 (n) x 128 (k); 32 batch rows per stage, transposed while they
+// are staged: thread (column c = t & 63, octet o = t >> 6) loads the 8 consecutive batch rows 8o..8o+7 of its dY
+// column (and of two X columns), converts and writes them as ONE 16-byte LDS row segment, so the LDS images are
+// [n][m] / [k][m] and the MFMA fragments (8 consecutive m per lane) are ds_read_b128.  Split-K over gridDim.z with a
+// deterministic second-stage sum, as the f32 kernel; the bias gradient is summed in exact fp32 from the staged
+// registers.
+template <int NPROD, int PF, bool VEC_X>
+__global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                                const float *__restrict__ X, int64_t ldx,
+                                                                float *__restrict__ P, float *__restrict__ Pb,
+                                                                int64_t M, int N, int K, int64_t rows_per_split) {
+    constexpr int NP = BfProd<NPROD>::NP;
+    __shared__ __attribute__((aligned(16))) __bf16 Yt[NP][TN_BN][BF_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Xt[NP][TN_BK][BF_LD];
+    __shared__ float bred[4][TN_BN];
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * TN_BK;
+    const int n0 = blockIdx.y * TN_BN;
+    const int64_t mbeg = (int64_t)blockIdx.z * rows_per_split;
+    int64_t mend = mbeg + rows_per_split;
+    if (mend > M) mend = M;
+    const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
+    const int nt = (w & 1) * 32, kt = (w >> 1) * 64;
+    const int c = t & 63, o = t >> 6;
+    const bool y_ok = (n0 + c) < N;
+    const int kx = k0 + 2 * c;
+
+    float ry[PF][8];
+    f32x2 rx[PF][8];
+    auto load_tile = [&](int64_t mm, float (&dy_)[8], f32x2 (&dx_)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t m = mm + 8 * o + r;
+            const bool ok = m < mend;
+            dy_[r] = (ok && y_ok) ? dY[m * lddy + n0 + c] : 0.f;
+            f32x2 v = {0.f, 0.f};
+            if (ok) {
+                const float *px = X + m * ldx + kx;
+                if (VEC_X && kx + 1 < K) {
+                    v = *reinterpret_cast<const f32x2 *>(px);
+                } else {
+                    if (kx < K) v.x = px[0];
+                    if (kx + 1 < K) v.y = px[1];
+                }
+            }
+            dx_[r] = v;
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+    }
+    float bsum = 0.f;
+    const bool do_bias = (Pb != nullptr) && (blockIdx.x == 0);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (mbeg + (int64_t)p * TN_BM < mend) load_tile(mbeg + (int64_t)p * TN_BM, ry[p], rx[p]);
+    for (int64_t mm0 = mbeg; mm0 < mend; mm0 += (int64_t)PF * TN_BM) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int64_t mm = mm0 + (int64_t)p * TN_BM;
+            if (mm >= mend) break;
+            __syncthreads();
+            {
+                f32x8 vy, vx0, vx1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    vy[r] = ry[p][r];
+                    vx0[r] = rx[p][r].x;
+                    vx1[r] = rx[p][r].y;
+                }
+                if (do_bias)
+                    bsum += ((ry[p][0] + ry[p][1]) + (ry[p][2] + ry[p][3])) + ((ry[p][4] + ry[p][5]) + (ry[p][6] + ry[p][7]));
+                bf16x8 pc[NP];
+                bf_split8<NP>(vy, pc);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Yt[q][c][8 * o]) = pc[q];
+                bf_split8<NP>(vx0, pc);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c][8 * o]) = pc[q];
+                bf_split8<NP>(vx1, pc);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c + 1][8 * o]) = pc[q];
+            }
+            __syncthreads();
+            if (mm + (int64_t)PF * TN_BM < mend) load_tile(mm + (int64_t)PF * TN_BM, ry[p], rx[p]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 a[NP], b0[NP], b1[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    a[q] = *reinterpret_cast<const bf16x8 *>(&Yt[q][nt + i][ks * 16 + 8 * h]);
+                    b0[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + i][ks * 16 + 8 * h]);
+                    b1[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + 32 + i][ks * 16 + 8 * h]);
+                }
+#pragma unroll
+                for (int pr = 0; pr < NPROD; ++pr) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)],
+                                                                   acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b1[BfProd<NPROD>::pb(pr)],
+                                                                   acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *Pz = P + (int64_t)blockIdx.z * N * K;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = k0 + kt + kk * 32 + i;
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (n < N) Pz[(int64_t)n * K + k] = (kk == 0 ? acc0[r] : acc1[r]);
+        }
+    }
+    if (do_bias) {
+        bred[o][c] = bsum;
+        __syncthreads();
+        if (t < TN_BN && n0 + t < N)
+            Pb[(int64_t)blockIdx.z * N + n0 + t] = (bred[0][t] + bred[1][t]) + (bred[2][t] + bred[3][t]);
+    }
+}
+
+// second stage of the split-K wgrad: 16 output elements x 16 slices per workgroup; slice q sums partials q, q+16, ...
+// and the 16 slice sums are combined in a fixed order (deterministic).  One thread per element with a serial loop
+// over S is latency-bound: 512 dependent-address loads for a 64 x 64 layer.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ P, const float *__restrict__ Pb,
                                                            int S, int N, int K, float *__restrict__ dw,
                                                            int64_t lddw, float *__restrict__ db, int accumulate) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + c;
     const int64_t nk = (int64_t)N * K;
-    if (e < nk) {
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += P[(int64_t)z * nk + e];
+    const bool is_w = e < nk, is_b = !is_w && e < nk + N && db != nullptr;
+    float s = 0.f;
+    if (is_w) {
+#pragma unroll 4
+        for (int z = q; z < S; z += 16) s += P[(int64_t)z * nk + e];
+    } else if (is_b) {
+        const int n = (int)(e - nk);
+#pragma unroll 4
+        for (int z = q; z < S; z += 16) s += Pb[(int64_t)z * N + n];
+    }
+    red[q][c] = s;
+    __syncthreads();
+    if (q != 0) return;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) s += red[j][c];
+    if (is_w) {
         const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
         float *d = dw + (int64_t)n * lddw + k;
         *d = accumulate ? (*d + s) : s;
-    } else if (e < nk + N && db != nullptr) {
+    } else if (is_b) {
         const int n = (int)(e - nk);
-        float s = 0.f;
-        for (int z = 0; z < S; ++z) s += Pb[(int64_t)z * N + n];
         db[n] = accumulate ? (db[n] + s) : s;
     }
 }
@@ -250,6 +769,18 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float *__restrict__
     }
 }
 
+// process-wide matrix-core precision for the GEMM entry points (rp_linear_fwd / rp_linear_wgrad)
+static int g_matmul_precision = RP_MATMUL_BF16X6;
+
+extern "C" int rp_set_matmul_precision(int mode) {
+    RP_REQUIRE(mode == RP_MATMUL_FP32 || mode == RP_MATMUL_BF16 || mode == RP_MATMUL_BF16X3 || mode == RP_MATMUL_BF16X6,
+               "set_matmul_precision: unknown mode %d", mode);
+    g_matmul_precision = mode;
+    return RP_OK;
+}
+
+extern "C" int rp_get_matmul_precision(void) { return g_matmul_precision; }
+
 extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, float *out,
                              int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux,
                              rp_stream_t stream) {
@@ -261,8 +792,44 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     if (M == 0) return RP_OK;
     const bool va = (lda % 4 == 0) && rp_aligned16(a);
     const bool vw = (ldw % 4 == 0) && rp_aligned16(w);
-    dim3 grid((unsigned)rp_cdiv(M, BM), (unsigned)rp_cdiv(N, BN));
     hipStream_t s = (hipStream_t)stream;
+    const int mode = g_matmul_precision;
+    if (mode != RP_MATMUL_FP32) {
+        if (K <= 64) {  // A-stationary walk over the output columns
+            if (mode == RP_MATMUL_BF16X6) run_smallk<6>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
+            else if (mode == RP_MATMUL_BF16X3) run_smallk<3>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
+            else run_smallk<1>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
+            RP_LAUNCH_CHECK("linear_fwd (bf16 split, short K)");
+            return RP_OK;
+        }
+        // 64-row tiles when 128-row tiles would give the 256 CUs fewer than ~4 workgroups each
+        const bool small = rp_cdiv(M, 128) * rp_cdiv(N, BN) < 1024 && M > 64;
+        dim3 grid((unsigned)rp_cdiv(M, small ? 64 : 128), (unsigned)rp_cdiv(N, BN));
+#define CALLB(NPROD, WM, PF, VA, VW)                                                                                    \
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<NPROD, WM, PF, VA, VW>), grid, dim3(256), 0, s, a, lda, w, ldw, bias, out, \
+                       ldo, M, N, K, act, aux, ldaux)
+#define CALLV(NPROD, WM, PF)                            \
+    do {                                                \
+        if (va && vw) CALLB(NPROD, WM, PF, true, true); \
+        else if (va) CALLB(NPROD, WM, PF, true, false); \
+        else if (vw) CALLB(NPROD, WM, PF, false, true); \
+        else CALLB(NPROD, WM, PF, false, false);        \
+    } while (0)
+#define CALLP(NPROD)                   \
+    do {                               \
+        if (small) CALLV(NPROD, 2, 3); \
+        else CALLV(NPROD, 4, 2);       \
+    } while (0)
+        if (mode == RP_MATMUL_BF16X6) CALLP(6);
+        else if (mode == RP_MATMUL_BF16X3) CALLP(3);
+        else CALLP(1);
+#undef CALLP
+#undef CALLV
+#undef CALLB
+        RP_LAUNCH_CHECK("linear_fwd (bf16 split)");
+        return RP_OK;
+    }
+    dim3 grid((unsigned)rp_cdiv(M, BM), (unsigned)rp_cdiv(N, BN));
 #define CALL(VA, VW)                                                                                              \
     hipLaunchKernelGGL((linear_fwd_kernel<VA, VW>), grid, dim3(256), 0, s, a, lda, w, ldw, bias, out, ldo, M, N, K, \
                        act, aux, ldaux)
@@ -278,7 +845,7 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
 static void wgrad_plan(int64_t M, int N, int K, int *S, int64_t *rows) {
     const int64_t tiles = rp_cdiv(K, TN_BK) * rp_cdiv(N, TN_BN);
     int64_t s = rp_cdiv(1024, tiles);
-    if (s > 128) s = 128;
+    if (s > 512) s = 512;  // a 64 x 64 layer has ONE output tile: all the parallelism must come from the batch split
     if (s < 1) s = 1;
     int64_t r = rp_cdiv(rp_cdiv(M, s), TN_BM) * TN_BM;
     if (r < TN_BM) r = TN_BM;
@@ -313,6 +880,24 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     const bool vx = (ldx % 4 == 0) && rp_aligned16(x);
     dim3 grid((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, TN_BN), (unsigned)S);
     hipStream_t s = (hipStream_t)stream;
+    const int mode = g_matmul_precision;
+    if (mode != RP_MATMUL_FP32) {
+        const bool vx2 = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+#define CALLB(NPROD)                                                                                                   \
+    do {                                                                                                               \
+        if (vx2)                                                                                                       \
+            hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 2, true>), grid, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, \
+                               M, N, K, rows);                                                                         \
+        else                                                                                                           \
+            hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 2, false>), grid, dim3(256), 0, s, dy, lddy, x, ldx, P,   \
+                               Pb, M, N, K, rows);                                                                     \
+    } while (0)
+        if (mode == RP_MATMUL_BF16X6) CALLB(6);
+        else if (mode == RP_MATMUL_BF16X3) CALLB(3);
+        else CALLB(1);
+#undef CALLB
+        RP_LAUNCH_CHECK("linear_wgrad partial (bf16 split)");
+    } else {
 #define CALL(VY, VX)                                                                                                \
     hipLaunchKernelGGL((linear_wgrad_partial_kernel<VY, VX>), grid, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, N, K, \
                        rows)
@@ -322,8 +907,9 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     else CALL(false, false);
 #undef CALL
     RP_LAUNCH_CHECK("linear_wgrad partial");
+    }
     const int64_t total = (int64_t)N * K + N;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 256)), dim3(256), 0, s, P, Pb, S, N, K, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, S, N, K, dw,
                        lddw, db, accumulate);
     RP_LAUNCH_CHECK("linear_wgrad reduce");
     return RP_OK;

@@ -22,12 +22,24 @@ def _unit_inner(t: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # K4  Linear (+bias, +ReLU)   — layers/deep.py:62-72
 # ----------------------------------------------------------------------------------------------
+def _rows16(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear keeps W as [N, K] with row stride K; when K is not a multiple of 4 (DeepFM: 1677) its rows are not
+    16-byte aligned and the GEMM would have to fetch W with scalar loads.  A [N, ceil4(K)] staging copy (a few
+    hundred KB, one small launch) restores dwordx4 loads; the extra columns are never read (K is passed on)."""
+    K = w.shape[1]
+    if K % 4 == 0 or K <= 64 or not w.is_cuda:
+        return w
+    buf = torch.empty((w.shape[0], (K + 3) // 4 * 4), dtype=w.dtype, device=w.device)
+    buf[:, :K].copy_(w)
+    return buf[:, :K]
+
+
 class _LinearAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act: int):
         x = _unit_inner(x)
         K = weight.shape[1]
-        y = hip.linear_fwd(x, weight, bias, act, K=K)
+        y = hip.linear_fwd(x, _rows16(weight), bias, act, K=K)
         ctx.act, ctx.K, ctx.has_bias = act, K, bias is not None
         ctx.save_for_backward(x, weight, y if act == ACT_RELU else None)
         return y
@@ -39,11 +51,11 @@ class _LinearAct(torch.autograd.Function):
         dpre = hip.relu_bwd(dy, y) if ctx.act == ACT_RELU else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = hip.transpose(weight)  # [K, N]: the dgrad GEMM is the same NT kernel on W^T
+            # [ldx, N]: the dgrad GEMM is the same NT kernel on W^T; zero rows beyond K make it write the zeros of
+            # x's padding columns itself (a strided fill of those columns costs more than the whole GEMM)
+            wt = hip.transpose(weight, rows_out=x.shape[1])
             dx = torch.empty_like(x)
-            if x.shape[1] > ctx.K:
-                dx[:, ctx.K:].zero_()
-            hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx[:, :ctx.K] if x.shape[1] > ctx.K else dx)
+            hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
         return dx, dw, db, None
@@ -188,9 +200,13 @@ class _LinearInputMajor(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            if x.shape[1] > h:
-                dx[:, h:].zero_()
-            hip.linear_fwd(dz, Wm, None, ACT_NONE, out=dx[:, :h] if x.shape[1] > h else dx)  # dz @ Wm^T
+            if x.shape[1] > h:  # zero rows appended to Wm: the GEMM writes the padding columns' zeros itself
+                Wp = torch.empty((x.shape[1], Wm.shape[1]), dtype=Wm.dtype, device=Wm.device)
+                Wp[:h].copy_(Wm)
+                Wp[h:].zero_()
+            else:
+                Wp = Wm
+            hip.linear_fwd(dz, Wp, None, ACT_NONE, out=dx)  # dz @ Wm^T
         if ctx.needs_input_grad[1]:
             dW, _ = hip.linear_wgrad(x[:, :h], dz, N, want_bias=False)  # roles swapped: x^T @ dz -> [h, N]
         if ctx.needs_input_grad[2]:

@@ -52,6 +52,8 @@ _SIGNATURES = {
                                          _vp, _sz, _vp]),
     "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "rp_set_matmul_precision": (C.c_int, [_i32]),
+    "rp_get_matmul_precision": (C.c_int, []),
     "rp_fm_pool_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_fm_pool_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "rp_batchnorm_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -86,6 +88,10 @@ def lib():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _lib = handle
+        mode = os.environ.get("RP_MATMUL_PRECISION")  # fp32 | bf16 | bf16x3 | bf16x6 (library default)
+        if mode:
+            if handle.rp_set_matmul_precision(MATMUL_MODES[mode]) != 0:
+                raise RuntimeError(f"RP_MATMUL_PRECISION={mode}: rejected by the library")
     return _lib
 
 
@@ -129,11 +135,23 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
 _timing = None
 
 
-def enable_timing(on: bool = True):
-    """Start/stop recording a (start, end) HIP-event pair around every C-ABI call, on the stream the
-    kernels are launched on.  Read with timing_summary() after a torch.cuda.synchronize()."""
-    global _timing
+def enable_timing(on: bool = True, only=None):
+    """Record a HIP-event pair around every C-ABI call (`only`: just the named entry points).  An event record is
+    a barrier packet in the queue: timing every launch of a step serialises kernels that would otherwise overlap
+    and costs host time, so a throughput measurement should restrict it to the few launches it reports."""
+    global _timing, _timing_only
     _timing = {} if on else None
+    _timing_only = None if only is None else frozenset(only)
+
+
+_timing_only = None
+_timing_paused = False
+
+
+def pause_timing(paused: bool):
+    """Keep the recorded events but stop/resume recording new ones (lets a benchmark sample every n-th step)."""
+    global _timing_paused
+    _timing_paused = bool(paused)
 
 
 class _Timed:
@@ -143,13 +161,14 @@ class _Timed:
         self.name = name
 
     def __enter__(self):
-        if _timing is not None:
+        self.ev = None
+        if _timing is not None and not _timing_paused and (_timing_only is None or self.name in _timing_only):
             self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self.ev[0].record()
         return self
 
     def __exit__(self, *exc):
-        if _timing is not None:
+        if self.ev is not None:
             self.ev[1].record()
             _timing.setdefault(self.name, []).append(self.ev)
         return False
@@ -265,10 +284,16 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     return dw, db
 
 
-def transpose(w):
+def transpose(w, rows_out: Optional[int] = None):
+    """w [R, C] -> [C, R]; with rows_out > C the result has rows_out rows, the extra ones zero (a dgrad GEMM on it
+    then writes exact zeros into the padding columns of a padded activation gradient)."""
     _req(w, torch.float32, "w")
     R, Cc = w.shape
-    out = torch.empty((Cc, R), dtype=torch.float32, device=w.device)
+    if rows_out is not None and rows_out > Cc:
+        out = torch.empty((rows_out, R), dtype=torch.float32, device=w.device)
+        out[Cc:].zero_()  # contiguous tail: a few rows
+    else:
+        out = torch.empty((Cc, R), dtype=torch.float32, device=w.device)
     with _Timed("transpose"):
         _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R, R, Cc, _stream()), "rp_transpose")
     return out
@@ -432,6 +457,19 @@ def mmoe_combine_bwd(z, K: int, E: int, T: int, gate, dout):
         _check(lib().rp_mmoe_combine_bwd(z.data_ptr(), _rowmajor(z, "z"), K, E, T, gate.data_ptr(), dout.data_ptr(),
                                          dz.data_ptr(), K * E + T * E, B, _stream()), "rp_mmoe_combine_bwd")
     return dz
+
+
+MATMUL_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+
+
+def set_matmul_precision(mode: str):
+    """GEMM matrix-core mode: 'bf16x6' (default, fp32-faithful split-bf16), 'bf16x3', 'bf16', 'fp32' (f32 MFMA)."""
+    _check(lib().rp_set_matmul_precision(MATMUL_MODES[mode]), "rp_set_matmul_precision")
+
+
+def get_matmul_precision() -> str:
+    v = lib().rp_get_matmul_precision()
+    return {n: k for k, n in MATMUL_MODES.items()}[v]
 
 
 def fm_pool_fwd(x2d, F: int, D: int, want_sum: bool, want_bi: bool):

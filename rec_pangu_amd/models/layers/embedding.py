@@ -221,7 +221,7 @@ class EmbeddingLayer(nn.Module):
     def _idx_list(self, X):
         return [X[c].long().reshape(-1).contiguous() for c in self.emb_feature]
 
-    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 32):
+    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 64):
         """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
         self._ensure_packed()
         return self._gather(self._idx_list(X), None, dense, want_fm, pad_to)

@@ -159,7 +159,20 @@ def test_embed_grad_reduce_vs_autograd(hip, rows, D, B, with_fm, with_dx):
     (129, 100, 37, 37, "none"),         # nothing aligned
     (256, 512, 649, 672, "none"),       # MMOE expert GEMM shape
 ])
-def test_linear_fwd(hip, M, N, K, lda_pad, act):
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32", "bf16x3", "bf16"])
+def test_linear_fwd(hip, M, N, K, lda_pad, act, mode):
+    """every matrix-core mode against an fp64 product; the tolerance is the mode's contract (include/rec_pangu_hip.h):
+    bf16x6 is held to the same bound as the exact f32 MFMA."""
+    hip.set_matmul_precision(mode)
+    try:
+        assert hip.get_matmul_precision() == mode
+        _linear_fwd_case(hip, M, N, K, lda_pad, act, *{"fp32": (1e-5, 2e-5), "bf16x6": (1e-5, 2e-5),
+                                                       "bf16x3": (1e-4, 2e-4), "bf16": (5e-2, 5e-2)}[mode])
+    finally:
+        hip.set_matmul_precision("bf16x6")
+
+
+def _linear_fwd_case(hip, M, N, K, lda_pad, act, rtol, atol):
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.zeros(M, lda_pad)
     a[:, :K] = torch.randn(M, K, generator=g)
@@ -169,19 +182,28 @@ def test_linear_fwd(hip, M, N, K, lda_pad, act):
     if act == "relu":
         ref = ref.relu()
     out = hip.linear_fwd(a.to(DEV), w.to(DEV), b.to(DEV), hip.ACT_RELU if act == "relu" else hip.ACT_NONE, K=K)
-    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=rtol, atol=atol)
     # transpose-detecting mask epilogue (asymmetric aux)
     aux = torch.randn(M, N, generator=g)
     out2 = hip.linear_fwd(a.to(DEV), w.to(DEV), None, hip.ACT_MASK, aux=aux.to(DEV), K=K)
     ref2 = (a[:, :K].double() @ w.double().t()) * (aux > 0)
-    torch.testing.assert_close(out2.cpu().double(), ref2, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(out2.cpu().double(), ref2, rtol=rtol, atol=atol)
 
 
 @pytest.mark.parametrize("M,N,K,ldx_pad", [
     (24, 16, 43, 64), (4099, 64, 1677, 1696), (65536, 64, 64, 64), (1000, 1, 64, 64), (513, 100, 37, 37),
     (2048, 512, 649, 672),
 ])
-def test_linear_wgrad(hip, M, N, K, ldx_pad):
+@pytest.mark.parametrize("mode", ["bf16x6", "fp32", "bf16x3", "bf16"])
+def test_linear_wgrad(hip, M, N, K, ldx_pad, mode):
+    hip.set_matmul_precision(mode)
+    try:
+        _linear_wgrad_case(hip, M, N, K, ldx_pad, {"fp32": 1.0, "bf16x6": 1.0, "bf16x3": 20.0, "bf16": 3000.0}[mode])
+    finally:
+        hip.set_matmul_precision("bf16x6")
+
+
+def _linear_wgrad_case(hip, M, N, K, ldx_pad, slack):
     g = torch.Generator().manual_seed(M + N + K + 1)
     x = torch.zeros(M, ldx_pad)
     x[:, :K] = torch.randn(M, K, generator=g)
@@ -189,12 +211,12 @@ def test_linear_wgrad(hip, M, N, K, ldx_pad):
     dw, db = hip.linear_wgrad(dy.to(DEV), x.to(DEV), K)
     ref_w = dy.double().t() @ x[:, :K].double()
     ref_b = dy.double().sum(dim=0)
-    tol = 2e-6 * M ** 0.5 * 4  # fp32 accumulation over M terms
-    torch.testing.assert_close(dw.cpu().double(), ref_w, rtol=1e-4, atol=tol * 10)
+    tol = 2e-6 * M ** 0.5 * 4 * slack  # fp32 accumulation over M terms (x the mode's product error)
+    torch.testing.assert_close(dw.cpu().double(), ref_w, rtol=1e-4 * slack, atol=tol * 10)
     torch.testing.assert_close(db.cpu().double(), ref_b, rtol=1e-4, atol=tol * 10)
     # accumulate=True adds on top
     dw2, db2 = hip.linear_wgrad(dy.to(DEV), x.to(DEV), K, dw=dw.clone(), db=db.clone(), accumulate=True)
-    torch.testing.assert_close(dw2.cpu().double(), 2 * ref_w, rtol=1e-4, atol=tol * 20)
+    torch.testing.assert_close(dw2.cpu().double(), 2 * ref_w, rtol=1e-4 * slack, atol=tol * 20)
     torch.testing.assert_close(db2.cpu().double(), 2 * ref_b, rtol=1e-4, atol=tol * 20)
 
 
