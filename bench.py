@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="global batch")
+    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step (weak scaling)")
     ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
@@ -187,10 +187,12 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     n_table_rows = model.embedding_layer.arena.shape[0]
 
-    local_B = B // world
-    batches = [synth_batch(enc, B, 100 + i, dev) for i in range(4)]
-    if world > 1:
-        batches = [{k: v[rank * local_B:(rank + 1) * local_B].contiguous() for k, v in b.items()} for b in batches]
+    # WEAK scaling: every GPU works on its own `--batch` samples (65536, the configuration BASELINE.json quotes),
+    # so the global batch is world x 65536 and per-GPU work is constant as N grows.  Each rank draws its own
+    # batches; the tables are row-sharded and the lookup all-to-all serves the whole global batch.
+    local_B = args.batch
+    B = local_B * world
+    batches = [synth_batch(enc, local_B, 100 + 17 * rank + i, dev) for i in range(4)]
 
     def step(i):
         data = batches[i % len(batches)]
@@ -345,19 +347,19 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": f"samples/sec {type(model).__name__} Criteo-shape bsz={B} (train step: fwd+bwd+dense Adam+zero_grad)"
-                      if args.mode == "train" else f"samples/sec {type(model).__name__} Criteo-shape bsz={B} (forward only)",
+            "metric": f"samples/sec {type(model).__name__} Criteo-shape bsz={local_B}/GPU (train step: fwd+bwd+dense Adam+zero_grad)"
+                      if args.mode == "train" else f"samples/sec {type(model).__name__} Criteo-shape bsz={local_B}/GPU (forward only)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{type(model).__name__} ({args.model}), {F} sparse fields (Criteo-Kaggle "
                                    f"cardinalities/{args.vocab_scale}, "
                                    f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D={D} + {ND} dense, "
-                                   f"global batch {B}, uniform ids"
+                                   f"batch {local_B} per GPU (global {B}), uniform ids"
                                    + (f", MLP {list(hidden)}" if args.model == "deepfm" else
                                       (", MLP [64,64,64]" if args.model != "mmoe" else ", 4 experts x 128, towers [256,128]"))
                                    + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
-                       "global_batch": B,
+                       "global_batch": B, "per_gpu_batch": local_B,
                        "optimizer": ("dense Adam, reference semantics, executed lazily (bit-identical; all rows flushed "
                                      "to the last step inside the timed region)" if args.optimizer == "lazy"
                                      else "dense Adam (reference semantics, every row streamed each step, fused zero_grad)"),

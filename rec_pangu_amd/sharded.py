@@ -9,11 +9,13 @@ Partition.  Global batch B is split into contiguous local batches of b = B/G sam
 mod-sharding spreads both capacity and traffic (Criteo's three 5-10 M-row tables hold 76 % of the rows,
 its 3..30-row tables are the hottest), without per-table placement decisions.
 
-One exchange each way per step (the only data-path collectives):
+One exchange each way per step (the only data-path collectives), over the DEDUPLICATED requests of the local batch
+(see _Route: ~0.55 M distinct rows out of 1.7 M requests at b = 65536 with Criteo cardinalities):
   forward   ids  : all_to_all_single of int64 local-row ids, bucketed by owner (sizes via a G-int all-to-all)
-            rows : owner gathers its rows -> all_to_all_single back ([n, D] fp32, ~b*F/G rows per peer:
-                   26 624 x 256 B = 6.8 MB per xGMI link at B=65536, G=8 — every peer pair has its own link)
-  backward  grads: the same route reversed, then a local sort + segmented reduce into the local dense gradient
+            rows : owner gathers its rows -> all_to_all_single back ([n_unique, D] fp32; every peer pair has its
+                   own xGMI link, so the G-1 transfers of a rank run concurrently)
+  backward  grads: request gradients are segment-summed per unique row locally, travel the same route reversed,
+                   then a local sort + segmented reduce adds them into the owner's dense gradient
 Dense parameters are replicated; `allreduce_dense_grads` averages their gradients in ONE flat bucket
 (0.46 MB for the default MLP: latency-bound, so one collective, not one per tensor).
 Embedding-row gradients are scaled by 1/G before they travel, so the update equals the 1-GPU update on
@@ -37,41 +39,62 @@ def _a2a(out, inp, out_splits, in_splits, group):
 
 
 class _Route:
-    """Bucketing of n row requests by owner rank + the split sizes of the exchange."""
+    """One lookup exchange: the n = F*b row requests of the local batch are DEDUPLICATED and bucketed by owner.
 
-    def __init__(self, keys: torch.Tensor, world: int, group):
-        dest = keys % world
-        self.order = torch.argsort(dest, stable=True)  # positions (pair ids) in send order
-        send_counts = torch.bincount(dest, minlength=world)
+    A request for global arena row r goes to rank r % G as local row r // G.  Sorting the composite key
+    (owner << lbits | local_row) groups the requests by owner and, inside an owner, by row — so the unique rows of
+    each owner are contiguous and already in send order, and equal requests are adjacent (one `unique_consecutive`).
+    Only the unique rows travel: with Criteo-like cardinalities a 65536-sample batch asks for ~0.55 M distinct rows
+    out of 1.7 M requests, which cuts both all-to-alls (rows forward, row gradients backward) by 3x.
+      slot_sorted[j] : unique-row slot of the j-th request in sorted order (ascending, runs of equal slots)
+      pos_sorted[j]  : which request (pair id p = f*b + i) that is
+      slot_of_pair[p]: the slot request p reads its row from
+    """
+
+    def __init__(self, keys: torch.Tensor, layer):
+        world, lbits = layer.world, layer.lbits
+        comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
+        nbits = lbits + max(1, (world - 1).bit_length())
+        if keys.is_cuda and nbits <= 31:
+            from . import hip
+            sk, sp = hip.sort_pairs(comp.to(torch.int32), end_bit=nbits)  # rocPRIM radix sort, (key, position) pairs
+        else:
+            sk, sp = torch.sort(comp, stable=True)
+        uniq, inverse = torch.unique_consecutive(sk, return_inverse=True)
+        send_counts = torch.bincount((uniq >> lbits).long(), minlength=world)
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=group)
-        self.send = send_counts.tolist()  # one host sync per exchange: RCCL wants sizes on the host
-        self.recv = recv_counts.tolist()
-        self.local_rows = torch.div(keys, world, rounding_mode="floor")[self.order].contiguous()
-        self.n_recv = sum(self.recv)
+        dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
+        # one host sync per exchange: the collective wants its split sizes on the host
+        self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
+        self.local_rows = (uniq & ((1 << lbits) - 1)).long().contiguous()
+        self.n_unique, self.n_recv = int(uniq.numel()), sum(self.recv)
+        self.slot_sorted = inverse.to(torch.int32).contiguous()
+        self.pos_sorted = sp.to(torch.int32).contiguous()
+        self.slot_of_pair = torch.empty((keys.numel(),), dtype=torch.int64, device=keys.device)
+        self.slot_of_pair[sp.long()] = inverse.long()
 
 
 class _ShardedRows(torch.autograd.Function):
-    """rows_in_send_order[j] = global_arena[keys[order[j]]]; backward routes the row gradients back to the
-    owners and reduces them into the owner's local dense gradient."""
+    """rows[s] = global_arena[unique request s]; backward routes the per-unique-row gradients back to the owners
+    and reduces them into the owner's local dense gradient."""
 
     @staticmethod
     def forward(ctx, layer, keys, local_arena):
-        route = _Route(keys, layer.world, layer.group)
+        route = _Route(keys, layer)
         recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=keys.device)
         _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
         served = layer._local_gather(recv_rows)  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
-        rows = torch.empty((keys.numel(), local_arena.shape[1]), dtype=local_arena.dtype, device=keys.device)
+        rows = torch.empty((route.n_unique, local_arena.shape[1]), dtype=local_arena.dtype, device=keys.device)
         _a2a(rows, served, route.send, route.recv, layer.group)
         ctx.layer, ctx.route = layer, route
         ctx.save_for_backward(recv_rows)
-        ctx.mark_non_differentiable(route.order)
-        return rows, route.order
+        ctx.mark_non_differentiable(route.slot_of_pair, route.slot_sorted, route.pos_sorted)
+        return rows, route.slot_of_pair, route.slot_sorted, route.pos_sorted
 
     @staticmethod
-    def backward(ctx, g_rows, _g_order):
+    def backward(ctx, g_rows, *_unused):
         (recv_rows,) = ctx.saved_tensors
         layer, route = ctx.layer, ctx.route
         g_rows = (g_rows * (1.0 / layer.world)).contiguous()
@@ -82,37 +105,35 @@ class _ShardedRows(torch.autograd.Function):
 
 
 class _RowsToX(torch.autograd.Function):
-    """HIP: x[b, ldx] (+ FM) from the rows received in send order (bag size 1: row j serves pair order[j])."""
+    """HIP: x[b, ldx] (+ FM) from the unique rows received (request p reads slot slot_of_pair[p]); the backward is
+    the segmented sum of the request gradients per unique row (the same kernel the single-GPU gather backward
+    uses), so what travels back is again one row per unique request."""
 
     @staticmethod
-    def forward(ctx, rows, inv, dense: List[torch.Tensor], order, b: int, F: int, ldx: int, want_fm: bool,
-                err_flag):
+    def forward(ctx, rows, slot_of_pair, dense: List[torch.Tensor], slot_sorted, pos_sorted, b: int, F: int, ldx: int,
+                want_fm: bool, err_flag):
         from . import hip
         n, D = rows.shape
         dev = rows.device
-        zero = torch.zeros((1,), dtype=torch.int64, device=dev)
-        cnt = torch.full((1,), n, dtype=torch.int64, device=dev)
-        idx = [inv[f * b:(f + 1) * b] for f in range(F)]
-        x, fm, ssum, _ = hip.embed_gather_fwd(rows, zero.expand(F).contiguous(), cnt.expand(F).contiguous(), idx, dense,
-                                              ldx, want_fm, want_fm, False, err_flag)
+        zero = torch.zeros((F,), dtype=torch.int64, device=dev)
+        cnt = torch.full((F,), n, dtype=torch.int64, device=dev)
+        idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
+        x, fm, ssum, _ = hip.embed_gather_fwd(rows, zero, cnt, idx, dense, ldx, want_fm, want_fm, False, err_flag)
         ctx.cfg = (b, F, D, want_fm)
-        ctx.save_for_backward(rows, order, ssum)
+        ctx.save_for_backward(rows, slot_sorted, pos_sorted, ssum)
         return (x, fm) if want_fm else x
 
     @staticmethod
     def backward(ctx, dx, dfm=None):
         from . import hip
-        rows, order, ssum = ctx.saved_tensors
+        rows, slot_sorted, pos_sorted, ssum = ctx.saved_tensors
         b, F, D, want_fm = ctx.cfg
-        n = rows.shape[0]
         g_rows = torch.empty_like(rows)
-        ident = torch.arange(n, dtype=torch.int32, device=rows.device)
         gfm = dfm.contiguous() if (want_fm and dfm is not None) else None
         dx = None if dx is None else Fh._unit_inner(dx)
-        # run length 1 everywhere: "key" j = position in send order, its single pair is order[j]
-        hip.embed_grad_reduce(ident, order.to(torch.int32), b, D, dx, gfm, ssum if gfm is not None else None,
+        hip.embed_grad_reduce(slot_sorted, pos_sorted, b, D, dx, gfm, ssum if gfm is not None else None,
                               rows if gfm is not None else None, g_rows, accumulate=False)
-        return g_rows, None, None, None, None, None, None, None, None
+        return g_rows, None, None, None, None, None, None, None, None, None
 
 
 class ShardedEmbeddingLayer(nn.Module):
@@ -131,6 +152,7 @@ class ShardedEmbeddingLayer(nn.Module):
         for r in rows[:-1]:
             base.append(base[-1] + r)
         self.total_rows = sum(rows)
+        self.lbits = max(1, int((self.total_rows + world - 1) // world).bit_length())  # bits of a local row id
         self.register_buffer("_row_base", torch.tensor(base, dtype=torch.int64, device=full_layer.arena.device),
                              persistent=False)
         self.register_buffer("_row_count", torch.tensor(rows, dtype=torch.int64, device=full_layer.arena.device),
@@ -237,17 +259,15 @@ class ShardedEmbeddingLayer(nn.Module):
             p.grad = upd if p.grad is None else p.grad + upd
 
     # ---- forward ------------------------------------------------------------------------------------
-    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 32):
+    def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 64):
         keys = self._keys(X)
         F, D = len(self.emb_feature), self.embedding_dim
         b = keys.numel() // F
-        rows, order = _ShardedRows.apply(self, keys, self.local_arena)
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=order.device)
+        rows, slot_of_pair, slot_sorted, pos_sorted = _ShardedRows.apply(self, keys, self.local_arena)
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
-        out = _RowsToX.apply(rows, inv, dense, order, b, F, ldx, want_fm, self._err)
+        out = _RowsToX.apply(rows, slot_of_pair, dense, slot_sorted, pos_sorted, b, F, ldx, want_fm, self._err)
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)
@@ -260,12 +280,10 @@ class ShardedEmbeddingLayer(nn.Module):
             x, _ = self.gather_concat(X, [], want_fm=False, pad_to=1)
             return x.view(x.shape[0], F, D)
         keys = self._keys(X)
-        rows, order = _ShardedRows.apply(self, keys, self.local_arena)
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=order.device)
+        rows, slot_of_pair, _, _ = _ShardedRows.apply(self, keys, self.local_arena)
         if self.check_indices == "sync":
             self.raise_if_bad_index()
-        return rows[inv].view(F, -1, D).permute(1, 0, 2)
+        return rows[slot_of_pair].view(F, -1, D).permute(1, 0, 2)
 
     # ---- checkpoints in the reference layout ------------------------------------------------------------
     def full_tables(self) -> Dict[str, torch.Tensor]:
