@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 CRITEO_CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
                10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; v_mfma_f32_32x32x16_bf16)
 
 
 def criteo_enc_dict(scale=1):
@@ -329,14 +330,21 @@ def main():
                     "traffic": pmc_traffic(dominant) if (args.model == "deepfm" and world == 1) else None,
                     "algorithmic_bytes_per_launch": alg_bytes[dominant]}
     if mlp_flops is not None:
-        # MFMA-bound variant: report the GEMM launches against the exact-fp32 matrix-core peak (157.3 TFLOP/s)
-        tot_ms = {n: timing[n][0] * timing[n][1] / args.steps for n in mlp_flops if n in timing}
+        # MFMA-bound variant: the GEMM launches against the dense bf16 matrix-core peak (the GEMMs run on
+        # v_mfma_f32_32x32x16_bf16 with split-bf16 operands: `achieved` counts ALGORITHMIC flops, the matrix core
+        # issues `mfma_products_per_flop` bf16 products for each of them)
+        n_timed_steps = len(range(0, args.steps, ev_stride))  # events were recorded on these steps only
+        tot_ms = {n: timing[n][0] * timing[n][1] / n_timed_steps for n in mlp_flops if n in timing}
         if tot_ms:
             n = max(tot_ms, key=tot_ms.get)
             tf = mlp_flops[n] / (tot_ms[n] * 1e-3) / 1e12
-            roofline = {"kernel": n, "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": round(tf / 157.3, 4), "traffic": None,
-                        "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32) peak; flops = all launches of this entry per step"}
+            nprod = {"bf16x6": 6, "bf16x3": 3, "bf16": 1, "fp32": 1}[hip.get_matmul_precision()]
+            peak = 157.3 if hip.get_matmul_precision() == "fp32" else MFMA_BF16_PEAK_TF
+            roofline = {"kernel": n, "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tf / peak, 4), "traffic": None,
+                        "matmul_precision": hip.get_matmul_precision(), "mfma_products_per_flop": nprod,
+                        "mfma_issue_frac": round(tf * nprod / peak, 4),
+                        "note": "flops = all launches of this entry per step; fp32 operands, fp32 accumulation"}
     gather = None
     if "embed_gather_fwd" in timing:
         a = alg_bytes["embed_gather_fwd"] / (timing["embed_gather_fwd"][1] * 1e-3) / 1e9
