@@ -286,6 +286,11 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
 
     // PF tiles of global loads are kept in flight per workgroup (a register ring): one tile per workgroup is a few
     // KB, and at 2-4 resident workgroups per CU that is far too little to cover HBM latency at full bandwidth.
+    // The ring only works if the compiler can COUNT the loads in flight: gfx950 has one in-order counter (vmcnt) for
+    // all global loads, and a load behind a branch (a bounds guard) makes every wait a vmcnt(0) — i.e. each tile
+    // would wait for the loads issued for the tile PF steps ahead, exposing the full memory latency per tile.  So an
+    // interior workgroup (all rows / columns in range, 16-byte aligned operands) runs its full k tiles through a
+    // straight-line loop with unguarded loads; the guarded loop below finishes the last tiles and serves the edges.
     f32x4 ra[PF][RA], rw[PF][2];
     auto load_tile = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[2]) {
 #pragma unroll
@@ -300,6 +305,18 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
                             : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    const float *a_row[RA];
+    const float *w_row[2];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) a_row[j] = A + (m0 + lr + 32 * j) * lda + lc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w_row[j] = W + (int64_t)(n0 + lr + 32 * j) * ldw + lc;
+    auto load_tile_full = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[2]) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) da[j] = *reinterpret_cast<const f32x4 *>(a_row[j] + k0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dw[j] = *reinterpret_cast<const f32x4 *>(w_row[j] + k0);
+    };
 
     f32x16 acc[NACC];
 #pragma unroll
@@ -307,52 +324,74 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    const int nk = (K + BK - 1) / BK;
+    auto stage = [&](const f32x4 (&sa)[RA], const f32x4 (&sw)[2]) {
+        __syncthreads();
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
-        if (p < nk) load_tile(p * BK, ra[p], rw[p]);
-    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+        for (int j = 0; j < RA; ++j) {
+            bf16x4 pc[NP];
+            bf_split4<NP>(sa[j], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + 32 * j][lc]) = pc[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x4 pc[NP];
+            bf_split4<NP>(sw[j], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[q][lr + 32 * j][lc]) = pc[q];
+        }
+        __syncthreads();
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const bf16x8 *>(&As[q][32 * wm + i][ks * 16 + 8 * h]);
+#pragma unroll
+            for (int nt = 0; nt < NACC; ++nt) {
+                const int col0 = (WM == 4) ? nt * 32 : wn * 32;
+                if (n0 + col0 >= N) continue;  // wave-uniform
+                bf16x8 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(&Ws[q][col0 + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int pr = 0; pr < NPROD; ++pr)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b[BfProd<NPROD>::pb(pr)],
+                                                                      acc[nt], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    const int nkf = K / BK;  // k tiles that need no column guard
+    int kbeg = 0;
+    if (VEC_A && VEC_W && (m0 + BMT <= M) && (n0 + BN <= N) && nkf >= 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_tile_full(p * BK, ra[p], rw[p]);
+        const int nloop = (nkf - PF) / PF;
+        for (int it = 0; it < nloop; ++it) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                stage(ra[p], rw[p]);
+                load_tile_full((it * PF + p + PF) * BK, ra[p], rw[p]);
+                compute();
+            }
+        }
+        kbeg = nloop * PF;  // tiles kbeg .. kbeg+PF-1 are in the ring
+    } else {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (p < nk) load_tile(p * BK, ra[p], rw[p]);
+    }
+    for (int kt0 = kbeg; kt0 < nk; kt0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int kt = kt0 + p;
             if (kt >= nk) break;
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < RA; ++j) {
-                bf16x4 pc[NP];
-                bf_split4<NP>(ra[p][j], pc);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + 32 * j][lc]) = pc[q];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x4 pc[NP];
-                bf_split4<NP>(rw[p][j], pc);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[q][lr + 32 * j][lc]) = pc[q];
-            }
-            __syncthreads();
+            stage(ra[p], rw[p]);
             if (kt + PF < nk) load_tile((kt + PF) * BK, ra[p], rw[p]);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    a[q] = *reinterpret_cast<const bf16x8 *>(&As[q][32 * wm + i][ks * 16 + 8 * h]);
-#pragma unroll
-                for (int nt = 0; nt < NACC; ++nt) {
-                    const int col0 = (WM == 4) ? nt * 32 : wn * 32;
-                    if (n0 + col0 >= N) continue;  // wave-uniform
-                    bf16x8 b[NP];
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        b[q] = *reinterpret_cast<const bf16x8 *>(&Ws[q][col0 + i][ks * 16 + 8 * h]);
-#pragma unroll
-                    for (int pr = 0; pr < NPROD; ++pr)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)],
-                                                                          b[BfProd<NPROD>::pb(pr)], acc[nt], 0, 0, 0);
-                }
-            }
+            compute();
         }
     }
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -626,6 +665,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
             dx_[r] = v;
         }
     };
+    // interior tile: unguarded loads -> straight-line main loop -> counted vmcnt waits (see linear_fwd_bf16_kernel)
+    const float *yb = dY + (mbeg + 8 * o) * lddy + n0 + c;
+    const float *xb = X + (mbeg + 8 * o) * ldx + kx;
+    auto load_tile_full = [&](int64_t moff, float (&dy_)[8], f32x2 (&dx_)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            dy_[r] = yb[(moff + r) * lddy];
+            dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
+        }
+    };
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -635,55 +684,78 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
     }
     float bsum = 0.f;
     const bool do_bias = (Pb != nullptr) && (blockIdx.x == 0);
+
+    auto stage = [&](const float (&sy)[8], const f32x2 (&sx)[8]) {
+        __syncthreads();
+        f32x8 vy, vx0, vx1;
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
-        if (mbeg + (int64_t)p * TN_BM < mend) load_tile(mbeg + (int64_t)p * TN_BM, ry[p], rx[p]);
-    for (int64_t mm0 = mbeg; mm0 < mend; mm0 += (int64_t)PF * TN_BM) {
+        for (int r = 0; r < 8; ++r) {
+            vy[r] = sy[r];
+            vx0[r] = sx[r].x;
+            vx1[r] = sx[r].y;
+        }
+        if (do_bias) bsum += ((sy[0] + sy[1]) + (sy[2] + sy[3])) + ((sy[4] + sy[5]) + (sy[6] + sy[7]));
+        bf16x8 pc[NP];
+        bf_split8<NP>(vy, pc);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Yt[q][c][8 * o]) = pc[q];
+        bf_split8<NP>(vx0, pc);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c][8 * o]) = pc[q];
+        bf_split8<NP>(vx1, pc);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c + 1][8 * o]) = pc[q];
+        __syncthreads();
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[NP], b0[NP], b1[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                a[q] = *reinterpret_cast<const bf16x8 *>(&Yt[q][nt + i][ks * 16 + 8 * h]);
+                b0[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + i][ks * 16 + 8 * h]);
+                b1[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + 32 + i][ks * 16 + 8 * h]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < NPROD; ++pr) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)], acc0,
+                                                               0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b1[BfProd<NPROD>::pb(pr)], acc1,
+                                                               0, 0, 0);
+            }
+        }
+    };
+
+    const int64_t nst = (mend > mbeg) ? (mend - mbeg + TN_BM - 1) / TN_BM : 0;  // stages of 32 batch rows
+    const int64_t nstf = (mend > mbeg) ? (mend - mbeg) / TN_BM : 0;             // ... that are complete
+    int64_t sbeg = 0;
+    if (VEC_X && (n0 + TN_BN <= N) && (k0 + TN_BK <= K) && nstf >= 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_tile_full((int64_t)p * TN_BM, ry[p], rx[p]);
+        const int64_t nloop = (nstf - PF) / PF;
+        for (int64_t it = 0; it < nloop; ++it) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                stage(ry[p], rx[p]);
+                load_tile_full((it * PF + p + PF) * TN_BM, ry[p], rx[p]);
+                compute();
+            }
+        }
+        sbeg = nloop * PF;
+    } else {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (p < nst) load_tile(mbeg + (int64_t)p * TN_BM, ry[p], rx[p]);
+    }
+    for (int64_t s0 = sbeg; s0 < nst; s0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int64_t mm = mm0 + (int64_t)p * TN_BM;
-            if (mm >= mend) break;
-            __syncthreads();
-            {
-                f32x8 vy, vx0, vx1;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    vy[r] = ry[p][r];
-                    vx0[r] = rx[p][r].x;
-                    vx1[r] = rx[p][r].y;
-                }
-                if (do_bias)
-                    bsum += ((ry[p][0] + ry[p][1]) + (ry[p][2] + ry[p][3])) + ((ry[p][4] + ry[p][5]) + (ry[p][6] + ry[p][7]));
-                bf16x8 pc[NP];
-                bf_split8<NP>(vy, pc);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Yt[q][c][8 * o]) = pc[q];
-                bf_split8<NP>(vx0, pc);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c][8 * o]) = pc[q];
-                bf_split8<NP>(vx1, pc);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c + 1][8 * o]) = pc[q];
-            }
-            __syncthreads();
-            if (mm + (int64_t)PF * TN_BM < mend) load_tile(mm + (int64_t)PF * TN_BM, ry[p], rx[p]);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[NP], b0[NP], b1[NP];
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    a[q] = *reinterpret_cast<const bf16x8 *>(&Yt[q][nt + i][ks * 16 + 8 * h]);
-                    b0[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + i][ks * 16 + 8 * h]);
-                    b1[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + 32 + i][ks * 16 + 8 * h]);
-                }
-#pragma unroll
-                for (int pr = 0; pr < NPROD; ++pr) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)],
-                                                                   acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b1[BfProd<NPROD>::pb(pr)],
-                                                                   acc1, 0, 0, 0);
-                }
-            }
+            const int64_t st = s0 + p;
+            if (st >= nst) break;
+            stage(ry[p], rx[p]);
+            if (st + PF < nst) load_tile(mbeg + (st + PF) * TN_BM, ry[p], rx[p]);
+            compute();
         }
     }
     float *Pz = P + (int64_t)blockIdx.z * N * K;

@@ -128,7 +128,8 @@ class _RowsToX(torch.autograd.Function):
         from . import hip
         rows, slot_sorted, pos_sorted, ssum = ctx.saved_tensors
         b, F, D, want_fm = ctx.cfg
-        g_rows = torch.empty_like(rows)
+        # zero-initialised: runs of equal slots that cross a segment border are added atomically by the kernel
+        g_rows = torch.zeros_like(rows)
         gfm = dfm.contiguous() if (want_fm and dfm is not None) else None
         dx = None if dx is None else Fh._unit_inner(dx)
         hip.embed_grad_reduce(slot_sorted, pos_sorted, b, D, dx, gfm, ssum if gfm is not None else None,
