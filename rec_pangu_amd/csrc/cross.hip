@@ -24,53 +24,122 @@ __device__ __forceinline__ float block_allsum_256(float v, float *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// Forward: one 64-lane wave per row, persistent workgroups.  W (L rows), wfc and — when they fit in 64 KB of LDS
+// next to them — the biases are staged once per workgroup, zero-padded to 256-column chunks; lane l owns columns
+// 256j + 4l .. +3 of chunk j (dwordx4 global accesses, conflict-free ds_read_b128).  The row stays in registers
+// through all L layers; each layer is one dot product (wave shuffles, no barrier) and one axpy.
+#define CROSS_NJ 8  // 256-column chunks per row: d <= 2048
+template <bool VEC, bool B_LDS>
 __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
                                                            const float *__restrict__ W, const float *__restrict__ Bv,
                                                            const float *__restrict__ wfc, const float *__restrict__ bfc,
                                                            float *__restrict__ xout, int64_t ldo,
                                                            float *__restrict__ logit, float *__restrict__ s_out,
                                                            int64_t B) {
-    __shared__ float sh[4];
-    const int t = threadIdx.x;
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        float r0[CROSS_J], r[CROSS_J];
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            const int e = t + 256 * j;
-            r0[j] = (e < d) ? x0[b * ldx + e] : 0.f;
-            r[j] = r0[j];
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [L][dp] W | [dp] wfc | (B_LDS: [L][dp] biases)
+    const int dp = ((d + 255) / 256) * 256;
+    const int nrows = B_LDS ? 2 * L + 1 : L + 1;
+    for (int idx = threadIdx.x; idx < nrows * dp; idx += 256) {
+        const int l = idx / dp, e = idx - l * dp;
+        float v = 0.f;
+        if (e < d) {
+            if (l < L) v = W[(int64_t)l * d + e];
+            else if (l == L) v = (wfc != nullptr) ? wfc[e] : 0.f;
+            else v = Bv[(int64_t)(l - L - 1) * d + e];
         }
+        wl[idx] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nj = dp / 256;
+    const float *bl = wl + (L + 1) * dp;
+    // the next row's loads are issued before this row's arithmetic (register double buffer): a wave otherwise
+    // spends most of its time waiting for its own single row
+    auto load_row = [&](int64_t b, f32x4 (&dst)[CROSS_NJ]) {
+#pragma unroll
+        for (int j = 0; j < CROSS_NJ; ++j) {
+            const int e = 256 * j + 4 * lane;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            if (j < nj) {
+                if (VEC && e + 4 <= d) {
+                    xv = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + e);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e + k < d) xv[k] = x0[b * ldx + e + k];
+                }
+            }
+            dst[j] = xv;
+        }
+    };
+    const int64_t bstep = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 nx[CROSS_NJ];
+    if (b < B) load_row(b, nx);
+    for (; b < B; b += bstep) {
+        f32x4 r0[CROSS_NJ], r[CROSS_NJ];
+#pragma unroll
+        for (int j = 0; j < CROSS_NJ; ++j) {
+            r0[j] = nx[j];
+            r[j] = nx[j];
+        }
+        if (b + bstep < B) load_row(b + bstep, nx);
         for (int l = 0; l < L; ++l) {
             float part = 0.f;
 #pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) {
-                const int e = t + 256 * j;
-                if (e < d) part += r[j] * W[(int64_t)l * d + e];
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                if (j < nj) {
+                    const f32x4 pr = r[j] * *reinterpret_cast<const f32x4 *>(&wl[l * dp + 256 * j + 4 * lane]);
+                    part += (pr.x + pr.y) + (pr.z + pr.w);
+                }
             }
-            const float s = block_allsum_256(part, sh);
-            if (t == 0 && s_out != nullptr) s_out[b * L + l] = s;
 #pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) {
-                const int e = t + 256 * j;
-                if (e < d) r[j] = r[j] + (s * r0[j] + Bv[(int64_t)l * d + e]);
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const float sv = part;
+            if (lane == 0 && s_out != nullptr) s_out[b * L + l] = sv;
+#pragma unroll
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                if (j < nj) {
+                    const int e = 256 * j + 4 * lane;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (B_LDS) {
+                        bv = *reinterpret_cast<const f32x4 *>(&bl[l * dp + e]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (e + k < d) bv[k] = Bv[(int64_t)l * d + e + k];
+                    }
+                    r[j] = r[j] + (sv * r0[j] + bv);
+                }
             }
         }
         if (xout != nullptr) {
 #pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) {
-                const int e = t + 256 * j;
-                if (e < d) xout[b * ldo + e] = r[j];
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                const int e = 256 * j + 4 * lane;
+                if (j < nj) {
+                    if (VEC && e + 4 <= d) {
+                        *reinterpret_cast<f32x4 *>(xout + b * ldo + e) = r[j];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (e + k < d) xout[b * ldo + e + k] = r[j][k];
+                    }
+                }
             }
         }
         if (logit != nullptr) {
             float part = 0.f;
 #pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) {
-                const int e = t + 256 * j;
-                if (e < d) part += r[j] * wfc[e];
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                if (j < nj) {
+                    const f32x4 pr = r[j] * *reinterpret_cast<const f32x4 *>(&wl[L * dp + 256 * j + 4 * lane]);
+                    part += (pr.x + pr.y) + (pr.z + pr.w);
+                }
             }
-            const float z = block_allsum_256(part, sh);
-            if (t == 0) logit[b] = z + (bfc != nullptr ? bfc[0] : 0.f);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (lane == 0) logit[b] = part + (bfc != nullptr ? bfc[0] : 0.f);
         }
     }
 }
@@ -199,7 +268,11 @@ __global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restri
 // V[b] = [t_l A_l (l<L) | gl A_L | t_l (l<L) | gl] whose product with X_0 (and column sums) give every parameter
 // gradient.  HBM traffic: X_0 read once, dX_0 written once (+ the incoming gradient row when it is not the fc).
 // ------------------------------------------------------------------------------------------------
-#define CROSS_WJ 32  // floats per lane: d <= 2048
+// Execution: persistent workgroups; W (L rows) and wfc are staged ONCE per workgroup into LDS, zero-padded to a
+// multiple of 256 columns (every row used to re-fetch (L+1)*d floats from L2 through the 64 B/clk L1 — twice the
+// bytes of the HBM stream itself); lane l owns the 4 consecutive columns 256j + 4l .. +3 of chunk j, so X_0 / g / dX_0
+// move as dwordx4 and the W reads are conflict-free ds_read_b128.
+template <bool VEC>
 __global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
                                                                 const float *__restrict__ W,
                                                                 const float *__restrict__ wfc,
@@ -208,55 +281,99 @@ __global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__r
                                                                 const float *__restrict__ g_logit,
                                                                 float *__restrict__ dx0, int64_t lddx,
                                                                 float *__restrict__ V, int64_t B) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    float r0[CROSS_WJ], g[CROSS_WJ], gx0[CROSS_WJ];
-    const float gl = (g_logit != nullptr) ? g_logit[b] : 0.f;
-#pragma unroll
-    for (int j = 0; j < CROSS_WJ; ++j) {
-        const int e = lane + 64 * j;
-        const bool ok = e < d;
-        r0[j] = ok ? x0[b * ldx + e] : 0.f;
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [(L+1)][dp]
+    const int dp = ((d + 255) / 256) * 256;
+    for (int idx = threadIdx.x; idx < (L + 1) * dp; idx += 256) {
+        const int l = idx / dp, e = idx - l * dp;
         float v = 0.f;
-        if (ok && g_x != nullptr) v += g_x[b * ldg + e];
-        if (ok && g_logit != nullptr) v += gl * wfc[e];
-        g[j] = v;
-        gx0[j] = 0.f;
+        if (e < d) v = (l < L) ? W[(int64_t)l * d + e] : (wfc != nullptr ? wfc[e] : 0.f);
+        wl[idx] = v;
     }
-    float a_run = 1.f;  // A_L = 1 + sum_k s_k, then peeled back layer by layer
-    for (int l = 0; l < L; ++l) a_run += s_in[b * L + l];
-    float *Vb = V + b * (2 * L + 2);
-    if (lane == 0) {
-        Vb[L] = gl * a_run;
-        Vb[2 * L + 1] = gl;
-    }
-    for (int l = L - 1; l >= 0; --l) {
-        const float sl = s_in[b * L + l];
-        a_run -= sl;  // A_l
-        float part = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nj = dp / 256;
+    auto load_row = [&](int64_t b, f32x4 (&dx_)[CROSS_NJ], f32x4 (&dg_)[CROSS_NJ]) {
 #pragma unroll
-        for (int j = 0; j < CROSS_WJ; ++j) part += g[j] * r0[j];
+        for (int j = 0; j < CROSS_NJ; ++j) {
+            const int e = 256 * j + 4 * lane;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+            if (j < nj) {
+                if (VEC && e + 4 <= d) {
+                    xv = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + e);
+                    if (g_x != nullptr) gv = *reinterpret_cast<const f32x4 *>(g_x + b * ldg + e);
+                } else {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        const float tl = part;
-        if (lane == 0) {
-            Vb[l] = tl * a_run;
-            Vb[L + 1 + l] = tl;
+                    for (int k = 0; k < 4; ++k)
+                        if (e + k < d) {
+                            xv[k] = x0[b * ldx + e + k];
+                            if (g_x != nullptr) gv[k] = g_x[b * ldg + e + k];
+                        }
+                }
+            }
+            dx_[j] = xv;
+            dg_[j] = gv;
         }
+    };
+    const int64_t bstep = (int64_t)gridDim.x * 4;
+    int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 nx[CROSS_NJ], ng[CROSS_NJ];
+    if (b < B) load_row(b, nx, ng);
+    for (; b < B; b += bstep) {
+        f32x4 r0[CROSS_NJ], g[CROSS_NJ], gx0[CROSS_NJ];
+        const float gl = (g_logit != nullptr) ? g_logit[b] : 0.f;
 #pragma unroll
-        for (int j = 0; j < CROSS_WJ; ++j) {
-            const int e = lane + 64 * j;
-            if (e < d) {
-                gx0[j] += sl * g[j];
-                g[j] += tl * W[(int64_t)l * d + e];
+        for (int j = 0; j < CROSS_NJ; ++j) {
+            r0[j] = nx[j];
+            g[j] = ng[j];
+            if (j < nj) g[j] += gl * *reinterpret_cast<const f32x4 *>(&wl[L * dp + 256 * j + 4 * lane]);  // wfc
+            gx0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (b + bstep < B) load_row(b + bstep, nx, ng);  // in flight during this row's arithmetic
+        float a_run = 1.f;  // A_L = 1 + sum_k s_k, then peeled back layer by layer
+        for (int l = 0; l < L; ++l) a_run += s_in[b * L + l];
+        float *Vb = V + b * (2 * L + 2);
+        if (lane == 0) {
+            Vb[L] = gl * a_run;
+            Vb[2 * L + 1] = gl;
+        }
+        for (int l = L - 1; l >= 0; --l) {
+            const float sl = s_in[b * L + l];
+            a_run -= sl;  // A_l
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                const f32x4 pr = g[j] * r0[j];
+                part += (pr.x + pr.y) + (pr.z + pr.w);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            const float tl = part;
+            if (lane == 0) {
+                Vb[l] = tl * a_run;
+                Vb[L + 1 + l] = tl;
+            }
+#pragma unroll
+            for (int j = 0; j < CROSS_NJ; ++j) {
+                if (j < nj) {
+                    gx0[j] += sl * g[j];
+                    g[j] += tl * *reinterpret_cast<const f32x4 *>(&wl[l * dp + 256 * j + 4 * lane]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < CROSS_WJ; ++j) {
-        const int e = lane + 64 * j;
-        if (e < d) dx0[b * lddx + e] = gx0[j] + g[j];
+        for (int j = 0; j < CROSS_NJ; ++j) {
+            const int e = 256 * j + 4 * lane;
+            if (j < nj) {
+                const f32x4 o4 = gx0[j] + g[j];
+                if (VEC && e + 4 <= d) {
+                    *reinterpret_cast<f32x4 *>(dx0 + b * lddx + e) = o4;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (e + k < d) dx0[b * lddx + e + k] = o4[k];
+                }
+            }
+        }
     }
 }
 
@@ -266,11 +383,22 @@ extern "C" int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, 
     RP_REQUIRE(x0 && W && s_in && dx0 && V && B >= 0, "crossnet_bwd_rows: bad argument");
     RP_REQUIRE(g_x != nullptr || g_logit != nullptr, "crossnet_bwd_rows: no incoming gradient");
     RP_REQUIRE(g_logit == nullptr || wfc != nullptr, "crossnet_bwd_rows: logit gradient needs wfc");
-    if (d < 1 || d > 64 * CROSS_WJ || L < 1)
-        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) unsupported", d, 64 * CROSS_WJ);
+    if (d < 1 || d > 256 * CROSS_NJ || L < 1 || L > CROSS_MAXL)
+        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) / L=%d (max %d) unsupported", d, 256 * CROSS_NJ, L,
+                       CROSS_MAXL);
     if (B == 0) return RP_OK;
-    hipLaunchKernelGGL(crossnet_bwd_rows_kernel, dim3((unsigned)rp_cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, x0,
-                       ldx, d, L, W, wfc, s_in, g_x, ldg, g_logit, dx0, lddx, V, B);
+    const int dp = ((d + 255) / 256) * 256;
+    const size_t lds = (size_t)(L + 1) * dp * sizeof(float);  // <= 7 * 2048 * 4 = 56 KB
+    const bool vec = (ldx % 4 == 0) && (lddx % 4 == 0) && rp_aligned16(x0) && rp_aligned16(dx0) &&
+                     (g_x == nullptr || ((ldg % 4 == 0) && rp_aligned16(g_x)));
+    int64_t nb = rp_cdiv(B, 4);
+    if (nb > 2048) nb = 2048;  // persistent: each wave walks over B / (4 * 2048) rows, W staged once per workgroup
+    if (vec)
+        hipLaunchKernelGGL((crossnet_bwd_rows_kernel<true>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, x0,
+                           ldx, d, L, W, wfc, s_in, g_x, ldg, g_logit, dx0, lddx, V, B);
+    else
+        hipLaunchKernelGGL((crossnet_bwd_rows_kernel<false>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream,
+                           x0, ldx, d, L, W, wfc, s_in, g_x, ldg, g_logit, dx0, lddx, V, B);
     RP_LAUNCH_CHECK("crossnet_bwd_rows");
     return RP_OK;
 }
@@ -296,12 +424,25 @@ extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const
     RP_REQUIRE(x0 && W && Bv && B >= 0 && ldx >= d, "crossnet_fwd: bad argument");
     RP_REQUIRE(xout != nullptr || logit != nullptr, "crossnet_fwd: nothing to produce");
     RP_REQUIRE(logit == nullptr || wfc != nullptr, "crossnet_fwd: logit needs wfc");
-    if (d < 1 || d > 256 * CROSS_J || L < 1 || L > CROSS_MAXL)
-        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) / L=%d (max %d) unsupported", d, 256 * CROSS_J, L,
+    if (d < 1 || d > 256 * CROSS_NJ || L < 1 || L > CROSS_MAXL)
+        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d (max %d) / L=%d (max %d) unsupported", d, 256 * CROSS_NJ, L,
                        CROSS_MAXL);
     if (B == 0) return RP_OK;
-    hipLaunchKernelGGL(crossnet_fwd_kernel, dim3(B < 65536 * 4 ? (unsigned)B : 65536u * 4), dim3(256), 0,
-                       (hipStream_t)stream, x0, ldx, d, L, W, Bv, wfc, bfc, xout, ldo, logit, s_out, B);
+    const int dp = ((d + 255) / 256) * 256;
+    const bool b_lds = (size_t)(2 * L + 1) * dp * sizeof(float) <= 64 * 1024;
+    const size_t lds = (size_t)(b_lds ? 2 * L + 1 : L + 1) * dp * sizeof(float);
+    const bool vec = (ldx % 4 == 0) && rp_aligned16(x0) && (xout == nullptr || ((ldo % 4 == 0) && rp_aligned16(xout)));
+    int64_t nb = rp_cdiv(B, 4);
+    if (nb > 2048) nb = 2048;
+    hipStream_t st = (hipStream_t)stream;
+#define CF(VEC, BL)                                                                                                   \
+    hipLaunchKernelGGL((crossnet_fwd_kernel<VEC, BL>), dim3((unsigned)nb), dim3(256), lds, st, x0, ldx, d, L, W, Bv, wfc, \
+                       bfc, xout, ldo, logit, s_out, B)
+    if (vec && b_lds) CF(true, true);
+    else if (vec) CF(true, false);
+    else if (b_lds) CF(false, true);
+    else CF(false, false);
+#undef CF
     RP_LAUNCH_CHECK("crossnet_fwd");
     return RP_OK;
 }
