@@ -286,6 +286,11 @@ def main():
         alg_bytes["mmoe_combine_bwd"] = local_B * 4 * (2 * (K_ * E_ + T_ * E_) + T_ * K_)
     if args.model == "autoint":
         att = model.self_attention[0]
+        npj = 4 if att.W_res is not None else 3
+        # split form: QKVR in (+ residual rows when there is no W_res), out + row statistics back; backward: QKVR,
+        # out, dout in, dQKVR out
+        alg_bytes["attention_core_fwd"] = local_B * 4 * (F * (npj + 1) * att.output_dim + 2 * att.num_heads * F)
+        alg_bytes["attention_core_bwd"] = local_B * 4 * (F * (2 * npj + 2) * att.output_dim + 2 * att.num_heads * F)
         alg_bytes["field_attention_fwd"] = local_B * 4 * F * (D + att.output_dim)
         alg_bytes["field_attention_bwd"] = local_B * 4 * F * (2 * D + att.output_dim)
     mfma_flops = {}
@@ -346,7 +351,7 @@ def main():
                         "mfma_issue_frac": round(tf * nprod / peak, 4),
                         "note": "flops = all launches of this entry per step; fp32 operands, fp32 accumulation"}
     gather = None
-    if "embed_gather_fwd" in timing:
+    if "embed_gather_fwd" in timing and prof["embed_gather_fwd"][0] == n_prof:  # exactly one gather launch per step
         a = alg_bytes["embed_gather_fwd"] / (timing["embed_gather_fwd"][1] * 1e-3) / 1e9
         gather = {"kernel": "embed_gather_fwd", "bound": "hbm", "achieved": round(a, 1), "peak": HBM_PEAK_GBS,
                   "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),

@@ -194,6 +194,20 @@ int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float
                          const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
                          int64_t lddx, float *V, int64_t B, rp_stream_t stream);
 
+/* ---- K7 (split form): the T x T core of the field self-attention; projections are rp_linear_fwd GEMMs ------
+ * replaces attention.py:20-33,73-94 for one AutoInt layer once QKVR = X . [Wq|Wk|Wv|Wres]^T has been computed for
+ * all B*T token rows (row-major [B*T, ldq], columns Q | K | V | R, each H*a wide; nproj = 3 without W_res, the
+ * residual then being xres [B*T, ldr] = X itself).  Heads are the reference's RAW view of a sample's flat [T*H*a]
+ * buffer.  out [B*T, H*a] = relu(softmax(Q K^T [/scale]) V + R); stats [B, H*T, 2] = per-row (max, sum) of the
+ * softmax, consumed by the backward.  Backward writes dqkvr (same layout; the R block = ReLU-masked dout) and, when
+ * nproj == 3, dxres.  Limits: a <= 16 and a sample's Q,K,V,dO within 64 KB of LDS (rp_attention_core_fits). */
+int rp_attention_core_fits(int T, int H, int a);
+int rp_attention_core_fwd(const float *qkvr, int64_t ldq, int nproj, const float *xres, int64_t ldr, int T, int H,
+                          int a, float scale, float *out, float *stats, int64_t B, rp_stream_t stream);
+int rp_attention_core_bwd(const float *qkvr, int64_t ldq, int nproj, const float *out, const float *dout,
+                          const float *stats, int T, int H, int a, float scale, float *dqkvr, int64_t lddq,
+                          float *dxres, int64_t lddr, int64_t B, rp_stream_t stream);
+
 /* ---- stand-alone FM pooling on a [B,F,D] tensor -------------------------------------------------------
  * replaces layers/interaction.py:36-44 when the caller already holds the stacked embeddings (in DeepFM/FM the
  * gather kernel produces the term itself).  x[b] = F rows of D floats at x + b*ldb.

@@ -170,6 +170,36 @@ class _FieldAttention(torch.autograd.Function):
         return dx, dW, None, None, None, None, None, None
 
 
+class _AttentionCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkvr, xres, T: int, H: int, a: int, scale: float):
+        qkvr = qkvr.contiguous()
+        nproj = qkvr.shape[1] // (H * a)
+        xr = None if nproj == 4 else _unit_inner(xres)
+        out, stats = hip.attention_core_fwd(qkvr, nproj, xr, T, H, a, scale)
+        ctx.cfg = (nproj, T, H, a, scale)
+        ctx.save_for_backward(qkvr, out, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkvr, out, stats = ctx.saved_tensors
+        nproj, T, H, a, scale = ctx.cfg
+        dqkvr, dxres = hip.attention_core_bwd(qkvr, nproj, out, dout.contiguous(), stats, T, H, a, scale)
+        return dqkvr, dxres, None, None, None, None
+
+
+def field_attention_split(X, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float = 0.0):
+    """Same layer as field_attention, split: ONE matrix-core GEMM for all projections of all B*T tokens
+    (rp_linear_fwd; its dgrad / wgrad give dX and the weight gradients), then the T x T attention core per sample
+    (rp_attention_core_*).  X [B, T, Din] -> [B, T, H*a]."""
+    B = X.shape[0]
+    x2 = X.reshape(B * T, Din)
+    qkvr = linear_act(x2, W, None, ACT_NONE)                       # [B*T, (3|4)*H*a]
+    out = _AttentionCore.apply(qkvr, None if has_res else x2, T, H, a, scale)
+    return out.view(B, T, H * a)
+
+
 def field_attention(x, W, T: int, Din: int, H: int, a: int, has_res: bool, scale: float = 0.0):
     """x [B, >=T*Din] -> relu(attention + residual) [B, T, H*a];  W = cat(Wq, Wk, Wv[, Wres]) [(3|4)*H*a, Din]."""
     return _FieldAttention.apply(x, W, T, Din, H, a, has_res, scale)

@@ -52,6 +52,10 @@ _SIGNATURES = {
                                          _vp, _sz, _vp]),
     "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "rp_attention_core_fits": (C.c_int, [_i32, _i32, _i32]),
+    "rp_attention_core_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "rp_attention_core_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _i64,
+                                        _vp]),
     "rp_set_matmul_precision": (C.c_int, [_i32]),
     "rp_get_matmul_precision": (C.c_int, []),
     "rp_fm_pool_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
@@ -435,6 +439,36 @@ def field_attention_bwd(x, W, T: int, Din: int, H: int, a: int, has_res: bool, s
                                             dW.data_ptr(), B, ws.data_ptr(), nbytes.value, _stream()),
                "rp_field_attention_bwd")
     return dx, dW
+
+
+def attention_core_fits(T: int, H: int, a: int) -> bool:
+    return bool(lib().rp_attention_core_fits(T, H, a))
+
+
+def attention_core_fwd(qkvr, nproj: int, xres, T: int, H: int, a: int, scale: float):
+    """qkvr [B*T, nproj*H*a] (Q|K|V|R), xres [B*T, H*a] when nproj == 3 -> out [B*T, H*a], stats [B, H*T, 2]."""
+    _req(qkvr, torch.float32, "qkvr")
+    BT = qkvr.shape[0]
+    B = BT // T
+    out = torch.empty((BT, H * a), dtype=torch.float32, device=qkvr.device)
+    stats = torch.empty((B, H * T, 2), dtype=torch.float32, device=qkvr.device)
+    with _Timed("attention_core_fwd"):
+        _check(lib().rp_attention_core_fwd(qkvr.data_ptr(), _rowmajor(qkvr, "qkvr"), nproj, _ptr(xres),
+                                           _rowmajor(xres, "xres") if xres is not None else 0, T, H, a, scale,
+                                           out.data_ptr(), stats.data_ptr(), B, _stream()), "rp_attention_core_fwd")
+    return out, stats
+
+
+def attention_core_bwd(qkvr, nproj: int, out, dout, stats, T: int, H: int, a: int, scale: float):
+    BT = qkvr.shape[0]
+    dqkvr = torch.empty_like(qkvr)
+    dxres = torch.empty((BT, H * a), dtype=torch.float32, device=qkvr.device) if nproj == 3 else None
+    with _Timed("attention_core_bwd"):
+        _check(lib().rp_attention_core_bwd(qkvr.data_ptr(), _rowmajor(qkvr, "qkvr"), nproj, out.data_ptr(), dout.data_ptr(),
+                                           stats.data_ptr(), T, H, a, scale, dqkvr.data_ptr(), _rowmajor(dqkvr, "dqkvr"),
+                                           _ptr(dxres), H * a if dxres is not None else 0, BT // T, _stream()),
+               "rp_attention_core_bwd")
+    return dqkvr, dxres
 
 
 def mmoe_combine_fwd(z, K: int, E: int, T: int):

@@ -69,12 +69,14 @@ class MultiHeadAttention(nn.Module):
                 and self._fits_lds(query.shape[1]))
 
     def _fits_lds(self, T) -> bool:
-        """The one-launch layer keeps a sample's Q/K/V/P and the stacked weights in the CU's 160 KB LDS; very
-        wide configurations (H*a*Din of the order of 64x64 and up) do not fit and are composed from device ops."""
+        """Either HIP form of the layer applies: the split form (projection GEMM + per-sample T x T core: head width
+        <= 16, a sample's Q/K/V within 64 KB of LDS) or the older one-launch layer (everything, weights included, in
+        the CU's 160 KB LDS).  Configurations neither covers are composed from device ops."""
         from ... import hip
         key = (T, self.input_dim, self.num_heads, self.attention_dim, self.W_res is not None)
         if getattr(self, "_fit_key", None) != key:
-            self._fit_key, self._fit = key, hip.field_attention_fits(*key)
+            self._fit_key = key
+            self._fit = hip.attention_core_fits(T, self.num_heads, self.attention_dim) or hip.field_attention_fits(*key)
         return self._fit
 
     def _fused(self, X):
@@ -82,7 +84,13 @@ class MultiHeadAttention(nn.Module):
         ws = [self.W_q.weight, self.W_k.weight, self.W_v.weight]
         if self.W_res is not None:
             ws.append(self.W_res.weight)
-        out = Fh.field_attention(X.reshape(B, T * Din), torch.cat(ws, dim=0), T, Din, self.num_heads,
+        from ... import hip
+        W = torch.cat(ws, dim=0)
+        if hip.attention_core_fits(T, self.num_heads, self.attention_dim):
+            # projections on the matrix core as one GEMM over all B*T tokens + the T x T core per sample
+            return Fh.field_attention_split(X, W, T, Din, self.num_heads, self.attention_dim, self.W_res is not None,
+                                            float(self.scale or 0.0))
+        out = Fh.field_attention(X.reshape(B, T * Din), W, T, Din, self.num_heads,
                                  self.attention_dim, self.W_res is not None, float(self.scale or 0.0))
         return out  # [B, T, H*a]
 

@@ -177,6 +177,35 @@ def test_field_attention_vs_oracle(B, T, din, heads, adim, scale):
     _close(dw.grad.cpu(), torch.cat([w.grad for w in rw]), rel=3e-4, what="dW")
 
 
+@pytest.mark.parametrize("B,T,din,heads,adim,scale", [(1000, 26, 64, 1, 8, False), (513, 26, 64, 2, 16, True),
+                                                       (300, 16, 40, 4, 10, False), (70, 39, 16, 4, 8, False),
+                                                       (257, 26, 8, 1, 8, False), (65, 70, 12, 3, 5, True)])
+def test_field_attention_split_form_vs_oracle(B, T, din, heads, adim, scale):
+    """projection GEMM (rp_linear_fwd) + T x T core (rp_attention_core_*): output and every gradient vs the oracle,
+    including H*T > 64 rows per sample, a non-power-of-two head width and the no-W_res case (Din == H*a)."""
+    from rec_pangu_amd import functional as Fh, hip
+    g = torch.Generator().manual_seed(B + T + din)
+    HA = heads * adim
+    has_res = din != HA
+    assert hip.attention_core_fits(T, heads, adim)
+    x = torch.randn(B, T, din, generator=g)
+    ws = [torch.randn(HA, din, generator=g) / din ** 0.5 for _ in range(4 if has_res else 3)]
+    coef = torch.randn(B, T, HA, generator=g)
+    rx = x.clone().requires_grad_(True)
+    rw = [w.clone().requires_grad_(True) for w in ws]
+    ref = R.mhsa(rx, rw[0], rw[1], rw[2], rw[3] if has_res else None, heads, adim, use_scale=scale)
+    (ref * coef).sum().backward()
+    dx = x.to(DEV).requires_grad_(True)
+    dw = torch.cat(ws).to(DEV).requires_grad_(True)
+    n0 = hip.launch_count()
+    out = Fh.field_attention_split(dx, dw, T, din, heads, adim, has_res, adim ** 0.5 if scale else 0.0)
+    assert hip.launch_count() >= n0 + 2
+    _close(out.detach().cpu(), ref.detach(), what="out")
+    (out * coef.to(DEV)).sum().backward()
+    _close(dx.grad.cpu(), rx.grad, rel=2e-4, what="dX")
+    _close(dw.grad.cpu(), torch.cat([w.grad for w in rw]), rel=3e-4, what="dW")
+
+
 # ------------------------------------------------------------------------------------------------ MMOE
 @pytest.mark.parametrize("B,h,ld,K,E,T", [(24, 43, 64, 16, 3, 2), (2048, 649, 672, 128, 4, 2), (333, 100, 100, 20, 8, 4),
                                            (100, 30, 32, 300, 2, 1)])
