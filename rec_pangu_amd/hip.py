@@ -293,13 +293,14 @@ def transpose(w, rows_out: Optional[int] = None):
     then writes exact zeros into the padding columns of a padded activation gradient)."""
     _req(w, torch.float32, "w")
     R, Cc = w.shape
+    R4 = (R + 3) // 4 * 4  # 16-byte aligned rows (the GEMM then fetches them with dwordx4, unguarded)
     if rows_out is not None and rows_out > Cc:
-        out = torch.empty((rows_out, R), dtype=torch.float32, device=w.device)
-        out[Cc:].zero_()  # contiguous tail: a few rows
+        out = torch.empty((rows_out, R4), dtype=torch.float32, device=w.device)[:, :R]
+        out[Cc:].zero_()  # tail: a few rows
     else:
-        out = torch.empty((Cc, R), dtype=torch.float32, device=w.device)
+        out = torch.empty((Cc, R4), dtype=torch.float32, device=w.device)[:, :R]
     with _Timed("transpose"):
-        _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R, R, Cc, _stream()), "rp_transpose")
+        _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, _stream()), "rp_transpose")
     return out
 
 
