@@ -264,25 +264,32 @@ __device__ __forceinline__ void bf_split8(f32x8 v, bf16x8 (&p)[NP]) {
 // NT:  out[M,N] = act(A[M,K] . W[N,K]^T + bias).  Block tile (32*WM) x 64 x 32, 4 waves:
 //   WM = 4: wave w owns rows 32w.. and both 32-column halves;   WM = 2: waves are 2 (rows) x 2 (column halves) — used
 //   when the 128-row grid would leave the chip under-filled (skinny N).
-template <int NPROD, int WM, int PF, bool VEC_A, bool VEC_W>
+// Wave tiling is a template: WM x WN waves (WM*WN = 4), each owning MI x NI MFMA tiles of 32 x 32:
+//   <4,1,1,2>  128 x 64   rows split over the waves, both column halves per wave           (skinny N, large grid)
+//   <2,2,1,1>   64 x 64   used when the 128-row grid would leave the chip under-filled
+//   <2,2,2,2>  128 x 128  each wave 64 x 64: every A / B fragment read from LDS feeds two MFMA tiles — the wide
+//                         (compute-bound) layers, where LDS fragment traffic per MFMA is what limits the matrix core
+template <int NPROD, int WM, int WN, int MI, int NI, int PF, bool VEC_A, bool VEC_W>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__restrict__ A, int64_t lda,
                                                               const float *__restrict__ W, int64_t ldw,
                                                               const float *__restrict__ bias, float *__restrict__ C,
                                                               int64_t ldc, int64_t M, int N, int K, int act,
                                                               const float *__restrict__ aux, int64_t ldaux) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int NP = BfProd<NPROD>::NP;
-    constexpr int BMT = 32 * WM;
-    constexpr int NACC = (WM == 4) ? 2 : 1;
-    constexpr int RA = BMT / 32;
+    constexpr int BMT = 32 * MI * WM;
+    constexpr int BNT = 32 * NI * WN;
+    constexpr int RA = BMT / 32;  // A rows staged per thread
+    constexpr int RW = BNT / 32;  // W rows staged per thread
     __shared__ __attribute__((aligned(16))) __bf16 As[NP][BMT][BF_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][BN][BF_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][BNT][BF_LD];
     const int t = threadIdx.x;
     const int64_t m0 = (int64_t)blockIdx.x * BMT;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BNT;
     const int lr = t >> 3, lc = (t & 7) * 4;
     const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
-    const int wm = (WM == 4) ? w : (w & 1);
-    const int wn = (WM == 4) ? 0 : (w >> 1);
+    const int wm = w % WM, wn = w / WM;
+    const int arow0 = 32 * MI * wm, bcol0 = 32 * NI * wn;
 
     // PF tiles of global loads are kept in flight per workgroup (a register ring): one tile per workgroup is a few
     // KB, and at 2-4 resident workgroups per CU that is far too little to cover HBM latency at full bandwidth.
@@ -291,40 +298,42 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     // would wait for the loads issued for the tile PF steps ahead, exposing the full memory latency per tile.  So an
     // interior workgroup (all rows / columns in range, 16-byte aligned operands) runs its full k tiles through a
     // straight-line loop with unguarded loads; the guarded loop below finishes the last tiles and serves the edges.
-    f32x4 ra[PF][RA], rw[PF][2];
-    auto load_tile = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[2]) {
+    f32x4 ra[PF][RA], rw[PF][RW];
+    auto load_tile = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[RW]) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int64_t m = m0 + lr + 32 * j;
             da[j] = (m < M) ? load4_guard(A + m * lda + k0 + lc, K - (k0 + lc), VEC_A) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RW; ++j) {
             const int n = n0 + lr + 32 * j;
             dw[j] = (n < N) ? load4_guard(W + (int64_t)n * ldw + k0 + lc, K - (k0 + lc), VEC_W)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     const float *a_row[RA];
-    const float *w_row[2];
+    const float *w_row[RW];
 #pragma unroll
     for (int j = 0; j < RA; ++j) a_row[j] = A + (m0 + lr + 32 * j) * lda + lc;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w_row[j] = W + (int64_t)(n0 + lr + 32 * j) * ldw + lc;
-    auto load_tile_full = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[2]) {
+    for (int j = 0; j < RW; ++j) w_row[j] = W + (int64_t)(n0 + lr + 32 * j) * ldw + lc;
+    auto load_tile_full = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[RW]) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) da[j] = *reinterpret_cast<const f32x4 *>(a_row[j] + k0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dw[j] = *reinterpret_cast<const f32x4 *>(w_row[j] + k0);
+        for (int j = 0; j < RW; ++j) dw[j] = *reinterpret_cast<const f32x4 *>(w_row[j] + k0);
     };
 
-    f32x16 acc[NACC];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int a = 0; a < NACC; ++a)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto stage = [&](const f32x4 (&sa)[RA], const f32x4 (&sw)[2]) {
+    auto stage = [&](const f32x4 (&sa)[RA], const f32x4 (&sw)[RW]) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
             for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + 32 * j][lc]) = pc[q];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < RW; ++j) {
             bf16x4 pc[NP];
             bf_split4<NP>(sw[j], pc);
 #pragma unroll
@@ -345,20 +354,25 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[NP];
+            bf16x8 a[MI][NP];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) a[q] = *reinterpret_cast<const bf16x8 *>(&As[q][32 * wm + i][ks * 16 + 8 * h]);
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int nt = 0; nt < NACC; ++nt) {
-                const int col0 = (WM == 4) ? nt * 32 : wn * 32;
+                for (int q = 0; q < NP; ++q)
+                    a[mi][q] = *reinterpret_cast<const bf16x8 *>(&As[q][arow0 + 32 * mi + i][ks * 16 + 8 * h]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col0 = bcol0 + 32 * ni;
                 if (n0 + col0 >= N) continue;  // wave-uniform
                 bf16x8 b[NP];
 #pragma unroll
                 for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(&Ws[q][col0 + i][ks * 16 + 8 * h]);
 #pragma unroll
                 for (int pr = 0; pr < NPROD; ++pr)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b[BfProd<NPROD>::pb(pr)],
-                                                                      acc[nt], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][BfProd<NPROD>::pa(pr)],
+                                                                              b[BfProd<NPROD>::pb(pr)], acc[mi][ni], 0, 0, 0);
             }
         }
     };
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     const int nk = (K + BK - 1) / BK;
     const int nkf = K / BK;  // k tiles that need no column guard
     int kbeg = 0;
-    if (VEC_A && VEC_W && (m0 + BMT <= M) && (n0 + BN <= N) && nkf >= 2 * PF) {
+    if (VEC_A && VEC_W && (m0 + BMT <= M) && (n0 + BNT <= N) && nkf >= 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) load_tile_full(p * BK, ra[p], rw[p]);
         const int nloop = (nkf - PF) / PF;
@@ -396,21 +410,23 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     }
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int nt = 0; nt < NACC; ++nt) {
-        const int col0 = (WM == 4) ? nt * 32 : wn * 32;
-        const int n = n0 + col0 + i;
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + bcol0 + 32 * ni + i;
         if (n >= N) continue;
         const float bv = (bias != nullptr) ? bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m >= M) continue;
-            float v = acc[nt][r] + bv;
-            if (act == RP_ACT_RELU)
-                v = v > 0.f ? v : 0.f;
-            else if (act == RP_ACT_MASK)
-                v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
-            C[m * ldc + n] = v;
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + arow0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= M) continue;
+                float v = acc[mi][ni][r] + bv;
+                if (act == RP_ACT_RELU)
+                    v = v > 0.f ? v : 0.f;
+                else if (act == RP_ACT_MASK)
+                    v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+                C[m * ldc + n] = v;
+            }
         }
     }
 }
@@ -623,35 +639,38 @@ static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw,
 // [n][m] / [k][m] and the MFMA fragments (8 consecutive m per lane) are ds_read_b128.  Split-K over gridDim.z with a
 // deterministic second-stage sum, as the f32 kernel; the bias gradient is summed in exact fp32 from the staged
 // registers.
-template <int NPROD, int PF, bool VEC_X>
-__global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
+template <int NPROD, int NA, int PF, bool VEC_X>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                 const float *__restrict__ X, int64_t ldx,
                                                                 float *__restrict__ P, float *__restrict__ Pb,
                                                                 int64_t M, int N, int K, int64_t rows_per_split) {
+    // output tile (64*NA) n x 128 k; waves 2 (n) x 2 (k), each NA x 2 MFMA tiles (NA = 2 for wide layers: every
+    // fragment read from LDS then feeds two MFMA tiles)
     constexpr int NP = BfProd<NPROD>::NP;
-    __shared__ __attribute__((aligned(16))) __bf16 Yt[NP][TN_BN][BF_LD];
+    constexpr int BNT = TN_BN * NA;
+    __shared__ __attribute__((aligned(16))) __bf16 Yt[NP][BNT][BF_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Xt[NP][TN_BK][BF_LD];
-    __shared__ float bred[4][TN_BN];
+    __shared__ float bred[4][BNT];
     const int t = threadIdx.x;
     const int k0 = blockIdx.x * TN_BK;
-    const int n0 = blockIdx.y * TN_BN;
+    const int n0 = blockIdx.y * BNT;
     const int64_t mbeg = (int64_t)blockIdx.z * rows_per_split;
     int64_t mend = mbeg + rows_per_split;
     if (mend > M) mend = M;
     const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
-    const int nt = (w & 1) * 32, kt = (w >> 1) * 64;
+    const int nt = (w & 1) * 32 * NA, kt = (w >> 1) * 64;
     const int c = t & 63, o = t >> 6;
-    const bool y_ok = (n0 + c) < N;
     const int kx = k0 + 2 * c;
 
-    float ry[PF][8];
+    float ry[PF][NA][8];
     f32x2 rx[PF][8];
-    auto load_tile = [&](int64_t mm, float (&dy_)[8], f32x2 (&dx_)[8]) {
+    auto load_tile = [&](int64_t mm, float (&dy_)[NA][8], f32x2 (&dx_)[8]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int64_t m = mm + 8 * o + r;
             const bool ok = m < mend;
-            dy_[r] = (ok && y_ok) ? dY[m * lddy + n0 + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) dy_[u][r] = (ok && n0 + c + 64 * u < N) ? dY[m * lddy + n0 + c + 64 * u] : 0.f;
             f32x2 v = {0.f, 0.f};
             if (ok) {
                 const float *px = X + m * ldx + kx;
@@ -668,37 +687,48 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
     // interior tile: unguarded loads -> straight-line main loop -> counted vmcnt waits (see linear_fwd_bf16_kernel)
     const float *yb = dY + (mbeg + 8 * o) * lddy + n0 + c;
     const float *xb = X + (mbeg + 8 * o) * ldx + kx;
-    auto load_tile_full = [&](int64_t moff, float (&dy_)[8], f32x2 (&dx_)[8]) {
+    auto load_tile_full = [&](int64_t moff, float (&dy_)[NA][8], f32x2 (&dx_)[8]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            dy_[r] = yb[(moff + r) * lddy];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) dy_[u][r] = yb[(moff + r) * lddy + 64 * u];
             dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
         }
     };
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NA][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc0[r] = 0.f;
-        acc1[r] = 0.f;
-    }
-    float bsum = 0.f;
+    for (int u = 0; u < NA; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[u][0][r] = 0.f;
+            acc[u][1][r] = 0.f;
+        }
+    float bsum[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) bsum[u] = 0.f;
     const bool do_bias = (Pb != nullptr) && (blockIdx.x == 0);
 
-    auto stage = [&](const float (&sy)[8], const f32x2 (&sx)[8]) {
+    auto stage = [&](const float (&sy)[NA][8], const f32x2 (&sx)[8]) {
         __syncthreads();
-        f32x8 vy, vx0, vx1;
+        f32x8 vx0, vx1;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            vy[r] = sy[r];
             vx0[r] = sx[r].x;
             vx1[r] = sx[r].y;
         }
-        if (do_bias) bsum += ((sy[0] + sy[1]) + (sy[2] + sy[3])) + ((sy[4] + sy[5]) + (sy[6] + sy[7]));
         bf16x8 pc[NP];
-        bf_split8<NP>(vy, pc);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Yt[q][c][8 * o]) = pc[q];
+        for (int u = 0; u < NA; ++u) {
+            f32x8 vy;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) vy[r] = sy[u][r];
+            if (do_bias)
+                bsum[u] += ((sy[u][0] + sy[u][1]) + (sy[u][2] + sy[u][3])) + ((sy[u][4] + sy[u][5]) + (sy[u][6] + sy[u][7]));
+            bf_split8<NP>(vy, pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Yt[q][c + 64 * u][8 * o]) = pc[q];
+        }
         bf_split8<NP>(vx0, pc);
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8 *>(&Xt[q][2 * c][8 * o]) = pc[q];
@@ -710,19 +740,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
     auto compute = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[NP], b0[NP], b1[NP];
+            bf16x8 a[NA][NP], b0[NP], b1[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                a[q] = *reinterpret_cast<const bf16x8 *>(&Yt[q][nt + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int u = 0; u < NA; ++u)
+                    a[u][q] = *reinterpret_cast<const bf16x8 *>(&Yt[q][nt + 32 * u + i][ks * 16 + 8 * h]);
                 b0[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + i][ks * 16 + 8 * h]);
                 b1[q] = *reinterpret_cast<const bf16x8 *>(&Xt[q][kt + 32 + i][ks * 16 + 8 * h]);
             }
 #pragma unroll
             for (int pr = 0; pr < NPROD; ++pr) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)], acc0,
-                                                               0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<NPROD>::pa(pr)], b1[BfProd<NPROD>::pb(pr)], acc1,
-                                                               0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)],
+                                                                        acc[u][0], 0, 0, 0);
+                    acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][BfProd<NPROD>::pa(pr)], b1[BfProd<NPROD>::pb(pr)],
+                                                                        acc[u][1], 0, 0, 0);
+                }
             }
         }
     };
@@ -730,7 +765,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
     const int64_t nst = (mend > mbeg) ? (mend - mbeg + TN_BM - 1) / TN_BM : 0;  // stages of 32 batch rows
     const int64_t nstf = (mend > mbeg) ? (mend - mbeg) / TN_BM : 0;             // ... that are complete
     int64_t sbeg = 0;
-    if (VEC_X && (n0 + TN_BN <= N) && (k0 + TN_BK <= K) && nstf >= 2 * PF) {
+    if (VEC_X && (n0 + BNT <= N) && (k0 + TN_BK <= K) && nstf >= 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) load_tile_full((int64_t)p * TN_BM, ry[p], rx[p]);
         const int64_t nloop = (nstf - PF) / PF;
@@ -760,20 +795,23 @@ __global__ __launch_bounds__(256) void linear_wgrad_bf16_kernel(const float *__r
     }
     float *Pz = P + (int64_t)blockIdx.z * N * K;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const int k = k0 + kt + kk * 32 + i;
-        if (k >= K) continue;
+    for (int u = 0; u < NA; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + nt + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (n < N) Pz[(int64_t)n * K + k] = (kk == 0 ? acc0[r] : acc1[r]);
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = k0 + kt + kk * 32 + i;
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + nt + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) Pz[(int64_t)n * K + k] = acc[u][kk][r];
+            }
         }
-    }
     if (do_bias) {
-        bred[o][c] = bsum;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) bred[o][c + 64 * u] = bsum[u];
         __syncthreads();
-        if (t < TN_BN && n0 + t < N)
-            Pb[(int64_t)blockIdx.z * N + n0 + t] = (bred[0][t] + bred[1][t]) + (bred[2][t] + bred[3][t]);
+        for (int e = t; e < BNT; e += 256)
+            if (n0 + e < N) Pb[(int64_t)blockIdx.z * N + n0 + e] = (bred[0][e] + bred[1][e]) + (bred[2][e] + bred[3][e]);
     }
 }
 
@@ -874,23 +912,27 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
             RP_LAUNCH_CHECK("linear_fwd (bf16 split, short K)");
             return RP_OK;
         }
-        // 64-row tiles when 128-row tiles would give the 256 CUs fewer than ~4 workgroups each
-        const bool small = rp_cdiv(M, 128) * rp_cdiv(N, BN) < 1024 && M > 64;
-        dim3 grid((unsigned)rp_cdiv(M, small ? 64 : 128), (unsigned)rp_cdiv(N, BN));
-#define CALLB(NPROD, WM, PF, VA, VW)                                                                                    \
-    hipLaunchKernelGGL((linear_fwd_bf16_kernel<NPROD, WM, PF, VA, VW>), grid, dim3(256), 0, s, a, lda, w, ldw, bias, out, \
-                       ldo, M, N, K, act, aux, ldaux)
-#define CALLV(NPROD, WM, PF)                            \
-    do {                                                \
-        if (va && vw) CALLB(NPROD, WM, PF, true, true); \
-        else if (va) CALLB(NPROD, WM, PF, true, false); \
-        else if (vw) CALLB(NPROD, WM, PF, false, true); \
-        else CALLB(NPROD, WM, PF, false, false);        \
+        // tile shape: 128 x 128 (each wave 64 x 64) for wide outputs; 128 x 64 otherwise, 64 x 64 when that grid
+        // would give the 256 CUs fewer than ~4 workgroups each
+        const int64_t n128 = rp_cdiv(N, 128) * 128;
+        const bool big = N >= 256 && (n128 - N) * 8 <= N && rp_cdiv(M, 128) * (n128 / 128) >= 1024;
+        const bool small = !big && rp_cdiv(M, 128) * rp_cdiv(N, BN) < 1024 && M > 64;
+        dim3 grid((unsigned)rp_cdiv(M, small ? 64 : 128), (unsigned)rp_cdiv(N, big ? 128 : BN));
+#define CALLB(NPROD, WM, WN, MI, NI, PF, VA, VW)                                                                      \
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<NPROD, WM, WN, MI, NI, PF, VA, VW>), grid, dim3(256), 0, s, a, lda, w, \
+                       ldw, bias, out, ldo, M, N, K, act, aux, ldaux)
+#define CALLV(NPROD, WM, WN, MI, NI, PF)                            \
+    do {                                                            \
+        if (va && vw) CALLB(NPROD, WM, WN, MI, NI, PF, true, true); \
+        else if (va) CALLB(NPROD, WM, WN, MI, NI, PF, true, false); \
+        else if (vw) CALLB(NPROD, WM, WN, MI, NI, PF, false, true); \
+        else CALLB(NPROD, WM, WN, MI, NI, PF, false, false);        \
     } while (0)
-#define CALLP(NPROD)                   \
-    do {                               \
-        if (small) CALLV(NPROD, 2, 3); \
-        else CALLV(NPROD, 4, 2);       \
+#define CALLP(NPROD)                              \
+    do {                                          \
+        if (big) CALLV(NPROD, 2, 2, 2, 2, 2);     \
+        else if (small) CALLV(NPROD, 2, 2, 1, 1, 3); \
+        else CALLV(NPROD, 4, 1, 1, 2, 2);         \
     } while (0)
         if (mode == RP_MATMUL_BF16X6) CALLP(6);
         else if (mode == RP_MATMUL_BF16X3) CALLP(3);
@@ -914,11 +956,27 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     return RP_OK;
 }
 
+static bool wgrad_wide(int N) { return g_matmul_precision != RP_MATMUL_FP32 && N >= 128; }  // 128 x 128 output tiles
+
 static void wgrad_plan(int64_t M, int N, int K, int *S, int64_t *rows) {
-    const int64_t tiles = rp_cdiv(K, TN_BK) * rp_cdiv(N, TN_BN);
+    const int64_t tiles = rp_cdiv(K, TN_BK) * rp_cdiv(N, wgrad_wide(N) ? 2 * TN_BN : TN_BN);
+    // batch splits: enough workgroups to fill the chip (256 CUs x 2 resident), and a count that fills its last wave
+    // of workgroups — 1120 workgroups on 512 slots run as 3 rounds, the last one 19 % full
     int64_t s = rp_cdiv(1024, tiles);
     if (s > 512) s = 512;  // a 64 x 64 layer has ONE output tile: all the parallelism must come from the batch split
-    if (s < 1) s = 1;
+    if (tiles * s > 512) {
+        int64_t best = s;
+        double best_eff = 0.0;
+        for (int64_t c = rp_cdiv(768, tiles); c <= rp_cdiv(1536, tiles); ++c) {
+            if (c < 1 || c > 512) continue;
+            const double eff = (double)(tiles * c) / (double)(rp_cdiv(tiles * c, 512) * 512);
+            if (eff > best_eff + 1e-9) {
+                best_eff = eff;
+                best = c;
+            }
+        }
+        s = best;
+    }
     int64_t r = rp_cdiv(rp_cdiv(M, s), TN_BM) * TN_BM;
     if (r < TN_BM) r = TN_BM;
     *rows = r;
@@ -955,19 +1013,23 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     const int mode = g_matmul_precision;
     if (mode != RP_MATMUL_FP32) {
         const bool vx2 = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
-#define CALLB(NPROD)                                                                                                   \
-    do {                                                                                                               \
-        if (vx2)                                                                                                       \
-            hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 2, true>), grid, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, \
-                               M, N, K, rows);                                                                         \
-        else                                                                                                           \
-            hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 2, false>), grid, dim3(256), 0, s, dy, lddy, x, ldx, P,   \
-                               Pb, M, N, K, rows);                                                                     \
+        const bool wide = wgrad_wide(N);
+        dim3 gridb((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, wide ? 2 * TN_BN : TN_BN), (unsigned)S);
+#define CALLW(NPROD, NA, VX)                                                                                            \
+    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, 2, VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
+                       N, K, rows)
+#define CALLB(NPROD)                          \
+    do {                                      \
+        if (wide && vx2) CALLW(NPROD, 2, true);   \
+        else if (wide) CALLW(NPROD, 2, false);    \
+        else if (vx2) CALLW(NPROD, 1, true);      \
+        else CALLW(NPROD, 1, false);              \
     } while (0)
         if (mode == RP_MATMUL_BF16X6) CALLB(6);
         else if (mode == RP_MATMUL_BF16X3) CALLB(3);
         else CALLB(1);
 #undef CALLB
+#undef CALLW
         RP_LAUNCH_CHECK("linear_wgrad partial (bf16 split)");
     } else {
 #define CALL(VY, VX)                                                                                                \

@@ -23,7 +23,10 @@ for mode in sys.argv[1:] or ["bf16x6"]:
                                   (1664, 64, 64, 64, "L1 dgrad N=1664"),
                                   (64, 64, 64, 64, "hidden"),
                                   (512, 649, 672, 649, "mmoe experts"),
-                                  (1024, 1677, 1696, 1677, "wide L1 fwd")]:
+                                  (1024, 1677, 1696, 1677, "wide L1 fwd"),
+                                  (1024, 1680, 1728, 1680, "wide L1 fwd aligned"),
+                                  (512, 1024, 1024, 1024, "wide L2 fwd"),
+                                  (1728, 1024, 1024, 1024, "wide L1 dgrad")]:
         a = torch.randn(M, lda, device=dev)
         w = torch.randn(N, ldw, device=dev)[:, :K] if ldw != K else torch.randn(N, K, device=dev)
         out = torch.empty(M, N, device=dev)
