@@ -194,6 +194,37 @@ int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float
                          const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
                          int64_t lddx, float *V, int64_t B, rp_stream_t stream);
 
+/* ---- K6 (bf16 matrix core): a CIN layer with at most 32 x 32 (field, map) pairs per channel ----------------
+ * replaces interaction.py:157-171 for such a layer (a FIRST layer: X_{k-1} = X_0, H = M <= 32) on
+ * v_mfma_f32_32x32x16_bf16 with split-bf16 operands (fp32-faithful, 6 products).  The X_{k-1} fragments stay in
+ * registers, the channels' weights stream past as bf16 pieces  wp [O][3][32][32]  = (hi, mid, lo) of W[o, row, col]
+ * zero-padded to 32 x 32 (hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)).
+ *   fwd   : out [B, O, D] and/or pooled [B, O] (= sum_d out); bias [O] optional
+ *   bwd_x : dx[b,r,:] = sum_o (gout[b,o,:] + gpool[b,o]) sum_c wp[o][r][c] xk[b,c,:]   — X_0-role gradient with
+ *           wp from W[o,h,m], X_{k-1}-role gradient with W[o,m,h]; for a first layer W[o,h,m] + W[o,m,h] gives the
+ *           whole gradient in one pass.  The weight gradient stays with rp_cin_layer_bwd_w.
+ * Limits: rows, contraction <= 32, D in {32, 64} (rp_cin_bs_fits). */
+int rp_cin_bs_fits(int H, int M, int D);
+int rp_cin_bs_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const void *wp, const float *bias, int H,
+                  int M, int O, int D, float *out, float *pooled, int64_t B, rp_stream_t stream);
+int rp_cin_bs_bwd_x(const float *xk, int64_t ldk, const void *wp, const float *gout, const float *gpool, int R, int Cn,
+                    int O, int D, float *dx, int64_t lddx, int64_t B, rp_stream_t stream);
+
+/* ---- K6 (last layer): the collapsed final CIN layer ------------------------------------------------------
+ * replaces interaction.py:157-171 for the LAST layer: with no activation and linear pooling + fc behind it, it
+ * enters the logit only as  p[b] = sum_d sum_{h,m} V[h,m] X_0[b,h,d] X_{L-1}[b,m,d],  V = sum_o c[o] W_L[o].
+ * x0 [B, ld0] holds H rows of D floats per sample, xp [B, ldp] M rows of D floats; vt = V^T zero-padded to [M, 32].
+ * bwd_x: dx0[b,h,:] = g[b] sum_m V[h,m] Xp[b,m,:], dxp[b,m,:] = g[b] sum_h V[h,m] X0[b,h,:];  bwd_v: dV [H, M].
+ * Limits: H <= 32, D <= 64 (rp_cin_last_fits). */
+int rp_cin_last_fits(int H, int M, int D);
+int rp_cin_last_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *vt, int H, int M, int D,
+                    float *pooled, int64_t B, rp_stream_t stream);
+int rp_cin_last_bwd_x(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *vt, const float *g, int H,
+                      int M, int D, float *dx0, int64_t ldd0, float *dxp, int64_t lddp, int64_t B, rp_stream_t stream);
+int rp_cin_last_bwd_v_workspace_bytes(int64_t B, int H, int M, size_t *bytes);
+int rp_cin_last_bwd_v(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *g, int H, int M, int D,
+                      float *dV, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+
 /* ---- K7 (split form): the T x T core of the field self-attention; projections are rp_linear_fwd GEMMs ------
  * replaces attention.py:20-33,73-94 for one AutoInt layer once QKVR = X . [Wq|Wk|Wv|Wres]^T has been computed for
  * all B*T token rows (row-major [B*T, ldq], columns Q | K | V | R, each H*a wide; nproj = 3 without W_res, the

@@ -1,0 +1,249 @@
+// xDeepFM CIN layer on the bf16 matrix core (split-bf16 operands), "B-stationary" form, gfx950.
+//   reference: layers/interaction.py:157-171
+//     X_k[b,o,d] = sum_{h<H} X_0[b,h,d] * T_o[h,(b,d)],    T_o[h,(b,d)] = sum_{m<M} W[o,h,m] X_{k-1}[b,m,d]    (+ bias[o])
+// T_o is a GEMM tile: rows h (<= 32), columns r = (b,d), contraction over m (<= 32 here: a first layer, where
+// X_{k-1} = X_0).  The f32-MFMA kernels of cin.hip stage the samples in LDS and re-read them for every channel; here
+// the roles are turned around: a wave keeps the X_{k-1} fragments of its column tiles IN REGISTERS for the whole
+// kernel (B operand: lane = column r, 8 consecutive m per k-octet; 24 VGPRs per 32-column tile) and the 128 channels'
+// weights stream past — pre-split into bf16 pieces on the host side ([O][3][32][32] bf16, 6 KB per channel, L2-resident),
+// four channels per LDS buffer, double buffered, one barrier per four channels.  Per (channel, column tile):
+// 2 k-steps x 6 products = 12 v_mfma_f32_32x32x16_bf16, then the epilogue in the C layout
+// (col = lane & 31 = column r, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = h):
+//   MODE 0 (forward)    y[o,r] = sum_h X_0[h,r] * acc[h,r]   (16 fma + one cross-half shuffle), out[b,o,d], pooled[b,o]
+//   MODE 1 (backward-x) dX[h,r] += G[o,r] * acc[h,r]          (G = dL/dX_k[b,o,d] + dL/dpooled[b,o])
+// Backward-x with weights W[o,h,m] gives the gradient of the X_0 role, with W[o,m,h] that of the X_{k-1} role; for a
+// first layer both are X_0 and ONE pass with W[o,h,m] + W[o,m,h] gives the whole gradient.
+// A wave owns the two 32-column tiles of one sample (D = 64) or of two samples (D = 32): 4 waves = 4 (8) samples
+// per workgroup.  FULL = all of them exist: straight-line channel loop (counted vmcnt, see gemm.hip); the tail of the
+// batch runs the guarded instantiation.
+#include "common.h"
+
+typedef __bf16 cbbf8 __attribute__((ext_vector_type(8)));
+typedef float cbf8 __attribute__((ext_vector_type(8)));
+
+#define CB_OG 4      // channels per LDS buffer
+#define CB_LD 40     // bf16 per LDS row (32 data + 8 pad -> 80 B, conflict-free ds_read_b128)
+
+__device__ __forceinline__ void cb_split(cbf8 v, cbbf8 (&p)[3]) {
+    p[0] = __builtin_convertvector(v, cbbf8);
+    v -= __builtin_convertvector(p[0], cbf8);
+    p[1] = __builtin_convertvector(v, cbbf8);
+    v -= __builtin_convertvector(p[1], cbf8);
+    p[2] = __builtin_convertvector(v, cbbf8);
+}
+
+// xk   : contraction operand X_{k-1} rows, [B, ldk] with Mc rows of D floats per sample (Mc <= 32)
+// xe   : MODE 0: X_0 ([B, lde], Hr rows of D floats) for the epilogue;  MODE 1: unused
+// wp   : weights as bf16 pieces [O][3][32][32] (row = output row of the tile, col = contraction index), zero padded
+// MODE 0: bias [O] or null, out [B, O*D] (ldo = O*D) or null, pooled [B, O] or null
+// MODE 1: gout [B, O*D] or null, gpool [B, O] or null, dx [B, lddx] (Hr rows of D floats written)
+template <int MODE, bool FULL>
+__global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ xk, int64_t ldk, int Mc,
+                                                     const float *__restrict__ xe, int64_t lde, int Hr,
+                                                     const __bf16 *__restrict__ wp, int O, int D,
+                                                     const float *__restrict__ bias, float *__restrict__ out,
+                                                     float *__restrict__ pooled, const float *__restrict__ gout,
+                                                     const float *__restrict__ gpool, float *__restrict__ dx,
+                                                     int64_t lddx, int64_t B) {
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[2][CB_OG][3][32][CB_LD];
+    const int t = threadIdx.x;
+    const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
+    const int tps = D / 32;                    // 32-column tiles per sample (1 or 2)
+    const int spw = 2 / tps;                   // samples per wave (2 tiles per wave)
+    const int64_t bw = ((int64_t)blockIdx.x * 4 + w) * spw;  // first sample of this wave
+    int64_t bt[2];
+    int dt[2];
+    bool ok[2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        bt[ti] = bw + (tps == 2 ? 0 : ti);
+        dt[ti] = (tps == 2 ? ti * 32 : 0) + i;
+        ok[ti] = FULL || bt[ti] < B;
+        if (!ok[ti]) bt[ti] = B - 1;  // clamp: loads stay in range, stores are suppressed
+    }
+    // B fragments: lane = column (b, d), k = 16*ks + 8*hh + e
+    cbbf8 bf[2][2][3];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            cbf8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = ks * 16 + 8 * hh + e;
+                v[e] = (m < Mc) ? xk[bt[ti] * ldk + (int64_t)m * D + dt[ti]] : 0.f;
+            }
+            cb_split(v, bf[ti][ks]);
+        }
+    // epilogue operands in the C layout: row h = (r&3) + 8*(r>>2) + 4*hh
+    float ep[2][16];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (MODE == 0) ep[ti][r] = (h < Hr) ? xe[bt[ti] * lde + (int64_t)h * D + dt[ti]] : 0.f;
+            else ep[ti][r] = 0.f;  // dX accumulator
+        }
+
+    // weight stream: 4 channels = 4*3*32 rows of 64 B = 1536 16-byte chunks per buffer -> 6 per thread
+    const int ngrp = (O + CB_OG - 1) / CB_OG;
+    f32x4 wr[6];
+    auto w_load = [&](int grp) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int chunk = t + 256 * u;           // [oo][q][row][c16]: row-major 16-byte chunks
+            const int oo = chunk / 384;              // 3*32*4 chunks per channel
+            int o = grp * CB_OG + oo;
+            if (o >= O) o = O - 1;                   // (harmless re-read; such channels are never consumed)
+            wr[u] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(wp) +
+                                                     ((int64_t)o * 384 + (chunk - oo * 384)) * 16);
+        }
+    };
+    auto w_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int chunk = t + 256 * u;
+            const int oo = chunk / 384, rem = chunk - oo * 384;
+            const int q = rem / 128, rr = (rem - q * 128) >> 2, c16 = rem & 3;
+            *reinterpret_cast<f32x4 *>(&Wl[buf][oo][q][rr][c16 * 8]) = wr[u];
+        }
+    };
+    w_load(0);
+    for (int grp = 0; grp < ngrp; ++grp) {
+        const int buf = grp & 1;
+        w_store(buf);
+        // LDS-only barrier (no release fence: the output stores of the previous group must not be drained here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        w_load(grp + 1 < ngrp ? grp + 1 : grp);
+#pragma unroll
+        for (int oo = 0; oo < CB_OG; ++oo) {
+            const int o = grp * CB_OG + oo;
+            if (!FULL && o >= O) break;
+            cbbf8 a[2][3];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    a[ks][q] = *reinterpret_cast<const cbbf8 *>(&Wl[buf][oo][q][i][ks * 16 + 8 * hh]);
+            float ysum = 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    // hi*lo + lo*hi + mid*mid + hi*mid + mid*hi + hi*hi  (smallest terms first)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], bf[ti][ks][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][2], bf[ti][ks][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], bf[ti][ks][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], bf[ti][ks][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], bf[ti][ks][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], bf[ti][ks][0], acc, 0, 0, 0);
+                }
+                if (MODE == 0) {
+                    float y = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) y += ep[ti][r] * acc[r];
+                    y += __shfl_xor(y, 32, 64);  // the other 16 rows live in the other lane half
+                    const float yb = y + (bias != nullptr ? bias[o] : 0.f);
+                    // FULL: both lane halves hold the same value and store it to the same address (a lane-dependent
+                    // guard would put the store behind a branch and the weight prefetch behind a vmcnt(0))
+                    if (out != nullptr && (FULL || (hh == 0 && ok[ti]))) out[(bt[ti] * O + o) * D + dt[ti]] = yb;
+                    if (pooled != nullptr) {
+                        if (tps == 2) {
+                            ysum += yb;  // both tiles belong to this wave's sample
+                        } else {
+                            float s = (hh == 0) ? yb : 0.f;
+#pragma unroll
+                            for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);  // every lane: the total
+                            if (FULL || (l == 0 && ok[ti])) pooled[bt[ti] * O + o] = s;
+                        }
+                    }
+                } else {
+                    float gv = 0.f;
+                    if (gout != nullptr) gv = gout[(bt[ti] * O + o) * D + dt[ti]];
+                    if (gpool != nullptr) gv += gpool[bt[ti] * O + o];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ep[ti][r] += gv * acc[r];
+                }
+            }
+            if (MODE == 0 && pooled != nullptr && tps == 2) {
+                float s = (hh == 0) ? ysum : 0.f;
+#pragma unroll
+                for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);  // every lane: the total
+                if (FULL || (l == 0 && ok[0])) pooled[bt[0] * O + o] = s;
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (h < Hr && ok[ti]) dx[bt[ti] * lddx + (int64_t)h * D + dt[ti]] = ep[ti][r];
+            }
+    }
+}
+
+extern "C" int rp_cin_bs_fits(int H, int M, int D) { return (H >= 1 && H <= 32 && M >= 1 && M <= 32 && (D == 32 || D == 64)) ? 1 : 0; }
+
+static int cb_check(int Hr, int Mc, int O, int D) {
+    if (!rp_cin_bs_fits(Hr, Mc, D) || O < 1)
+        return rp_fail(RP_ERR_UNSUPPORTED, "cin_bs: rows=%d contraction=%d (<=32) D=%d (32|64) O=%d unsupported", Hr, Mc, D, O);
+    return RP_OK;
+}
+
+template <int MODE>
+static void cb_launch(const float *xk, int64_t ldk, int Mc, const float *xe, int64_t lde, int Hr, const void *wp, int O,
+                      int D, const float *bias, float *out, float *pooled, const float *gout, const float *gpool,
+                      float *dx, int64_t lddx, int64_t B, hipStream_t s) {
+    const int spb = 4 * (D == 64 ? 1 : 2);  // samples per workgroup
+    const int64_t Bf = (O % CB_OG == 0) ? (B / spb) * spb : 0;  // the straight-line kernel also wants whole channel groups
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(wp);
+    if (Bf > 0)
+        hipLaunchKernelGGL((cin_bs_kernel<MODE, true>), dim3((unsigned)(Bf / spb)), dim3(256), 0, s, xk, ldk, Mc, xe, lde, Hr,
+                           w, O, D, bias, out, pooled, gout, gpool, dx, lddx, Bf);
+    if (B > Bf) {  // tail samples (or every sample when O is not a multiple of 4): guarded instantiation
+        const int64_t o1 = Bf;
+        hipLaunchKernelGGL((cin_bs_kernel<MODE, false>), dim3((unsigned)rp_cdiv(B - Bf, spb)), dim3(256), 0, s, xk + o1 * ldk, ldk, Mc,
+                           xe ? xe + o1 * lde : nullptr, lde, Hr, w, O, D, bias, out ? out + o1 * (int64_t)O * D : nullptr,
+                           pooled ? pooled + o1 * O : nullptr, gout ? gout + o1 * (int64_t)O * D : nullptr,
+                           gpool ? gpool + o1 * O : nullptr, dx ? dx + o1 * lddx : nullptr, lddx, B - Bf);
+    }
+}
+
+// forward of one CIN layer with at most 32 x 32 (field, map) pairs per channel.
+//   x0 [B, ld0]: H rows of D floats; xp [B, ldp]: M rows of D floats (may alias x0); wp: [O][3][32][32] bf16 pieces of
+//   W[o, h, m] (row h, column m, zero padded); out [B, O, D] and/or pooled [B, O].
+extern "C" int rp_cin_bs_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const void *wp,
+                             const float *bias, int H, int M, int O, int D, float *out, float *pooled, int64_t B,
+                             rp_stream_t stream) {
+    RP_REQUIRE(x0 && xp && wp && (out || pooled) && B >= 0, "cin_bs_fwd: null pointer");
+    int rc = cb_check(H, M, O, D);
+    if (rc != RP_OK) return rc;
+    RP_REQUIRE(ld0 >= (int64_t)H * D && ldp >= (int64_t)M * D, "cin_bs_fwd: ld too small");
+    if (B == 0) return RP_OK;
+    cb_launch<0>(xp, ldp, M, x0, ld0, H, wp, O, D, bias, out, pooled, nullptr, nullptr, nullptr, 0, B, (hipStream_t)stream);
+    RP_LAUNCH_CHECK("cin_bs_fwd");
+    return RP_OK;
+}
+
+// dx[b, r, d] = sum_o (gout[b,o,d] + gpool[b,o]) * sum_c Wp[o][r][c] * xk[b, c, d]     (r < R rows, c < C contraction)
+//   X_0-role gradient : xk = X_{k-1}, (R, C) = (H, M), wp from W[o,h,m]
+//   X_{k-1}-role grad : xk = X_0,     (R, C) = (M, H), wp from W[o,m,h] (transposed)
+//   first layer       : xk = X_0,     (R, C) = (H, H), wp from W[o,h,m] + W[o,m,h]: the whole gradient in one pass
+extern "C" int rp_cin_bs_bwd_x(const float *xk, int64_t ldk, const void *wp, const float *gout, const float *gpool, int R,
+                               int Cn, int O, int D, float *dx, int64_t lddx, int64_t B, rp_stream_t stream) {
+    RP_REQUIRE(xk && wp && dx && (gout || gpool) && B >= 0, "cin_bs_bwd_x: null pointer");
+    int rc = cb_check(R, Cn, O, D);
+    if (rc != RP_OK) return rc;
+    RP_REQUIRE(ldk >= (int64_t)Cn * D && lddx >= (int64_t)R * D, "cin_bs_bwd_x: ld too small");
+    if (B == 0) return RP_OK;
+    cb_launch<1>(xk, ldk, Cn, nullptr, 0, R, wp, O, D, nullptr, nullptr, nullptr, gout, gpool, dx, lddx, B,
+                 (hipStream_t)stream);
+    RP_LAUNCH_CHECK("cin_bs_bwd_x");
+    return RP_OK;
+}

@@ -124,8 +124,14 @@ class _CINLayer(torch.autograd.Function):
         same = xp is None
         xp_t = x0 if same else _unit_inner(xp)
         W = W.contiguous()
-        out, pooled = hip.cin_layer_fwd(x0, xp_t, W, bias, H, M, D, want_out, True)
-        ctx.cfg = (H, M, D, same, bias is not None, want_out)
+        O = W.shape[0]
+        # first layers (X_{k-1} = X_0, <= 32 fields) run on the bf16 matrix core (rp_cin_bs_*)
+        bs = same and hip.get_matmul_precision() != "fp32" and hip.cin_bs_fits(H, M, D)
+        if bs:
+            out, pooled = hip.cin_bs_fwd(x0, xp_t, hip.bf16_pieces(W.view(O, H, M)), bias, H, M, O, D, want_out, True)
+        else:
+            out, pooled = hip.cin_layer_fwd(x0, xp_t, W, bias, H, M, D, want_out, True)
+        ctx.cfg = (H, M, D, same, bias is not None, want_out, bs)
         ctx.save_for_backward(x0, None if same else xp_t, W)
         if want_out:
             return out, pooled
@@ -134,12 +140,50 @@ class _CINLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         x0, xp, W = ctx.saved_tensors
-        H, M, D, same, has_bias, want_out = ctx.cfg
+        H, M, D, same, has_bias, want_out, bs = ctx.cfg
         g_out, g_pool = (grads if want_out else (None, grads[0]))
         g_out = None if g_out is None else g_out.contiguous()
         g_pool = None if g_pool is None else _unit_inner(g_pool)
+        if bs:
+            O = W.shape[0]
+            W3 = W.view(O, H, M)
+            # X_0 enters in both roles: one pass with W[o,h,m] + W[o,m,h] gives its whole gradient
+            gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
+            dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
+            dW, db = hip.cin_layer_bwd_w(x0, x0, W, H, M, D, g_out, g_pool, has_bias)
+            return dx0, None, dW, db, None, None, None, None
         dx0, dxp, dW, db = hip.cin_layer_bwd(x0, x0 if same else xp, W, H, M, D, g_out, g_pool, has_bias)
         return dx0, dxp, dW, db, None, None, None, None
+
+
+class _CINLast(torch.autograd.Function):
+    """The collapsed last CIN layer: p[b] = sum_d sum_{h,m} V[h,m] X_0[b,h,d] X_{L-1}[b,m,d]  (rp_cin_last_*)."""
+
+    @staticmethod
+    def forward(ctx, x0, xp, V, H: int, M: int, D: int):
+        x0 = _unit_inner(x0)
+        same = xp is None
+        xp_t = x0 if same else _unit_inner(xp)
+        vt = torch.zeros((M, 32), dtype=torch.float32, device=x0.device)
+        vt[:, :H] = V.reshape(H, M).t()
+        ctx.cfg = (H, M, D, same)
+        ctx.save_for_backward(x0, None if same else xp_t, vt)
+        return hip.cin_last_fwd(x0, xp_t, vt, H, M, D)
+
+    @staticmethod
+    def backward(ctx, gp):
+        x0, xp, vt = ctx.saved_tensors
+        H, M, D, same = ctx.cfg
+        dx0, dxp, dV = hip.cin_last_bwd(x0, x0 if same else xp, vt, gp.reshape(-1).contiguous(), H, M, D)
+        if same:  # first layer == last layer: both roles are X_0 (M == H, same row layout)
+            dx0 = dx0 + dxp
+            dxp = None
+        return dx0, dxp, dV.reshape(1, H * M), None, None, None
+
+
+def cin_last(x0, xp, V, H: int, M: int, D: int):
+    """x0 [B, >=H*D], xp [B, M*D] or None (X_{L-1} = X_0), V [1, H*M] -> [B, 1]."""
+    return _CINLast.apply(x0, xp, V, H, M, D)
 
 
 def cin_layer(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool = True):

@@ -52,6 +52,14 @@ _SIGNATURES = {
                                          _vp, _sz, _vp]),
     "rp_mmoe_combine_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_mmoe_combine_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "rp_cin_bs_fits": (C.c_int, [_i32, _i32, _i32]),
+    "rp_cin_bs_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "rp_cin_bs_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
+    "rp_cin_last_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "rp_cin_last_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "rp_cin_last_bwd_v_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
+    "rp_cin_last_bwd_v": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _sz, _vp]),
     "rp_attention_core_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_attention_core_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
     "rp_attention_core_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _i64,
@@ -440,6 +448,100 @@ def field_attention_bwd(x, W, T: int, Din: int, H: int, a: int, has_res: bool, s
                                             dW.data_ptr(), B, ws.data_ptr(), nbytes.value, _stream()),
                "rp_field_attention_bwd")
     return dx, dW
+
+
+def cin_bs_fits(H: int, M: int, D: int) -> bool:
+    return bool(lib().rp_cin_bs_fits(H, M, D))
+
+
+def bf16_pieces(w3: torch.Tensor) -> torch.Tensor:
+    """[O, R, C] fp32 (R, C <= 32) -> [O, 3, 32, 32] bf16: (hi, mid, lo) with w = hi + mid + lo (+ 2^-24 |w|), zero
+    padded — the operand format of the split-bf16 matrix-core kernels (round-to-nearest-even conversions, exactly
+    what v_cvt_pk_bf16_f32 does in the kernels that split on the fly)."""
+    O, R, Cc = w3.shape
+    pad = torch.zeros((O, 32, 32), dtype=torch.float32, device=w3.device)
+    pad[:, :R, :Cc] = w3
+    hi = pad.to(torch.bfloat16)
+    r1 = pad - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo], dim=1).contiguous()
+
+
+def cin_bs_fwd(x0, xp, wp, bias, H: int, M: int, O: int, D: int, want_out: bool, want_pool: bool):
+    B = x0.shape[0]
+    out = torch.empty((B, O, D), dtype=torch.float32, device=x0.device) if want_out else None
+    pooled = torch.empty((B, O), dtype=torch.float32, device=x0.device) if want_pool else None
+    with _Timed("cin_bs_fwd"):
+        _check(lib().rp_cin_bs_fwd(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"), wp.data_ptr(),
+                                   _ptr(bias), H, M, O, D, _ptr(out), _ptr(pooled), B, _stream()), "rp_cin_bs_fwd")
+    return out, pooled
+
+
+def cin_bs_bwd_x(xk, wp, g_out, g_pool, R: int, Cn: int, O: int, D: int, like):
+    """-> dx shaped like `like` ([B, >= R*D], zero beyond R*D)."""
+    B = xk.shape[0]
+    dx = torch.empty_like(like)
+    if like.shape[1] > R * D:
+        dx[:, R * D:].zero_()
+    with _Timed("cin_bs_bwd_x"):
+        _check(lib().rp_cin_bs_bwd_x(xk.data_ptr(), _rowmajor(xk, "xk"), wp.data_ptr(), _ptr(g_out), _ptr(g_pool), R, Cn, O,
+                                     D, dx.data_ptr(), _rowmajor(dx, "dx"), B, _stream()), "rp_cin_bs_bwd_x")
+    return dx
+
+
+def cin_layer_bwd_w(x0, xp, W, H: int, M: int, D: int, g_out, g_pool, want_bias: bool):
+    """dW like W, dbias [O] or None (rp_cin_layer_bwd_w alone)."""
+    B, O = x0.shape[0], W.shape[0]
+    ldgp = _rowmajor(g_pool, "g_pool") if g_pool is not None else 0
+    dW = torch.empty_like(W)
+    db = torch.empty((O,), dtype=torch.float32, device=x0.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_cin_layer_bwd_w_workspace_bytes(B, H, M, O, C.byref(nbytes)), "rp_cin_layer_bwd_w_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x0.device)
+    with _Timed("cin_layer_bwd_w"):
+        _check(lib().rp_cin_layer_bwd_w(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"),
+                                        _ptr(g_out), _ptr(g_pool), ldgp, dW.data_ptr(), _ptr(db), H, M, O, D, B,
+                                        ws.data_ptr(), nbytes.value, _stream()), "rp_cin_layer_bwd_w")
+    return dW, db
+
+
+def cin_last_fits(H: int, M: int, D: int) -> bool:
+    return bool(lib().rp_cin_last_fits(H, M, D))
+
+
+def cin_last_fwd(x0, xp, vt, H: int, M: int, D: int):
+    """x0 [B, >=H*D], xp [B, >=M*D], vt [M, 32] (V^T zero padded) -> pooled [B, 1]."""
+    _req(x0, torch.float32, "x0")
+    B = x0.shape[0]
+    pooled = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
+    with _Timed("cin_last_fwd"):
+        _check(lib().rp_cin_last_fwd(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"), vt.data_ptr(),
+                                     H, M, D, pooled.data_ptr(), B, _stream()), "rp_cin_last_fwd")
+    return pooled
+
+
+def cin_last_bwd(x0, xp, vt, g, H: int, M: int, D: int):
+    """-> dx0 (shape of x0, zero beyond H*D), dxp (shape of xp), dV [H, M]."""
+    B = x0.shape[0]
+    dx0, dxp = torch.empty_like(x0), torch.empty_like(xp)
+    if x0.shape[1] > H * D:
+        dx0[:, H * D:].zero_()
+    if xp.shape[1] > M * D:
+        dxp[:, M * D:].zero_()
+    with _Timed("cin_last_bwd_x"):
+        _check(lib().rp_cin_last_bwd_x(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"),
+                                       vt.data_ptr(), g.data_ptr(), H, M, D, dx0.data_ptr(), _rowmajor(dx0, "dx0"),
+                                       dxp.data_ptr(), _rowmajor(dxp, "dxp"), B, _stream()), "rp_cin_last_bwd_x")
+    dV = torch.empty((H, M), dtype=torch.float32, device=x0.device)
+    nbytes = _sz(0)
+    _check(lib().rp_cin_last_bwd_v_workspace_bytes(B, H, M, C.byref(nbytes)), "rp_cin_last_bwd_v_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x0.device)
+    with _Timed("cin_last_bwd_v"):
+        _check(lib().rp_cin_last_bwd_v(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"), g.data_ptr(),
+                                       H, M, D, dV.data_ptr(), B, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_cin_last_bwd_v")
+    return dx0, dxp, dV
 
 
 def attention_core_fits(T: int, H: int, a: int) -> bool:

@@ -126,7 +126,12 @@ class CompressedInteractionNet(nn.Module):
             raise NotImplementedError("CIN on HIP collapses the last layer into fc: output_dim must be 1")
         V = c_last @ conv.weight.view(O, H * M)                              # [1, H*M]   (weight-space, tiny)
         vb = (c_last @ conv.bias.view(O, 1)).view(1)                         # c . bias_L
-        logit = Fh.cin_layer(x0, xp, V, vb, H, M, D, want_out=False)         # [B,1] = sum_o c[o] pooled_L[b,o]
+        from ... import hip
+        if hip.cin_last_fits(H, M, D):
+            # dedicated HBM-bound kernels for the single collapsed channel; the bias enters as D * (c . bias_L)
+            logit = Fh.cin_last(x0, xp, V, H, M, D) + D * vb
+        else:
+            logit = Fh.cin_layer(x0, xp, V, vb, H, M, D, want_out=False)     # [B,1] = sum_o c[o] pooled_L[b,o]
         if pooled:
             logit = logit + Fh.linear_act(torch.cat(pooled, dim=-1), self.fc.weight[:, :n_prev].contiguous(), None)
         return logit + self.fc.bias
