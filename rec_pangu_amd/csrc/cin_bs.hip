@@ -38,7 +38,7 @@ __device__ __forceinline__ void cb_split(cbf8 v, cbbf8 (&p)[3]) {
 // MODE 0: bias [O] or null, out [B, O*D] (ldo = O*D) or null, pooled [B, O] or null
 // MODE 1: gout [B, O*D] or null, gpool [B, O] or null, dx [B, lddx] (Hr rows of D floats written)
 template <int MODE, bool FULL>
-__global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ xk, int64_t ldk, int Mc,
+__global__ __launch_bounds__(256, 2) void cin_bs_kernel(const float *__restrict__ xk, int64_t ldk, int Mc,
                                                      const float *__restrict__ xe, int64_t lde, int Hr,
                                                      const __bf16 *__restrict__ wp, int O, int D,
                                                      const float *__restrict__ bias, float *__restrict__ out,
@@ -109,6 +109,22 @@ __global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ x
             *reinterpret_cast<f32x4 *>(&Wl[buf][oo][q][rr][c16 * 8]) = wr[u];
         }
     };
+    // MODE 1: the upstream gradients of a channel group are fetched together at the top of the group
+    float gc[CB_OG][2];
+    auto g_load = [&](int grp) {
+#pragma unroll
+        for (int oo = 0; oo < CB_OG; ++oo) {
+            int o = grp * CB_OG + oo;
+            if (o >= O) o = O - 1;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                float gv = 0.f;
+                if (gout != nullptr) gv = gout[(bt[ti] * O + o) * D + dt[ti]];
+                if (gpool != nullptr) gv += gpool[bt[ti] * O + o];
+                gc[oo][ti] = gv;
+            }
+        }
+    };
     w_load(0);
     for (int grp = 0; grp < ngrp; ++grp) {
         const int buf = grp & 1;
@@ -116,6 +132,7 @@ __global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ x
         // LDS-only barrier (no release fence: the output stores of the previous group must not be drained here)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         w_load(grp + 1 < ngrp ? grp + 1 : grp);
+        if (MODE == 1) g_load(grp);  // consumed one to four channels of MFMA work later
 #pragma unroll
         for (int oo = 0; oo < CB_OG; ++oo) {
             const int o = grp * CB_OG + oo;
@@ -162,9 +179,7 @@ __global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ x
                         }
                     }
                 } else {
-                    float gv = 0.f;
-                    if (gout != nullptr) gv = gout[(bt[ti] * O + o) * D + dt[ti]];
-                    if (gpool != nullptr) gv += gpool[bt[ti] * O + o];
+                    const float gv = gc[oo][ti];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ep[ti][r] += gv * acc[r];
                 }
@@ -175,6 +190,9 @@ __global__ __launch_bounds__(256) void cin_bs_kernel(const float *__restrict__ x
                 for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);  // every lane: the total
                 if (FULL || (l == 0 && ok[0])) pooled[bt[0] * O + o] = s;
             }
+            // keep the scheduler from interleaving the four channels of a group: it buys nothing (the matrix core is
+            // busy either way) and the extra live accumulators cost the second wave per SIMD
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (MODE == 1) {
@@ -201,7 +219,9 @@ static void cb_launch(const float *xk, int64_t ldk, int Mc, const float *xe, int
                       int D, const float *bias, float *out, float *pooled, const float *gout, const float *gpool,
                       float *dx, int64_t lddx, int64_t B, hipStream_t s) {
     const int spb = 4 * (D == 64 ? 1 : 2);  // samples per workgroup
-    const int64_t Bf = (O % CB_OG == 0) ? (B / spb) * spb : 0;  // the straight-line kernel also wants whole channel groups
+    // the straight-line kernel also wants whole channel groups; MODE 1 has no stores in its channel loop (nothing for a
+    // conservative vmcnt to drain) and its fully unrolled FULL form spills, so it always runs the guarded form
+    const int64_t Bf = (MODE == 0 && O % CB_OG == 0) ? (B / spb) * spb : 0;
     const __bf16 *w = reinterpret_cast<const __bf16 *>(wp);
     if (Bf > 0)
         hipLaunchKernelGGL((cin_bs_kernel<MODE, true>), dim3((unsigned)(Bf / spb)), dim3(256), 0, s, xk, ldk, Mc, xe, lde, Hr,
