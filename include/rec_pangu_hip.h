@@ -202,13 +202,18 @@ int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float
  *   fwd   : out [B, O, D] and/or pooled [B, O] (= sum_d out); bias [O] optional
  *   bwd_x : dx[b,r,:] = sum_o (gout[b,o,:] + gpool[b,o]) sum_c wp[o][r][c] xk[b,c,:]   — X_0-role gradient with
  *           wp from W[o,h,m], X_{k-1}-role gradient with W[o,m,h]; for a first layer W[o,h,m] + W[o,m,h] gives the
- *           whole gradient in one pass.  The weight gradient stays with rp_cin_layer_bwd_w.
+ *           whole gradient in one pass.
  * Limits: rows, contraction <= 32, D in {32, 64} (rp_cin_bs_fits). */
 int rp_cin_bs_fits(int H, int M, int D);
 int rp_cin_bs_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const void *wp, const float *bias, int H,
                   int M, int O, int D, float *out, float *pooled, int64_t B, rp_stream_t stream);
 int rp_cin_bs_bwd_x(const float *xk, int64_t ldk, const void *wp, const float *gout, const float *gpool, int R, int Cn,
                     int O, int D, float *dx, int64_t lddx, int64_t B, rp_stream_t stream);
+/* dW [O, H*M], db [O] (optional): dW[o,h,m] = sum_{b,d} (gout + gpool)[b,o,d] X_0[b,h,d] X_{k-1}[b,m,d] */
+int rp_cin_bs_bwd_w_workspace_bytes(int64_t B, int O, size_t *bytes);
+int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *gout, const float *gpool,
+                    int H, int M, int O, int D, float *dW, float *db, int64_t B, void *workspace, size_t workspace_bytes,
+                    rp_stream_t stream);
 
 /* ---- K6 (last layer): the collapsed final CIN layer ------------------------------------------------------
  * replaces interaction.py:157-171 for the LAST layer: with no activation and linear pooling + fc behind it, it

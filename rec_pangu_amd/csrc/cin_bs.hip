@@ -267,3 +267,184 @@ extern "C" int rp_cin_bs_bwd_x(const float *xk, int64_t ldk, const void *wp, con
     RP_LAUNCH_CHECK("cin_bs_bwd_x");
     return RP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[o,h,m] = sum_{b,d} G[b,o,d] X_0[b,h,d] X_{k-1}[b,m,d],  db[o] = sum_{b,d} G[b,o,d]        (G = gout + gpool)
+// A TN GEMM per channel (32 x 32 output tile, contraction index r = (b,d)) on the bf16 matrix core — with NO LDS and
+// NO barriers: every operand is "contraction-contiguous" in memory, so a lane can load its MFMA fragment directly:
+//   A fragment, lane (row h, k-octet)  = G[b,o,d0..d0+7] * X_0[b,h,d0..d0+7]   (two 32-byte reads, the G one broadcast)
+//   B fragment, lane (col m, k-octet)  = X_{k-1}[b,m,d0..d0+7]                 (the X_0 octet itself in a first layer)
+// Each wave owns CW_CH = 4 channels (4 accumulator tiles) and walks over its workgroup's chunk of samples; the four
+// waves of a workgroup take four channel groups of the SAME samples, so their X_0 reads share the L1.  Partials per
+// sample chunk go to a workspace; a second kernel sums them in a fixed order (deterministic) and strips the padding.
+#define CW_CH 4
+__global__ __launch_bounds__(256) void cin_bs_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0,
+                                                           const float *__restrict__ xp, int64_t ldp, int H, int M,
+                                                           int O, int D, const float *__restrict__ gout,
+                                                           const float *__restrict__ gpool, float *__restrict__ P,
+                                                           float *__restrict__ Pb, int64_t B, int64_t b_per_blk) {
+    const int t = threadIdx.x;
+    const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
+    const int o0 = (blockIdx.y * 4 + w) * CW_CH;  // this wave's channels
+    const int64_t bbeg = (int64_t)blockIdx.x * b_per_blk;
+    int64_t bend = bbeg + b_per_blk;
+    if (bend > B) bend = B;
+    const bool same = (xp == x0) && (ldp == ld0);
+    f32x16 acc[CW_CH];
+#pragma unroll
+    for (int u = 0; u < CW_CH; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    float bsum[CW_CH];
+#pragma unroll
+    for (int u = 0; u < CW_CH; ++u) bsum[u] = 0.f;
+    const int nks = D / 16;  // k-steps per sample
+    if (o0 < O) {
+        for (int64_t b = bbeg; b < bend; ++b) {
+            for (int ks = 0; ks < nks; ++ks) {
+                const int d0 = ks * 16 + 8 * hh;
+                cbf8 vx, vp;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    vx[e] = 0.f;
+                    vp[e] = 0.f;
+                }
+                if (i < H) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(x0 + b * ld0 + (int64_t)i * D + d0);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(x0 + b * ld0 + (int64_t)i * D + d0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vx[e] = q0[e];
+                        vx[4 + e] = q1[e];
+                    }
+                }
+                if (same) {
+                    vp = vx;
+                } else if (i < M) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(xp + b * ldp + (int64_t)i * D + d0);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4 *>(xp + b * ldp + (int64_t)i * D + d0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vp[e] = q0[e];
+                        vp[4 + e] = q1[e];
+                    }
+                }
+                cbbf8 bq[3];
+                cb_split(vp, bq);
+#pragma unroll
+                for (int u = 0; u < CW_CH; ++u) {
+                    int o = o0 + u;
+                    if (o >= O) o = O - 1;  // a channel past the end recomputes the last one; its tile is never stored
+                    cbf8 vg;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vg[e] = 0.f;
+                    if (gout != nullptr) {
+                        const f32x4 q0 = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0);
+                        const f32x4 q1 = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            vg[e] = q0[e];
+                            vg[4 + e] = q1[e];
+                        }
+                    }
+                    if (gpool != nullptr) {
+                        const float gp = gpool[b * O + o];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vg[e] += gp;
+                    }
+                    bsum[u] += ((vg[0] + vg[1]) + (vg[2] + vg[3])) + ((vg[4] + vg[5]) + (vg[6] + vg[7]));
+                    cbbf8 a[3];
+                    cb_split(vg * vx, a);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partials: P[chunk][o][h][m] (32 x 32 padded); C layout: col (m) = lane & 31, row (h) = (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+    for (int u = 0; u < CW_CH; ++u) {
+        const int o = o0 + u;
+        if (o >= O) continue;
+        float *Pz = P + ((int64_t)blockIdx.x * O + o) * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            Pz[h * 32 + i] = acc[u][r];
+        }
+        if (Pb != nullptr) {
+            // every lane of a half summed the same G octets: lane 0 holds the octets with 8*0, lane 32 those with 8*1
+            const float other = __shfl_xor(bsum[u], 32, 64);
+            if (l == 0) Pb[(int64_t)blockIdx.x * O + o] = bsum[u] + other;
+        }
+    }
+}
+
+// dW[o, h*M + m] = sum_chunk P[chunk][o][h][m];  db[o] = sum_chunk Pb[chunk][o]   (16 x 16 threads, fixed order)
+__global__ __launch_bounds__(256) void cin_bs_wsum_kernel(const float *__restrict__ P, const float *__restrict__ Pb, int S,
+                                                          int O, int H, int M, float *__restrict__ dW,
+                                                          float *__restrict__ db) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int64_t nw = (int64_t)O * H * M;
+    const int64_t e = (int64_t)blockIdx.x * 16 + c;
+    const bool is_w = e < nw, is_b = !is_w && e < nw + O && db != nullptr;
+    float s = 0.f;
+    if (is_w) {
+        const int o = (int)(e / (H * M)), rem = (int)(e - (int64_t)o * H * M), h = rem / M, m = rem - h * M;
+        const int64_t src = (int64_t)o * 1024 + h * 32 + m;
+        for (int z = q; z < S; z += 16) s += P[(int64_t)z * O * 1024 + src];
+    } else if (is_b) {
+        const int o = (int)(e - nw);
+        for (int z = q; z < S; z += 16) s += Pb[(int64_t)z * O + o];
+    }
+    red[q][c] = s;
+    __syncthreads();
+    if (q != 0) return;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) s += red[j][c];
+    if (is_w) dW[e] = s;
+    else if (is_b) db[e - nw] = s;
+}
+
+static int64_t cw_chunks(int64_t B) {
+    int64_t n = B < 256 ? B : 256;
+    return n < 1 ? 1 : n;
+}
+
+extern "C" int rp_cin_bs_bwd_w_workspace_bytes(int64_t B, int O, size_t *bytes) {
+    RP_REQUIRE(bytes && B >= 0 && O >= 1, "cin_bs_bwd_w_workspace_bytes: bad argument");
+    *bytes = (size_t)cw_chunks(B) * O * (1024 + 1) * sizeof(float) + 256;
+    return RP_OK;
+}
+
+extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *gout,
+                               const float *gpool, int H, int M, int O, int D, float *dW, float *db, int64_t B,
+                               void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(x0 && xp && dW && workspace && (gout || gpool) && B >= 1, "cin_bs_bwd_w: bad argument");
+    int rc = cb_check(H, M, O, D);
+    if (rc != RP_OK) return rc;
+    RP_REQUIRE(ld0 >= (int64_t)H * D && ldp >= (int64_t)M * D && ld0 % 4 == 0 && ldp % 4 == 0 && rp_aligned16(x0) &&
+                   rp_aligned16(xp) && (gout == nullptr || rp_aligned16(gout)),
+               "cin_bs_bwd_w: rows must be 16-byte aligned (ld multiple of 4 floats)");
+    size_t need = 0;
+    rp_cin_bs_bwd_w_workspace_bytes(B, O, &need);
+    RP_REQUIRE(workspace_bytes >= need, "cin_bs_bwd_w: workspace %zu < %zu", workspace_bytes, need);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t nc = cw_chunks(B);
+    const int64_t per = rp_cdiv(B, nc);
+    const int64_t ncx = rp_cdiv(B, per);
+    float *Pb = P + (size_t)ncx * O * 1024;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cin_bs_bwd_w_kernel, dim3((unsigned)ncx, (unsigned)rp_cdiv(O, 4 * CW_CH)), dim3(256), 0, s, x0, ld0, xp, ldp,
+                       H, M, O, D, gout, gpool, P, db ? Pb : nullptr, B, per);
+    RP_LAUNCH_CHECK("cin_bs_bwd_w");
+    const int64_t total = (int64_t)O * H * M + O;
+    hipLaunchKernelGGL(cin_bs_wsum_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, (int)ncx, O, H, M, dW, db);
+    RP_LAUNCH_CHECK("cin_bs_bwd_w reduce");
+    return RP_OK;
+}

@@ -150,7 +150,11 @@ class _CINLayer(torch.autograd.Function):
             # X_0 enters in both roles: one pass with W[o,h,m] + W[o,m,h] gives its whole gradient
             gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
             dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
-            dW, db = hip.cin_layer_bwd_w(x0, x0, W, H, M, D, g_out, g_pool, has_bias)
+            if x0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0:
+                dW, db = hip.cin_bs_bwd_w(x0, x0, g_out, gp, H, M, O, D, has_bias)
+                dW = dW.view_as(W)
+            else:
+                dW, db = hip.cin_layer_bwd_w(x0, x0, W, H, M, D, g_out, g_pool, has_bias)
             return dx0, None, dW, db, None, None, None, None
         dx0, dxp, dW, db = hip.cin_layer_bwd(x0, x0 if same else xp, W, H, M, D, g_out, g_pool, has_bias)
         return dx0, dxp, dW, db, None, None, None, None

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "rp_cin_bs_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_bs_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_cin_bs_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "rp_cin_bs_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_last_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_cin_last_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
@@ -488,6 +490,21 @@ def cin_bs_bwd_x(xk, wp, g_out, g_pool, R: int, Cn: int, O: int, D: int, like):
         _check(lib().rp_cin_bs_bwd_x(xk.data_ptr(), _rowmajor(xk, "xk"), wp.data_ptr(), _ptr(g_out), _ptr(g_pool), R, Cn, O,
                                      D, dx.data_ptr(), _rowmajor(dx, "dx"), B, _stream()), "rp_cin_bs_bwd_x")
     return dx
+
+
+def cin_bs_bwd_w(x0, xp, g_out, g_pool, H: int, M: int, O: int, D: int, want_bias: bool):
+    """dW [O, H*M], dbias [O] or None on the bf16 matrix core (rp_cin_bs_bwd_w); g_pool must be packed [B, O]."""
+    B = x0.shape[0]
+    dW = torch.empty((O, H * M), dtype=torch.float32, device=x0.device)
+    db = torch.empty((O,), dtype=torch.float32, device=x0.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_cin_bs_bwd_w_workspace_bytes(B, O, C.byref(nbytes)), "rp_cin_bs_bwd_w_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x0.device)
+    with _Timed("cin_bs_bwd_w"):
+        _check(lib().rp_cin_bs_bwd_w(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"), _ptr(g_out),
+                                     _ptr(g_pool), H, M, O, D, dW.data_ptr(), _ptr(db), B, ws.data_ptr(), nbytes.value,
+                                     _stream()), "rp_cin_bs_bwd_w")
+    return dW, db
 
 
 def cin_layer_bwd_w(x0, xp, W, H: int, M: int, D: int, g_out, g_pool, want_bias: bool):
