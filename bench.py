@@ -302,6 +302,17 @@ def main():
         # flop per launch averaged over the launches of a step (fwd: one chain; bwd_x: two chains; bwd_w: one)
         mfma_flops = {"cin_layer_fwd": local_B * per / len(units), "cin_layer_bwd_x": 2 * local_B * per / len(units),
                       "cin_layer_bwd_w": local_B * per / len(units)}
+        # first layer on the bf16 matrix core (rp_cin_bs_*): 2*H*M*O*D flop per sample per pass (bwd_x: ONE pass with the
+        # symmetrised weights), collapsed last layer (rp_cin_last_*): HBM-bound on X_{L-1}
+        f1 = 2.0 * F * F * units[0] * D * local_B
+        bf16_mfma_flops = {"cin_bs_fwd": f1, "cin_bs_bwd_x": f1, "cin_bs_bwd_w": f1}
+        if len(units) > 1:
+            xl = local_B * units[-2] * D * 4
+            alg_bytes["cin_last_fwd"] = xl + local_B * F * D * 4
+            alg_bytes["cin_last_bwd_x"] = 2 * (xl + local_B * F * D * 4)
+            alg_bytes["cin_last_bwd_v"] = xl + local_B * F * D * 4
+    else:
+        bf16_mfma_flops = {}
     mlp_flops = None
     if args.model == "deepfm" and hidden != (64, 64, 64):
         dims = [F * D + ND] + list(hidden) + [1]
@@ -320,10 +331,18 @@ def main():
             k["algorithmic_GBps"] = round(alg_bytes[name] / (mean_ms * 1e-3) / 1e9, 1)
         kernels[name] = k
     # dominant = largest share of the step among the launches timed INSIDE the timed region
-    total = {n: c * m for n, (c, m) in timing.items() if n in alg_bytes or n in mfma_flops}
+    total = {n: c * m for n, (c, m) in timing.items() if n in alg_bytes or n in mfma_flops or n in bf16_mfma_flops}
     dominant = max(total, key=total.get) if total else None
     roofline = None
-    if dominant in mfma_flops:
+    if dominant in bf16_mfma_flops:
+        tf = bf16_mfma_flops[dominant] / (timing[dominant][1] * 1e-3) / 1e12
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                    "matmul_precision": "bf16x6", "mfma_products_per_flop": 6,
+                    "mfma_issue_frac": round(tf * 6 * (32 * 32) / (F * F) / MFMA_BF16_PEAK_TF, 4),
+                    "note": "algorithmic flops 2*H*M*O*D per sample; the matrix core runs 32x32 tiles (H, M padded from "
+                            f"{F}) with 6 bf16 products per flop: mfma_issue_frac counts those"}
+    elif dominant in mfma_flops:
         tf = mfma_flops[dominant] / (timing[dominant][1] * 1e-3) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
                     "frac": round(tf / 157.3, 4), "traffic": None,
