@@ -128,7 +128,11 @@ def _stream() -> int:
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"expected a HIP-device tensor, got one on {t.device}")
+    return t.data_ptr()
 
 
 def _req(t: torch.Tensor, dtype, name: str):
@@ -200,6 +204,9 @@ def timing_summary():
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * max(len(tensors), 1))()
     for i, t in enumerate(tensors):
+        if not t.is_cuda:  # a host pointer inside a launch packet is a GPU memory fault, not an exception
+            raise RuntimeError(f"Expected all tensors to be on the same device: input {i} is on {t.device} but the "
+                               "model is on the HIP device (move the batch with .to(device))")
         arr[i] = t.data_ptr()
     return arr
 
