@@ -1016,7 +1016,7 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
         const bool wide = wgrad_wide(N);
         dim3 gridb((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, wide ? 2 * TN_BN : TN_BN), (unsigned)S);
 #define CALLW(NPROD, NA, VX)                                                                                            \
-    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, 2, VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
+    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, (NA == 1 ? 1 : 2), VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
                        N, K, rows)
 #define CALLB(NPROD)                          \
     do {                                      \

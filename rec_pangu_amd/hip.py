@@ -124,7 +124,9 @@ def _check(rc: int, what: str):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of torch's current stream: torch.cuda.current_stream() builds a Stream object (~10 us per call,
+    # dozens of launches per step)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:

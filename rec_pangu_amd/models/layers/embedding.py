@@ -59,7 +59,21 @@ class EmbeddingLayer(nn.Module):
 
     # ------------------------------------------------------------------ arena bookkeeping
     def _tables(self):
-        return [self.embedding_layer[c].weight for c in self.emb_feature]
+        """The per-table Parameters in field order.  Cached: walking the ModuleDict costs ~100 us per call at 26
+        tables and this runs several times per step; the cache is dropped when a table Parameter object is replaced
+        (set_weights, load with assign=True, ...), which the identity check below detects."""
+        mods = self.__dict__.get("_tab_mods")
+        tabs = self.__dict__.get("_tab_cache")
+        if mods is not None:
+            for m, p in zip(mods, tabs):
+                if m._parameters["weight"] is not p:
+                    mods = None
+                    break
+        if mods is None:
+            mods = [self.embedding_layer[c] for c in self.emb_feature]
+            tabs = [m.weight for m in mods]
+            self.__dict__["_tab_mods"], self.__dict__["_tab_cache"] = mods, tabs
+        return tabs
 
     def table_parameters(self):
         return self._tables()

@@ -96,6 +96,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.lazy_tables = lazy_tables
         self._arena_state: Dict[int, dict] = {}
         self._stores = {}
+        self._plans: Dict[int, list] = {}
 
     @staticmethod
     def _store_of(p):
@@ -125,12 +126,16 @@ class FusedAdam(torch.optim.Optimizer):
             ms: List[torch.Tensor] = []
             vs: List[torch.Tensor] = []
             stores, arena_ok = {}, {}
-            for p in group["params"]:
+            plan = self._plans.get(id(group))  # (param, its arena store or None), resolved once per parameter list
+            if plan is None or len(plan) != len(group["params"]):
+                plan = self._plans[id(group)] = [(p, self._store_of(p)) for p in group["params"]]
+            for p, store in plan:
                 if p.grad is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("FusedAdam only updates HIP-device parameters (use make_adam for CPU models)")
-                store = self._store_of(p)
+                if store is not None and getattr(p, "_rp_store", None) is None:
+                    store = None  # the table was detached from its arena since the plan was made
                 if store is not None:
                     sid = id(store)
                     if sid not in arena_ok:  # one check per layer, not per table
