@@ -37,17 +37,21 @@ def criteo_enc_dict(scale=1):
 
 
 def synth_batch(enc, B, seed, device):
-    g = torch.Generator().manual_seed(seed)
+    """One synthetic batch, generated on `device` (a CPU generator would take seconds per 65536 x 40 batch and the
+    bench draws a DIFFERENT batch for every step: with a handful of recycled batches every embedding row would be
+    revisited within a few steps, which hides the cost of the lazy optimizer's replay of skipped steps)."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
     b = {}
     for k, v in enc.items():
         if "min" in v:
-            b[k] = torch.rand(B, generator=g)
-        else:
-            b[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g)  # uniform: worst case for caches
-    b["label"] = (torch.rand(B, generator=g) < 0.25).float()
+            b[k] = torch.rand(B, generator=g, device=dev)
+        else:  # uniform ids: worst case for caches
+            b[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g, device=dev)
+    b["label"] = (torch.rand(B, generator=g, device=dev) < 0.25).float()
     b["task1_label"] = b["label"]
-    b["task2_label"] = (torch.rand(B, generator=g) < 0.1).float()
-    return {k: t.to(device) for k, t in b.items()}
+    b["task2_label"] = (torch.rand(B, generator=g, device=dev) < 0.1).float()
+    return b
 
 
 def mmoe_enc_dict(scale=1):
@@ -193,7 +197,9 @@ def main():
     # batches; the tables are row-sharded and the lookup all-to-all serves the whole global batch.
     local_B = args.batch
     B = local_B * world
-    batches = [synth_batch(enc, local_B, 100 + 17 * rank + i, dev) for i in range(4)]
+    # a distinct batch per step (capped at 512 batches = 8.8 GB of ids at Criteo shape)
+    n_batches = min(args.steps + args.warmup, 512)
+    batches = [synth_batch(enc, local_B, 100 + 100003 * rank + i, dev) for i in range(n_batches)]
 
     def step(i):
         data = batches[i % len(batches)]

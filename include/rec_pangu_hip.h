@@ -305,7 +305,8 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  *   rp_lazy_adam_flush  replay every row up to t_target (before a checkpoint / state_dict / eval of raw tables) */
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
-int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size, float *bc2_sqrt);
+int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,
+                         float *inv_bc2_sqrt); /* {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)}, computed in double */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
                       float beta1, float beta2, float eps, rp_stream_t stream);

@@ -24,15 +24,43 @@ __device__ __forceinline__ f32x4 rp_fma(f32x4 a, f32x4 b, f32x4 c) { return __bu
 __device__ __forceinline__ float rp_splat(float x, float) { return x; }
 __device__ __forceinline__ f32x4 rp_splat(float x, f32x4) { return f32x4{x, x, x, x}; }
 
+// sqrt / reciprocal on the hardware approximations (v_sqrt_f32, v_rcp_f32: 1 ulp): the IEEE-rounded forms expand to
+// ~10 instructions each, and the lazy replay of skipped steps is bound by exactly this arithmetic (one sqrt and one
+// reciprocal per element per skipped step).  The dense kernel and the replay share this function, so they stay
+// bit-identical to each other; against torch.optim.Adam the difference is ~3e-7 relative on the UPDATE term.
+__device__ __forceinline__ float rp_sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ f32x4 rp_sqrt_fast(f32x4 x) {
+    return f32x4{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y), __builtin_amdgcn_sqrtf(x.z),
+                 __builtin_amdgcn_sqrtf(x.w)};
+}
+__device__ __forceinline__ float rp_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ f32x4 rp_rcp_fast(f32x4 x) {
+    return f32x4{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y), __builtin_amdgcn_rcpf(x.z),
+                 __builtin_amdgcn_rcpf(x.w)};
+}
+
+// inv_bc2_sqrt = 1 / sqrt(1 - b2^t)
 template <typename T>
 __device__ __forceinline__ void adam1(T &p, const T g, T &m, T &v, float one_m_b1, float b2, float one_m_b2,
-                                      float step_size, float bc2_sqrt, float eps) {
+                                      float step_size, float inv_bc2_sqrt, float eps) {
     const T c1 = rp_splat(one_m_b1, p), c2 = rp_splat(one_m_b2, p), ns = rp_splat(-step_size, p);
     m = rp_fma(g - m, c1, m);                      // m + (g - m)(1 - b1)
     const T vb = v * b2;                           // rounded once
     v = rp_fma(c2 * g, g, vb);                     // b2 v + ((1 - b2) g) g
-    const T denom = __builtin_elementwise_sqrt(v) / bc2_sqrt + eps;
-    p = rp_fma(ns, m / denom, p);                  // p - step_size * (m / denom)
+    const T denom = rp_fma(rp_sqrt_fast(v), rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
+    p = rp_fma(ns, m * rp_rcp_fast(denom), p);     // p - step_size * (m / denom)
+}
+
+// a zero-gradient step (the lazy replay): the same function with g = 0 folded by hand — (0 - m)(1 - b1) + m and
+// b2 v + 0 round exactly as the general form does, so the result is bit-identical to adam1(p, 0, m, v, ...)
+template <typename T>
+__device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &v, float one_m_b1, float b2, float step_size,
+                                                float inv_bc2_sqrt, float eps) {
+    const T c1 = rp_splat(one_m_b1, p), ns = rp_splat(-step_size, p);
+    m = rp_fma(-m, c1, m);
+    v = v * b2;
+    const T denom = rp_fma(rp_sqrt_fast(v), rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
+    p = rp_fma(ns, m * rp_rcp_fast(denom), p);
 }
 
 template <bool ZERO_G>
@@ -91,7 +119,7 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)std::sqrt(bc2);
+    const float bc2_sqrt = (float)(1.0 / std::sqrt(bc2));  // the kernels multiply by the reciprocal
     int64_t bx = rp_cdiv(rp_cdiv(maxn, 4), 256);
     if (bx > 8192) bx = 8192;
     if (bx < 1) bx = 1;
@@ -146,12 +174,12 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
         f32x4 p = *reinterpret_cast<f32x4 *>(P + off);
         f32x4 m = *reinterpret_cast<f32x4 *>(Mo + off);
         f32x4 v = *reinterpret_cast<f32x4 *>(Vo + off);
-        f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(zero));  // opaque: adam1 must compile exactly as in the dense kernel (bit-exact replay)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (l0 > 0) {
+#pragma unroll 4
             for (int j = l0 + 1; j <= t_catch; ++j) {
                 const float2 s = sc[j];
-                adam1<f32x4>(p, zero, m, v, c.one_m_b1, c.b2, c.one_m_b2, s.x, s.y, c.eps);
+                adam1_zero_grad<f32x4>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
             }
         }
         if (real_step) {
@@ -183,11 +211,10 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
             f32x4 p = *reinterpret_cast<f32x4 *>(P + off);
             f32x4 m = *reinterpret_cast<f32x4 *>(Mo + off);
             f32x4 v = *reinterpret_cast<f32x4 *>(Vo + off);
-            f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(zero));  // opaque: adam1 must compile exactly as in the dense kernel (bit-exact replay)
+#pragma unroll 4
             for (int j = l0 + 1; j <= t_target; ++j) {
                 const float2 s = sc[j];
-                adam1<f32x4>(p, zero, m, v, c.one_m_b1, c.b2, c.one_m_b2, s.x, s.y, c.eps);
+                adam1_zero_grad<f32x4>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
             }
             *reinterpret_cast<f32x4 *>(P + off) = p;
             *reinterpret_cast<f32x4 *>(Mo + off) = m;
@@ -221,7 +248,7 @@ extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t 
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     *step_size = (float)((double)lr / bc1);
-    *bc2_sqrt = (float)std::sqrt(bc2);
+    *bc2_sqrt = (float)(1.0 / std::sqrt(bc2));  // reciprocal: what adam1() multiplies sqrt(v) by
     return RP_OK;
 }
 
