@@ -270,8 +270,9 @@ def main():
     n_pairs = F * local_B
     row_b = D * 4
     alg_bytes = {
-        # dX row + sum_f v row per pair, table row read + gradient row written per unique row
-        "embed_grad_reduce": (2 * n_pairs + 2 * n_unique) * row_b,
+        # dX row per pair (+ the sum_f v row per pair unless the FM term is folded into the dgrad: DeepFM at D = 64),
+        # table row read + gradient row written per unique row
+        "embed_grad_reduce": ((1 if (args.model == "deepfm" and D == 64) else 2) * n_pairs + 2 * n_unique) * row_b,
         # p,m,v read+written, g read + cleared, per unique touched row
         "lazy_adam_rows_step": 8 * n_unique * row_b,
         # p,m,v read+written per unique row that skipped at least one step (upper bound: all of them)

@@ -90,6 +90,8 @@ int rp_sort_pairs_i32(void *workspace, size_t workspace_bytes, const int32_t *ke
                       int32_t *pos_out, int64_t n, int end_bit, rp_stream_t stream);
 /*   grad_arena[key] (+)= sum over pairs p=(f,b) with that key of
  *        dx[b, f*D:(f+1)*D]  +  (gfm ? gfm[b] * (sum_in[b,:] - arena[key,:]) : 0)
+ *        (sum_in may be NULL with gfm given: the gfm[b]*sum_in[b,:] part was already added to dx by
+ *         rp_linear_fwd_rowadd, only the -gfm[b]*arena[key,:] part is applied here)
  *   dx may be NULL (FM-only models), gfm may be NULL (no FM term), not both.
  *   accumulate=0: rows must be zero on entry (rp_zero_rows), complete runs are stored;
  *   accumulate=1: everything is added to what is there.                                     */
@@ -243,6 +245,14 @@ int rp_attention_core_fwd(const float *qkvr, int64_t ldq, int nproj, const float
 int rp_attention_core_bwd(const float *qkvr, int64_t ldq, int nproj, const float *out, const float *dout,
                           const float *stats, int T, int H, int a, float scale, float *dqkvr, int64_t lddq,
                           float *dxres, int64_t lddr, int64_t B, rp_stream_t stream);
+
+/* dgrad with a fused row-scaled periodic addend (the DeepFM gather backward's FM term folded into dX):
+ *   out[M,N] = a[M,K] . w[N,K]^T + row_scale[m] * row_add[m, n % 64]  for n < add_cols   (no bias / activation)
+ * Only K <= 64 (multiple of 4), M % 128 == 0, N % 64 == 0, add_cols % 64 == 0, 16-byte aligned rows and a split-bf16
+ * matmul mode; otherwise RP_ERR_UNSUPPORTED and the caller uses rp_linear_fwd + the sum_in path of the reduce. */
+int rp_linear_fwd_rowadd(const float *a, int64_t lda, const float *w, int64_t ldw, float *out, int64_t ldo, int64_t M,
+                         int N, int K, const float *row_scale, const float *row_add, int64_t ld_add, int add_cols,
+                         rp_stream_t stream);
 
 /* ---- stand-alone FM pooling on a [B,F,D] tensor -------------------------------------------------------
  * replaces layers/interaction.py:36-44 when the caller already holds the stacked embeddings (in DeepFM/FM the

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
                 if (dx != nullptr) r[j] = V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
                 if (gfm != nullptr) {
                     gf[j] = gfm[bb[j]];
-                    r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);
+                    if (sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);  // else: folded upstream
                     w[j] = V::load(arena + (int64_t)k[j] * D + c);  // the looked-up row itself (FM: -g * v)
                 }
             }
@@ -289,11 +289,12 @@ extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *s
                                     const float *arena, float *grad_arena, int accumulate, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && sorted_pos && grad_arena, "embed_grad_reduce: null pointer");
     RP_REQUIRE(dx != nullptr || gfm != nullptr, "embed_grad_reduce: neither dx nor gfm given");
-    RP_REQUIRE(gfm == nullptr || (sum_in && arena), "embed_grad_reduce: FM term needs sum_in and arena");
+    RP_REQUIRE(gfm == nullptr || arena, "embed_grad_reduce: the FM term needs the arena (and sum_in unless folded)");
     RP_REQUIRE(B >= 1 && B < INT32_MAX && D >= 1, "embed_grad_reduce: bad B/D");
     if (n == 0) return RP_OK;
     const bool v4 = (D % 4 == 0) && (dx == nullptr || ((ldx % 4 == 0) && rp_aligned16(dx))) &&
-                    rp_aligned16(grad_arena) && (gfm == nullptr || (rp_aligned16(sum_in) && rp_aligned16(arena)));
+                    rp_aligned16(grad_arena) &&
+                    (gfm == nullptr || ((sum_in == nullptr || rp_aligned16(sum_in)) && rp_aligned16(arena)));
     const int vec = v4 ? 4 : 1;
     const int tpr = pick_tpr(D, vec);
     const unsigned grid = (unsigned)rp_cdiv(rp_cdiv(n, RP_SEG), 256 / tpr);

@@ -443,13 +443,19 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
 // for it when no branch separates them — any guarded load/store in the loop turns it into vmcnt(0), a full store
 // round trip (microseconds under a saturated write stream) per tile.  Edges run the guarded instantiation.
 #define SK_LD 72
-template <int NPROD, int ACT, bool FULL>
+// ROWADD (interior tiles, no activation): out[m, n] += rs[m] * radd[m, n % 64] for the first `nadd` 64-column tiles —
+// the DeepFM gather backward's FM term g_fm[b] * S[b, :] folded into the dgrad that produces dX (D = 64: one tile =
+// one field), so the segmented reduce reads one row per (sample, field) pair instead of two.
+template <int NPROD, int ACT, bool FULL, bool ROWADD = false>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_smallk_kernel(const float *__restrict__ A, int64_t lda,
                                                                      const float *__restrict__ W, int64_t ldw,
                                                                      const float *__restrict__ bias,
                                                                      float *__restrict__ C, int64_t ldc, int64_t M,
                                                                      int N, int K, const float *__restrict__ aux,
-                                                                     int64_t ldaux, int ntiles) {
+                                                                     int64_t ldaux, int ntiles,
+                                                                     const float *__restrict__ rs = nullptr,
+                                                                     const float *__restrict__ radd = nullptr,
+                                                                     int64_t ldadd = 0, int nadd = 0) {
     constexpr int NP = BfProd<NPROD>::NP;
     __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NP][BN][SK_LD];
     const int t = threadIdx.x;
@@ -488,6 +494,17 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_smallk_kernel(const float
                 v[4 + e] = v1[e];
             }
             bf_split8<NP>(v, af[ks]);
+        }
+    }
+    // ROWADD operands in the C layout: rows (r&3) + 8*(r>>2) + 4*h of this wave's 32, column i of each tile half
+    float rsv[16], sv[2][16];
+    if (ROWADD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+            rsv[r] = rs[m];
+            sv[0][r] = radd[m * ldadd + i];
+            sv[1][r] = radd[m * ldadd + 32 + i];
         }
     }
     f32x4 rw[4];
@@ -561,9 +578,11 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_smallk_kernel(const float
 #pragma unroll
                     for (int r = 0; r < 16; ++r) cp[((r & 3) + 8 * (r >> 2)) * ldc] = (mk[r] > 0.f) ? acc[r] + bv : 0.f;
                 } else {
+                    const float fsel = (ROWADD && tile < nadd) ? 1.f : 0.f;  // (a select, not a branch)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[r] + bv;
+                        float v = acc[r] + bv;
+                        if (ROWADD) v = __builtin_fmaf(fsel * rsv[r], sv[nt][r], v);
                         cp[((r & 3) + 8 * (r >> 2)) * ldc] = (ACT == RP_ACT_RELU) ? fmaxf(v, 0.f) : v;
                     }
                 }
@@ -879,6 +898,21 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float *__restrict__
     }
 }
 
+template <int NPROD>
+static void launch_smallk_rowadd(const float *a, int64_t lda, const float *w, int64_t ldw, float *out, int64_t ldo,
+                                 int64_t M, int N, int K, const float *rs, const float *radd, int64_t ldadd, int nadd,
+                                 hipStream_t s) {
+    const int64_t mb = M / 128;
+    const int tiles = N / BN;
+    int64_t ysplit = rp_cdiv(768, mb);
+    if (ysplit > tiles) ysplit = tiles;
+    if (ysplit < 1) ysplit = 1;
+    const int per = (int)rp_cdiv(tiles, ysplit);
+    dim3 grid((unsigned)mb, (unsigned)rp_cdiv(tiles, per));
+    hipLaunchKernelGGL((linear_fwd_bf16_smallk_kernel<NPROD, RP_ACT_NONE, true, true>), grid, dim3(256), 0, s, a, lda, w, ldw,
+                       nullptr, out, ldo, M, N, K, nullptr, 0, per, rs, radd, ldadd, nadd);
+}
+
 // process-wide matrix-core precision for the GEMM entry points (rp_linear_fwd / rp_linear_wgrad)
 static int g_matmul_precision = RP_MATMUL_BF16X6;
 
@@ -890,6 +924,28 @@ extern "C" int rp_set_matmul_precision(int mode) {
 }
 
 extern "C" int rp_get_matmul_precision(void) { return g_matmul_precision; }
+
+// out[M,N] = a[M,K] . w[N,K]^T  +  row_scale[m] * row_add[m, n % 64] for n < add_cols       (no bias, no activation)
+// Restricted to what the DeepFM dgrad needs and the straight-line short-K kernel covers: K <= 64 and a multiple of 4,
+// M % 128 == 0, N % 64 == 0, add_cols % 64 == 0, 16-byte aligned rows, a split-bf16 matmul mode.  Anything else:
+// RP_ERR_UNSUPPORTED (the caller composes rp_linear_fwd and keeps the FM term in rp_embed_grad_reduce).
+extern "C" int rp_linear_fwd_rowadd(const float *a, int64_t lda, const float *w, int64_t ldw, float *out, int64_t ldo,
+                                    int64_t M, int N, int K, const float *row_scale, const float *row_add,
+                                    int64_t ld_add, int add_cols, rp_stream_t stream) {
+    RP_REQUIRE(a && w && out && row_scale && row_add, "linear_fwd_rowadd: null pointer");
+    RP_REQUIRE(lda >= K && ldw >= K && ldo >= N && ld_add >= 64, "linear_fwd_rowadd: leading dimension too small");
+    const int mode = g_matmul_precision;
+    const bool ok = mode != RP_MATMUL_FP32 && K >= 4 && K <= 64 && K % 4 == 0 && M >= 128 && M % 128 == 0 && N >= 64 &&
+                    N % 64 == 0 && add_cols >= 0 && add_cols % 64 == 0 && add_cols <= N && lda % 4 == 0 && ldw % 4 == 0 &&
+                    rp_aligned16(a) && rp_aligned16(w);
+    if (!ok) return rp_fail(RP_ERR_UNSUPPORTED, "linear_fwd_rowadd: shape/alignment/mode outside the fused kernel");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == RP_MATMUL_BF16X6) launch_smallk_rowadd<6>(a, lda, w, ldw, out, ldo, M, N, K, row_scale, row_add, ld_add, add_cols / 64, s);
+    else if (mode == RP_MATMUL_BF16X3) launch_smallk_rowadd<3>(a, lda, w, ldw, out, ldo, M, N, K, row_scale, row_add, ld_add, add_cols / 64, s);
+    else launch_smallk_rowadd<1>(a, lda, w, ldw, out, ldo, M, N, K, row_scale, row_add, ld_add, add_cols / 64, s);
+    RP_LAUNCH_CHECK("linear_fwd_rowadd");
+    return RP_OK;
+}
 
 extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, float *out,
                              int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux,

@@ -34,12 +34,45 @@ def _rows16(w: torch.Tensor) -> torch.Tensor:
     return buf[:, :K]
 
 
+class FMFold:
+    """Link between the gather node and the first Linear that consumes its output x (DeepFM): the FM part of the
+    embedding gradient, g_fm[b] * S[b, :] added to every field's slice of dX[b], is folded into the dgrad GEMM that
+    produces dX (rp_linear_fwd_rowadd) instead of being applied per (sample, field) pair in the segmented reduce.
+    `dfm` is recorded by _GradTap (tap_fm_grad) when the loss backward produces it, before any Linear runs."""
+    __slots__ = ("ssum", "ncols", "dfm", "folded")
+
+    def __init__(self, ssum, ncols):
+        self.ssum, self.ncols, self.dfm, self.folded = ssum, ncols, None, False
+
+
+class _GradTap(torch.autograd.Function):
+    """Identity whose backward records the incoming gradient in an FMFold.  Applied to the FM output AFTER the MLP
+    forward, so that in the backward pass (later nodes run first) it fires before the MLP's first Linear computes dX.
+    (A tensor hook would not do: hooks of a non-leaf tensor run only when its grad_fn — the gather, which also waits
+    for dX — is about to execute.)"""
+
+    @staticmethod
+    def forward(ctx, t, link):
+        ctx.link = link
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.link.dfm = g
+        return g, None
+
+
+def tap_fm_grad(fm, link):
+    return _GradTap.apply(fm, link)
+
+
 class _LinearAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int):
+    def forward(ctx, x, weight, bias, act: int, fm_link=None):
         x = _unit_inner(x)
         K = weight.shape[1]
         y = hip.linear_fwd(x, _rows16(weight), bias, act, K=K)
+        ctx.fm_link = fm_link
         ctx.act, ctx.K, ctx.has_bias = act, K, bias is not None
         ctx.save_for_backward(x, weight, y if act == ACT_RELU else None)
         return y
@@ -55,19 +88,24 @@ class _LinearAct(torch.autograd.Function):
             # x's padding columns itself (a strided fill of those columns costs more than the whole GEMM)
             wt = hip.transpose(weight, rows_out=x.shape[1])
             dx = torch.empty_like(x)
-            hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx)
+            lk = ctx.fm_link
+            if lk is not None and lk.dfm is not None and lk.ssum is not None and hip.linear_fwd_rowadd(
+                    dpre, wt, lk.dfm.reshape(-1).contiguous(), lk.ssum, lk.ncols, dx):
+                lk.folded = True  # the gather backward now only applies the -g_fm * v part
+            else:
+                hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def linear_act(x, weight, bias=None, act: int = ACT_NONE):
+def linear_act(x, weight, bias=None, act: int = ACT_NONE, fm_link=None):
     """act(x[:, :K] @ weight^T + bias) for 2-D x; x may carry zero padding columns beyond K."""
     lead = None
     if x.dim() != 2:
         lead = x.shape[:-1]
         x = x.reshape(-1, x.shape[-1])
-    y = _LinearAct.apply(x, weight, bias, act)
+    y = _LinearAct.apply(x, weight, bias, act, fm_link)
     return y if lead is None else y.reshape(*lead, y.shape[-1])
 
 
@@ -473,6 +511,7 @@ class _EmbedGather(torch.autograd.Function):
                                                  want_fm, want_fm and need_grad, need_grad and pre is None,
                                                  store.err_flag)
         ctx.store, ctx.want_fm, ctx.B = store, want_fm, idx[0].shape[0]
+        ctx.link = store._fm_link = FMFold(ssum, len(idx) * store.embedding_dim) if (want_fm and need_grad) else None
         ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
         if pre is not None:
             keys = pre[0] if need_grad else None
@@ -488,6 +527,8 @@ class _EmbedGather(torch.autograd.Function):
         if dx is not None:
             dx = _unit_inner(dx)
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
+        if ctx.link is not None and ctx.link.folded:
+            ssum = None  # g_fm * S is already inside dx (rp_linear_fwd_rowadd)
         store.accumulate_grad(keys, ctx.B, dx, gfm, ssum, presorted=ctx.presorted)
         return (None,) * (6 + len(store.emb_feature))
 

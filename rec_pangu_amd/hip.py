@@ -30,6 +30,7 @@ _SIGNATURES = {
     "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
     "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "rp_linear_wgrad_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
@@ -286,6 +287,22 @@ def linear_fwd(a, w, bias, act: int = ACT_NONE, aux=None, K: Optional[int] = Non
         _check(lib().rp_linear_fwd(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldo, M, N, K, act,
                                _ptr(aux), ldaux, _stream()), "rp_linear_fwd")
     return out
+
+
+def linear_fwd_rowadd(a, w, row_scale, row_add, add_cols: int, out) -> bool:
+    """out = a @ w^T + row_scale[:, None] * tile(row_add)[:, :add_cols]; False when the fused kernel does not cover
+    the shape (nothing was launched)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if not (get_matmul_precision() != "fp32" and K <= 64 and K % 4 == 0 and M % 128 == 0 and M >= 128 and N % 64 == 0
+            and add_cols % 64 == 0 and 0 < add_cols <= N and row_add.shape[1] == 64 and a.stride(0) % 4 == 0
+            and w.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and out.shape[1] >= N):
+        return False
+    with _Timed("linear_fwd"):
+        _check(lib().rp_linear_fwd_rowadd(a.data_ptr(), _rowmajor(a, "a"), w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(),
+                                          _rowmajor(out, "out"), M, N, K, row_scale.data_ptr(), row_add.data_ptr(),
+                                          _rowmajor(row_add, "row_add"), add_cols, _stream()), "rp_linear_fwd_rowadd")
+    return True
 
 
 def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want_bias: bool = True):

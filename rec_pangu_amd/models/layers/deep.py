@@ -53,7 +53,8 @@ class MLP(nn.Module):
             chain.append(get_activation(output_activation))
         self.net = nn.Sequential(*chain)
 
-    def forward(self, x):
+    def forward(self, x, fm_link=None):
+        """`fm_link` (DeepFM on HIP): lets the first Linear's dgrad absorb the FM part of the embedding gradient."""
         if not x.is_cuda:
             return self.net(x)  # BASELINE config 0 (CPU plumbing)
         mods = list(self.net)
@@ -62,7 +63,8 @@ class MLP(nn.Module):
             m = mods[i]
             if isinstance(m, nn.Linear):
                 fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE)
+                x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE,
+                                  fm_link=fm_link if i == 0 else None)
                 i += 2 if fuse_relu else 1
             elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2:
                 x = Fh.batch_norm(x, m)

@@ -54,6 +54,7 @@ class EmbeddingLayer(nn.Module):
         self._dev_meta = None
         self._lazy = None        # optim.LazyAdamRows when the optimiser runs the exact lazy dense Adam
         self._presorted = None   # (keys, sorted keys, sorted positions) of the batch being looked up
+        self._fm_link = None     # functional.FMFold of the last gather that produced an FM term
         self._tag_tables()
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 

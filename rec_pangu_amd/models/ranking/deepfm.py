@@ -8,6 +8,7 @@ from typing import Dict, List
 
 import torch
 
+from ... import functional as Fh
 from ..base_model import BaseModel, build_loss
 from ..layers import FM_Layer, MLP
 from ..utils import get_dnn_input_dim, get_linear_input
@@ -29,7 +30,12 @@ class DeepFM(BaseModel):
     def forward(self, data, is_training=True):
         if self.on_hip:
             x, fm_out = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=True)
-            return self._finish([fm_out, self.dnn(x)], data, is_training, self.loss_fun)
+            link = getattr(self.embedding_layer, "_fm_link", None)
+            if link is None or not fm_out.requires_grad:
+                return self._finish([fm_out, self.dnn(x)], data, is_training, self.loss_fun)
+            deep = self.dnn(x, fm_link=link)
+            # tapped AFTER the MLP forward: its backward (d loss / d fm -> link) then runs before the MLP's
+            return self._finish([Fh.tap_fm_grad(fm_out, link), deep], data, is_training, self.loss_fun)
         sparse_embedding = self.embedding_layer(data)
         dnn_input = torch.cat((sparse_embedding.flatten(start_dim=1), get_linear_input(self.enc_dict, data)), dim=1)
         return self._finish([self.fm(sparse_embedding), self.dnn(dnn_input)], data, is_training, self.loss_fun)

@@ -131,6 +131,8 @@ def test_deepfm_criteo_shape_midsize_vs_oracle():
     model = model.to(DEV)
     out = model(_to_dev(batch))
     out["loss"].backward()
+    # at this shape the FM part of the embedding gradient rides in the first Linear's dgrad (rp_linear_fwd_rowadd)
+    assert model.embedding_layer._fm_link is not None and model.embedding_layer._fm_link.folded
     torch.testing.assert_close(out["pred"].cpu(), ref["pred"].detach(), rtol=0, atol=1e-4)
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=0, atol=1e-4)
     for k, p in model.named_parameters():
