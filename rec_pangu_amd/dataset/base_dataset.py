@@ -74,5 +74,9 @@ class BaseDataset(Dataset):
             data['label'] = self._label[index]
         return data
 
+    def _label_columns(self):
+        """label tensors by the key __getitem__ gives them (DeviceBatchLoader moves whole columns)."""
+        return {'label': self._label} if 'label' in self.df.columns else {}
+
     def __len__(self) -> int:
         return len(self.df)

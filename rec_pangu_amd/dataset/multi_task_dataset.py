@@ -25,3 +25,6 @@ class MultiTaskDataset(BaseDataset):
         for name, t in self._task_labels.items():
             data[name] = t[index]
         return data
+
+    def _label_columns(self):
+        return dict(self._task_labels)

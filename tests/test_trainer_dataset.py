@@ -150,3 +150,25 @@ def test_benchmark_trainer_multitask_list(tmp_path):
     res = pd.read_csv(csv)
     assert list(res["model_name"]) == names
     assert {"test_task1_roc_auc_score", "test_task2_log_loss", "train_model_time"} <= set(res.columns)
+
+
+def test_device_batch_loader_yields_the_dataloader_batches(tmp_path):
+    """DeviceBatchLoader = the same batch dicts as torch's DataLoader over the same dataset,
+    without the per-sample __getitem__/collate; RankTrainer takes it in place of a DataLoader."""
+    from rec_pangu_amd.dataset import DeviceBatchLoader
+    meta, train_loader, valid_loader, test_loader, enc, _ = _loaders_in_reference_order()
+    fast = DeviceBatchLoader(valid_loader.dataset, batch_size=valid_loader.batch_size, shuffle=False)
+    assert len(fast) == len(valid_loader)
+    for a, b in zip(fast, valid_loader):
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+    shuffled = DeviceBatchLoader(train_loader.dataset, batch_size=32, shuffle=True,
+                                 generator=torch.Generator().manual_seed(0))
+    seen = torch.cat([b["label"] for b in shuffled])
+    assert seen.numel() == len(train_loader.dataset)
+    assert torch.equal(seen.sort().values, train_loader.dataset._label.sort().values)
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=4, hidden_units=[8], enc_dict=enc)
+    m = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path)).fit(model, shuffled, fast, epoch=1, lr=1e-3)
+    assert set(m) == {"roc_auc_score", "log_loss"}
