@@ -216,6 +216,11 @@ int rp_cin_bs_bwd_w_workspace_bytes(int64_t B, int O, size_t *bytes);
 int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *gout, const float *gpool,
                     int H, int M, int O, int D, float *dW, float *db, int64_t B, void *workspace, size_t workspace_bytes,
                     rp_stream_t stream);
+/* first layer only (X_{k-1} = X_0, O <= 128): the same dW [O, H*H] / db through the symmetric pair form — the products
+ * X_0[h] X_0[m] are formed once per (pair, contraction row) instead of once per channel, and dWs[o, pair] is ONE TN GEMM */
+int rp_cin_pair_bwd_w_workspace_bytes(int64_t B, int H, int O, size_t *bytes);
+int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout, const float *gpool, int H, int O, int D, float *dW,
+                      float *db, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);
 
 /* ---- K6 (last layer): the collapsed final CIN layer ------------------------------------------------------
  * replaces interaction.py:157-171 for the LAST layer: with no activation and linear pooling + fc behind it, it

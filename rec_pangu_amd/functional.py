@@ -189,7 +189,10 @@ class _CINLayer(torch.autograd.Function):
             gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
             dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
             if x0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0:
-                dW, db = hip.cin_bs_bwd_w(x0, x0, g_out, gp, H, M, O, D, has_bias)
+                if O <= 128:  # symmetric pair form: products formed once, 2.9x fewer matrix-core passes
+                    dW, db = hip.cin_pair_bwd_w(x0, g_out, gp, H, O, D, has_bias)
+                else:
+                    dW, db = hip.cin_bs_bwd_w(x0, x0, g_out, gp, H, M, O, D, has_bias)
                 dW = dW.view_as(W)
             else:
                 dW, db = hip.cin_layer_bwd_w(x0, x0, W, H, M, D, g_out, g_pool, has_bias)

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "rp_cin_bs_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "rp_cin_bs_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "rp_cin_pair_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
+    "rp_cin_pair_bwd_w": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_last_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_cin_last_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
@@ -530,6 +532,20 @@ def cin_bs_bwd_w(x0, xp, g_out, g_pool, H: int, M: int, O: int, D: int, want_bia
         _check(lib().rp_cin_bs_bwd_w(x0.data_ptr(), _rowmajor(x0, "x0"), xp.data_ptr(), _rowmajor(xp, "xp"), _ptr(g_out),
                                      _ptr(g_pool), H, M, O, D, dW.data_ptr(), _ptr(db), B, ws.data_ptr(), nbytes.value,
                                      _stream()), "rp_cin_bs_bwd_w")
+    return dW, db
+
+
+def cin_pair_bwd_w(x0, g_out, g_pool, H: int, O: int, D: int, want_bias: bool):
+    """first-layer dW [O, H*H], dbias [O] or None in the symmetric pair form (rp_cin_pair_bwd_w); O <= 128."""
+    B = x0.shape[0]
+    dW = torch.empty((O, H * H), dtype=torch.float32, device=x0.device)
+    db = torch.empty((O,), dtype=torch.float32, device=x0.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_cin_pair_bwd_w_workspace_bytes(B, H, O, C.byref(nbytes)), "rp_cin_pair_bwd_w_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=x0.device)
+    with _Timed("cin_pair_bwd_w"):
+        _check(lib().rp_cin_pair_bwd_w(x0.data_ptr(), _rowmajor(x0, "x0"), _ptr(g_out), _ptr(g_pool), H, O, D, dW.data_ptr(),
+                                       _ptr(db), B, ws.data_ptr(), nbytes.value, _stream()), "rp_cin_pair_bwd_w")
     return dW, db
 
 
