@@ -459,8 +459,8 @@ extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, in
 // form (no padding of 26 -> 32 in either dimension, half the pairs).  dW[o,h,m] = dW[o,m,h] = dWs[o, p(h,m)].
 // Workgroup tile 128 (o) x 128 (pairs), waves 2 x 2, each 64 x 64 (4 MFMA tiles); stage = 32 contraction rows = a
 // sample's d-half: X_0's half-sample goes through LDS once (fp32), the pair products are formed from it.
-// G rows are loaded 8 threads per 128-byte row (whole lines per wave instruction); the next stage's loads are issued
-// before this stage's MFMA block.
+// The next stage's loads are issued before this stage's MFMA block.  (Loading G 8 threads per 128-byte row, whole lines
+// per wave instruction, measured SLOWER than one 32-byte octet per thread: twice the LDS store instructions.)
 #define CP_LD 40
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
     const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
     const int wa = (w & 1) * 64, wb = (w >> 1) * 64;  // this wave's 64 x 64 block: rows (o) wa.., columns (pairs) wb..
     const int c = t & 63, oct = t >> 6;                // B image: pairs 2c, 2c+1, contraction octet oct
-    const int gr = t >> 3, gs = t & 7;                 // A image: rows gr + 32 j, contraction floats 4 gs .. 4 gs + 3
+    const int gr = t >> 3, gs = t & 7;                 // X_0 stage: row gr, floats 4 gs .. 4 gs + 3
     const int p0 = blockIdx.y * 128;
     const int64_t bbeg = (int64_t)blockIdx.x * b_per_blk;
     int64_t bend = bbeg + b_per_blk;
@@ -499,40 +499,50 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
     const int nhalf = D / 32;
     const bool do_bias = (Pb != nullptr) && (blockIdx.y == 0);
     __syncthreads();
     const int h0 = ph[2 * c], m0_ = pm[2 * c], h1 = ph[2 * c + 1], m1_ = pm[2 * c + 1];
     const int64_t nstage = (bend - bbeg) * nhalf;
-    f32x4 gq[4], xq;
-    float gpq[4];
-    auto load_stage = [&](int64_t st) {
-        const int64_t b = bbeg + st / nhalf;
-        const int d0 = (int)(st % nhalf) * 32;
+    f32x4 gq[2][2], xq;
+    float gpq[2];
+    int64_t lb = bbeg;  // (sample, d-half) of the next stage to load
+    int lh = 0;
+    auto load_stage = [&]() {
+        const int64_t b = lb;
+        const int d0 = lh * 32;
+        if (++lh == nhalf) {
+            lh = 0;
+            ++lb;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = gr + 32 * j;
-            gq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gpq[j] = 0.f;
+        for (int u = 0; u < 2; ++u) {  // rows c and c + 64, contraction octet oct
+            const int o = c + 64 * u;
+            gq[u][0] = gq[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gpq[u] = 0.f;
             if (o < O) {
-                if (gout != nullptr) gq[j] = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 4 * gs);
-                if (gpool != nullptr) gpq[j] = gpool[b * O + o];
+                if (gout != nullptr) {
+                    gq[u][0] = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 8 * oct);
+                    gq[u][1] = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 8 * oct + 4);
+                }
+                if (gpool != nullptr) gpq[u] = gpool[b * O + o];
             }
         }
         xq = f32x4{0.f, 0.f, 0.f, 0.f};
         if (gr < H) xq = *reinterpret_cast<const f32x4 *>(x0 + b * ld0 + (int64_t)gr * D + d0 + 4 * gs);
     };
-    if (nstage > 0) load_stage(0);
+    if (nstage > 0) load_stage();
     for (int64_t st = 0; st < nstage; ++st) {
-        cbf8 vg[2];  // rows (gr, gr+32) and (gr+64, gr+96), one quad each
+        cbf8 vg[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vg[j >> 1][4 * (j & 1) + e] = gq[j][e] + gpq[j];
-            if (do_bias)
-                bsum[j] += (vg[j >> 1][4 * (j & 1)] + vg[j >> 1][4 * (j & 1) + 1]) +
-                           (vg[j >> 1][4 * (j & 1) + 2] + vg[j >> 1][4 * (j & 1) + 3]);
+            for (int e = 0; e < 4; ++e) {
+                vg[u][e] = gq[u][0][e] + gpq[u];
+                vg[u][4 + e] = gq[u][1][e] + gpq[u];
+            }
+            if (do_bias) bsum[u] += ((vg[u][0] + vg[u][1]) + (vg[u][2] + vg[u][3])) + ((vg[u][4] + vg[u][5]) + (vg[u][6] + vg[u][7]));
         }
         __syncthreads();  // previous stage's fragment reads (and Xs reads) are done
         *reinterpret_cast<f32x4 *>(&Xs[gr][4 * gs]) = xq;
@@ -541,12 +551,7 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
         for (int u = 0; u < 2; ++u) {
             cb_split(vg[u], pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const bf16x4 lo = __builtin_shufflevector(pc[q], pc[q], 0, 1, 2, 3);
-                const bf16x4 hi = __builtin_shufflevector(pc[q], pc[q], 4, 5, 6, 7);
-                *reinterpret_cast<bf16x4 *>(&At[q][gr + 64 * u][4 * gs]) = lo;
-                *reinterpret_cast<bf16x4 *>(&At[q][gr + 64 * u + 32][4 * gs]) = hi;
-            }
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&At[q][c + 64 * u][8 * oct]) = pc[q];
         }
         __syncthreads();  // Xs complete
         {
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
 #pragma unroll
             for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][2 * c + 1][8 * oct]) = pc[q];
         }
-        if (st + 1 < nstage) load_stage(st + 1);
+        if (st + 1 < nstage) load_stage();
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -605,16 +610,13 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
                 if (o < O) Pz[(int64_t)o * npair + p] = acc[u][v][r];
             }
         }
-    if (do_bias) {  // the 8 threads of a row hold its partial sums
+    if (do_bias) {  // row c + 64 u: the four octet owners (one per wave) hold its partial sums
+        __syncthreads();
+        float *bred = reinterpret_cast<float *>(&At[0][0][0]);  // [4][128]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = bsum[j];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            const int o = gr + 32 * j;
-            if (gs == 0 && o < O) Pb[(int64_t)blockIdx.x * O + o] = s;
-        }
+        for (int u = 0; u < 2; ++u) bred[oct * 128 + c + 64 * u] = bsum[u];
+        __syncthreads();
+        if (t < 128 && t < O) Pb[(int64_t)blockIdx.x * O + t] = (bred[t] + bred[128 + t]) + (bred[256 + t] + bred[384 + t]);
     }
 }
 
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(256) void cin_pair_wsum_kernel(const float *__restr
 }
 
 static int64_t cp_chunks(int64_t B, int ntile) {
-    int64_t n = rp_cdiv(512, ntile);  // ~512 workgroups (2 resident per CU)
+    int64_t n = 512 / ntile;  // <= 512 workgroups = one resident round (2 per CU); one more would double the time
     if (n > B) n = B;
     return n < 1 ? 1 : n;
 }
