@@ -218,6 +218,13 @@ int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, int64_t ldp, 
                     rp_stream_t stream);
 /* first layer only (X_{k-1} = X_0, O <= 128): the same dW [O, H*H] / db through the symmetric pair form — the products
  * X_0[h] X_0[m] are formed once per (pair, contraction row) instead of once per channel, and dWs[o, pair] is ONE TN GEMM */
+int rp_cin_pair_fits(int H, int O, int D); /* H <= 32, O <= 128, D in {32, 64} */
+/* forward of the same layer as ONE GEMM over the pair products: X_1[b,o,d] = bias[o] + sum_p Ws[o,p] X_0[b,h_p,d] X_0[b,m_p,d],
+ * Ws[o,(h,m)] = W[o,h,m] + W[o,m,h] (h < m; W[o,h,h] on the diagonal), pairs row-major over the upper triangle.
+ * wsp: Ws split into bf16 pieces (hi, mid, lo), [3][128][KP] with KP = 32*ceil(H(H+1)/2 / 32), zero padded.
+ * out [B, O*D] or NULL, pooled [B, O] (sum over d) or NULL. */
+int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, const float *bias, int H, int O, int D, float *out,
+                    float *pooled, int64_t B, rp_stream_t stream);
 int rp_cin_pair_bwd_w_workspace_bytes(int64_t B, int H, int O, size_t *bytes);
 int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout, const float *gpool, int H, int O, int D, float *dW,
                       float *db, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);

@@ -462,7 +462,7 @@ extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, in
 // The next stage's loads are issued before this stage's MFMA block.  (Loading G 8 threads per 128-byte row, whole lines
 // per wave instruction, measured SLOWER than one 32-byte octet per thread: twice the LDS store instructions.)
 #define CP_LD 40
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int npair, const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool,
@@ -694,5 +694,169 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
     hipLaunchKernelGGL(cin_pair_wsum_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, (int)ncx, O, H, npair, dW,
                        db);
     RP_LAUNCH_CHECK("cin_pair_bwd_w reduce");
+    return RP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pair form
+// First layer (X_{k-1} = X_0):  X_1[b,o,d] = bias[o] + sum_p Ws[o,p] Pr[p,(b,d)],   Pr[p,(b,d)] = X_0[b,h_p,d] X_0[b,m_p,d],
+// Ws[o,(h,m)] = W[o,h,m] + W[o,m,h] (h < m), W[o,h,h] — one NN GEMM with M = O <= 128 rows, K = NPAIR, N = B*D columns.
+// wsp: Ws as bf16 pieces [3][128][KP] (KP = NPAIR rounded up to 32, zero padded rows/columns), contraction-contiguous.
+// Workgroup: all 128 rows x 128 columns (128/D samples); X_0 of those samples sits in LDS (fp32) for the whole kernel,
+// each stage (32 pairs) copies the A tile L2 -> LDS and forms the B tile from LDS X_0.  Waves 2 x 2, each 64 x 64.
+__global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
+                                                              int npair, int KP, const __bf16 *__restrict__ wsp,
+                                                              const float *__restrict__ bias, float *__restrict__ out,
+                                                              float *__restrict__ pooled, int64_t B) {
+    __shared__ __attribute__((aligned(16))) __bf16 At[3][128][CP_LD];  // Ws[o][p]
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[3][128][CP_LD];  // Pr[col][p]
+    __shared__ __attribute__((aligned(16))) float Xs[32][132];          // X_0[h][col]
+    __shared__ __attribute__((aligned(16))) unsigned tab[544];          // pair p -> (h*132) | (m*132) << 16
+    const int t = threadIdx.x;
+    const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
+    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;
+    const int col = t & 127, oq = t >> 7;
+    const int spb = 128 / D;  // samples per workgroup
+    const int64_t bs0 = (int64_t)blockIdx.x * spb;
+    for (int p = t; p < KP; p += 256) {
+        int pp = p < npair ? p : 0, h = 0;  // padding pairs: any valid rows (their weights are zero)
+        while (pp >= H - h) {
+            pp -= H - h;
+            ++h;
+        }
+        tab[p] = (unsigned)(h * 132) | ((unsigned)((h + pp) * 132) << 16);
+    }
+    {
+        const int64_t b = bs0 + col / D;
+        const int d = col % D;
+        for (int h = oq; h < H; h += 2) Xs[h][col] = (b < B) ? x0[b * ld0 + (int64_t)h * D + d] : 0.f;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+    // A tile copy: 3 pieces x 128 rows x 4 sixteen-byte chunks = 1536 chunks, 6 per thread
+    f32x4 aq[6];
+    auto load_a = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = t + 256 * u;
+            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
+            aq[u] = *reinterpret_cast<const f32x4 *>(wsp + ((int64_t)(q * 128 + row) * KP + st * 32 + ch * 8));
+        }
+    };
+    const int nst = KP / 32;
+    load_a(0);
+    __syncthreads();  // Xs, tab
+    const float *xcol = &Xs[0][col];
+    for (int st = 0; st < nst; ++st) {
+        // B tile: this thread's column, pair octets 2 oq and 2 oq + 1
+        cbbf8 pb[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k0 = st * 32 + 8 * (2 * oq + j);
+            const u32x4 t0 = *reinterpret_cast<const u32x4 *>(&tab[k0]);
+            const u32x4 t1 = *reinterpret_cast<const u32x4 *>(&tab[k0 + 4]);
+            cbf8 pr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pr[e] = xcol[t0[e] & 0xffffu] * xcol[t0[e] >> 16];
+                pr[4 + e] = xcol[t1[e] & 0xffffu] * xcol[t1[e] >> 16];
+            }
+            cb_split(pr, pb[j]);
+        }
+        __syncthreads();  // previous stage's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = t + 256 * u;
+            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
+            *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * (2 * oq + j)]) = pb[j][q];
+        if (st + 1 < nst) load_a(st + 1);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            cbbf8 a[2][3], bq[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
+                    bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][2], acc[u][v], 0, 0, 0);
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][2], bq[v][0], acc[u][v], 0, 0, 0);
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][1], acc[u][v], 0, 0, 0);
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][1], acc[u][v], 0, 0, 0);
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][0], acc[u][v], 0, 0, 0);
+                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][0], acc[u][v], 0, 0, 0);
+                }
+        }
+    }
+    // epilogue: C layout col = wb + 32 v + i, row o = wa + 32 u + (r&3) + 8*(r>>2) + 4*hh
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = wa + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float bo = (bias != nullptr && o < O) ? bias[o] : 0.f;
+            float val[2], ps[2];
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                val[v] = acc[u][v][r] + bo;
+                const int cc = wb + 32 * v + i;
+                const int64_t b = bs0 + cc / D;
+                if (out != nullptr && o < O && b < B) out[(b * O + o) * D + (cc % D)] = val[v];
+            }
+            if (pooled == nullptr) continue;
+            if (D == 64) {
+                ps[0] = val[0] + val[1];
+                ps[1] = 0.f;
+            } else {
+                ps[0] = val[0];
+                ps[1] = val[1];
+            }
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                if (v == 1 && D == 64) break;
+                float s = ps[v];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                s += __shfl_xor(s, 16);
+                const int64_t b = bs0 + (wb + 32 * v) / D;
+                if (i == 0 && o < O && b < B) pooled[b * O + o] = s;
+            }
+        }
+}
+
+extern "C" int rp_cin_pair_fits(int H, int O, int D) { return H >= 1 && H <= 32 && O >= 1 && O <= 128 && (D == 32 || D == 64); }
+
+// wsp: bf16 [3][128][KP], KP = 32 * ceil(H(H+1)/2 / 32)
+extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, const float *bias, int H, int O, int D, float *out,
+                               float *pooled, int64_t B, rp_stream_t stream) {
+    RP_REQUIRE(x0 && wsp && (out || pooled) && B >= 0, "cin_pair_fwd: bad argument");
+    if (!rp_cin_pair_fits(H, O, D))
+        return rp_fail(RP_ERR_UNSUPPORTED, "cin_pair_fwd: H=%d (<=32) O=%d (<=128) D=%d (32|64) unsupported", H, O, D);
+    RP_REQUIRE(ld0 >= (int64_t)H * D && rp_aligned16(wsp), "cin_pair_fwd: bad leading dimension / alignment");
+    if (B == 0) return RP_OK;
+    const int npair = H * (H + 1) / 2;
+    const int KP = (int)rp_cdiv(npair, 32) * 32;
+    const int64_t nblk = rp_cdiv(B * D, 128);
+    hipLaunchKernelGGL(cin_pair_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x0, ld0, H, O, D, npair, KP,
+                       reinterpret_cast<const __bf16 *>(wsp), bias, out, pooled, B);
+    RP_LAUNCH_CHECK("cin_pair_fwd");
     return RP_OK;
 }

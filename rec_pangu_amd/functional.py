@@ -165,7 +165,9 @@ class _CINLayer(torch.autograd.Function):
         O = W.shape[0]
         # first layers (X_{k-1} = X_0, <= 32 fields) run on the bf16 matrix core (rp_cin_bs_*)
         bs = same and hip.get_matmul_precision() != "fp32" and hip.cin_bs_fits(H, M, D)
-        if bs:
+        if bs and hip.cin_pair_fits(H, O, D):  # one GEMM over the H(H+1)/2 pair products
+            out, pooled = hip.cin_pair_fwd(x0, hip.cin_pair_pieces(W.view(O, H, M)), bias, H, O, D, want_out, True)
+        elif bs:
             out, pooled = hip.cin_bs_fwd(x0, xp_t, hip.bf16_pieces(W.view(O, H, M)), bias, H, M, O, D, want_out, True)
         else:
             out, pooled = hip.cin_layer_fwd(x0, xp_t, W, bias, H, M, D, want_out, True)

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "rp_cin_bs_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "rp_cin_bs_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "rp_cin_pair_fits": (C.c_int, [_i32, _i32, _i32]),
+    "rp_cin_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
     "rp_cin_pair_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_cin_pair_bwd_w": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
@@ -533,6 +535,36 @@ def cin_bs_bwd_w(x0, xp, g_out, g_pool, H: int, M: int, O: int, D: int, want_bia
                                      _ptr(g_pool), H, M, O, D, dW.data_ptr(), _ptr(db), B, ws.data_ptr(), nbytes.value,
                                      _stream()), "rp_cin_bs_bwd_w")
     return dW, db
+
+
+def cin_pair_fits(H: int, O: int, D: int) -> bool:
+    return bool(lib().rp_cin_pair_fits(H, O, D))
+
+
+def cin_pair_pieces(W3):
+    """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] as bf16 pieces [3, 128, KP] (rp_cin_pair_fwd's wsp)."""
+    O, H, _ = W3.shape
+    iu = torch.triu_indices(H, H, device=W3.device)  # row-major upper triangle
+    ws = W3[:, iu[0], iu[1]] + W3[:, iu[1], iu[0]] * (iu[0] != iu[1]).to(W3.dtype)
+    npair = ws.shape[1]
+    kp = (npair + 31) // 32 * 32
+    full = torch.zeros((128, kp), dtype=torch.float32, device=W3.device)
+    full[:O, :npair] = ws
+    hi = full.to(torch.bfloat16)
+    r1 = full - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack((hi, mid, lo)).contiguous()
+
+
+def cin_pair_fwd(x0, wsp, bias, H: int, O: int, D: int, want_out: bool, want_pool: bool):
+    B = x0.shape[0]
+    out = torch.empty((B, O, D), dtype=torch.float32, device=x0.device) if want_out else None
+    pooled = torch.empty((B, O), dtype=torch.float32, device=x0.device) if want_pool else None
+    with _Timed("cin_pair_fwd"):
+        _check(lib().rp_cin_pair_fwd(x0.data_ptr(), _rowmajor(x0, "x0"), wsp.data_ptr(), _ptr(bias), H, O, D, _ptr(out),
+                                     _ptr(pooled), B, _stream()), "rp_cin_pair_fwd")
+    return out, pooled
 
 
 def cin_pair_bwd_w(x0, g_out, g_pool, H: int, O: int, D: int, want_bias: bool):
