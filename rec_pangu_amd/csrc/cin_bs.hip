@@ -860,167 +860,3 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
     RP_LAUNCH_CHECK("cin_pair_fwd");
     return RP_OK;
 }
-
-// ------------------------------------------------------------------------------------------------ input gradient, pair form
-// First layer (both roles are X_0):
-//     T[p,(b,d)]   = sum_o Ws[o,p] G[o,(b,d)]                      one GEMM, M = NPAIR rows, K = O, N = B*D columns
-//     dX_0[b,h,d]  = sum_{p = (h,m) or (m,h)} T[p,(b,d)] X_0[b,m,d]   (the diagonal pair adds T x_h twice = 2 W[h,h] x_h)
-// wst: Ws^T as bf16 pieces [3][KPT][128] (KPT = NPAIR rounded up to 128, K = o contiguous, zero padded).
-// Workgroup: 128 columns (128/D samples), all pair tiles one after the other (K = O in 32-row stages each); after a
-// pair tile its T (in the accumulators) is folded into dxs[h][col] in LDS — waves of the lower row half first, then
-// the upper half, so the summation order is fixed — and dX_0 is stored once at the end.
-__global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
-                                                                int D, int npair, int KPT, const __bf16 *__restrict__ wst,
-                                                                const float *__restrict__ gout,
-                                                                const float *__restrict__ gpool, float *__restrict__ dx,
-                                                                int64_t lddx, int64_t B) {
-    __shared__ __attribute__((aligned(16))) __bf16 At[3][128][CP_LD];  // Ws^T[p][o]; X_0[h][col] (fp32) in the epilogue
-    __shared__ __attribute__((aligned(16))) __bf16 Bt[3][128][CP_LD];  // G[col][o]
-    __shared__ __attribute__((aligned(16))) float dxs[32][132];         // dX_0[h][col]
-    __shared__ unsigned tab[640];                                        // pair p -> (h*132) | (m*132) << 16
-    const int t = threadIdx.x;
-    const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
-    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;
-    const int col = t & 127, oq = t >> 7;
-    const int spb = 128 / D;
-    const int64_t bs0 = (int64_t)blockIdx.x * spb;
-    const int64_t bcol = bs0 + col / D;  // this thread's sample (B-tile formation, X_0 / dX_0 rows)
-    const int dcol = col % D;
-    const bool colok = bcol < B;
-    for (int p = t; p < KPT; p += 256) {
-        int pp = p < npair ? p : 0, h = 0;
-        while (pp >= H - h) {
-            pp -= H - h;
-            ++h;
-        }
-        tab[p] = (unsigned)(h * 132) | ((unsigned)((h + pp) * 132) << 16);
-    }
-    for (int h = oq; h < 32; h += 2) dxs[h][col] = 0.f;
-    float *Xe = reinterpret_cast<float *>(&At[0][0][0]);  // [32][132] floats = 16.9 KB of At's 30 KB
-    const int nks = (O + 31) / 32, ntile = KPT / 128, nst = nks * ntile;
-    f32x4 aq[6];
-    float gq[16];
-    auto load_stage = [&](int st) {
-        const int tile = st / nks, ks = st - tile * nks;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
-            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
-            aq[u] = *reinterpret_cast<const f32x4 *>(wst + ((int64_t)(q * KPT + tile * 128 + row) * 128 + ks * 32 + ch * 8));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int o = ks * 32 + 8 * (2 * oq + j) + e;
-                float g = 0.f;
-                if (colok && o < O) {
-                    if (gout != nullptr) g = gout[(bcol * O + o) * D + dcol];
-                    if (gpool != nullptr) g += gpool[bcol * O + o];
-                }
-                gq[8 * j + e] = g;
-            }
-    };
-    f32x16 acc[2][2];
-    load_stage(0);
-    for (int st = 0; st < nst; ++st) {
-        const int tile = st / nks, ks_ = st - tile * nks;
-        if (ks_ == 0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int v = 0; v < 2; ++v)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
-        }
-        cbbf8 pb[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            cbf8 gv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = gq[8 * j + e];
-            cb_split(gv, pb[j]);
-        }
-        __syncthreads();  // previous stage's fragment reads / previous tile's epilogue are done
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
-            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
-            *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * (2 * oq + j)]) = pb[j][q];
-        if (st + 1 < nst) load_stage(st + 1);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            cbbf8 a[2][3], bq[2][3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
-                    bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][2], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][2], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][0], acc[u][v], 0, 0, 0);
-                }
-        }
-        if (ks_ != nks - 1) continue;
-        // ---- this pair tile's T is complete: fold it into dxs
-        __syncthreads();  // At is free
-        for (int h = oq; h < H; h += 2) Xe[h * 132 + col] = colok ? x0[bcol * ld0 + (int64_t)h * D + dcol] : 0.f;
-        __syncthreads();
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if ((w & 1) == half) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned e = tab[tile * 128 + wa + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh];
-                        const int offh = (int)(e & 0xffffu), offm = (int)(e >> 16);
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const int cc = wb + 32 * v + i;
-                            const float tv = acc[u][v][r];
-                            atomicAdd(&dxs[0][0] + offh + cc, tv * Xe[offm + cc]);
-                            atomicAdd(&dxs[0][0] + offm + cc, tv * Xe[offh + cc]);
-                        }
-                    }
-            }
-            __syncthreads();
-        }
-    }
-    if (colok)
-        for (int h = oq; h < H; h += 2) dx[bcol * lddx + (int64_t)h * D + dcol] = dxs[h][col];
-}
-
-// wst: bf16 [3][KPT][128], KPT = 128 * ceil(H(H+1)/2 / 128); dx rows [B, lddx], the first H*D floats are written
-extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, const float *gout, const float *gpool, int H,
-                                 int O, int D, float *dx, int64_t lddx, int64_t B, rp_stream_t stream) {
-    RP_REQUIRE(x0 && wst && dx && (gout || gpool) && B >= 0, "cin_pair_bwd_x: bad argument");
-    if (!rp_cin_pair_fits(H, O, D))
-        return rp_fail(RP_ERR_UNSUPPORTED, "cin_pair_bwd_x: H=%d (<=32) O=%d (<=128) D=%d (32|64) unsupported", H, O, D);
-    RP_REQUIRE(ld0 >= (int64_t)H * D && lddx >= (int64_t)H * D && rp_aligned16(wst),
-               "cin_pair_bwd_x: bad leading dimension / alignment");
-    if (B == 0) return RP_OK;
-    const int npair = H * (H + 1) / 2;
-    const int KPT = (int)rp_cdiv(npair, 128) * 128;
-    const int64_t nblk = rp_cdiv(B * D, 128);
-    hipLaunchKernelGGL(cin_pair_bwd_x_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x0, ld0, H, O, D, npair,
-                       KPT, reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B);
-    RP_LAUNCH_CHECK("cin_pair_bwd_x");
-    return RP_OK;
-}

@@ -60,7 +60,6 @@ _SIGNATURES = {
     "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_pair_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
-    "rp_cin_pair_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "rp_cin_pair_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_cin_pair_bwd_w": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
@@ -550,33 +549,16 @@ def _bf16_split3(full):
     return torch.stack((hi, mid, lo)).contiguous()
 
 
-def cin_pair_pieces(W3, transposed: bool = False):
+def cin_pair_pieces(W3):
     """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the diagonal) as bf16
-    pieces: [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32) or, transposed, [3, KPT, 128]
-    (rp_cin_pair_bwd_x's wst, KPT = pairs rounded up to 128)."""
+    pieces [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32)."""
     O, H, _ = W3.shape
     iu = torch.triu_indices(H, H, device=W3.device)  # row-major upper triangle
     ws = W3[:, iu[0], iu[1]] + W3[:, iu[1], iu[0]] * (iu[0] != iu[1]).to(W3.dtype)
     npair = ws.shape[1]
-    if transposed:
-        full = torch.zeros(((npair + 127) // 128 * 128, 128), dtype=torch.float32, device=W3.device)
-        full[:npair, :O] = ws.t()
-    else:
-        full = torch.zeros((128, (npair + 31) // 32 * 32), dtype=torch.float32, device=W3.device)
-        full[:O, :npair] = ws
+    full = torch.zeros((128, (npair + 31) // 32 * 32), dtype=torch.float32, device=W3.device)
+    full[:O, :npair] = ws
     return _bf16_split3(full)
-
-
-def cin_pair_bwd_x(x0, wst, g_out, g_pool, H: int, O: int, D: int, like):
-    """-> dX_0 shaped like `like` ([B, >= H*D], zero beyond H*D)."""
-    B = x0.shape[0]
-    dx = torch.empty_like(like)
-    if like.shape[1] > H * D:
-        dx[:, H * D:].zero_()
-    with _Timed("cin_pair_bwd_x"):
-        _check(lib().rp_cin_pair_bwd_x(x0.data_ptr(), _rowmajor(x0, "x0"), wst.data_ptr(), _ptr(g_out), _ptr(g_pool), H, O, D,
-                                       dx.data_ptr(), _rowmajor(dx, "dx"), B, _stream()), "rp_cin_pair_bwd_x")
-    return dx
 
 
 def cin_pair_fwd(x0, wsp, bias, H: int, O: int, D: int, want_out: bool, want_pool: bool):
