@@ -39,17 +39,33 @@ __global__ __launch_bounds__(256) void cin_last_kernel(const float *__restrict__
             T[h] = 0.f;
         }
         const float gb = BWD ? g[b] : 0.f;
-        for (int m = 0; m < M; ++m) {
-            const float *vm = vt + (int64_t)m * CL_MAXH;  // wave-uniform -> scalar loads
-            const float xv = dok ? xpb[(int64_t)m * D + lane] : 0.f;
-            float dsum = 0.f;
+        // X_{L-1} rows four at a time, the next four in flight while these are consumed (one 256-byte row per wave
+        // load: without this the loop is latency-bound at ~2.4 TB/s)
+        float xn[4];
 #pragma unroll
-            for (int h = 0; h < CL_MAXH; ++h) {
-                const float v = vm[h];
-                T[h] += v * xv;
-                if (BWD) dsum += v * x[h];
+        for (int j = 0; j < 4; ++j) xn[j] = (j < M && dok) ? xpb[(int64_t)j * D + lane] : 0.f;
+        for (int m0 = 0; m0 < M; m0 += 4) {
+            float xc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xc[j] = xn[j];
+                xn[j] = (m0 + 4 + j < M && dok) ? xpb[(int64_t)(m0 + 4 + j) * D + lane] : 0.f;
             }
-            if (BWD && dok) dxp[b * lddp + (int64_t)m * D + lane] = gb * dsum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + j;
+                if (m >= M) break;
+                const float *vm = vt + (int64_t)m * CL_MAXH;  // wave-uniform -> scalar loads
+                const float xv = xc[j];
+                float dsum = 0.f;
+#pragma unroll
+                for (int h = 0; h < CL_MAXH; ++h) {
+                    const float v = vm[h];
+                    T[h] += v * xv;
+                    if (BWD) dsum += v * x[h];
+                }
+                if (BWD && dok) dxp[b * lddp + (int64_t)m * D + lane] = gb * dsum;
+            }
         }
         if (BWD) {
 #pragma unroll
