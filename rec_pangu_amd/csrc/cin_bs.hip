@@ -583,17 +583,17 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
                 }
             }
+            // product-major: consecutive MFMAs go to four different accumulators (smallest terms first per accumulator)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int pr = 0; pr < 6; ++pr) {
+                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
+                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][2], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][2], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][0], acc[u][v], 0, 0, 0);
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
+            }
         }
     }
     // partials P[chunk][o][pair]; C layout: col (pair) = lane & 31, row (o) = (r&3) + 8*(r>>2) + 4*hh
@@ -791,17 +791,17 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
                 }
             }
+            // product-major: consecutive MFMAs go to four different accumulators (smallest terms first per accumulator)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int pr = 0; pr < 6; ++pr) {
+                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
+                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
 #pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][2], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][2], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][1], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][1], bq[v][0], acc[u][v], 0, 0, 0);
-                    acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][0], bq[v][0], acc[u][v], 0, 0, 0);
-                }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
+            }
         }
     }
     // epilogue: C layout col = wb + 32 v + i, row o = wa + 32 u + (r&3) + 8*(r>>2) + 4*hh
