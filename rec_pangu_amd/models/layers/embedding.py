@@ -23,6 +23,9 @@ from torch import nn
 
 from ... import functional as Fh
 
+# the last (id tensors, versions, arena signature) -> (keys, sorted keys, positions); see EmbeddingLayer._sorted_keys
+_SORT_CACHE = None
+
 
 class EmbeddingLayer(nn.Module):
     def __init__(self, enc_dict: Dict[str, Dict[str, Union[int, str]]], embedding_dim: int) -> None:
@@ -126,6 +129,7 @@ class EmbeddingLayer(nn.Module):
         self.embedding_dim = arena.shape[1]
         self._point_at(arena)
         self._grad_arena, self._touched, self._grad_clean = None, None, True
+        self._rows_sig_cache = None
 
     @property
     def arena(self) -> torch.Tensor:
@@ -239,11 +243,37 @@ class EmbeddingLayer(nn.Module):
     def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 64):
         """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
         self._ensure_packed()
-        return self._gather(self._idx_list(X), None, dense, want_fm, pad_to)
+        return self._gather(self._idx_list(X), None, dense, want_fm, pad_to, src=tuple(X[c] for c in self.emb_feature))
 
-    def _gather(self, idx, meta, dense, want_fm: bool, pad_to: int):
+    def _sorted_keys(self, idx, row_base, row_count, src, lookup_only: bool = False):
+        """(keys, sorted keys, positions) of this batch's row requests.  Two layers with the same vocabularies fed the
+        same batch (a model's D-wide tables and its LR_Layer's 1-wide ones) ask for the same arena rows: the second one
+        reuses the first one's sort.  The cache entry keeps the id tensors alive, so `is` + `_version` identify them."""
+        from ... import hip
+        global _SORT_CACHE
+        sig = (self._rows_sig(), str(self._arena.device))
+        if src is not None and _SORT_CACHE is not None:
+            c_src, c_ver, c_sig, c_out = _SORT_CACHE
+            if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
+                    and c_ver == tuple(t._version for t in src):
+                return c_out
+        if lookup_only:
+            return None
+        keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
+        sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        out = (keys, sk, sp)
+        if src is not None:
+            _SORT_CACHE = (src, tuple(t._version for t in src), sig, out)
+        return out
+
+    def _rows_sig(self):
+        if getattr(self, "_rows_sig_cache", None) is None:
+            self._rows_sig_cache = tuple(int(t.shape[0]) for t in self._tables())
+        return self._rows_sig_cache
+
+    def _gather(self, idx, meta, dense, want_fm: bool, pad_to: int, src=None):
         """idx: one contiguous int64 [n] per addressed table; meta = (row_base, row_count) of those tables or None
-        for all fields in order."""
+        for all fields in order; src: the batch's id tensors (identity = sort cache key) or None."""
         F, D = len(idx), self.embedding_dim
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
@@ -253,11 +283,12 @@ class EmbeddingLayer(nn.Module):
         if self._lazy is not None and self._lazy.t > 0:
             # exact lazy dense Adam: the rows this batch reads must first replay the zero-gradient steps they
             # skipped.  The (row, position) sort the backward needs anyway is done here and reused there.
-            from ... import hip
-            keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
-            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            keys, sk, sp = self._sorted_keys(idx, row_base, row_count, src if meta is None else None)
             self._lazy.replay(self, sk)
             self._presorted = (keys, sk, sp)
+        elif src is not None and meta is None and torch.is_grad_enabled():
+            # no replay to do (dense Adam / first step): the backward sorts — unless another layer already has
+            self._presorted = self._sorted_keys(idx, row_base, row_count, src, lookup_only=True)
         out = Fh.embed_gather(self, idx, dense, ldx, want_fm, meta)
         if self.check_indices == "sync":
             self.raise_if_bad_index()
