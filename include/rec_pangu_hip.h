@@ -324,7 +324,9 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  *   rp_lazy_adam_rows   for every UNIQUE row of `sorted_keys` (sorted; duplicates skipped): replay steps
  *                       last+1 .. t_target(-1); if real_step also apply step t_target with g = grad row
  *                       (and clear it if zero_grad); last[row] = t_target
- *   rp_lazy_adam_flush  replay every row up to t_target (before a checkpoint / state_dict / eval of raw tables) */
+ *   rp_lazy_adam_flush  replay every row up to t_target (before a checkpoint / state_dict / eval of raw tables)
+ * Any D >= 1: 16-byte vector rows when D % 4 == 0 and the arenas are 16-byte aligned, scalar lanes otherwise (D = 1:
+ * the LR_Layer's tables). */
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
 int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,

@@ -147,13 +147,14 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
 // The replay runs the SAME adam1() as the dense kernel with g = 0 and the per-step scalars of each
 // skipped step (sc[j] = {lr_j/(1-b1^j), sqrt(1-b2^j)}), so the result is bit-identical to having run the
 // dense kernel every step — at ~1/10 of the HBM traffic (only touched rows move).
-// One 16-lane (D/4) group per sorted key position; only run heads work (unique rows, no write race).
+// One D/4-lane group (D lanes when D is not a multiple of 4) per sorted key position; only run heads work
+// (unique rows, no write race).
 // ------------------------------------------------------------------------------------------------
 struct LazyCfg {
     float one_m_b1, b2, one_m_b2, eps;
 };
 
-template <int TPR>
+template <int TPR, typename T>
 __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
                                                              float *__restrict__ P, float *__restrict__ G,
                                                              float *__restrict__ Mo, float *__restrict__ Vo,
@@ -169,34 +170,34 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
     const int l0 = last[row];
     const int t_catch = real_step ? t_target - 1 : t_target;
     if (!real_step && (l0 == 0 || l0 >= t_catch)) return;  // never updated (identity) or already current
-    for (int cidx = t * 4; cidx < D; cidx += TPR * 4) {
+    constexpr int VW = sizeof(T) / sizeof(float);  // f32x4 rows (D % 4 == 0, 16-byte aligned arenas) or scalars
+    for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
         const int64_t off = (int64_t)row * D + cidx;
-        f32x4 p = *reinterpret_cast<f32x4 *>(P + off);
-        f32x4 m = *reinterpret_cast<f32x4 *>(Mo + off);
-        f32x4 v = *reinterpret_cast<f32x4 *>(Vo + off);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        T p = *reinterpret_cast<T *>(P + off);
+        T m = *reinterpret_cast<T *>(Mo + off);
+        T v = *reinterpret_cast<T *>(Vo + off);
         if (l0 > 0) {
 #pragma unroll 4
             for (int j = l0 + 1; j <= t_catch; ++j) {
                 const float2 s = sc[j];
-                adam1_zero_grad<f32x4>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
+                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
             }
         }
         if (real_step) {
-            const f32x4 g = *reinterpret_cast<const f32x4 *>(G + off);
+            const T g = *reinterpret_cast<const T *>(G + off);
             const float2 s = sc[t_target];
-            adam1<f32x4>(p, g, m, v, c.one_m_b1, c.b2, c.one_m_b2, s.x, s.y, c.eps);
-            if (zero_grad) *reinterpret_cast<f32x4 *>(G + off) = zero;
+            adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.one_m_b2, s.x, s.y, c.eps);
+            if (zero_grad) *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
         }
-        *reinterpret_cast<f32x4 *>(P + off) = p;
-        *reinterpret_cast<f32x4 *>(Mo + off) = m;
-        *reinterpret_cast<f32x4 *>(Vo + off) = v;
+        *reinterpret_cast<T *>(P + off) = p;
+        *reinterpret_cast<T *>(Mo + off) = m;
+        *reinterpret_cast<T *>(Vo + off) = v;
     }
     // a never-updated row stays at last = 0 until its first real step: nothing to replay for it
     if (t == 0 && (real_step || l0 > 0)) last[row] = t_target;
 }
 
-template <int TPR>
+template <int TPR, typename T>
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, float *__restrict__ P,
                                                               float *__restrict__ Mo, float *__restrict__ Vo,
                                                               int32_t *__restrict__ last,
@@ -206,40 +207,49 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
     for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR; row < R; row += (int64_t)gridDim.x * GPB) {
         const int l0 = last[row];
         if (l0 <= 0 || l0 >= t_target) continue;
-        for (int cidx = t * 4; cidx < D; cidx += TPR * 4) {
+        constexpr int VW = sizeof(T) / sizeof(float);
+        for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
             const int64_t off = row * D + cidx;
-            f32x4 p = *reinterpret_cast<f32x4 *>(P + off);
-            f32x4 m = *reinterpret_cast<f32x4 *>(Mo + off);
-            f32x4 v = *reinterpret_cast<f32x4 *>(Vo + off);
+            T p = *reinterpret_cast<T *>(P + off);
+            T m = *reinterpret_cast<T *>(Mo + off);
+            T v = *reinterpret_cast<T *>(Vo + off);
 #pragma unroll 4
             for (int j = l0 + 1; j <= t_target; ++j) {
                 const float2 s = sc[j];
-                adam1_zero_grad<f32x4>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
+                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
             }
-            *reinterpret_cast<f32x4 *>(P + off) = p;
-            *reinterpret_cast<f32x4 *>(Mo + off) = m;
-            *reinterpret_cast<f32x4 *>(Vo + off) = v;
+            *reinterpret_cast<T *>(P + off) = p;
+            *reinterpret_cast<T *>(Mo + off) = m;
+            *reinterpret_cast<T *>(Vo + off) = v;
         }
         if (t == 0) last[row] = t_target;
     }
 }
 
-static int lazy_tpr(int D) {
-    int need = D / 4, tpr = 1;
+static int lazy_tpr(int D, int vw) {
+    int need = (D + vw - 1) / vw, tpr = 1;
     while (tpr < need && tpr < 64) tpr <<= 1;
     return tpr;
 }
 
-#define LAZY_DISPATCH(tpr, CALL) \
-    switch (tpr) {               \
-        case 1: CALL(1); break;  \
-        case 2: CALL(2); break;  \
-        case 4: CALL(4); break;  \
-        case 8: CALL(8); break;  \
-        case 16: CALL(16); break;\
-        case 32: CALL(32); break;\
-        default: CALL(64); break;\
+#define LAZY_DISPATCH_T(tpr, TY, CALL) \
+    switch (tpr) {                      \
+        case 1: CALL(1, TY); break;     \
+        case 2: CALL(2, TY); break;     \
+        case 4: CALL(4, TY); break;     \
+        case 8: CALL(8, TY); break;     \
+        case 16: CALL(16, TY); break;   \
+        case 32: CALL(32, TY); break;   \
+        default: CALL(64, TY); break;   \
     }
+#define LAZY_DISPATCH(tpr, vw, CALL)                 \
+    do {                                             \
+        if (vw == 4) {                               \
+            LAZY_DISPATCH_T(tpr, f32x4, CALL)        \
+        } else {                                     \
+            LAZY_DISPATCH_T(tpr, float, CALL)        \
+        }                                            \
+    } while (0)
 
 // host helper shared with the python side: the two per-step scalars exactly as rp_adam_step derives them
 extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,
@@ -257,19 +267,19 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
                                  int zero_grad, float beta1, float beta2, float eps, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_rows: null pointer");
     RP_REQUIRE(!real_step || g, "lazy_adam_rows: a real step needs the gradient arena");
-    RP_REQUIRE(D >= 4 && D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g)),
-               "lazy_adam_rows: D must be a multiple of 4 and the arenas 16-byte aligned");
+    RP_REQUIRE(D >= 1, "lazy_adam_rows: D must be positive");
+    const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
     RP_REQUIRE(t_target >= (real_step ? 1 : 0) && t_target < INT32_MAX, "lazy_adam_rows: bad step");
     if (n == 0) return RP_OK;
     LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps};
-    const int tpr = lazy_tpr(D);
+    const int tpr = lazy_tpr(D, vw);
     const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
-#define CALL(T)                                                                                                  \
-    hipLaunchKernelGGL((lazy_adam_rows_kernel<T>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
+#define CALL(T, TY)                                                                                                  \
+    hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
                        sc, (int)t_target, real_step, zero_grad, c)
-    LAZY_DISPATCH(tpr, CALL)
+    LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_rows");
     return RP_OK;
@@ -279,19 +289,19 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
                                   const float *step_scalars, int64_t t_target, float beta1, float beta2, float eps,
                                   rp_stream_t stream) {
     RP_REQUIRE(p && m && v && last && step_scalars, "lazy_adam_flush: null pointer");
-    RP_REQUIRE(D >= 4 && D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v),
-               "lazy_adam_flush: D must be a multiple of 4 and the arenas 16-byte aligned");
+    RP_REQUIRE(D >= 1, "lazy_adam_flush: D must be positive");
+    const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v)) ? 4 : 1;
     if (rows == 0 || t_target <= 0) return RP_OK;
     LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps};
-    const int tpr = lazy_tpr(D);
+    const int tpr = lazy_tpr(D, vw);
     int64_t nb = rp_cdiv(rows, 256 / tpr);
     if (nb > 65536) nb = 65536;
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
-#define CALL(T)                                                                                              \
-    hipLaunchKernelGGL((lazy_adam_flush_kernel<T>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, m, v, last, sc, \
+#define CALL(T, TY)                                                                                              \
+    hipLaunchKernelGGL((lazy_adam_flush_kernel<T, TY>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, m, v, last, sc, \
                        (int)t_target, c)
-    LAZY_DISPATCH(tpr, CALL)
+    LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_flush");
     return RP_OK;

@@ -152,7 +152,7 @@ class FusedAdam(torch.optim.Optimizer):
                 vs.append(st["exp_avg_sq"])
             for sid, store in stores.items():
                 self._stores[sid] = store
-                use_lazy = self.lazy_tables and store.embedding_dim % 4 == 0
+                use_lazy = self.lazy_tables
                 if use_lazy:
                     lz = store._lazy
                     if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
