@@ -190,6 +190,7 @@ def main():
     model.train()
     opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"))
     n_params = sum(p.numel() for p in model.parameters())
+    n_table_params = sum(p.numel() for m in model.modules() if hasattr(m, "table_parameters") for p in m.table_parameters())
     n_table_rows = model.embedding_layer.arena.shape[0]
 
     # WEAK scaling: every GPU works on its own `--batch` samples (65536, the configuration BASELINE.json quotes),
@@ -282,7 +283,7 @@ def main():
         # table rows read + int64 ids read + [B, F*D+ND] fp32 output written
         "embed_gather_fwd": local_B * (F * (D * 4 + 8) + (F * D + ND) * 4),
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
-        "adam_step": 7 * 4 * (n_params),
+        "adam_step": 7 * 4 * (n_params - (n_table_params if args.optimizer == "lazy" else 0)),
     }
     d_in = F * D + ND
     alg_bytes["crossnet_fwd"] = local_B * d_in * 4                      # X_0 read once, only a logit leaves
