@@ -9,7 +9,7 @@ import torch
 
 from . import hip
 
-ACT_NONE, ACT_RELU = hip.ACT_NONE, hip.ACT_RELU
+ACT_NONE, ACT_RELU, ACT_MASK = hip.ACT_NONE, hip.ACT_RELU, hip.ACT_MASK
 
 
 def _unit_inner(t: torch.Tensor) -> torch.Tensor:
@@ -66,13 +66,25 @@ def tap_fm_grad(fm, link):
     return _GradTap.apply(fm, link)
 
 
+class ReluLink:
+    """Hand-off between a Linear+ReLU (producer) and the Linear that consumes its output: the consumer's dgrad GEMM
+    applies the producer's ReLU mask in its epilogue (RP_ACT_MASK with aux = its own input, y > 0 <=> pre > 0) and
+    leaves the tensor here; the producer's backward skips its relu_bwd pass when the gradient it receives IS that
+    tensor.  Holding the reference also keeps autograd from accumulating another consumer's gradient into it in
+    place; a summed gradient is a different tensor and takes the ordinary path (masking twice is harmless)."""
+    __slots__ = ("dx",)
+
+    def __init__(self):
+        self.dx = None
+
+
 class _LinearAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, act: int, fm_link=None):
+    def forward(ctx, x, weight, bias, act: int, fm_link=None, in_link=None, out_link=None):
         x = _unit_inner(x)
         K = weight.shape[1]
         y = hip.linear_fwd(x, _rows16(weight), bias, act, K=K)
-        ctx.fm_link = fm_link
+        ctx.fm_link, ctx.in_link, ctx.out_link = fm_link, in_link, out_link
         ctx.act, ctx.K, ctx.has_bias = act, K, bias is not None
         ctx.save_for_backward(x, weight, y if act == ACT_RELU else None)
         return y
@@ -81,7 +93,15 @@ class _LinearAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _unit_inner(dy)
-        dpre = hip.relu_bwd(dy, y) if ctx.act == ACT_RELU else dy
+        dpre = dy
+        if ctx.act == ACT_RELU:
+            lk = ctx.out_link
+            masked = lk is not None and lk.dx is not None and lk.dx.data_ptr() == dy.data_ptr() \
+                and lk.dx.shape == dy.shape and lk.dx.stride() == dy.stride()
+            if lk is not None:
+                lk.dx = None
+            if not masked:
+                dpre = hip.relu_bwd(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # [ldx, N]: the dgrad GEMM is the same NT kernel on W^T; zero rows beyond K make it write the zeros of
@@ -92,20 +112,25 @@ class _LinearAct(torch.autograd.Function):
             if lk is not None and lk.dfm is not None and lk.ssum is not None and hip.linear_fwd_rowadd(
                     dpre, wt, lk.dfm.reshape(-1).contiguous(), lk.ssum, lk.ncols, dx):
                 lk.folded = True  # the gather backward now only applies the -g_fm * v part
+            elif ctx.in_link is not None:
+                hip.linear_fwd(dpre, wt, None, ACT_MASK, aux=x, out=dx)  # x = relu(...) of the producer: its mask
+                ctx.in_link.dx = dx
             else:
                 hip.linear_fwd(dpre, wt, None, ACT_NONE, out=dx)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def linear_act(x, weight, bias=None, act: int = ACT_NONE, fm_link=None):
-    """act(x[:, :K] @ weight^T + bias) for 2-D x; x may carry zero padding columns beyond K."""
+def linear_act(x, weight, bias=None, act: int = ACT_NONE, fm_link=None, in_link=None, out_link=None):
+    """act(x[:, :K] @ weight^T + bias) for 2-D x; x may carry zero padding columns beyond K.
+    in_link / out_link: ReluLink shared with the producing / consuming layer (see ReluLink)."""
     lead = None
     if x.dim() != 2:
         lead = x.shape[:-1]
         x = x.reshape(-1, x.shape[-1])
-    y = _LinearAct.apply(x, weight, bias, act, fm_link)
+        in_link = None
+    y = _LinearAct.apply(x, weight, bias, act, fm_link, in_link, out_link if lead is None else None)
     return y if lead is None else y.reshape(*lead, y.shape[-1])
 
 

@@ -59,19 +59,24 @@ class MLP(nn.Module):
             return self.net(x)  # BASELINE config 0 (CPU plumbing)
         mods = list(self.net)
         i = 0
+        pending = None  # ReluLink of the Linear+ReLU whose output x currently is (nothing in between)
         while i < len(mods):
             m = mods[i]
             if isinstance(m, nn.Linear):
                 fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                out_link = Fh.ReluLink() if fuse_relu else None
                 x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE,
-                                  fm_link=fm_link if i == 0 else None)
+                                  fm_link=fm_link if i == 0 else None, in_link=pending, out_link=out_link)
+                pending = out_link
                 i += 2 if fuse_relu else 1
             elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2:
                 x = Fh.batch_norm(x, m)
+                pending = None
                 i += 1
             elif isinstance(m, nn.Dropout) and not (self.training and m.p > 0):
                 i += 1
             else:
                 x = m(x)
+                pending = None
                 i += 1
         return x
