@@ -412,9 +412,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res))
+    # the JSON line is the LAST thing on stdout: RCCL's init banner sits in the C stdio buffer until exit otherwise
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if sharded:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

@@ -337,6 +337,21 @@ int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, fl
 int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last, const float *step_scalars,
                        int64_t t_target, float beta1, float beta2, float eps, rp_stream_t stream);
 
+/* ---- request routing for row-sharded tables (rec_pangu_amd/sharded.py; no reference counterpart: the reference is
+ * single-device).  Arena row r lives on rank r % world at local row r / world.
+ *   rp_shard_keys   keys_out[f*B + b] = (owner << lbits) | local_row of id_f[b] (int32; range check / flag / row 0 as
+ *                   the gather does); owner bits + lbits <= 31
+ *   rp_route_build  from the SORTED keys (rp_sort_pairs_i32): slot_sorted [n] int32 = unique-request slot of the j-th
+ *                   sorted request; slot_of_pair [n] int64 = slot of request p; uniq_rows [n] int64 whose first
+ *                   counts[world] entries are the local rows to ask for, grouped by ascending owner (the all-to-all
+ *                   send order); counts [world+1] int64 = unique requests per owner, then their total */
+int rp_shard_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
+                  int world, int lbits, int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
+int rp_route_workspace_bytes(int64_t n, int world, size_t *bytes);
+int rp_route_build(void *workspace, size_t workspace_bytes, const int32_t *sorted_keys, const int32_t *sorted_pos,
+                   int64_t n, int world, int lbits, int32_t *slot_sorted, int64_t *slot_of_pair, int64_t *uniq_rows,
+                   int64_t *counts, rp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+// Request routing for row-sharded tables (rec_pangu_amd/sharded.py: one process per GPU, arena row r lives on rank
+// r % G at local row r / G).  Nothing like this exists in the reference (single device); these two entries replace the
+// ~30 elementwise / unique / bincount launches the host side would otherwise spend on building one exchange:
+//   rp_shard_keys   ids of a batch -> composite keys (owner << lbits | local row), range-checked like the gather
+//   rp_route_build  sorted composite keys -> unique-request slots, the rows to ask each owner for, per-owner counts
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+struct RouteIdx {
+    const int64_t *p[RP_MAX_FIELDS];
+};
+
+__global__ __launch_bounds__(256) void shard_keys_kernel(const int64_t *__restrict__ row_base,
+                                                         const int64_t *__restrict__ row_count, RouteIdx idx, int F,
+                                                         int64_t B, int world, int lbits, int32_t *__restrict__ keys_out,
+                                                         int32_t *__restrict__ err_flag) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (b >= B || f >= F) return;
+    int64_t id = idx.p[f][b];
+    if (id < 0 || id >= row_count[f]) {  // like the gather: flag, then row 0 so the exchange stays well-formed
+        *err_flag = 1;
+        id = 0;
+    }
+    const int64_t row = row_base[f] + id;
+    keys_out[(int64_t)f * B + b] = (int32_t)(((row % world) << lbits) | (row / world));
+}
+
+extern "C" int rp_shard_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F,
+                             int64_t B, int world, int lbits, int32_t *keys_out, int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(row_base && row_count && idx_ptrs && keys_out && err_flag, "shard_keys: null pointer");
+    RP_REQUIRE(F >= 1 && F <= RP_MAX_FIELDS && B >= 0, "shard_keys: bad F/B");
+    RP_REQUIRE(world >= 1 && lbits >= 1 && lbits <= 30, "shard_keys: bad world/lbits");
+    int obits = 1;
+    while ((1 << obits) < world) ++obits;
+    RP_REQUIRE(lbits + obits <= 31, "shard_keys: owner (%d bits) + local row (%d bits) do not fit an int32 key", obits, lbits);
+    RP_REQUIRE((int64_t)F * B < (int64_t)INT32_MAX, "shard_keys: F*B overflows int32 positions");
+    if (B == 0) return RP_OK;
+    RouteIdx ip;
+    for (int f = 0; f < F; ++f) {
+        RP_REQUIRE(idx_ptrs[f], "shard_keys: idx_ptrs[%d] is null", f);
+        ip.p[f] = idx_ptrs[f];
+    }
+    hipLaunchKernelGGL(shard_keys_kernel, dim3((unsigned)rp_cdiv(B, 256), (unsigned)F), dim3(256), 0, (hipStream_t)stream,
+                       row_base, row_count, ip, F, B, world, lbits, keys_out, err_flag);
+    RP_LAUNCH_CHECK("shard_keys");
+    return RP_OK;
+}
+
+__global__ __launch_bounds__(256) void route_flags_kernel(const int32_t *__restrict__ sk, int64_t n, int32_t *__restrict__ flags,
+                                                          int64_t *__restrict__ starts, int world) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flags[j] = (j == 0 || sk[j] != sk[j - 1]) ? 1 : 0;
+    if (j <= world) starts[j] = -1;  // (world + 1 <= n is not required: see the launch)
+}
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(const int32_t *__restrict__ sk, const int32_t *__restrict__ sp,
+                                                            const int32_t *__restrict__ incl, int64_t n, int lbits,
+                                                            int32_t *__restrict__ slot_sorted,
+                                                            int64_t *__restrict__ slot_of_pair,
+                                                            int64_t *__restrict__ uniq_rows, int64_t *__restrict__ starts) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t key = sk[j];
+    const int32_t slot = incl[j] - 1;
+    slot_sorted[j] = slot;
+    slot_of_pair[sp[j]] = slot;
+    const bool head = (j == 0) || (sk[j - 1] != key);
+    if (head) {
+        uniq_rows[slot] = (int64_t)(key & ((1 << lbits) - 1));
+        const int owner = key >> lbits;
+        if (j == 0 || (sk[j - 1] >> lbits) != owner) starts[owner] = slot;  // first unique request of this owner
+    }
+}
+
+// counts[o] = unique requests owned by o (o < world), counts[world] = total; owners nobody asked have start -1
+__global__ void route_counts_kernel(const int32_t *__restrict__ incl, int64_t n, int world, const int64_t *__restrict__ starts,
+                                    int64_t *__restrict__ counts) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t total = incl[n - 1];
+    int64_t nxt = total;
+    for (int o = world - 1; o >= 0; --o) {
+        const int64_t st = starts[o];
+        if (st < 0) {
+            counts[o] = 0;
+        } else {
+            counts[o] = nxt - st;
+            nxt = st;
+        }
+    }
+    counts[world] = total;
+}
+
+static size_t route_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int route_scan_bytes(int64_t n, size_t *bytes) {
+    size_t tb = 0;
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, nullptr);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route scan size query: %s", hipGetErrorString(e));
+    *bytes = tb;
+    return RP_OK;
+}
+
+extern "C" int rp_route_workspace_bytes(int64_t n, int world, size_t *bytes) {
+    RP_REQUIRE(bytes && n >= 0 && n < INT32_MAX && world >= 1, "route_workspace_bytes: bad argument");
+    size_t tb = 0;
+    int rc = route_scan_bytes(n > 0 ? n : 1, &tb);
+    if (rc != RP_OK) return rc;
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    *bytes = 2 * route_align(nn * sizeof(int32_t)) + route_align((size_t)(world + 1) * sizeof(int64_t)) + route_align(tb) + 256;
+    return RP_OK;
+}
+
+// sorted_keys / sorted_pos: rp_sort_pairs_i32 of rp_shard_keys' output (n pairs).
+//   slot_sorted  [n] int32 : unique-request slot of the j-th sorted request (ascending)
+//   slot_of_pair [n] int64 : slot of request p (p = f*B + b): the row of the received block request p reads
+//   uniq_rows    [n] int64 : the first counts[world] entries are the local rows to ask for, grouped by owner in
+//                            ascending owner order (= all_to_all send order)
+//   counts [world+1] int64 : unique requests per owner, then their total
+extern "C" int rp_route_build(void *workspace, size_t workspace_bytes, const int32_t *sorted_keys, const int32_t *sorted_pos,
+                              int64_t n, int world, int lbits, int32_t *slot_sorted, int64_t *slot_of_pair,
+                              int64_t *uniq_rows, int64_t *counts, rp_stream_t stream) {
+    RP_REQUIRE(workspace && sorted_keys && sorted_pos && slot_sorted && slot_of_pair && uniq_rows && counts,
+               "route_build: null pointer");
+    RP_REQUIRE(n >= 1 && n < INT32_MAX && world >= 1 && lbits >= 1 && lbits <= 30, "route_build: bad n/world/lbits");
+    size_t need = 0, tb = 0;
+    int rc = rp_route_workspace_bytes(n, world, &need);
+    if (rc != RP_OK) return rc;
+    RP_REQUIRE(workspace_bytes >= need, "route_build: workspace %zu < %zu bytes", workspace_bytes, need);
+    rc = route_scan_bytes(n, &tb);
+    if (rc != RP_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    int32_t *flags = reinterpret_cast<int32_t *>(base);
+    int32_t *incl = reinterpret_cast<int32_t *>(base + route_align((size_t)n * sizeof(int32_t)));
+    int64_t *starts = reinterpret_cast<int64_t *>(base + 2 * route_align((size_t)n * sizeof(int32_t)));
+    void *temp = reinterpret_cast<char *>(starts) + route_align((size_t)(world + 1) * sizeof(int64_t));
+    const int64_t nf = n > world + 1 ? n : world + 1;  // the flag launch also clears starts[0..world]
+    hipLaunchKernelGGL(route_flags_kernel, dim3((unsigned)rp_cdiv(nf, 256)), dim3(256), 0, s, sorted_keys, n, flags, starts, world);
+    RP_LAUNCH_CHECK("route flags");
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(temp, tb, (const int32_t *)flags, incl, (int)n, s);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route_build scan: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, s, sorted_keys, sorted_pos, incl, n,
+                       lbits, slot_sorted, slot_of_pair, uniq_rows, starts);
+    RP_LAUNCH_CHECK("route scatter");
+    hipLaunchKernelGGL(route_counts_kernel, dim3(1), dim3(64), 0, s, incl, n, world, starts, counts);
+    RP_LAUNCH_CHECK("route counts");
+    rp_count_launch();
+    return RP_OK;
+}

@@ -86,6 +86,9 @@ _SIGNATURES = {
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
     "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
     "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
                                     _vp]),
@@ -835,6 +838,35 @@ def embed_keys(row_base, row_count, idx: List[torch.Tensor], err_flag):
         _check(lib().rp_embed_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, keys.data_ptr(),
                                    err_flag.data_ptr(), _stream()), "rp_embed_keys")
     return keys
+
+
+def shard_keys(row_base, row_count, idx: List[torch.Tensor], world: int, lbits: int, err_flag):
+    """composite (owner << lbits | local row) int32 keys of a batch's row requests, p = f*B + b (rp_shard_keys)."""
+    F, B = len(idx), idx[0].shape[0]
+    keys = torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
+    with _Timed("shard_keys"):
+        _check(lib().rp_shard_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, world, lbits,
+                                   keys.data_ptr(), err_flag.data_ptr(), _stream()), "rp_shard_keys")
+    return keys
+
+
+def route_build(sorted_keys, sorted_pos, world: int, lbits: int):
+    """-> (slot_sorted int32 [n], slot_of_pair int64 [n], uniq_rows int64 [n] (first counts[world] valid),
+    counts int64 [world+1]) from the sorted composite keys (rp_route_build)."""
+    n = sorted_keys.numel()
+    dev = sorted_keys.device
+    slot_sorted = torch.empty((n,), dtype=torch.int32, device=dev)
+    slot_of_pair = torch.empty((n,), dtype=torch.int64, device=dev)
+    uniq_rows = torch.empty((n,), dtype=torch.int64, device=dev)
+    counts = torch.empty((world + 1,), dtype=torch.int64, device=dev)
+    nbytes = _sz(0)
+    _check(lib().rp_route_workspace_bytes(n, world, C.byref(nbytes)), "rp_route_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    with _Timed("route_build"):
+        _check(lib().rp_route_build(ws.data_ptr(), nbytes.value, sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, world,
+                                    lbits, slot_sorted.data_ptr(), slot_of_pair.data_ptr(), uniq_rows.data_ptr(),
+                                    counts.data_ptr(), _stream()), "rp_route_build")
+    return slot_sorted, slot_of_pair, uniq_rows, counts
 
 
 def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int):

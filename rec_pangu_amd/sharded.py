@@ -51,20 +51,34 @@ class _Route:
       slot_of_pair[p]: the slot request p reads its row from
     """
 
-    def __init__(self, keys: torch.Tensor, layer):
+    def __init__(self, keys, layer):
+        """keys: int64 arena rows [n] (p = f*b + i) — or, on a HIP device, the list of per-field id tensors (the
+        range check, the composite keys and everything after the sort then run in rp_shard_keys / rp_route_build)."""
         world, lbits = layer.world, layer.lbits
-        comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
         nbits = lbits + max(1, (world - 1).bit_length())
-        if keys.is_cuda and nbits <= 31:
+        if isinstance(keys, (list, tuple)):
             from . import hip
-            sk, sp = hip.sort_pairs(comp.to(torch.int32), end_bit=nbits)  # rocPRIM radix sort, (key, position) pairs
-        else:
-            sk, sp = torch.sort(comp, stable=True)
+            idx = keys
+            n = len(idx) * idx[0].numel()
+            comp = hip.shard_keys(layer._row_base, layer._row_count, idx, world, lbits, layer._err_flag(idx[0].device))
+            sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # rocPRIM radix sort, (key, position) pairs
+            self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
+            self.pos_sorted = sp
+            send_counts = counts[:world]
+            recv_counts = torch.empty_like(send_counts)
+            dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
+            # one host sync per exchange: the collective wants its split sizes on the host
+            self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
+            self.n_unique, self.n_recv = sum(self.send), sum(self.recv)
+            self.local_rows = uniq_rows[:self.n_unique]
+            self.n_requests = n
+            return
+        comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
+        sk, sp = torch.sort(comp, stable=True)
         uniq, inverse = torch.unique_consecutive(sk, return_inverse=True)
         send_counts = torch.bincount((uniq >> lbits).long(), minlength=world)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
-        # one host sync per exchange: the collective wants its split sizes on the host
         self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
         self.local_rows = (uniq & ((1 << lbits) - 1)).long().contiguous()
         self.n_unique, self.n_recv = int(uniq.numel()), sum(self.recv)
@@ -72,6 +86,7 @@ class _Route:
         self.pos_sorted = sp.to(torch.int32).contiguous()
         self.slot_of_pair = torch.empty((keys.numel(),), dtype=torch.int64, device=keys.device)
         self.slot_of_pair[sp.long()] = inverse.long()
+        self.n_requests = keys.numel()
 
 
 class _ShardedRows(torch.autograd.Function):
@@ -81,12 +96,13 @@ class _ShardedRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, keys, local_arena):
         route = _Route(keys, layer)
-        recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=keys.device)
+        dev = local_arena.device
+        recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=dev)
         _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
         served = layer._local_gather(recv_rows)  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
-        rows = torch.empty((route.n_unique, local_arena.shape[1]), dtype=local_arena.dtype, device=keys.device)
+        rows = torch.empty((route.n_unique, local_arena.shape[1]), dtype=local_arena.dtype, device=dev)
         _a2a(rows, served, route.send, route.recv, layer.group)
         ctx.layer, ctx.route = layer, route
         ctx.save_for_backward(recv_rows)
@@ -97,7 +113,7 @@ class _ShardedRows(torch.autograd.Function):
     def backward(ctx, g_rows, *_unused):
         (recv_rows,) = ctx.saved_tensors
         layer, route = ctx.layer, ctx.route
-        g_rows = (g_rows * (1.0 / layer.world)).contiguous()
+        g_rows = g_rows.contiguous() if layer.world == 1 else (g_rows * (1.0 / layer.world)).contiguous()
         recv_g = torch.empty((route.n_recv, g_rows.shape[1]), dtype=g_rows.dtype, device=g_rows.device)
         _a2a(recv_g, g_rows, route.recv, route.send, layer.group)
         layer._local_scatter_add(recv_rows, recv_g, presorted=ctx.presorted)
@@ -200,11 +216,22 @@ class ShardedEmbeddingLayer(nn.Module):
             self._err.zero_()
             raise IndexError("index out of range in self")
 
+    def _err_flag(self, device):
+        if self._err is None or self._err.device != device:
+            self._err = torch.zeros((1,), dtype=torch.int32, device=device)
+        return self._err
+
+    def _requests(self, X):
+        """what _Route takes: the per-field id tensors on a HIP device whose composite keys fit an int32 (the kernels
+        do the rest), else the int64 arena-row keys built with torch ops."""
+        if self.local_arena.is_cuda and self.lbits + max(1, (self.world - 1).bit_length()) <= 31:
+            return [X[c].long().reshape(-1).contiguous() for c in self.emb_feature]
+        return self._keys(X)
+
     def _keys(self, X):
         idx = torch.stack([X[c].long().reshape(-1) for c in self.emb_feature])  # [F, b]
         bad = (idx < 0) | (idx >= self._row_count[:, None])
-        if self._err is None or self._err.device != idx.device:
-            self._err = torch.zeros((1,), dtype=torch.int32, device=idx.device)
+        self._err_flag(idx.device)
         self._err |= bad.any().to(torch.int32)
         # like the kernel: flag, then use row 0 so the exchange itself stays well-formed on every rank
         idx = torch.where(bad, torch.zeros_like(idx), idx)
@@ -261,9 +288,9 @@ class ShardedEmbeddingLayer(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------
     def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 64):
-        keys = self._keys(X)
+        keys = self._requests(X)
         F, D = len(self.emb_feature), self.embedding_dim
-        b = keys.numel() // F
+        b = keys[0].numel() if isinstance(keys, list) else keys.numel() // F
         rows, slot_of_pair, slot_sorted, pos_sorted = _ShardedRows.apply(self, keys, self.local_arena)
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to

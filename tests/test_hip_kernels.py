@@ -308,3 +308,43 @@ def test_full_size_gather_properties(hip):
     lhs = G.double().sum(dim=0)
     rhs = dx[:, :F * D].double().view(B, F, D).sum(dim=(0, 1))
     torch.testing.assert_close(lhs, rhs, rtol=2e-4, atol=5e-3)  # fp32 row sums of up to 20k addends per hot row
+
+
+@pytest.mark.parametrize("world,rows,b", [(1, [5, 1000, 37], 300), (2, [3, 20000, 64, 7], 513), (8, [4, 100000, 900, 2, 50], 1000),
+                                          (8, [1, 1], 64)])
+def test_route_kernels_vs_torch(world, rows, b):
+    """rp_shard_keys + rp_sort_pairs_i32 + rp_route_build against the torch formulation the CPU (gloo) path uses
+    (sharded._Route): slots, per-pair slots, rows to request and per-owner counts are identical integers — including
+    owners nobody asks (tiny tables, world 8) and an out-of-range id (flagged, row 0)."""
+    from rec_pangu_amd import hip
+    g = torch.Generator().manual_seed(world * 1000 + b)
+    F = len(rows)
+    idx = [torch.randint(0, r, (b,), generator=g) for r in rows]
+    idx[0][3] = rows[0] + 5  # bad id
+    base = torch.tensor([sum(rows[:f]) for f in range(F)], dtype=torch.int64)
+    cnt = torch.tensor(rows, dtype=torch.int64)
+    total = sum(rows)
+    lbits = max(1, int((total + world - 1) // world).bit_length())
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    comp = hip.shard_keys(base.to(DEV), cnt.to(DEV), [t.to(DEV) for t in idx], world, lbits, err)
+    assert int(err.item()) == 1
+    # torch reference (bad id -> row 0 of its table)
+    ids = torch.stack(idx)
+    ids = torch.where((ids < 0) | (ids >= cnt[:, None]), torch.zeros_like(ids), ids)
+    keys = (ids + base[:, None]).reshape(-1)
+    comp_ref = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
+    assert torch.equal(comp.cpu().long(), comp_ref)
+    nbits = lbits + max(1, (world - 1).bit_length())
+    sk, sp = hip.sort_pairs(comp, end_bit=nbits)
+    slot_sorted, slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
+    rk, rp_ = torch.sort(comp_ref, stable=True)
+    uniq, inverse = torch.unique_consecutive(rk, return_inverse=True)
+    assert torch.equal(sk.cpu().long(), rk) and torch.equal(sp.cpu().long(), rp_)
+    assert torch.equal(slot_sorted.cpu().long(), inverse)
+    ref_sop = torch.empty_like(keys)
+    ref_sop[rp_] = inverse
+    assert torch.equal(slot_of_pair.cpu(), ref_sop)
+    counts = counts.cpu()
+    assert int(counts[world]) == uniq.numel()
+    assert torch.equal(counts[:world], torch.bincount(uniq >> lbits, minlength=world))
+    assert torch.equal(uniq_rows[:uniq.numel()].cpu(), uniq & ((1 << lbits) - 1))
