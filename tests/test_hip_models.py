@@ -191,3 +191,40 @@ def test_sharded_layer_hip_primitives_single_rank():
                         assert (tab.cpu() - ref).abs().max() <= tol, f"{name}/{lname}/{col} after 2 steps"
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["deepfm", "xdeepfm", "dcn", "autoint"])
+def test_full_size_split_batch_property(name):
+    """BASELINE.json's full batch (65536 samples, 26 Criteo-shaped fields + 13 dense, D = 64; vocabularies / 16 to keep
+    the test light) has no CPU oracle run — instead a size-independent property of these models (no BatchNorm): the
+    samples are independent, so the full-batch predictions equal those of its two halves run separately, the loss is
+    their mean, and the gradients are the mean of the halves' gradients (linearity of the backward)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    enc = bench.criteo_enc_dict(16)
+    torch.manual_seed(7)
+    model = bench.build_model(name, enc).to(DEV)
+    model.eval()  # Dropout off (these models have no BatchNorm); the backward below is the training backward
+    B = 65536
+    full = bench.synth_batch(enc, B, 11, DEV)
+    halves = [{k: v[:B // 2] for k, v in full.items()}, {k: v[B // 2:] for k, v in full.items()}]
+
+    def run(batch):
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        out["loss"].backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return out["pred"].detach().clone(), float(out["loss"].detach()), grads
+
+    pf, lf, gf = run(full)
+    p0, l0, g0 = run(halves[0])
+    p1, l1, g1 = run(halves[1])
+    torch.testing.assert_close(pf, torch.cat([p0, p1]), rtol=1e-5, atol=1e-6)
+    assert abs(lf - 0.5 * (l0 + l1)) <= 1e-5 * max(1.0, abs(lf))
+    assert set(gf) == set(g0) == set(g1)
+    for k in gf:
+        ref = 0.5 * (g0[k] + g1[k])
+        tol = 2e-4 * max(1e-6, float(ref.abs().max()))
+        assert float((gf[k] - ref).abs().max()) <= tol, f"{name}: {k}: {float((gf[k] - ref).abs().max())} > {tol}"
