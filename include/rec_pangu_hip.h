@@ -114,8 +114,8 @@ int rp_linear_wgrad_workspace_bytes(int64_t M, int N, int K, size_t *bytes);
 int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dw, int64_t lddw,
                     float *db, int64_t M, int N, int K, int accumulate, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
-/* out[C,R] = in[R,C]^T (weights for the dgrad GEMM) */
-int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
+/* out[C,R] = in[R,C]^T (weights for the dgrad GEMM); rows C .. C_out-1 of out (C_out >= C) are written as zeros */
+int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, rp_stream_t stream);
 /* y = dy * (act_out > 0), elementwise over [M,N] */
 int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
                 int64_t M, int N, rp_stream_t stream);

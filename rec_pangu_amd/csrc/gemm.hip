@@ -869,21 +869,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// out rows C .. C_out-1 (if any) are written as zeros
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int64_t ldin,
-                                                        float *__restrict__ out, int64_t ldout, int R, int C) {
+                                                        float *__restrict__ out, int64_t ldout, int R, int C, int C_out) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         const int r = r0 + ty + j, c = c0 + tx;
-        if (r < R && c < C) tile[ty + j][tx] = in[(int64_t)r * ldin + c];
+        tile[ty + j][tx] = (r < R && c < C) ? in[(int64_t)r * ldin + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         const int c = c0 + ty + j, r = r0 + tx;
-        if (r < R && c < C) out[(int64_t)c * ldout + r] = tile[tx][ty + j];
+        if (r < R && c < C_out) out[(int64_t)c * ldout + r] = tile[tx][ty + j];
     }
 }
 
@@ -1105,11 +1106,11 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     return RP_OK;
 }
 
-extern "C" int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C,
+extern "C" int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out,
                             rp_stream_t stream) {
-    RP_REQUIRE(in && out && R >= 1 && C >= 1 && ldin >= C && ldout >= R, "transpose: bad argument");
-    dim3 grid((unsigned)rp_cdiv(C, 32), (unsigned)rp_cdiv(R, 32));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C);
+    RP_REQUIRE(in && out && R >= 1 && C >= 1 && C_out >= C && ldin >= C && ldout >= R, "transpose: bad argument");
+    dim3 grid((unsigned)rp_cdiv(C_out, 32), (unsigned)rp_cdiv(R, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C, C_out);
     RP_LAUNCH_CHECK("transpose");
     return RP_OK;
 }

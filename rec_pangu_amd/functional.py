@@ -479,6 +479,7 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d):
 class _SigmoidBCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, label, apply_sigmoid: bool, p_eps: float, weight: float, *addends):
+        ctx.set_materialize_grads(False)  # `pred` is normally not differentiated: no zero dpred, no dead arithmetic
         adds = [a.contiguous() for a in addends]
         label = label.contiguous()
         pred, loss = hip.sigmoid_bce_fwd(adds, label, apply_sigmoid, p_eps, weight)

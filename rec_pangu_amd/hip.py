@@ -33,7 +33,7 @@ _SIGNATURES = {
     "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
     "rp_linear_wgrad_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
-    "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
@@ -337,13 +337,11 @@ def transpose(w, rows_out: Optional[int] = None):
     _req(w, torch.float32, "w")
     R, Cc = w.shape
     R4 = (R + 3) // 4 * 4  # 16-byte aligned rows (the GEMM then fetches them with dwordx4, unguarded)
-    if rows_out is not None and rows_out > Cc:
-        out = torch.empty((rows_out, R4), dtype=torch.float32, device=w.device)[:, :R]
-        out[Cc:].zero_()  # tail: a few rows
-    else:
-        out = torch.empty((Cc, R4), dtype=torch.float32, device=w.device)[:, :R]
+    rows = max(Cc, rows_out or 0)
+    out = torch.empty((rows, R4), dtype=torch.float32, device=w.device)[:, :R]
     with _Timed("transpose"):
-        _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, _stream()), "rp_transpose")
+        _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, _stream()),
+               "rp_transpose")
     return out
 
 
