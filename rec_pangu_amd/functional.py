@@ -459,6 +459,8 @@ class _BatchNormApply(torch.autograd.Function):
 def batch_norm(x, bn: torch.nn.BatchNorm1d):
     """nn.BatchNorm1d semantics on the HIP kernels, including the running-statistics update in training mode."""
     use_batch = bn.training or not bn.track_running_stats or bn.running_mean is None
+    if use_batch and type(bn) is not torch.nn.BatchNorm1d:
+        return bn(x)  # sharded.SyncBatchNorm1d: global-batch statistics (torch ops + one all-reduce each way)
     if use_batch:
         y, mean, var = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps)
         if bn.training and bn.track_running_stats and bn.running_mean is not None:

@@ -331,6 +331,88 @@ class ShardedEmbeddingLayer(nn.Module):
         return out
 
 
+class _SyncBatchNormFn(torch.autograd.Function):
+    """BatchNorm1d over the GLOBAL batch (all ranks' local batches): one all-reduce of (sum, sum of squares, count)
+    per feature in forward, one of (sum dy, sum dy*xhat) in backward.  Gradients follow the local-loss convention of
+    this module (every rank backpropagates its own mean loss; row gradients are scaled 1/G when they travel and dense
+    gradients are averaged by allreduce_dense_grads), so the means below are over all N = sum of local batch sizes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, group):
+        C = x.shape[1]
+        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.shape[0])])])
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        n = stats[-1]
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
+        invstd = torch.rsqrt(var + eps)
+        xhat = (x - mean) * invstd
+        ctx.group = group
+        ctx.save_for_backward(xhat, invstd, weight, n)
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * weight + bias, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        xhat, invstd, weight, n = ctx.saved_tensors
+        C = dy.shape[1]
+        dyx = dy * xhat
+        dw, db = dyx.sum(0), dy.sum(0)
+        s = torch.cat([db, dw])
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=ctx.group)
+        dx = (weight * invstd) * (dy - s[:C] / n - xhat * (s[C:] / n))
+        return dx, dw, db, None, None
+
+
+class SyncBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d whose training-mode statistics span every rank's local batch, so that a model with BatchNorm
+    towers (MMOE & co.) trained on G ranks equals the single-process run on the global batch.  Same
+    parameters, buffers and state_dict keys as nn.BatchNorm1d; eval mode is the stock layer.  Device-agnostic torch
+    ops (gloo on CPU, RCCL on HIP tensors)."""
+
+    group = None
+
+    @classmethod
+    def from_bn(cls, bn: nn.BatchNorm1d, group=None):
+        m = cls(bn.num_features, eps=bn.eps, momentum=bn.momentum, affine=bn.affine,
+                track_running_stats=bn.track_running_stats)
+        m.load_state_dict(bn.state_dict())
+        if bn.affine:
+            m.weight, m.bias = bn.weight, bn.bias  # the very same Parameters (optimizers built earlier keep working)
+        sd = bn.state_dict()
+        if len(sd):
+            m.to(next(iter(sd.values())).device)
+        m.train(bn.training)
+        m.group = group
+        return m
+
+    def forward(self, x):
+        if not (self.training or not self.track_running_stats or self.running_mean is None) or x.dim() != 2:
+            return super().forward(x)
+        w = self.weight if self.affine else torch.ones(self.num_features, dtype=x.dtype, device=x.device)
+        b = self.bias if self.affine else torch.zeros(self.num_features, dtype=x.dtype, device=x.device)
+        y, mean, var, n = _SyncBatchNormFn.apply(x, w, b, self.eps, self.group)
+        if self.training and self.track_running_stats and self.running_mean is not None:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                self.running_var.mul_(1 - mom).add_(var * (n / (n - 1).clamp_min(1.0)), alpha=mom)
+        return y
+
+
+def sync_batchnorm(model: nn.Module, group=None) -> nn.Module:
+    """Replace every nn.BatchNorm1d of `model` by SyncBatchNorm1d (in place; same names, parameters and buffers)."""
+    def swap(mod):
+        for name, child in list(mod.named_children()):
+            if type(child) is nn.BatchNorm1d:
+                mod._modules[name] = SyncBatchNorm1d.from_bn(child, group)  # (also inside a ModuleList with named entries)
+            else:
+                swap(child)
+    swap(model)
+    return model
+
+
 def shard_model_tables(model: nn.Module, world: int, rank: int, group=None) -> nn.Module:
     """Replace every EmbeddingLayer of `model` by its row-sharded counterpart (in place).  Build the model
     identically on every rank first (same seed): the shards are cut from that common initialisation."""
@@ -343,6 +425,8 @@ def shard_model_tables(model: nn.Module, world: int, rank: int, group=None) -> n
             else:
                 swap(child)
     swap(model)
+    if world > 1:
+        sync_batchnorm(model, group)  # BatchNorm towers: statistics over the global batch
     return model
 
 

@@ -228,3 +228,38 @@ def test_full_size_split_batch_property(name):
         ref = 0.5 * (g0[k] + g1[k])
         tol = 2e-4 * max(1e-6, float(ref.abs().max()))
         assert float((gf[k] - ref).abs().max()) <= tol, f"{name}: {k}: {float((gf[k] - ref).abs().max())} > {tol}"
+
+
+def test_sync_batchnorm_on_hip_single_rank():
+    """SyncBatchNorm1d (what the towers use on G > 1 ranks) on HIP tensors under a 1-rank RCCL group: with one rank the
+    global batch is the local batch, so the MMOE step must equal the plain HIP model's (rp_batchnorm_* kernels)."""
+    import socket
+    import torch.distributed as dist
+    from rec_pangu_amd.sharded import sync_batchnorm, SyncBatchNorm1d
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    try:
+        g = load_golden("model_mmoe_train.npz")
+        outs = []
+        for sync in (False, True):
+            model = build("mmoe_train").to(DEV)
+            model.train(CASES["mmoe_train"][1])
+            if sync:
+                sync_batchnorm(model)
+                assert any(isinstance(m, SyncBatchNorm1d) for m in model.modules())
+            out = model(_to_dev(g["batch"]))
+            out["loss"].backward()
+            outs.append((out, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                         {k: v.detach().clone() for k, v in model.named_buffers() if "running" in k}))
+        for k in ("task1_pred", "task2_pred", "loss"):
+            torch.testing.assert_close(outs[1][0][k].detach(), outs[0][0][k].detach(), rtol=1e-5, atol=1e-6)
+        for k, v in outs[0][1].items():
+            tol = 1e-4 * max(1e-2, float(v.abs().max()))  # (pre-BatchNorm biases: both sides are ~1e-8 rounding noise)
+            assert float((outs[1][1][k] - v).abs().max()) <= tol, k
+        for k, v in outs[0][2].items():
+            torch.testing.assert_close(outs[1][2][k], v, rtol=1e-5, atol=1e-6)
+    finally:
+        dist.destroy_process_group()

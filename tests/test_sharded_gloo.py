@@ -112,3 +112,99 @@ def test_two_ranks_equal_single_process(name):
     for k, v in ret[1]["dense2"].items():
         torch.testing.assert_close(v, sd[k].detach(), rtol=1e-4, atol=1e-6)
     assert all(ret[r]["raised"] for r in range(world))
+
+
+def _build_mmoe():
+    from rec_pangu_amd.models.multi_task import MMOE
+    from conftest import small_enc_dict
+    torch.manual_seed(4321)
+    m = MMOE(num_task=2, n_expert=3, embedding_dim=8, mmoe_hidden_dim=12, hidden_dim=[10, 6], dropouts=[0.0, 0.0],
+             enc_dict=small_enc_dict())
+    m.train()  # BatchNorm in training mode: batch statistics
+    return m
+
+
+def _mmoe_batch(B=32):
+    g = torch.Generator().manual_seed(99)
+    from conftest import small_enc_dict
+    batch = {}
+    for k, v in small_enc_dict().items():
+        if "vocab_size" in v:
+            batch[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g)
+        else:
+            batch[k] = torch.rand(B, generator=g)
+    batch["task1_label"] = (torch.rand(B, generator=g) < 0.4).float()
+    batch["task2_label"] = (torch.rand(B, generator=g) < 0.2).float()
+    return batch
+
+
+def _mmoe_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads, SyncBatchNorm1d
+        batch = _mmoe_batch()
+        b = batch["task1_label"].shape[0] // world
+        local = {k: v[rank * b:(rank + 1) * b].clone() for k, v in batch.items()}
+        model = shard_model_tables(_build_mmoe(), world, rank)
+        assert any(isinstance(m, SyncBatchNorm1d) for m in model.modules())
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        res = {}
+        for step in range(2):
+            out = model(local)
+            out["loss"].backward()
+            allreduce_dense_grads(model)
+            if step == 0:
+                res["pred"] = [out[f"task{i + 1}_pred"].detach().clone() for i in range(2)]
+                res["loss"] = out["loss"].detach().clone()
+                res["grads"] = {k: p.grad.clone() for k, p in model.named_parameters() if "local_arena" not in k}
+                res["buffers"] = {k: v.clone() for k, v in model.named_buffers() if "running" in k}
+            opt.step()
+            model.zero_grad()
+        res["dense2"] = {k: p.detach().clone() for k, p in model.named_parameters() if "local_arena" not in k}
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mmoe_batchnorm_two_ranks_equal_single_process():
+    """MMOE's towers carry BatchNorm1d in training mode: with SyncBatchNorm1d (global-batch statistics, swapped in by
+    shard_model_tables) two ranks reproduce the single-process run on the global batch — predictions, loss, dense
+    gradients, weights after two Adam steps and the running statistics."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mmoe_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert len(ret) == world
+    batch = _mmoe_batch()
+    model = _build_mmoe()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for step in range(2):
+        out = model({k: v.clone() for k, v in batch.items()})
+        out["loss"].backward()
+        if step == 0:
+            for i in range(2):
+                pred = torch.cat([ret[r]["pred"][i] for r in range(world)])
+                torch.testing.assert_close(pred, out[f"task{i + 1}_pred"].detach(), rtol=1e-5, atol=1e-6)
+            mean_loss = sum(ret[r]["loss"] for r in range(world)) / world
+            torch.testing.assert_close(mean_loss, out["loss"].detach(), rtol=1e-5, atol=1e-6)
+            ref = {k: p.grad.clone() for k, p in model.named_parameters()}
+            for k, gk in ret[0]["grads"].items():
+                torch.testing.assert_close(gk, ref[k], rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
+            # running statistics after the first step (later ones see the noise-driven pre-BatchNorm biases, below)
+            bufs = dict(model.named_buffers())
+            for k, v in ret[0]["buffers"].items():
+                torch.testing.assert_close(v, bufs[k], rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
+        opt.step()
+        model.zero_grad()
+    sd = dict(model.named_parameters())
+    for k, v in ret[1]["dense2"].items():
+        if float(ref[k].abs().max()) < 1e-6:
+            # a bias in front of a BatchNorm (ctr_hidden_j.bias, and ctr_batchnorm_j.bias when another Linear + BatchNorm
+            # follows) has an exactly-zero true gradient; what is left is rounding noise, which Adam normalises to
+            # +-lr steps whose sign depends on the summation order: not comparable (2 steps * lr bound only)
+            assert (v - sd[k].detach()).abs().max() <= 2 * 2 * 1e-2 + 1e-6
+            continue
+        torch.testing.assert_close(v, sd[k].detach(), rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
