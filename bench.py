@@ -36,7 +36,7 @@ def criteo_enc_dict(scale=1):
     return enc
 
 
-def synth_batch(enc, B, seed, device):
+def synth_batch(enc, B, seed, device, id_dist="uniform"):
     """One synthetic batch, generated on `device` (a CPU generator would take seconds per 65536 x 40 batch and the
     bench draws a DIFFERENT batch for every step: with a handful of recycled batches every embedding row would be
     revisited within a few steps, which hides the cost of the lazy optimizer's replay of skipped steps)."""
@@ -46,8 +46,13 @@ def synth_batch(enc, B, seed, device):
     for k, v in enc.items():
         if "min" in v:
             b[k] = torch.rand(B, generator=g, device=dev)
-        else:  # uniform ids: worst case for caches
+        elif id_dist == "uniform":  # uniform ids: worst case for caches, dedup and the lazy optimizer
             b[k] = torch.randint(0, v["vocab_size"] + 1, (B,), generator=g, device=dev)
+        else:  # "zipf": bounded power law with exponent 1.05 (SURVEY.md 8d's optional skewed run), id 0 the hottest
+            V1, s_ = float(v["vocab_size"] + 1), 1.05
+            u = torch.rand(B, generator=g, device=dev, dtype=torch.float64)
+            x = (1.0 + u * ((V1 + 1.0) ** (1.0 - s_) - 1.0)) ** (1.0 / (1.0 - s_))
+            b[k] = (x.floor().long() - 1).clamp_(0, v["vocab_size"])
     b["label"] = (torch.rand(B, generator=g, device=dev) < 0.25).float()
     b["task1_label"] = b["label"]
     b["task2_label"] = (torch.rand(B, generator=g, device=dev) < 0.1).float()
@@ -141,6 +146,8 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="samples per GPU per step (weak scaling)")
     ap.add_argument("--vocab-scale", type=int, default=1, help="divide every cardinality (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"],
+                    help="sparse id distribution: uniform (default, worst case) or a bounded Zipf(1.05)")
     ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "xdeepfm", "dcn", "autoint", "mmoe"],
                     help="deepfm = BASELINE headline config; the others are BASELINE configs 2-3 / siblings")
@@ -200,7 +207,7 @@ def main():
     B = local_B * world
     # a distinct batch per step (capped at 512 batches = 8.8 GB of ids at Criteo shape)
     n_batches = min(args.steps + args.warmup, 512)
-    batches = [synth_batch(enc, local_B, 100 + 100003 * rank + i, dev) for i in range(n_batches)]
+    batches = [synth_batch(enc, local_B, 100 + 100003 * rank + i, dev, args.id_dist) for i in range(n_batches)]
 
     def step(i):
         data = batches[i % len(batches)]
@@ -395,7 +402,8 @@ def main():
             "config": {"workload": f"{type(model).__name__} ({args.model}), {F} sparse fields (Criteo-Kaggle "
                                    f"cardinalities/{args.vocab_scale}, "
                                    f"{n_table_rows * world if world > 1 else n_table_rows} arena rows) x D={D} + {ND} dense, "
-                                   f"batch {local_B} per GPU (global {B}), uniform ids"
+                                   f"batch {local_B} per GPU (global {B}), "
+                                   + ("uniform ids" if args.id_dist == "uniform" else "bounded Zipf(1.05) ids")
                                    + (f", MLP {list(hidden)}" if args.model == "deepfm" else
                                       (", MLP [64,64,64]" if args.model != "mmoe" else ", 4 experts x 128, towers [256,128]"))
                                    + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
