@@ -225,6 +225,14 @@ int rp_cin_pair_fits(int H, int O, int D); /* H <= 32, O <= 128, D in {32, 64} *
  * out [B, O*D] or NULL, pooled [B, O] (sum over d) or NULL. */
 int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, const float *bias, int H, int O, int D, float *out,
                     float *pooled, int64_t B, rp_stream_t stream);
+/* dX_0 of the same layer (X_0 in both roles): T[p] = sum_o Ws[o,p] G[o], dX_0[h] = sum_{p=(h,m)|(m,h)} T[p] X_0[m].
+ * wst: Ws^T as bf16 pieces [3][KPT][128], KPT = 128*ceil(H(H+1)/2 / 128), zero padded.  gout [B,O*D] / gpool [B,O] (packed)
+ * as in rp_cin_bs_bwd_x.  lstart / lent (device int32): for pair tile t, half c (64 pairs) and field h the entries
+ * lent[lstart[(2t+c)*H + h] .. lstart[(2t+c)*H + h + 1]) = (local pair row) | (other field) << 8 of that half's pairs
+ * containing h, the diagonal pair listed twice.  dx rows [B, lddx]: the first H*D floats of each row are written. */
+int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, const float *gout, const float *gpool,
+                      const int32_t *lstart, const int32_t *lent, int H, int O, int D, float *dx, int64_t lddx, int64_t B,
+                      rp_stream_t stream);
 int rp_cin_pair_bwd_w_workspace_bytes(int64_t B, int H, int O, size_t *bytes);
 int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout, const float *gpool, int H, int O, int D, float *dW,
                       float *db, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);

@@ -860,3 +860,183 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
     RP_LAUNCH_CHECK("cin_pair_fwd");
     return RP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ input gradient, pair form
+// First layer (both roles are X_0):
+//     T[p,(b,d)]   = sum_o Ws[o,p] G[o,(b,d)]                        one GEMM, M = NPAIR rows, K = O, N = B*D columns
+//     dX_0[b,h,d]  = sum_{p = (h,m) or (m,h)} T[p,(b,d)] X_0[b,m,d]   (the diagonal pair counts twice: 2 W[h,h] x_h)
+// wst: Ws^T as bf16 pieces [3][KPT][128] (KPT = NPAIR rounded up to 128, K = o contiguous, zero padded).
+// Workgroup: 128 columns (128/D samples), all pair tiles one after the other, K = O in 32-row stages.
+//   * G is contraction-STRIDED for this GEMM (its rows are o): each stage's [32 o][128 col] slab is loaded row-wise
+//     (16-byte loads), parked in LDS as fp32 and read back column-wise (conflict-free) to form the B operand.
+//   * after a pair tile, T (in the accumulators) goes to LDS 64 pairs at a time and every thread GATHERS the terms of
+//     its own (h, column) outputs from a host-built list  (tile, half, h) -> [(local pair row, m)]  — wave-uniform
+//     scalar loads, no atomics, fixed summation order; dX_0 stays in registers until the end.
+// (A first version scattered T with LDS float atomics and loaded G with strided dword loads: 21 ms.)
+__global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
+                                                                int D, int KPT, const __bf16 *__restrict__ wst,
+                                                                const float *__restrict__ gout,
+                                                                const float *__restrict__ gpool, float *__restrict__ dx,
+                                                                int64_t lddx, int64_t B, const int *__restrict__ lstart,
+                                                                const int *__restrict__ lent) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 3 * 128 * CP_LD * 2 + 32 * 132 * 4];
+    typedef __bf16(*Tile)[128][CP_LD];
+    Tile At = reinterpret_cast<Tile>(smem);                                   // Ws^T[p][o]
+    Tile Bt = reinterpret_cast<Tile>(smem + 3 * 128 * CP_LD * 2);            // G[col][o]
+    float *Gs = reinterpret_cast<float *>(smem + 2 * 3 * 128 * CP_LD * 2);   // G[o][col] fp32, [32][132]
+    float *Ts = reinterpret_cast<float *>(smem);                              // epilogue: T[64 pairs][132]
+    float *Xe = reinterpret_cast<float *>(smem + 64 * 132 * 4);               // epilogue: X_0[32][132]
+    const int t = threadIdx.x;
+    const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
+    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;
+    const int col = t & 127, oq = __builtin_amdgcn_readfirstlane(t >> 7);
+    const int go = t >> 3, c16 = t & 7;  // G slab: row go, columns 16 c16 .. 16 c16 + 15
+    const int spb = 128 / D;
+    const int64_t bs0 = (int64_t)blockIdx.x * spb;
+    const int64_t bcol = bs0 + col / D;  // this thread's sample in the column role
+    const int dcol = col % D;
+    const bool colok = bcol < B;
+    const int64_t bg = bs0 + (16 * c16) / D;  // ... and in the slab-loading role
+    const int dg = (16 * c16) % D;
+    const bool gok = bg < B;
+    const int nks = (O + 31) / 32, ntile = KPT / 128, nst = nks * ntile;
+    f32x4 aq[6], gq[4];
+    float gp;
+    auto load_stage = [&](int st) {
+        const int tile = st / nks, ks = st - tile * nks;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = t + 256 * u;
+            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
+            aq[u] = *reinterpret_cast<const f32x4 *>(wst + ((int64_t)(q * KPT + tile * 128 + row) * 128 + ks * 32 + ch * 8));
+        }
+        const int o = ks * 32 + go;
+        const bool ok = gok && o < O;
+        gp = (ok && gpool != nullptr) ? gpool[bg * O + o] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            gq[j] = (ok && gout != nullptr) ? *reinterpret_cast<const f32x4 *>(gout + (bg * O + o) * D + dg + 4 * j)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    float dacc[16];
+#pragma unroll
+    for (int jh = 0; jh < 16; ++jh) dacc[jh] = 0.f;
+    f32x16 acc[2][2];
+    load_stage(0);
+    for (int st = 0; st < nst; ++st) {
+        const int tile = st / nks, ks_ = st - tile * nks;
+        if (ks_ == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+        }
+        __syncthreads();  // previous stage's fragment reads / previous tile's epilogue are done
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&Gs[go * 132 + 16 * c16 + 4 * j]) = gq[j] + gp;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int id = t + 256 * u;
+            const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
+            *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
+        }
+        __syncthreads();  // the slab is complete
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            cbf8 gv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = Gs[(8 * (2 * oq + j) + e) * 132 + col];
+            cbbf8 pc[3];
+            cb_split(gv, pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * (2 * oq + j)]) = pc[q];
+        }
+        if (st + 1 < nst) load_stage(st + 1);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            cbbf8 a[2][3], bq[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
+                    bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
+                }
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) {
+                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
+                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
+            }
+        }
+        if (ks_ != nks - 1) continue;
+        // ---- this pair tile's T is complete: fold it into the dX_0 registers, 64 pairs at a time
+        __syncthreads();  // At / Bt are free
+        for (int h = oq; h < H; h += 2) Xe[h * 132 + col] = colok ? x0[bcol * ld0 + (int64_t)h * D + dcol] : 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((w & 1) == half) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Ts[(32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh) * 132 + wb + 32 * v + i] = acc[u][v][r];
+            }
+            __syncthreads();
+            const int lbase = (tile * 2 + half) * H;
+#pragma unroll
+            for (int jh = 0; jh < 16; ++jh) {
+                const int h = oq + 2 * jh;
+                if (h < H) {
+                    const int e0 = lstart[lbase + h], e1 = lstart[lbase + h + 1];
+                    float a_ = dacc[jh];
+                    for (int e = e0; e < e1; ++e) {
+                        const int en = lent[e];
+                        a_ = __builtin_fmaf(Ts[(en & 255) * 132 + col], Xe[(en >> 8) * 132 + col], a_);
+                    }
+                    dacc[jh] = a_;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (colok) {
+#pragma unroll
+        for (int jh = 0; jh < 16; ++jh) {
+            const int h = oq + 2 * jh;
+            if (h < H) dx[bcol * lddx + (int64_t)h * D + dcol] = dacc[jh];
+        }
+    }
+}
+
+// wst: bf16 [3][KPT][128], KPT = 128 * ceil(H(H+1)/2 / 128).  lstart [2*(KPT/128)*H + 1] / lent: for pair tile t, half
+// c (64 pairs) and field h, entries lstart[(2t+c)*H + h] .. lstart[(2t+c)*H + h + 1] of lent list the pairs of that
+// half that contain h as  (local pair row 0..63) | (other field m) << 8  (the diagonal pair (h,h) is listed twice).
+// dx rows [B, lddx]: the first H*D floats of each row are written.
+extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, const float *gout, const float *gpool,
+                                 const int32_t *lstart, const int32_t *lent, int H, int O, int D, float *dx, int64_t lddx,
+                                 int64_t B, rp_stream_t stream) {
+    RP_REQUIRE(x0 && wst && dx && lstart && lent && (gout || gpool) && B >= 0, "cin_pair_bwd_x: bad argument");
+    if (!rp_cin_pair_fits(H, O, D))
+        return rp_fail(RP_ERR_UNSUPPORTED, "cin_pair_bwd_x: H=%d (<=32) O=%d (<=128) D=%d (32|64) unsupported", H, O, D);
+    RP_REQUIRE(ld0 >= (int64_t)H * D && lddx >= (int64_t)H * D && rp_aligned16(wst) && (gout == nullptr || rp_aligned16(gout)),
+               "cin_pair_bwd_x: bad leading dimension / alignment");
+    if (B == 0) return RP_OK;
+    const int npair = H * (H + 1) / 2;
+    const int KPT = (int)rp_cdiv(npair, 128) * 128;
+    const int64_t nblk = rp_cdiv(B * D, 128);
+    hipLaunchKernelGGL(cin_pair_bwd_x_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x0, ld0, H, O, D, KPT,
+                       reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent);
+    RP_LAUNCH_CHECK("cin_pair_bwd_x");
+    return RP_OK;
+}

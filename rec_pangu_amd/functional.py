@@ -214,8 +214,10 @@ class _CINLayer(torch.autograd.Function):
             W3 = W.view(O, H, M)
             # X_0 enters in both roles: one pass with W[o,h,m] + W[o,m,h] gives its whole gradient
             gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
-            # (a pair-form dX_0 was tried: its scatter epilogue and the transposed G operand cost more than they save)
-            dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
+            if hip.cin_pair_fits(H, O, D) and (g_out is None or g_out.data_ptr() % 16 == 0):
+                dx0 = hip.cin_pair_bwd_x(x0, hip.cin_pair_pieces(W3, transposed=True), g_out, gp, H, O, D, like=x0)
+            else:
+                dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
             if x0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0:
                 if O <= 128:  # symmetric pair form: products formed once, 2.9x fewer matrix-core passes
                     dW, db = hip.cin_pair_bwd_w(x0, g_out, gp, H, O, D, has_bias)

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_pair_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
+    "rp_cin_pair_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "rp_cin_pair_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_cin_pair_bwd_w": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
@@ -550,16 +551,65 @@ def _bf16_split3(full):
     return torch.stack((hi, mid, lo)).contiguous()
 
 
-def cin_pair_pieces(W3):
-    """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the diagonal) as bf16
-    pieces [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32)."""
+def _cin_pair_ws(W3):
     O, H, _ = W3.shape
     iu = torch.triu_indices(H, H, device=W3.device)  # row-major upper triangle
-    ws = W3[:, iu[0], iu[1]] + W3[:, iu[1], iu[0]] * (iu[0] != iu[1]).to(W3.dtype)
+    return W3[:, iu[0], iu[1]] + W3[:, iu[1], iu[0]] * (iu[0] != iu[1]).to(W3.dtype)
+
+
+def cin_pair_pieces(W3, transposed: bool = False):
+    """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the diagonal) as bf16
+    pieces: [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32) or, transposed, [3, KPT, 128]
+    (rp_cin_pair_bwd_x's wst, KPT = pairs rounded up to 128)."""
+    O = W3.shape[0]
+    ws = _cin_pair_ws(W3)
     npair = ws.shape[1]
-    full = torch.zeros((128, (npair + 31) // 32 * 32), dtype=torch.float32, device=W3.device)
-    full[:O, :npair] = ws
+    if transposed:
+        full = torch.zeros(((npair + 127) // 128 * 128, 128), dtype=torch.float32, device=W3.device)
+        full[:npair, :O] = ws.t()
+    else:
+        full = torch.zeros((128, (npair + 31) // 32 * 32), dtype=torch.float32, device=W3.device)
+        full[:O, :npair] = ws
     return _bf16_split3(full)
+
+
+_PAIR_LISTS = {}
+
+
+def cin_pair_lists(H: int, device):
+    """(lstart, lent) of rp_cin_pair_bwd_x for H fields, built once per (H, device)."""
+    key = (H, str(device))
+    if key not in _PAIR_LISTS:
+        pairs = [(h, m) for h in range(H) for m in range(h, H)]  # row-major upper triangle
+        ntile = (len(pairs) + 127) // 128
+        lstart, lent = [0], []
+        for tile in range(ntile):
+            for half in range(2):
+                lo = tile * 128 + half * 64
+                loc = {}
+                for pl, (h, m) in enumerate(pairs[lo:lo + 64]):
+                    loc.setdefault(h, []).append(pl | (m << 8))
+                    loc.setdefault(m, []).append(pl | (h << 8))  # (h == m: the diagonal pair twice)
+                for h in range(H):
+                    lent.extend(loc.get(h, []))
+                    lstart.append(len(lent))
+        _PAIR_LISTS[key] = (torch.tensor(lstart, dtype=torch.int32, device=device),
+                            torch.tensor(lent if lent else [0], dtype=torch.int32, device=device))
+    return _PAIR_LISTS[key]
+
+
+def cin_pair_bwd_x(x0, wst, g_out, g_pool, H: int, O: int, D: int, like):
+    """-> dX_0 shaped like `like` ([B, >= H*D], zero beyond H*D) in the pair form (rp_cin_pair_bwd_x)."""
+    B = x0.shape[0]
+    dx = torch.empty_like(like)
+    if like.shape[1] > H * D:
+        dx[:, H * D:].zero_()
+    lstart, lent = cin_pair_lists(H, x0.device)
+    with _Timed("cin_pair_bwd_x"):
+        _check(lib().rp_cin_pair_bwd_x(x0.data_ptr(), _rowmajor(x0, "x0"), wst.data_ptr(), _ptr(g_out), _ptr(g_pool),
+                                       lstart.data_ptr(), lent.data_ptr(), H, O, D, dx.data_ptr(), _rowmajor(dx, "dx"), B,
+                                       _stream()), "rp_cin_pair_bwd_x")
+    return dx
 
 
 def cin_pair_fwd(x0, wsp, bias, H: int, O: int, D: int, want_out: bool, want_pool: bool):
