@@ -1000,7 +1000,21 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__r
                 if (h < H) {
                     const int e0 = lstart[lbase + h], e1 = lstart[lbase + h + 1];
                     float a_ = dacc[jh];
-                    for (int e = e0; e < e1; ++e) {
+                    int e = e0;
+                    for (; e + 4 <= e1; e += 4) {  // four entries' scalar loads and LDS reads in flight together
+                        int en[4];
+                        float tv[4], xv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) en[u] = lent[e + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            tv[u] = Ts[(en[u] & 255) * 132 + col];
+                            xv[u] = Xe[(en[u] >> 8) * 132 + col];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a_ = __builtin_fmaf(tv[u], xv[u], a_);
+                    }
+                    for (; e < e1; ++e) {
                         const int en = lent[e];
                         a_ = __builtin_fmaf(Ts[(en & 255) * 132 + col], Xe[(en >> 8) * 132 + col], a_);
                     }
