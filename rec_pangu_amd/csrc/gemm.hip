@@ -969,6 +969,16 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
             RP_LAUNCH_CHECK("linear_fwd (bf16 split, short K)");
             return RP_OK;
         }
+        // a wide output that is not a multiple of 128 columns (the MMOE expert + gate GEMM: 520): the whole 128-column
+        // tiles go to the 128 x 128 kernel, the few columns left to a second launch (463 -> 377 us at M = 65536,
+        // K = 649: otherwise either a fifth, almost empty 128-wide tile or nine LDS-bound 64-wide tiles)
+        const int Nb = (N / 128) * 128;
+        if (N >= 256 && Nb < N && rp_cdiv(M, 128) * (Nb / 128) >= 1024) {
+            int rc = rp_linear_fwd(a, lda, w, ldw, bias, out, ldo, M, Nb, K, act, aux, ldaux, stream);
+            if (rc != RP_OK) return rc;
+            return rp_linear_fwd(a, lda, w + (int64_t)Nb * ldw, ldw, bias ? bias + Nb : nullptr, out + Nb, ldo, M, N - Nb, K,
+                                 act, aux ? aux + Nb : nullptr, ldaux, stream);
+        }
         // tile shape: 128 x 128 (each wave 64 x 64) for wide outputs; 128 x 64 otherwise, 64 x 64 when that grid
         // would give the 256 CUs fewer than ~4 workgroups each
         const int64_t n128 = rp_cdiv(N, 128) * 128;
