@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
                 if (gfm != nullptr) {
                     gf[j] = gfm[bb[j]];
                     if (sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);  // else: folded upstream
-                    w[j] = V::load(arena + (int64_t)k[j] * D + c);  // the looked-up row itself (FM: -g * v)
+                    // the looked-up row itself (FM: -g * v) — used once per run, at its last position in the segment
+                    if (j + 1 >= cnt || k[j + 1] != k[j]) w[j] = V::load(arena + (int64_t)k[j] * D + c);
                 }
             }
         }
