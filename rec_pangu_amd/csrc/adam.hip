@@ -203,26 +203,50 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
                                                               int32_t *__restrict__ last,
                                                               const float2 *__restrict__ sc, int t_target, LazyCfg c) {
     constexpr int GPB = 256 / TPR;
+    constexpr int VW = sizeof(T) / sizeof(float);
     const int t = threadIdx.x % TPR;
-    for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR; row < R; row += (int64_t)gridDim.x * GPB) {
-        const int l0 = last[row];
-        if (l0 <= 0 || l0 >= t_target) continue;
-        constexpr int VW = sizeof(T) / sizeof(float);
-        for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
-            const int64_t off = row * D + cidx;
-            T p = *reinterpret_cast<T *>(P + off);
-            T m = *reinterpret_cast<T *>(Mo + off);
-            T v = *reinterpret_cast<T *>(Vo + off);
-#pragma unroll 4
-            for (int j = l0 + 1; j <= t_target; ++j) {
-                const float2 s = sc[j];
-                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
-            }
-            *reinterpret_cast<T *>(P + off) = p;
-            *reinterpret_cast<T *>(Mo + off) = m;
-            *reinterpret_cast<T *>(Vo + off) = v;
+    const int64_t stride = (int64_t)gridDim.x * GPB;
+    // two rows per iteration: both rows' loads are issued before either replay starts (one row at a time left the
+    // memory pipe idle during the dependent load -> replay -> store chain)
+    for (int64_t row0 = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR; row0 < R; row0 += 2 * stride) {
+        int64_t rows[2] = {row0, row0 + stride};
+        int l0[2];
+        bool need[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            l0[u] = (rows[u] < R) ? last[rows[u]] : 0;
+            need[u] = l0[u] > 0 && l0[u] < t_target;
         }
-        if (t == 0) last[row] = t_target;
+        if (!need[0] && !need[1]) continue;
+        for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
+            T p[2], m[2], v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (need[u]) {
+                    const int64_t off = rows[u] * D + cidx;
+                    p[u] = *reinterpret_cast<T *>(P + off);
+                    m[u] = *reinterpret_cast<T *>(Mo + off);
+                    v[u] = *reinterpret_cast<T *>(Vo + off);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (need[u]) {
+#pragma unroll 4
+                    for (int j = l0[u] + 1; j <= t_target; ++j) {
+                        const float2 s = sc[j];
+                        adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.b2, s.x, s.y, c.eps);
+                    }
+                    const int64_t off = rows[u] * D + cidx;
+                    *reinterpret_cast<T *>(P + off) = p[u];
+                    *reinterpret_cast<T *>(Mo + off) = m[u];
+                    *reinterpret_cast<T *>(Vo + off) = v[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (t == 0 && need[u]) last[rows[u]] = t_target;
     }
 }
 
