@@ -292,6 +292,14 @@ def main():
         # dense Adam: read p,g,m,v + write p,m,v = 7 fp32 streams over every parameter
         "adam_step": 7 * 4 * (n_params - (n_table_params if args.optimizer == "lazy" else 0)),
     }
+    if getattr(model, "lr_layer", None) is not None:
+        # the LR_Layer's 1-wide tables go through the same entries once more per step: report the mean per launch
+        def both(f):
+            return (f(D) + f(1)) / 2
+        alg_bytes["embed_gather_fwd"] = both(lambda d_: local_B * (F * (d_ * 4 + 8) + (F * d_ + ND) * 4))
+        alg_bytes["embed_grad_reduce"] = both(lambda d_: (2 * n_pairs + 2 * n_unique) * d_ * 4)
+        alg_bytes["lazy_adam_rows_step"] = both(lambda d_: 8 * n_unique * d_ * 4)
+        alg_bytes["lazy_adam_rows_replay"] = both(lambda d_: 6 * n_unique * d_ * 4)
     d_in = F * D + ND
     alg_bytes["crossnet_fwd"] = local_B * d_in * 4                      # X_0 read once, only a logit leaves
     alg_bytes["crossnet_bwd_rows"] = 2 * local_B * d_in * 4             # X_0 read, dX_0 written
@@ -320,7 +328,10 @@ def main():
         # first layer on the bf16 matrix core (rp_cin_bs_*): 2*H*M*O*D flop per sample per pass (bwd_x: ONE pass with the
         # symmetrised weights), collapsed last layer (rp_cin_last_*): HBM-bound on X_{L-1}
         f1 = 2.0 * F * F * units[0] * D * local_B
-        bf16_mfma_flops = {"cin_bs_fwd": f1, "cin_bs_bwd_x": f1, "cin_bs_bwd_w": f1}
+        # ... or in the pair form (rp_cin_pair_*): ONE GEMM over the F(F+1)/2 pair products per pass, 2*O*npair*D flop/sample
+        fp_ = 2.0 * units[0] * (F * (F + 1) // 2) * D * local_B
+        bf16_mfma_flops = {"cin_bs_fwd": f1, "cin_bs_bwd_x": f1, "cin_bs_bwd_w": f1,
+                           "cin_pair_fwd": fp_, "cin_pair_bwd_x": fp_, "cin_pair_bwd_w": fp_}
         if len(units) > 1:
             xl = local_B * units[-2] * D * 4
             alg_bytes["cin_last_fwd"] = xl + local_B * F * D * 4
@@ -354,9 +365,12 @@ def main():
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TF,
                     "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TF, 4), "traffic": None,
                     "matmul_precision": "bf16x6", "mfma_products_per_flop": 6,
-                    "mfma_issue_frac": round(tf * 6 * (32 * 32) / (F * F) / MFMA_BF16_PEAK_TF, 4),
-                    "note": "algorithmic flops 2*H*M*O*D per sample; the matrix core runs 32x32 tiles (H, M padded from "
-                            f"{F}) with 6 bf16 products per flop: mfma_issue_frac counts those"}
+                    "mfma_issue_frac": round(tf * 6 * ((32 * 32) / (F * F) if "cin_bs" in dominant else 1.0)
+                                             / MFMA_BF16_PEAK_TF, 4),
+                    "note": ("algorithmic flops 2*H*M*O*D per sample; the matrix core runs 32x32 tiles (H, M padded from "
+                             f"{F}) with 6 bf16 products per flop: mfma_issue_frac counts those") if "cin_bs" in dominant
+                    else ("pair form: algorithmic flops 2*O*(H(H+1)/2)*D per sample for this pass, 6 bf16 products per "
+                          "flop on the matrix core (mfma_issue_frac)")}
     elif dominant in mfma_flops:
         tf = mfma_flops[dominant] / (timing[dominant][1] * 1e-3) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
