@@ -702,8 +702,10 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
 // Ws[o,(h,m)] = W[o,h,m] + W[o,m,h] (h < m), W[o,h,h] — one NN GEMM with M = O <= 128 rows, K = NPAIR, N = B*D columns.
 // wsp: Ws as bf16 pieces [3][128][KP] (KP = NPAIR rounded up to 32, zero padded rows/columns), contraction-contiguous.
 // Workgroup: all 128 rows x 128 columns (128/D samples); X_0 of those samples sits in LDS (fp32) for the whole kernel,
-// each stage (32 pairs) copies the A tile L2 -> LDS and forms the B tile from LDS X_0.  Waves 2 x 2, each 64 x 64.
-__global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
+// each stage (32 pairs) copies the A tile L2 -> LDS and forms the B tile from LDS X_0.  EIGHT waves, 4 (rows) x 2
+// (columns), each 32 x 64: hipcc schedules a stage as "all VALU / LDS, then the MFMAs back to back", so the overlap has
+// to come from other waves — four half-size waves per SIMD (120 VGPRs) beat two full-size ones (3.9 -> 3.35 ms).
+__global__ __launch_bounds__(512, 2) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
                                                               int npair, int KP, const __bf16 *__restrict__ wsp,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               float *__restrict__ pooled, int64_t B) {
@@ -713,11 +715,11 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) unsigned tab[544];          // pair p -> (h*132) | (m*132) << 16
     const int t = threadIdx.x;
     const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
-    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;
-    const int col = t & 127, oq = t >> 7;
+    const int wa = (w & 3) * 32, wb = (w >> 2) * 64;  // 8 waves: 4 (rows) x 2 (columns), each 32 x 64
+    const int col = t & 127, oq = t >> 7;             // B image: column, pair octet oq (0..3)
     const int spb = 128 / D;  // samples per workgroup
     const int64_t bs0 = (int64_t)blockIdx.x * spb;
-    for (int p = t; p < KP; p += 256) {
+    for (int p = t; p < KP; p += 512) {
         int pp = p < npair ? p : 0, h = 0;  // padding pairs: any valid rows (their weights are zero)
         while (pp >= H - h) {
             pp -= H - h;
@@ -728,21 +730,21 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
     {
         const int64_t b = bs0 + col / D;
         const int d = col % D;
-        for (int h = oq; h < H; h += 2) Xs[h][col] = (b < B) ? x0[b * ld0 + (int64_t)h * D + d] : 0.f;
+        for (int h = oq; h < H; h += 4) Xs[h][col] = (b < B) ? x0[b * ld0 + (int64_t)h * D + d] : 0.f;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[1][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 1; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
-    // A tile copy: 3 pieces x 128 rows x 4 sixteen-byte chunks = 1536 chunks, 6 per thread
-    f32x4 aq[6];
+    // A tile copy: 3 pieces x 128 rows x 4 sixteen-byte chunks = 1536 chunks, 3 per thread
+    f32x4 aq[3];
     auto load_a = [&](int st) {
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             aq[u] = *reinterpret_cast<const f32x4 *>(wsp + ((int64_t)(q * 128 + row) * KP + st * 32 + ch * 8));
         }
@@ -753,10 +755,10 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
     const float *xcol = &Xs[0][col];
     for (int st = 0; st < nst; ++st) {
         // B tile: this thread's column, pair octets 2 oq and 2 oq + 1
-        cbbf8 pb[2][3];
+        cbbf8 pb[1][3];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k0 = st * 32 + 8 * (2 * oq + j);
+        for (int j = 0; j < 1; ++j) {
+            const int k0 = st * 32 + 8 * oq;
             const u32x4 t0 = *reinterpret_cast<const u32x4 *>(&tab[k0]);
             const u32x4 t1 = *reinterpret_cast<const u32x4 *>(&tab[k0 + 4]);
             cbf8 pr;
@@ -769,27 +771,24 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
         }
         __syncthreads();  // previous stage's fragment reads are done
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * (2 * oq + j)]) = pb[j][q];
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pb[0][q];
         if (st + 1 < nst) load_a(st + 1);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            cbbf8 a[2][3], bq[2][3];
+            cbbf8 a[1][3], bq[2][3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                a[0][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
+                for (int u = 0; u < 2; ++u)
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
-                }
             }
             // product-major: consecutive MFMAs go to four different accumulators (smallest terms first per accumulator)
 #pragma unroll
@@ -797,7 +796,7 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
                 const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
                 const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 1; ++u)
 #pragma unroll
                     for (int v = 0; v < 2; ++v)
                         acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
@@ -806,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void cin_pair_fwd_kernel(const float *__res
     }
     // epilogue: C layout col = wb + 32 v + i, row o = wa + 32 u + (r&3) + 8*(r>>2) + 4*hh
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 1; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = wa + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -855,7 +854,7 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
     const int npair = H * (H + 1) / 2;
     const int KP = (int)rp_cdiv(npair, 32) * 32;
     const int64_t nblk = rp_cdiv(B * D, 128);
-    hipLaunchKernelGGL(cin_pair_fwd_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x0, ld0, H, O, D, npair, KP,
+    hipLaunchKernelGGL(cin_pair_fwd_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, npair, KP,
                        reinterpret_cast<const __bf16 *>(wsp), bias, out, pooled, B);
     RP_LAUNCH_CHECK("cin_pair_fwd");
     return RP_OK;
