@@ -457,13 +457,13 @@ extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, in
 // The A operand (G) needs no scaling at all (split only, shared by every pair tile), the B operand is formed once per
 // workgroup stage and shared by all O rows, and the matrix core does 2.9x fewer passes than the per-channel 32 x 32
 // form (no padding of 26 -> 32 in either dimension, half the pairs).  dW[o,h,m] = dW[o,m,h] = dWs[o, p(h,m)].
-// Workgroup tile 128 (o) x 128 (pairs), waves 2 x 2, each 64 x 64 (4 MFMA tiles); stage = 32 contraction rows = a
+// Workgroup tile 128 (o) x 128 (pairs), EIGHT waves 4 x 2, each 32 x 64 (2 MFMA tiles; see cin_pair_fwd_kernel); stage = 32 contraction rows = a
 // sample's d-half: X_0's half-sample goes through LDS once (fp32), the pair products are formed from it.
 // The next stage's loads are issued before this stage's MFMA block.  (Loading G 8 threads per 128-byte row, whole lines
 // per wave instruction, measured SLOWER than one 32-byte octet per thread: twice the LDS store instructions.)
 #define CP_LD 40
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
+__global__ __launch_bounds__(512, 2) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int npair, const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool,
                                                                 float *__restrict__ P, float *__restrict__ Pb, int64_t B,
@@ -474,9 +474,9 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
     __shared__ unsigned char ph[128], pm[128];                          // this tile's pairs
     const int t = threadIdx.x;
     const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
-    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;  // this wave's 64 x 64 block: rows (o) wa.., columns (pairs) wb..
-    const int c = t & 63, oct = t >> 6;                // B image: pairs 2c, 2c+1, contraction octet oct
-    const int gr = t >> 3, gs = t & 7;                 // X_0 stage: row gr, floats 4 gs .. 4 gs + 3
+    const int wa = (w & 3) * 32, wb = (w >> 2) * 64;  // 8 waves, 4 (rows o) x 2 (pair columns), each 32 x 64
+    const int c = t & 127, oct = t >> 7;               // A image: row c; B image: pair c; contraction octet oct
+    const int gr = (t >> 3) & 31, gs = t & 7;          // X_0 stage (threads 0..255): row gr, floats 4 gs .. 4 gs + 3
     const int p0 = blockIdx.y * 128;
     const int64_t bbeg = (int64_t)blockIdx.x * b_per_blk;
     int64_t bend = bbeg + b_per_blk;
@@ -492,21 +492,19 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
         ph[t] = (unsigned char)h;
         pm[t] = (unsigned char)(h + rem);
     }
-    f32x16 acc[2][2];
+    f32x16 acc[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int v = 0; v < 2; ++v)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
-    float bsum[2] = {0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+    float bsum = 0.f;
     const int nhalf = D / 32;
     const bool do_bias = (Pb != nullptr) && (blockIdx.y == 0);
     __syncthreads();
-    const int h0 = ph[2 * c], m0_ = pm[2 * c], h1 = ph[2 * c + 1], m1_ = pm[2 * c + 1];
+    const int h0 = ph[c], m0_ = pm[c];
     const int64_t nstage = (bend - bbeg) * nhalf;
-    f32x4 gq[2][2], xq;
-    float gpq[2];
+    f32x4 gq[2], xq;
+    float gpq;
     int64_t lb = bbeg;  // (sample, d-half) of the next stage to load
     int lh = 0;
     auto load_stage = [&]() {
@@ -516,105 +514,84 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_w_kernel(const float *__r
             lh = 0;
             ++lb;
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {  // rows c and c + 64, contraction octet oct
-            const int o = c + 64 * u;
-            gq[u][0] = gq[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gpq[u] = 0.f;
-            if (o < O) {
-                if (gout != nullptr) {
-                    gq[u][0] = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 8 * oct);
-                    gq[u][1] = *reinterpret_cast<const f32x4 *>(gout + (b * O + o) * D + d0 + 8 * oct + 4);
-                }
-                if (gpool != nullptr) gpq[u] = gpool[b * O + o];
+        gq[0] = gq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gpq = 0.f;
+        if (c < O) {  // row c, contraction octet oct
+            if (gout != nullptr) {
+                gq[0] = *reinterpret_cast<const f32x4 *>(gout + (b * O + c) * D + d0 + 8 * oct);
+                gq[1] = *reinterpret_cast<const f32x4 *>(gout + (b * O + c) * D + d0 + 8 * oct + 4);
             }
+            if (gpool != nullptr) gpq = gpool[b * O + c];
         }
         xq = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gr < H) xq = *reinterpret_cast<const f32x4 *>(x0 + b * ld0 + (int64_t)gr * D + d0 + 4 * gs);
+        if (t < 256 && gr < H) xq = *reinterpret_cast<const f32x4 *>(x0 + b * ld0 + (int64_t)gr * D + d0 + 4 * gs);
     };
     if (nstage > 0) load_stage();
     for (int64_t st = 0; st < nstage; ++st) {
-        cbf8 vg[2];
+        cbf8 vg;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vg[u][e] = gq[u][0][e] + gpq[u];
-                vg[u][4 + e] = gq[u][1][e] + gpq[u];
-            }
-            if (do_bias) bsum[u] += ((vg[u][0] + vg[u][1]) + (vg[u][2] + vg[u][3])) + ((vg[u][4] + vg[u][5]) + (vg[u][6] + vg[u][7]));
+        for (int e = 0; e < 4; ++e) {
+            vg[e] = gq[0][e] + gpq;
+            vg[4 + e] = gq[1][e] + gpq;
         }
+        if (do_bias) bsum += ((vg[0] + vg[1]) + (vg[2] + vg[3])) + ((vg[4] + vg[5]) + (vg[6] + vg[7]));
         __syncthreads();  // previous stage's fragment reads (and Xs reads) are done
-        *reinterpret_cast<f32x4 *>(&Xs[gr][4 * gs]) = xq;
+        if (t < 256) *reinterpret_cast<f32x4 *>(&Xs[gr][4 * gs]) = xq;
         cbbf8 pc[3];
+        cb_split(vg, pc);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            cb_split(vg[u], pc);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&At[q][c + 64 * u][8 * oct]) = pc[q];
-        }
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&At[q][c][8 * oct]) = pc[q];
         __syncthreads();  // Xs complete
         {
-            cbf8 a0, a1, b0, b1;
+            cbf8 a0, b0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 a0[e] = Xs[h0][8 * oct + e];
                 b0[e] = Xs[m0_][8 * oct + e];
-                a1[e] = Xs[h1][8 * oct + e];
-                b1[e] = Xs[m1_][8 * oct + e];
             }
             cb_split(a0 * b0, pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][2 * c][8 * oct]) = pc[q];
-            cb_split(a1 * b1, pc);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][2 * c + 1][8 * oct]) = pc[q];
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][c][8 * oct]) = pc[q];
         }
         if (st + 1 < nstage) load_stage();
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            cbbf8 a[2][3], bq[2][3];
+            cbbf8 a[3], bq[2][3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                a[q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
+                for (int u = 0; u < 2; ++u)
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
-                }
             }
-            // product-major: consecutive MFMAs go to four different accumulators (smallest terms first per accumulator)
+            // product-major: consecutive MFMAs alternate between the two accumulators (smallest terms first)
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) {
                 const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
                 const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v)
-                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < 2; ++v)
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bq[v][qb], acc[v], 0, 0, 0);
             }
         }
     }
     // partials P[chunk][o][pair]; C layout: col (pair) = lane & 31, row (o) = (r&3) + 8*(r>>2) + 4*hh
     float *Pz = P + (int64_t)blockIdx.x * O * npair;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int v = 0; v < 2; ++v) {
+        const int p = p0 + wb + 32 * v + i;
+        if (p >= npair) continue;
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int p = p0 + wb + 32 * v + i;
-            if (p >= npair) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = wa + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (o < O) Pz[(int64_t)o * npair + p] = acc[u][v][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int o = wa + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (o < O) Pz[(int64_t)o * npair + p] = acc[v][r];
         }
-    if (do_bias) {  // row c + 64 u: the four octet owners (one per wave) hold its partial sums
+    }
+    if (do_bias) {  // row c: its four octet owners hold the partial sums
         __syncthreads();
         float *bred = reinterpret_cast<float *>(&At[0][0][0]);  // [4][128]
-#pragma unroll
-        for (int u = 0; u < 2; ++u) bred[oct * 128 + c + 64 * u] = bsum[u];
+        bred[oct * 128 + c] = bsum;
         __syncthreads();
         if (t < 128 && t < O) Pb[(int64_t)blockIdx.x * O + t] = (bred[t] + bred[128 + t]) + (bred[256 + t] + bred[384 + t]);
     }
@@ -687,7 +664,7 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
     const int64_t ncx = rp_cdiv(B, per);
     float *Pb = P + (size_t)ncx * O * npair;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cin_pair_bwd_w_kernel, dim3((unsigned)ncx, (unsigned)ntile), dim3(256), 0, s, x0, ld0, H, O, D, npair,
+    hipLaunchKernelGGL(cin_pair_bwd_w_kernel, dim3((unsigned)ncx, (unsigned)ntile), dim3(512), 0, s, x0, ld0, H, O, D, npair,
                        gout, gpool, P, db ? Pb : nullptr, B, per);
     RP_LAUNCH_CHECK("cin_pair_bwd_w");
     const int64_t total = (int64_t)O * H * H + O;
