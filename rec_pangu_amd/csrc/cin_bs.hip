@@ -463,7 +463,7 @@ extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, in
 // per wave instruction, measured SLOWER than one 32-byte octet per thread: twice the LDS store instructions.)
 #define CP_LD 40
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512, 2) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
+__global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int npair, const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool,
                                                                 float *__restrict__ P, float *__restrict__ Pb, int64_t B,
@@ -682,7 +682,7 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
 // each stage (32 pairs) copies the A tile L2 -> LDS and forms the B tile from LDS X_0.  EIGHT waves, 4 (rows) x 2
 // (columns), each 32 x 64: hipcc schedules a stage as "all VALU / LDS, then the MFMAs back to back", so the overlap has
 // to come from other waves — four half-size waves per SIMD (120 VGPRs) beat two full-size ones (3.9 -> 3.35 ms).
-__global__ __launch_bounds__(512, 2) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
+__global__ __launch_bounds__(512, 4) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
                                                               int npair, int KP, const __bf16 *__restrict__ wsp,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               float *__restrict__ pooled, int64_t B) {
@@ -842,14 +842,15 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
 //     T[p,(b,d)]   = sum_o Ws[o,p] G[o,(b,d)]                        one GEMM, M = NPAIR rows, K = O, N = B*D columns
 //     dX_0[b,h,d]  = sum_{p = (h,m) or (m,h)} T[p,(b,d)] X_0[b,m,d]   (the diagonal pair counts twice: 2 W[h,h] x_h)
 // wst: Ws^T as bf16 pieces [3][KPT][128] (KPT = NPAIR rounded up to 128, K = o contiguous, zero padded).
-// Workgroup: 128 columns (128/D samples), all pair tiles one after the other, K = O in 32-row stages.
+// Workgroup: 128 columns (128/D samples), EIGHT waves 4 (pair rows) x 2 (columns) of 32 x 64 (see cin_pair_fwd_kernel), all
+// pair tiles one after the other, K = O in 32-row stages.
 //   * G is contraction-STRIDED for this GEMM (its rows are o): each stage's [32 o][128 col] slab is loaded row-wise
 //     (16-byte loads), parked in LDS as fp32 and read back column-wise (conflict-free) to form the B operand.
 //   * after a pair tile, T (in the accumulators) goes to LDS 64 pairs at a time and every thread GATHERS the terms of
 //     its own (h, column) outputs from a host-built list  (tile, half, h) -> [(local pair row, m)]  — wave-uniform
 //     scalar loads, no atomics, fixed summation order; dX_0 stays in registers until the end.
 // (A first version scattered T with LDS float atomics and loaded G with strided dword loads: 21 ms.)
-__global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
+__global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int KPT, const __bf16 *__restrict__ wst,
                                                                 const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool, float *__restrict__ dx,
@@ -864,9 +865,10 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__r
     float *Xe = reinterpret_cast<float *>(smem + 64 * 132 * 4);               // epilogue: X_0[32][132]
     const int t = threadIdx.x;
     const int w = t >> 6, l = t & 63, i = l & 31, hh = l >> 5;
-    const int wa = (w & 1) * 64, wb = (w >> 1) * 64;
-    const int col = t & 127, oq = __builtin_amdgcn_readfirstlane(t >> 7);
-    const int go = t >> 3, c16 = t & 7;  // G slab: row go, columns 16 c16 .. 16 c16 + 15
+    const int wr = w & 3;                             // 8 waves, 4 (pair rows) x 2 (columns), each 32 x 64
+    const int wa = wr * 32, wb = (w >> 2) * 64;
+    const int col = t & 127, oq = __builtin_amdgcn_readfirstlane(t >> 7);  // oq 0..3
+    const int go = (t >> 3) & 31, c16 = t & 7, gj = (t >> 8) * 2;  // G slab: row go, columns 16 c16 + 4 (gj + {0,1})
     const int spb = 128 / D;
     const int64_t bs0 = (int64_t)blockIdx.x * spb;
     const int64_t bcol = bs0 + col / D;  // this thread's sample in the column role
@@ -876,13 +878,13 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__r
     const int dg = (16 * c16) % D;
     const bool gok = bg < B;
     const int nks = (O + 31) / 32, ntile = KPT / 128, nst = nks * ntile;
-    f32x4 aq[6], gq[4];
+    f32x4 aq[3], gq[2];
     float gp;
     auto load_stage = [&](int st) {
         const int tile = st / nks, ks = st - tile * nks;
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             aq[u] = *reinterpret_cast<const f32x4 *>(wst + ((int64_t)(q * KPT + tile * 128 + row) * 128 + ks * 32 + ch * 8));
         }
@@ -890,89 +892,81 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__r
         const bool ok = gok && o < O;
         gp = (ok && gpool != nullptr) ? gpool[bg * O + o] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            gq[j] = (ok && gout != nullptr) ? *reinterpret_cast<const f32x4 *>(gout + (bg * O + o) * D + dg + 4 * j)
+        for (int j = 0; j < 2; ++j)
+            gq[j] = (ok && gout != nullptr) ? *reinterpret_cast<const f32x4 *>(gout + (bg * O + o) * D + dg + 4 * (gj + j))
                                             : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    float dacc[16];
+    float dacc[8];
 #pragma unroll
-    for (int jh = 0; jh < 16; ++jh) dacc[jh] = 0.f;
-    f32x16 acc[2][2];
+    for (int jh = 0; jh < 8; ++jh) dacc[jh] = 0.f;
+    f32x16 acc[2];
     load_stage(0);
     for (int st = 0; st < nst; ++st) {
         const int tile = st / nks, ks_ = st - tile * nks;
         if (ks_ == 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int v = 0; v < 2; ++v)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
         }
         __syncthreads();  // previous stage's fragment reads / previous tile's epilogue are done
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(&Gs[go * 132 + 16 * c16 + 4 * j]) = gq[j] + gp;
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(&Gs[go * 132 + 16 * c16 + 4 * (gj + j)]) = gq[j] + gp;
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int id = t + 256 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
         }
         __syncthreads();  // the slab is complete
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        {
             cbf8 gv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gv[e] = Gs[(8 * (2 * oq + j) + e) * 132 + col];
+            for (int e = 0; e < 8; ++e) gv[e] = Gs[(8 * oq + e) * 132 + col];
             cbbf8 pc[3];
             cb_split(gv, pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * (2 * oq + j)]) = pc[q];
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pc[q];
         }
         if (st + 1 < nst) load_stage(st + 1);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            cbbf8 a[2][3], bq[2][3];
+            cbbf8 a[3], bq[2][3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
+                a[q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    a[u][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + 32 * u + i][ks * 16 + 8 * hh]);
+                for (int u = 0; u < 2; ++u)
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
-                }
             }
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) {
                 const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
                 const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v)
-                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][qa], bq[v][qb], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < 2; ++v)
+                    acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bq[v][qb], acc[v], 0, 0, 0);
             }
         }
         if (ks_ != nks - 1) continue;
         // ---- this pair tile's T is complete: fold it into the dX_0 registers, 64 pairs at a time
         __syncthreads();  // At / Bt are free
-        for (int h = oq; h < H; h += 2) Xe[h * 132 + col] = colok ? x0[bcol * ld0 + (int64_t)h * D + dcol] : 0.f;
+        for (int h = oq; h < H; h += 4) Xe[h * 132 + col] = colok ? x0[bcol * ld0 + (int64_t)h * D + dcol] : 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if ((w & 1) == half) {
+            if ((wr >> 1) == half) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int v = 0; v < 2; ++v)
 #pragma unroll
-                    for (int v = 0; v < 2; ++v)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Ts[(32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh) * 132 + wb + 32 * v + i] = acc[u][v][r];
+                    for (int r = 0; r < 16; ++r)
+                        Ts[(32 * (wr & 1) + (r & 3) + 8 * (r >> 2) + 4 * hh) * 132 + wb + 32 * v + i] = acc[v][r];
             }
             __syncthreads();
             const int lbase = (tile * 2 + half) * H;
 #pragma unroll
-            for (int jh = 0; jh < 16; ++jh) {
-                const int h = oq + 2 * jh;
+            for (int jh = 0; jh < 8; ++jh) {
+                const int h = oq + 4 * jh;
                 if (h < H) {
                     const int e0 = lstart[lbase + h], e1 = lstart[lbase + h + 1];
                     float a_ = dacc[jh];
@@ -1002,8 +996,8 @@ __global__ __launch_bounds__(256, 2) void cin_pair_bwd_x_kernel(const float *__r
     }
     if (colok) {
 #pragma unroll
-        for (int jh = 0; jh < 16; ++jh) {
-            const int h = oq + 2 * jh;
+        for (int jh = 0; jh < 8; ++jh) {
+            const int h = oq + 4 * jh;
             if (h < H) dx[bcol * lddx + (int64_t)h * D + dcol] = dacc[jh];
         }
     }
@@ -1025,7 +1019,7 @@ extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, 
     const int npair = H * (H + 1) / 2;
     const int KPT = (int)rp_cdiv(npair, 128) * 128;
     const int64_t nblk = rp_cdiv(B * D, 128);
-    hipLaunchKernelGGL(cin_pair_bwd_x_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, x0, ld0, H, O, D, KPT,
+    hipLaunchKernelGGL(cin_pair_bwd_x_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, KPT,
                        reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent);
     RP_LAUNCH_CHECK("cin_pair_bwd_x");
     return RP_OK;
