@@ -270,17 +270,18 @@ __device__ __forceinline__ void bf_split8(f32x8 v, bf16x8 (&p)[NP]) {
 //   <2,2,2,2>  128 x 128  each wave 64 x 64: every A / B fragment read from LDS feeds two MFMA tiles — the wide
 //                         (compute-bound) layers, where LDS fragment traffic per MFMA is what limits the matrix core
 template <int NPROD, int WM, int WN, int MI, int NI, int PF, bool VEC_A, bool VEC_W>
-__global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__restrict__ A, int64_t lda,
+__global__ __launch_bounds__(64 * WM * WN) void linear_fwd_bf16_kernel(const float *__restrict__ A, int64_t lda,
                                                               const float *__restrict__ W, int64_t ldw,
                                                               const float *__restrict__ bias, float *__restrict__ C,
                                                               int64_t ldc, int64_t M, int N, int K, int act,
                                                               const float *__restrict__ aux, int64_t ldaux) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    constexpr int RPP = 8 * WM * WN;  // rows staged per pass: 8 threads (32 floats) per row
     constexpr int NP = BfProd<NPROD>::NP;
     constexpr int BMT = 32 * MI * WM;
     constexpr int BNT = 32 * NI * WN;
-    constexpr int RA = BMT / 32;  // A rows staged per thread
-    constexpr int RW = BNT / 32;  // W rows staged per thread
+    constexpr int RA = BMT / RPP;  // A rows staged per thread
+    constexpr int RW = BNT / RPP;  // W rows staged per thread
     __shared__ __attribute__((aligned(16))) __bf16 As[NP][BMT][BF_LD];
     __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][BNT][BF_LD];
     const int t = threadIdx.x;
@@ -302,12 +303,12 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     auto load_tile = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[RW]) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int64_t m = m0 + lr + 32 * j;
+            const int64_t m = m0 + lr + RPP * j;
             da[j] = (m < M) ? load4_guard(A + m * lda + k0 + lc, K - (k0 + lc), VEC_A) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < RW; ++j) {
-            const int n = n0 + lr + 32 * j;
+            const int n = n0 + lr + RPP * j;
             dw[j] = (n < N) ? load4_guard(W + (int64_t)n * ldw + k0 + lc, K - (k0 + lc), VEC_W)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -315,9 +316,9 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
     const float *a_row[RA];
     const float *w_row[RW];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) a_row[j] = A + (m0 + lr + 32 * j) * lda + lc;
+    for (int j = 0; j < RA; ++j) a_row[j] = A + (m0 + lr + RPP * j) * lda + lc;
 #pragma unroll
-    for (int j = 0; j < RW; ++j) w_row[j] = W + (int64_t)(n0 + lr + 32 * j) * ldw + lc;
+    for (int j = 0; j < RW; ++j) w_row[j] = W + (int64_t)(n0 + lr + RPP * j) * ldw + lc;
     auto load_tile_full = [&](int k0, f32x4 (&da)[RA], f32x4 (&dw)[RW]) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) da[j] = *reinterpret_cast<const f32x4 *>(a_row[j] + k0);
@@ -340,14 +341,14 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const float *__res
             bf16x4 pc[NP];
             bf_split4<NP>(sa[j], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + 32 * j][lc]) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[q][lr + RPP * j][lc]) = pc[q];
         }
 #pragma unroll
         for (int j = 0; j < RW; ++j) {
             bf16x4 pc[NP];
             bf_split4<NP>(sw[j], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[q][lr + 32 * j][lc]) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[q][lr + RPP * j][lc]) = pc[q];
         }
         __syncthreads();
     };
@@ -984,9 +985,9 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
         const int64_t n128 = rp_cdiv(N, 128) * 128;
         const bool big = N >= 256 && (n128 - N) * 8 <= N && rp_cdiv(M, 128) * (n128 / 128) >= 1024;
         const bool small = !big && rp_cdiv(M, 128) * rp_cdiv(N, BN) < 1024 && M > 64;
-        dim3 grid((unsigned)rp_cdiv(M, small ? 64 : 128), (unsigned)rp_cdiv(N, big ? 128 : BN));
+        dim3 grid((unsigned)rp_cdiv(M, 128), (unsigned)rp_cdiv(N, big ? 128 : BN));
 #define CALLB(NPROD, WM, WN, MI, NI, PF, VA, VW)                                                                      \
-    hipLaunchKernelGGL((linear_fwd_bf16_kernel<NPROD, WM, WN, MI, NI, PF, VA, VW>), grid, dim3(256), 0, s, a, lda, w, \
+    hipLaunchKernelGGL((linear_fwd_bf16_kernel<NPROD, WM, WN, MI, NI, PF, VA, VW>), grid, dim3(64 * WM * WN), 0, s, a, lda, w, \
                        ldw, bias, out, ldo, M, N, K, act, aux, ldaux)
 #define CALLV(NPROD, WM, WN, MI, NI, PF)                            \
     do {                                                            \
@@ -997,8 +998,8 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     } while (0)
 #define CALLP(NPROD)                              \
     do {                                          \
-        if (big) CALLV(NPROD, 2, 2, 2, 2, 2);     \
-        else if (small) CALLV(NPROD, 2, 2, 1, 1, 3); \
+        if (big) CALLV(NPROD, 4, 2, 1, 2, 2);     \
+        else if (small) CALLV(NPROD, 4, 2, 1, 1, 2); \
         else CALLV(NPROD, 4, 1, 1, 2, 2);         \
     } while (0)
         if (mode == RP_MATMUL_BF16X6) CALLP(6);
