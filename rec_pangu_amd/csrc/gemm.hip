@@ -267,7 +267,9 @@ __device__ __forceinline__ void bf_split8(f32x8 v, bf16x8 (&p)[NP]) {
 // Wave tiling is a template: WM x WN waves (WM*WN = 4), each owning MI x NI MFMA tiles of 32 x 32:
 //   <4,1,1,2>  128 x 64   rows split over the waves, both column halves per wave           (skinny N, large grid)
 //   <2,2,1,1>   64 x 64   used when the 128-row grid would leave the chip under-filled
-//   <2,2,2,2>  128 x 128  each wave 64 x 64: every A / B fragment read from LDS feeds two MFMA tiles — the wide
+//   <4,2,1,2>  128 x 128  EIGHT waves of 32 x 64 (four per SIMD: hipcc schedules a stage as "convert + LDS, then the MFMAs
+//                         back to back", so the overlap has to come from other waves; 8.3 -> 7.9 ms on the wide MLP
+//                         against <2,2,2,2>, four waves of 64 x 64) — the wide
 //                         (compute-bound) layers, where LDS fragment traffic per MFMA is what limits the matrix core
 template <int NPROD, int WM, int WN, int MI, int NI, int PF, bool VEC_A, bool VEC_W>
 __global__ __launch_bounds__(64 * WM * WN) void linear_fwd_bf16_kernel(const float *__restrict__ A, int64_t lda,
@@ -980,7 +982,7 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
             return rp_linear_fwd(a, lda, w + (int64_t)Nb * ldw, ldw, bias ? bias + Nb : nullptr, out + Nb, ldo, M, N - Nb, K,
                                  act, aux ? aux + Nb : nullptr, ldaux, stream);
         }
-        // tile shape: 128 x 128 (each wave 64 x 64) for wide outputs; 128 x 64 otherwise, 64 x 64 when that grid
+        // tile shape: 128 x 128 (eight waves of 32 x 64) for wide outputs; 128 x 64 otherwise — with eight waves when that grid
         // would give the 256 CUs fewer than ~4 workgroups each
         const int64_t n128 = rp_cdiv(N, 128) * 128;
         const bool big = N >= 256 && (n128 - N) * 8 <= N && rp_cdiv(M, 128) * (n128 / 128) >= 1024;
