@@ -101,3 +101,28 @@ def test_model_lazy_equals_dense_and_reference(name):
     for k in finals[False][2]:
         assert torch.equal(finals[False][2][k][0], finals[True][2][k][0]), f"exp_avg {k}"
         assert torch.equal(finals[False][2][k][1], finals[True][2][k][1]), f"exp_avg_sq {k}"
+
+
+def test_scalar_table_growth_keeps_lazy_exact(monkeypatch):
+    """The per-step scalar table grows in chunks (LazyAdamRows.TABLE_CHUNK = 1024 steps): with a chunk of 3 a 10-step
+    run with a learning-rate change crosses several extensions and must still equal the dense optimizer bit for bit."""
+    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows
+    monkeypatch.setattr(LazyAdamRows, "TABLE_CHUNK", 3)
+    g = load_golden("model_deepfm.npz")
+    batch = {k: v.to(DEV) for k, v in g["batch"].items()}
+    other = {k: (v.flip(0) if v.dtype.is_floating_point else torch.zeros_like(v)) for k, v in batch.items()}
+    finals = {}
+    for lazy in (False, True):
+        model = build("deepfm").to(DEV)
+        model.train(CASES["deepfm"][1])
+        opt = FusedAdam(model.parameters(), lr=1e-2, fuse_zero_grad=True, lazy_tables=lazy)
+        for i in range(10):
+            if i == 6:
+                for grp in opt.param_groups:
+                    grp["lr"] = 3e-3
+            model(batch if i % 3 else other)["loss"].backward()
+            opt.step()
+            model.zero_grad()
+        finals[lazy] = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in finals[False]:
+        assert torch.equal(finals[False][k], finals[True][k]), k
