@@ -63,3 +63,38 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle/"
                 assert "ref_ops" not in src, f"{f} references the oracle"
+
+
+def test_cin_pair_gather_lists_cover_every_pair_once_per_member():
+    """Host logic of rp_cin_pair_bwd_x (rec_pangu_amd.hip.cin_pair_lists): for every field h the lists of all pair-tile
+    halves together name each pair containing h exactly once per membership — the diagonal pair (h,h) twice — with
+    the right partner and the right local row; and the forward's pair order is the row-major upper triangle."""
+    import torch
+    from rec_pangu_amd import hip
+    for H in (1, 2, 5, 26, 32):
+        lstart, lent = hip.cin_pair_lists(H, torch.device("cpu"))
+        lstart, lent = lstart.tolist(), lent.tolist()
+        pairs = [(h, m) for h in range(H) for m in range(h, H)]
+        ntile = (len(pairs) + 127) // 128
+        assert len(lstart) == 2 * ntile * H + 1
+        seen = {h: [] for h in range(H)}
+        for tile in range(ntile):
+            for half in range(2):
+                lo = tile * 128 + half * 64
+                for h in range(H):
+                    li = (2 * tile + half) * H + h
+                    for e in lent[lstart[li]:lstart[li + 1]]:
+                        pl, m = e & 255, e >> 8
+                        assert 0 <= pl < 64 and lo + pl < len(pairs)
+                        assert sorted(pairs[lo + pl]) == sorted((h, m)), (H, tile, half, h, pl, m)
+                        seen[h].append(lo + pl)
+        for h in range(H):
+            want = sorted([p for p, (a, b) in enumerate(pairs) if a == h or b == h] +
+                          [p for p, (a, b) in enumerate(pairs) if a == h and b == h])
+            assert sorted(seen[h]) == want, (H, h)
+    # symmetric pair weights: row-major upper triangle, off-diagonal entries summed
+    W = torch.arange(2 * 3 * 3, dtype=torch.float32).view(2, 3, 3)
+    ws = hip._cin_pair_ws(W)
+    ref = torch.stack([torch.stack([W[o, 0, 0], W[o, 0, 1] + W[o, 1, 0], W[o, 0, 2] + W[o, 2, 0], W[o, 1, 1],
+                                    W[o, 1, 2] + W[o, 2, 1], W[o, 2, 2]]) for o in range(2)])
+    assert torch.equal(ws, ref)
