@@ -250,6 +250,131 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Replay with ONE ROW PER WAVE (rows of more than 16 floats).
+//
+// The replay of a row is a serial chain of (t - last[row]) zero-gradient steps, and that count differs from row to
+// row (a geometric distribution around table_rows / batch).  With several rows side by side in a wave (16 lanes x
+// float4 per row, the layout of lazy_adam_rows_kernel) every row waits for the longest chain of the four: ~2.1x the
+// mean.  Here the 64 lanes of a wave hold the (up to 64 * EPL) floats of ONE row, so the whole chain is wave-uniform:
+// the step count and the per-step scalars live in SGPRs (s_load of sc[j], scalar loop), no lane idles, and a wave
+// walks over the rows that need work among 64 consecutive candidates (a ballot over "is a run head / is behind"),
+// fetching the next row's p/m/v while the current one replays.  Same adam1_zero_grad() as everywhere else:
+// bit-identical to the dense kernel.
+// ------------------------------------------------------------------------------------------------
+template <int EPL>
+__device__ __forceinline__ void lazy_load_row(const float *__restrict__ P, const float *__restrict__ Mo,
+                                              const float *__restrict__ Vo, int64_t off, int lane, int D,
+                                              float (&p)[EPL], float (&m)[EPL], float (&v)[EPL]) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        // unguarded (a lane beyond the row re-reads its last column and never stores): a load behind a lane mask
+        // could not be counted by the in-order vmcnt waits either
+        const int cidx = (lane + 64 * e < D) ? lane + 64 * e : D - 1;
+        p[e] = P[off + cidx];
+        m[e] = Mo[off + cidx];
+        v[e] = Vo[off + cidx];
+    }
+}
+
+// `need`: this lane's candidate row must be replayed from step l0 (exclusive) to t_target (inclusive)
+template <int EPL, bool FULL>  // FULL: D == 64 * EPL, every lane stores (no lane mask -> no branch around the stores)
+__device__ __forceinline__ void lazy_replay_candidates(bool need, int row, int l0, int D, float *__restrict__ P,
+                                                       float *__restrict__ Mo, float *__restrict__ Vo,
+                                                       int32_t *__restrict__ last, const float2 *__restrict__ sc,
+                                                       int t_target, const LazyCfg &c) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long mask = __ballot(need);
+    if (mask == 0) return;
+    int src = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    int r = __builtin_amdgcn_readlane(row, src);
+    int l = __builtin_amdgcn_readlane(l0, src);
+    float p[EPL], m[EPL], v[EPL];
+    lazy_load_row<EPL>(P, Mo, Vo, (int64_t)r * D, lane, D, p, m, v);
+    for (;;) {
+        const bool more = mask != 0;  // wave-uniform
+        // the next row's loads are issued UNCONDITIONALLY (the last row is simply read once more): gfx950 counts loads
+        // on one in-order counter and a load behind a branch would turn the wait for THIS row's registers into
+        // vmcnt(0), i.e. into a wait for the prefetch
+        if (more) src = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int rn = __builtin_amdgcn_readlane(row, src);
+        const int ln = __builtin_amdgcn_readlane(l0, src);
+        float pn[EPL], mn[EPL], vn[EPL];
+        lazy_load_row<EPL>(P, Mo, Vo, (int64_t)rn * D, lane, D, pn, mn, vn);  // in flight during the replay below
+#pragma unroll 2
+        for (int j = l + 1; j <= t_target; ++j) {
+            const float2 s = sc[j];  // uniform address: scalar load
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) adam1_zero_grad<float>(p[e], m[e], v[e], c.one_m_b1, c.b2, s.x, s.y, c.eps);
+        }
+        const int64_t off = (int64_t)r * D;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int cidx = lane + 64 * e;
+            if (FULL || cidx < D) {
+                P[off + cidx] = p[e];
+                Mo[off + cidx] = m[e];
+                Vo[off + cidx] = v[e];
+            }
+        }
+        last[r] = t_target;  // every lane, same address, same value: one dword write and no branch
+        if (!more) break;
+        r = rn;
+        l = ln;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            p[e] = pn[e];
+            m[e] = mn[e];
+            v[e] = vn[e];
+        }
+    }
+}
+
+// candidates = 64 consecutive positions of the sorted key list; a position counts when it is a run head (unique rows,
+// no write race) whose row has been updated before (last > 0; otherwise m = v = 0 and a zero-gradient step is the
+// identity) and is behind t_target
+template <int EPL, bool FULL>
+__global__ __launch_bounds__(256) void lazy_replay_wave_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
+                                                               float *__restrict__ P, float *__restrict__ Mo,
+                                                               float *__restrict__ Vo, int32_t *__restrict__ last,
+                                                               const float2 *__restrict__ sc, int t_target, LazyCfg c) {
+    const int64_t i = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+    int row = 0, l0 = 0;
+    bool need = false;
+    if (i < n) {
+        row = sk[i];
+        if (i == 0 || sk[i - 1] != row) {
+            l0 = last[row];
+            need = l0 > 0 && l0 < t_target;
+        }
+    }
+    lazy_replay_candidates<EPL, FULL>(need, row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+}
+
+// candidates = 64 consecutive arena rows; the grid strides over the arena
+template <int EPL, bool FULL>
+__global__ __launch_bounds__(256) void lazy_flush_wave_kernel(int64_t R, int D, float *__restrict__ P,
+                                                              float *__restrict__ Mo, float *__restrict__ Vo,
+                                                              int32_t *__restrict__ last,
+                                                              const float2 *__restrict__ sc, int t_target, LazyCfg c) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; row0 < R; row0 += stride) {
+        const int64_t row = row0 + (threadIdx.x & 63);
+        int l0 = 0;
+        bool need = false;
+        if (row < R) {
+            l0 = last[row];
+            need = l0 > 0 && l0 < t_target;
+        }
+        lazy_replay_candidates<EPL, FULL>(need, (int)row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+    }
+}
+
+#define RP_LAZY_WAVE_MIN_D 17   // rows this wide or wider replay one row per wave
+#define RP_LAZY_WAVE_MAX_D 256  // 4 floats per lane
+
 static int lazy_tpr(int D, int vw) {
     int need = (D + vw - 1) / vw, tpr = 1;
     while (tpr < need && tpr < 64) tpr <<= 1;
@@ -300,6 +425,19 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
     const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
+    if (!real_step && D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {  // pure replay: one row per wave
+        const dim3 gw((unsigned)rp_cdiv(n, 256));
+#define CALLW(EPL, FULL)                                                                                              \
+    hipLaunchKernelGGL((lazy_replay_wave_kernel<EPL, FULL>), gw, dim3(256), 0, s, sorted_keys, n, D, p, m, v, last, sc, \
+                       (int)t_target, c)
+        if (D == 64) CALLW(1, true);
+        else if (D < 64) CALLW(1, false);
+        else if (D <= 128) CALLW(2, false);
+        else CALLW(4, false);
+#undef CALLW
+        RP_LAUNCH_CHECK("lazy_adam_rows (replay)");
+        return RP_OK;
+    }
 #define CALL(T, TY)                                                                                                  \
     hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
                        sc, (int)t_target, real_step, zero_grad, c)
@@ -322,6 +460,20 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     if (nb > 65536) nb = 65536;
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
+    if (D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {
+        int64_t nw = rp_cdiv(rows, 256);
+        if (nw > 65536) nw = 65536;
+#define CALLW(EPL, FULL)                                                                                                   \
+    hipLaunchKernelGGL((lazy_flush_wave_kernel<EPL, FULL>), dim3((unsigned)nw), dim3(256), 0, s, rows, D, p, m, v, last, sc, \
+                       (int)t_target, c)
+        if (D == 64) CALLW(1, true);
+        else if (D < 64) CALLW(1, false);
+        else if (D <= 128) CALLW(2, false);
+        else CALLW(4, false);
+#undef CALLW
+        RP_LAUNCH_CHECK("lazy_adam_flush (wave)");
+        return RP_OK;
+    }
 #define CALL(T, TY)                                                                                              \
     hipLaunchKernelGGL((lazy_adam_flush_kernel<T, TY>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, m, v, last, sc, \
                        (int)t_target, c)

@@ -184,10 +184,14 @@ def pause_timing(paused: bool):
 
 
 class _Timed:
-    __slots__ = ("name", "ev")
+    """`tag`: a launch-shape suffix (bench.py then reports one row per kernel shape instead of one per entry point);
+    `nbytes` / `flops`: algorithmic bytes moved / flops of this launch where the entry point knows them itself."""
+    __slots__ = ("name", "key", "ev", "meta")
 
-    def __init__(self, name):
+    def __init__(self, name, tag=None, nbytes=0, flops=0):
         self.name = name
+        self.key = name if tag is None else f"{name}[{tag}]"
+        self.meta = (nbytes, flops)
 
     def __enter__(self):
         self.ev = None
@@ -199,17 +203,27 @@ class _Timed:
     def __exit__(self, *exc):
         if self.ev is not None:
             self.ev[1].record()
-            _timing.setdefault(self.name, []).append(self.ev)
+            _timing.setdefault(self.key, []).append(self.ev)
+            if self.meta != (0, 0):
+                _timing_meta[self.key] = self.meta
         return False
 
 
+_timing_meta = {}
+
+
 def timing_summary():
-    """{entry point: (calls, mean milliseconds)} for the calls recorded since enable_timing(True)."""
+    """{entry point[shape tag]: (calls, mean milliseconds)} for the calls recorded since enable_timing(True)."""
     out = {}
     for name, evs in (_timing or {}).items():
         ms = [a.elapsed_time(b) for a, b in evs]
         out[name] = (len(ms), sum(ms) / max(len(ms), 1))
     return out
+
+
+def timing_meta():
+    """{entry point[shape tag]: (algorithmic bytes, flops) per launch} for the rows that carry them (the GEMMs)."""
+    return dict(_timing_meta)
 
 
 def _ptr_array(tensors: Sequence[torch.Tensor]):
@@ -241,7 +255,7 @@ def embed_gather_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense:
     fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
     ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_sum else None
     keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
-    with _Timed("embed_gather_fwd"):
+    with _Timed("embed_gather_fwd", f"D={D}"):
         _check(lib().rp_embed_gather_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
                                      _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, _ptr(fm), _ptr(ssum), _ptr(keys),
                                      err_flag.data_ptr(), _stream()), "rp_embed_gather_fwd")
@@ -267,7 +281,7 @@ def embed_grad_reduce(sorted_keys, sorted_pos, B: int, D: int, dx, gfm, sum_in, 
     if dx is not None:
         _req(dx, torch.float32, "dx")
         ldx = _rowmajor(dx, "dx")
-    with _Timed("embed_grad_reduce"):
+    with _Timed("embed_grad_reduce", f"D={D}"):
         _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
                                       _ptr(dx), ldx, _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(),
                                       int(accumulate), _stream()), "rp_embed_grad_reduce")
@@ -291,7 +305,7 @@ def linear_fwd(a, w, bias, act: int = ACT_NONE, aux=None, K: Optional[int] = Non
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldo = _rowmajor(out, "out")
     ldaux = _rowmajor(aux, "aux") if aux is not None else 0
-    with _Timed("linear_fwd"):
+    with _Timed("linear_fwd", f"{M}x{N}x{K}", 4 * (M * K + N * K + M * N * (2 if aux is not None else 1)), 2 * M * N * K):
         _check(lib().rp_linear_fwd(a.data_ptr(), lda, w.data_ptr(), ldw, _ptr(bias), out.data_ptr(), ldo, M, N, K, act,
                                _ptr(aux), ldaux, _stream()), "rp_linear_fwd")
     return out
@@ -306,7 +320,7 @@ def linear_fwd_rowadd(a, w, row_scale, row_add, add_cols: int, out) -> bool:
             and add_cols % 64 == 0 and 0 < add_cols <= N and row_add.shape[1] == 64 and a.stride(0) % 4 == 0
             and w.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0 and out.shape[1] >= N):
         return False
-    with _Timed("linear_fwd"):
+    with _Timed("linear_fwd", f"{M}x{N}x{K}+rowadd", 4 * (M * K + N * K + M * N + M * 65), 2 * M * N * K):
         _check(lib().rp_linear_fwd_rowadd(a.data_ptr(), _rowmajor(a, "a"), w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(),
                                           _rowmajor(out, "out"), M, N, K, row_scale.data_ptr(), row_add.data_ptr(),
                                           _rowmajor(row_add, "row_add"), add_cols, _stream()), "rp_linear_fwd_rowadd")
@@ -326,7 +340,7 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     nbytes = _sz(0)
     _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
-    with _Timed("linear_wgrad"):
+    with _Timed("linear_wgrad", f"{M}x{N}x{K}", 4 * (M * N + M * K + N * K), 2 * M * N * K):
         _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
                                  M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
     return dw, db
@@ -340,7 +354,7 @@ def transpose(w, rows_out: Optional[int] = None):
     R4 = (R + 3) // 4 * 4  # 16-byte aligned rows (the GEMM then fetches them with dwordx4, unguarded)
     rows = max(Cc, rows_out or 0)
     out = torch.empty((rows, R4), dtype=torch.float32, device=w.device)[:, :R]
-    with _Timed("transpose"):
+    with _Timed("transpose", f"{R}x{Cc}", 4 * (R * Cc + rows * R)):
         _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, _stream()),
                "rp_transpose")
     return out
@@ -349,7 +363,7 @@ def transpose(w, rows_out: Optional[int] = None):
 def relu_bwd(dy, act_out):
     M, N = dy.shape
     out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
-    with _Timed("relu_bwd"):
+    with _Timed("relu_bwd", f"{M}x{N}", 12 * M * N):
         _check(lib().rp_relu_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
                              out.data_ptr(), N, M, N, _stream()), "rp_relu_bwd")
     return out
@@ -791,7 +805,7 @@ def batchnorm_train_fwd(x, gamma, beta, eps: float):
     y = torch.empty((M, N), dtype=torch.float32, device=dev)
     mean, var, rstd = (torch.empty((N,), dtype=torch.float32, device=dev) for _ in range(3))
     ws, nb = _bn_ws(M, N, dev)
-    with _Timed("batchnorm_train_fwd"):
+    with _Timed("batchnorm_train_fwd", f"{M}x{N}", 16 * M * N):  # 3 reads + 1 write
         _check(lib().rp_batchnorm_train_fwd(x.data_ptr(), _rowmajor(x, "x"), _ptr(gamma), _ptr(beta), eps, y.data_ptr(),
                                             N, mean.data_ptr(), var.data_ptr(), rstd.data_ptr(), M, N, ws.data_ptr(),
                                             nb, _stream()), "rp_batchnorm_train_fwd")
@@ -804,7 +818,7 @@ def batchnorm_train_bwd(x, dy, mean, rstd, gamma):
     dx = torch.empty((M, N), dtype=torch.float32, device=dev)
     dgamma, dbeta = (torch.empty((N,), dtype=torch.float32, device=dev) for _ in range(2))
     ws, nb = _bn_ws(M, N, dev)
-    with _Timed("batchnorm_train_bwd"):
+    with _Timed("batchnorm_train_bwd", f"{M}x{N}", 20 * M * N):  # x, dy twice + dx
         _check(lib().rp_batchnorm_train_bwd(x.data_ptr(), _rowmajor(x, "x"), dy.data_ptr(), _rowmajor(dy, "dy"),
                                             mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), dx.data_ptr(), N,
                                             dgamma.data_ptr(), dbeta.data_ptr(), M, N, ws.data_ptr(), nb, _stream()),
@@ -815,7 +829,7 @@ def batchnorm_train_bwd(x, dy, mean, rstd, gamma):
 def batchnorm_apply(x, mean, rstd, gamma, beta):
     M, N = x.shape
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    with _Timed("batchnorm_apply"):
+    with _Timed("batchnorm_apply", f"{M}x{N}", 8 * M * N):
         _check(lib().rp_batchnorm_apply(x.data_ptr(), _rowmajor(x, "x"), mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
                                         _ptr(beta), y.data_ptr(), N, M, N, _stream()), "rp_batchnorm_apply")
     return y
@@ -824,7 +838,7 @@ def batchnorm_apply(x, mean, rstd, gamma, beta):
 def batchnorm_apply_bwd(dy, rstd, gamma):
     M, N = dy.shape
     dx = torch.empty((M, N), dtype=torch.float32, device=dy.device)
-    with _Timed("batchnorm_apply_bwd"):
+    with _Timed("batchnorm_apply_bwd", f"{M}x{N}", 8 * M * N):
         _check(lib().rp_batchnorm_apply_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), rstd.data_ptr(), _ptr(gamma),
                                             dx.data_ptr(), N, M, N, _stream()), "rp_batchnorm_apply_bwd")
     return dx
@@ -925,7 +939,7 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int):
 
 def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int, real_step: bool, zero_grad: bool,
                    beta1: float, beta2: float, eps: float):
-    with _Timed("lazy_adam_rows_step" if real_step else "lazy_adam_rows_replay"):
+    with _Timed("lazy_adam_rows_step" if real_step else "lazy_adam_rows_replay", f"D={D}"):
         _check(lib().rp_lazy_adam_rows(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
                                        m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_target,
                                        int(real_step), int(zero_grad), beta1, beta2, eps, _stream()),
@@ -933,7 +947,7 @@ def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int
 
 
 def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, beta1: float, beta2: float, eps: float):
-    with _Timed("lazy_adam_flush"):
+    with _Timed("lazy_adam_flush", f"D={D}"):
         _check(lib().rp_lazy_adam_flush(rows, D, p.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(),
                                         scalars.data_ptr(), t_target, beta1, beta2, eps, _stream()),
                "rp_lazy_adam_flush")

@@ -10,7 +10,7 @@ from torch import nn
 from torch.nn.init import xavier_normal_, constant_
 
 from .. import functional as Fh
-from .layers import EmbeddingLayer
+from .layers.embedding import make_embedding_layer
 from .utils import dense_columns
 
 
@@ -31,12 +31,14 @@ class BaseModel(nn.Module):
         super().__init__()
         self.enc_dict = enc_dict
         self.embedding_dim = embedding_dim
-        self.embedding_layer = EmbeddingLayer(enc_dict=self.enc_dict, embedding_dim=self.embedding_dim)
+        self.embedding_layer = make_embedding_layer(self.enc_dict, self.embedding_dim)
 
     # ---- init schemes (base_model.py:28-59) ---------------------------------------------------
     def _init_weights(self, module: nn.Module) -> None:
         if isinstance(module, nn.Embedding):
             xavier_normal_(module.weight.data)
+        elif hasattr(module, "init_tables"):  # row-sharded layer: the same per-table draws, kept only for its own rows
+            module.init_tables(xavier_normal_)
         elif isinstance(module, nn.Linear):
             xavier_normal_(module.weight.data)
             if module.bias is not None:
@@ -46,6 +48,12 @@ class BaseModel(nn.Module):
         """kaiming_normal_ on every >=2-D parameter (embedding tables included); 1-D left as built."""
         for weight in self.parameters():
             if len(weight.shape) == 1:
+                continue
+            shard = getattr(weight, "_rp_shard_init", None)
+            if shard is not None and shard() is not None:
+                # the local shard of row-sharded tables stands where the F table Parameters stand in parameters():
+                # draw the F tables in that order (one temporary at a time), keep this rank's rows
+                shard().init_tables(torch.nn.init.kaiming_normal_)
                 continue
             torch.nn.init.kaiming_normal_(weight)
 

@@ -26,6 +26,20 @@ from ... import functional as Fh
 # the last (id tensors, versions, arena signature) -> (keys, sorted keys, positions); see EmbeddingLayer._sorted_keys
 _SORT_CACHE = None
 
+# set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
+# only ever allocate their own shard (see make_embedding_layer)
+_SHARD_SPEC = None
+
+
+def make_embedding_layer(enc_dict, embedding_dim: int):
+    """What BaseModel / LR_Layer call to create their embedding layer: the arena-backed EmbeddingLayer, or — inside
+    `sharded.sharded_construction(world, rank)` — a ShardedEmbeddingLayer holding rows r % world == rank, initialised
+    with the very same RNG draws (table by table through a temporary) without ever allocating the full arena."""
+    if _SHARD_SPEC is None:
+        return EmbeddingLayer(enc_dict=enc_dict, embedding_dim=embedding_dim)
+    from ...sharded import ShardedEmbeddingLayer
+    return ShardedEmbeddingLayer.from_spec(enc_dict, embedding_dim, **_SHARD_SPEC)
+
 
 class EmbeddingLayer(nn.Module):
     def __init__(self, enc_dict: Dict[str, Dict[str, Union[int, str]]], embedding_dim: int) -> None:

@@ -9,14 +9,14 @@ from torch import nn
 
 from ... import functional as Fh
 from ..utils import get_dnn_input_dim, get_linear_input, dense_columns
-from .embedding import EmbeddingLayer
+from .embedding import make_embedding_layer
 
 
 class LR_Layer(nn.Module):
     def __init__(self, enc_dict):
         super(LR_Layer, self).__init__()
         self.enc_dict = enc_dict
-        self.emb_layer = EmbeddingLayer(enc_dict=self.enc_dict, embedding_dim=1)
+        self.emb_layer = make_embedding_layer(self.enc_dict, 1)
         self.dnn_input_dim = get_dnn_input_dim(self.enc_dict, 1)
         self.fc = nn.Linear(self.dnn_input_dim, 1)
 

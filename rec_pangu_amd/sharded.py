@@ -157,32 +157,80 @@ class ShardedEmbeddingLayer(nn.Module):
     """Drop-in for EmbeddingLayer inside a model whose tables are row-sharded over `world` ranks."""
 
     def __init__(self, full_layer, world: int, rank: int, group=None):
+        """Cut this rank's shard out of an existing (fully built) EmbeddingLayer — tests and small models.  Large models
+        are built sharded from the start (`from_spec` via `build_sharded_model`): no rank ever holds the full arena."""
         super().__init__()
         full_layer._ensure_packed()
-        self.enc_dict = full_layer.enc_dict
-        self.embedding_dim = full_layer.embedding_dim
-        self.emb_feature = list(full_layer.emb_feature)
-        self.world, self.rank, self.group = world, rank, group
-        self.check_indices = full_layer.check_indices
         rows = [p.shape[0] for p in full_layer.table_parameters()]
+        self._setup(full_layer.enc_dict, full_layer.embedding_dim, list(full_layer.emb_feature), rows, world, rank, group,
+                    full_layer.arena.device)
+        self.check_indices = full_layer.check_indices
+        # rows r with r % world == rank, in order: local row = r // world
+        self.local_arena = nn.Parameter(full_layer.arena.detach()[rank::world].clone())
+        self._tag()
+
+    @classmethod
+    def from_spec(cls, enc_dict, embedding_dim: int, world: int, rank: int, group=None, device=None):
+        """Build ONLY this rank's shard, consuming the global RNG exactly as EmbeddingLayer.__init__ does (one
+        N(0,1) draw per table, in enc_dict order): every table is drawn into a temporary of its full shape and the
+        rows r % world == rank are kept, so peak memory is the shard plus ONE table, and the values are those of the
+        single-process construction."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        cols = [c for c in enc_dict.keys() if "vocab_size" in enc_dict[c].keys()]
+        rows = [enc_dict[c]["vocab_size"] + 1 for c in cols]
+        dev = torch.empty(0, device=device).device  # resolves `with torch.device(...)` defaults
+        self._setup(enc_dict, embedding_dim, cols, rows, world, rank, group, dev)
+        n_local = (self.total_rows - rank + world - 1) // world
+        self.local_arena = nn.Parameter(torch.empty((n_local, embedding_dim), device=dev))
+        self._tag()
+        self.init_tables(nn.init.normal_)
+        return self
+
+    def _setup(self, enc_dict, embedding_dim, emb_feature, rows, world, rank, group, device):
+        self.enc_dict = enc_dict
+        self.embedding_dim = embedding_dim
+        self.emb_feature = emb_feature
+        self.world, self.rank, self.group = world, rank, group
+        self.check_indices = "sync"
         base = [0]
         for r in rows[:-1]:
             base.append(base[-1] + r)
+        self._rows, self._base = list(rows), base
         self.total_rows = sum(rows)
         self.lbits = max(1, int((self.total_rows + world - 1) // world).bit_length())  # bits of a local row id
-        self.register_buffer("_row_base", torch.tensor(base, dtype=torch.int64, device=full_layer.arena.device),
-                             persistent=False)
-        self.register_buffer("_row_count", torch.tensor(rows, dtype=torch.int64, device=full_layer.arena.device),
-                             persistent=False)
-        # rows r with r % world == rank, in order: local row = r // world
-        self.local_arena = nn.Parameter(full_layer.arena.detach()[rank::world].clone())
-        self.local_arena._rp_store = weakref.ref(self)  # FusedAdam finds the arena (and its lazy state) through this
+        self.register_buffer("_row_base", torch.tensor(base, dtype=torch.int64, device=device), persistent=False)
+        self.register_buffer("_row_count", torch.tensor(rows, dtype=torch.int64, device=device), persistent=False)
         self._touched, self._touched_unsorted = None, False
         self._grad_buf = None
         self._lazy = None
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
+
+    def _tag(self):
+        ref = weakref.ref(self)
+        self.local_arena._rp_store = ref       # FusedAdam finds the arena (and its lazy state) through this
+        self.local_arena._rp_shard_init = ref  # BaseModel.reset_parameters draws the tables through init_tables()
+
+    def _table_slice(self, f: int):
+        """(first row of table f owned by this rank, its local row) — the rank owns every world-th row from there"""
+        first = (self.rank - self._base[f]) % self.world
+        return first, (self._base[f] + first) // self.world
+
+    @torch.no_grad()
+    def init_tables(self, init_fn):
+        """Apply `init_fn` (nn.init.normal_ / kaiming_normal_ / xavier_normal_: the reference's schemes) table by
+        table in field order, as it would run over the F full [V+1, D] tables, keeping this rank's rows."""
+        self.flush_lazy()
+        a = self.local_arena.data
+        for f, r in enumerate(self._rows):
+            tmp = torch.empty((r, self.embedding_dim), dtype=a.dtype, device=a.device)
+            init_fn(tmp)
+            first, lrow = self._table_slice(f)
+            mine = tmp[first::self.world]
+            a[lrow:lrow + mine.shape[0]].copy_(mine)
+            del tmp
 
     # ---- EmbeddingLayer-compatible surface ------------------------------------------------------
     @property
@@ -427,6 +475,42 @@ def shard_model_tables(model: nn.Module, world: int, rank: int, group=None) -> n
     swap(model)
     if world > 1:
         sync_batchnorm(model, group)  # BatchNorm towers: statistics over the global batch
+    return model
+
+
+class sharded_construction:
+    """Context manager: models constructed inside it get ShardedEmbeddingLayers built shard-locally
+    (`ShardedEmbeddingLayer.from_spec`) wherever the single-process model has an EmbeddingLayer."""
+
+    def __init__(self, world: int, rank: int, group=None, device=None):
+        self.spec = dict(world=world, rank=rank, group=group, device=device)
+
+    def __enter__(self):
+        from .models.layers import embedding as E
+        self._prev = E._SHARD_SPEC
+        E._SHARD_SPEC = self.spec
+        return self
+
+    def __exit__(self, *exc):
+        from .models.layers import embedding as E
+        E._SHARD_SPEC = self._prev
+        return False
+
+
+def build_sharded_model(factory, world: int, rank: int, device=None, seed=None, group=None) -> nn.Module:
+    """`factory()` builds the model (e.g. lambda: DeepFM(...)); every rank calls this with the same seed.  The tables
+    are created row-sharded from the start — per-rank memory is arena / world plus one temporary table, never the full
+    arena — with the same initial values the single-process construction draws; dense parameters are replicated."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    with sharded_construction(world, rank, group, device):
+        if device is not None:
+            with torch.device(device):
+                model = factory()
+        else:
+            model = factory()
+    if world > 1:
+        sync_batchnorm(model, group)
     return model
 
 

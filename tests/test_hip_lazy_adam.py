@@ -19,11 +19,15 @@ def _gpu():
     hip.lib()
 
 
-@pytest.mark.parametrize("D", [64, 1, 6])  # 1: the LR_Layer's tables (scalar rows); 6: not a multiple of 4
-def test_lazy_rows_bit_identical_to_dense_kernel(D):
+# 1: the LR_Layer's tables (scalar rows); 6: not a multiple of 4; 64 / 40 / 100 / 200: the one-row-per-wave replay with
+# 1, 1 (partly filled), 2 and 4 floats per lane
+# steps = 97: replay chains of up to ~96 skipped steps (odd and even lengths: the replay loop is unrolled by two)
+@pytest.mark.parametrize("D,steps", [(64, 14), (1, 14), (6, 14), (40, 14), (100, 14), (200, 14), (64, 97), (40, 97),
+                                     (1, 97)])
+def test_lazy_rows_bit_identical_to_dense_kernel(D, steps):
     from rec_pangu_amd import hip
     g = torch.Generator().manual_seed(0)
-    R, steps = 5000, 14
+    R = 5000
     p0 = torch.randn(R, D, generator=g)
     b1, b2, eps = 0.9, 0.999, 1e-8
     pd, md, vd = p0.to(DEV), torch.zeros(R, D, device=DEV), torch.zeros(R, D, device=DEV)
@@ -36,7 +40,10 @@ def test_lazy_rows_bit_identical_to_dense_kernel(D):
         table[t] = torch.tensor(hip.adam_step_scalars(lr, b1, b2, t))
         dev_table = table.to(DEV)
         n = 300
-        rows = torch.cat([hot[torch.rand(40, generator=g) < 0.9], torch.randint(40, R // 2, (n,), generator=g)])
+        # (long runs: after step 10 only the first quarter is touched, so the rows of the second quarter that were
+        # updated early carry replay chains of up to steps - 1 skipped steps into the peeks and the final flush)
+        hi = R // 2 if (t <= 10 or steps <= 14) else R // 4
+        rows = torch.cat([hot[torch.rand(40, generator=g) < 0.9], torch.randint(40, hi, (n,), generator=g)])
         rows = rows[torch.randperm(rows.numel(), generator=g)]
         grad_rows = torch.randn(rows.numel(), D, generator=g)
         gd = torch.zeros(R, D).index_add_(0, rows, grad_rows).to(DEV)

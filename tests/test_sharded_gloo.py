@@ -31,18 +31,23 @@ def _build(name):
     return m
 
 
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, how, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     try:
-        from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads, ShardedEmbeddingLayer
+        from rec_pangu_amd.sharded import (shard_model_tables, build_sharded_model, allreduce_dense_grads,
+                                           ShardedEmbeddingLayer)
         g = load_golden(f"model_{name}.npz")
         B = g["batch"]["label"].shape[0]
         b = B // world
         local = {k: v[rank * b:(rank + 1) * b].clone() for k, v in g["batch"].items()}
-        model = shard_model_tables(_build(name), world, rank)
+        if how == "local":  # shard-local construction: the full arena never exists on any rank
+            model = build_sharded_model(lambda: _build(name), world, rank)
+            assert not any(type(m).__name__ == "EmbeddingLayer" for m in model.modules())
+        else:               # cut from a fully built model
+            model = shard_model_tables(_build(name), world, rank)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
         out = model(local)
         out["loss"].backward()
@@ -73,12 +78,12 @@ def _worker(rank, world, port, name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["deepfm", "xdeepfm"])
-def test_two_ranks_equal_single_process(name):
+@pytest.mark.parametrize("name,how", [("deepfm", "cut"), ("xdeepfm", "cut"), ("deepfm", "local"), ("xdeepfm", "local")])
+def test_two_ranks_equal_single_process(name, how):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), name, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, how, ret), nprocs=world, join=True)
     assert len(ret) == world
     g = load_golden(f"model_{name}.npz")
     # single-process run on the global batch
