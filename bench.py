@@ -89,11 +89,14 @@ def build_model(name, enc, hidden=(64, 64, 64)):
     raise ValueError(name)
 
 
+PMC_TAG = "deepfm"  # which profiles/r*_<tag>_pmc.json belongs to this run's configuration (set in main)
+
+
 def _pmc_rows():
-    """profiles/r*_pmc.json of the latest round: one row per (kernel name, grid size) with the mean duration rocprofv3
-    measured and the HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/summarize.py)."""
+    """profiles/r*_<config>_pmc.json of the latest round: one row per (kernel name, grid size) with the mean duration
+    rocprofv3 measured and the HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/summarize.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{PMC_TAG}_pmc.json")))
     if not files:
         return {}
     try:
@@ -215,6 +218,8 @@ def main():
     from rec_pangu_amd import hip
     from rec_pangu_amd.optim import make_adam
     hip.lib()
+    global PMC_TAG
+    PMC_TAG = args.model + ("_wide" if args.hidden != "64,64,64" else "") + ("_sharded" if args.sharded else "")
     if args.precision:
         hip.set_matmul_precision(args.precision)
     precision = hip.get_matmul_precision()

@@ -74,6 +74,9 @@ class EmbeddingLayer(nn.Module):
         self._fm_link = None     # functional.FMFold of the last gather that produced an FM term
         self._tag_tables()
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
+        # loading weights into a layer whose optimizer runs lazily: bring every row to the current step first, so that
+        # no skipped zero-gradient step is replayed on top of the loaded values later
+        self.register_load_state_dict_pre_hook(lambda module, *a, **k: module.flush_lazy())
 
     # ------------------------------------------------------------------ arena bookkeeping
     def _tables(self):
@@ -136,14 +139,26 @@ class EmbeddingLayer(nn.Module):
                 break
             off += r
         if ok and off == a.shape[0]:
+            tabs = self._tables()
+            if tabs and (getattr(tabs[0], "_rp_store", None) is None or tabs[0]._rp_store() is not self):
+                self._tag_tables()  # copy.deepcopy(model): the clone's tables still carried the original's weakref
             return
+        # a table was replaced behind our back (set_weights, .data assignment, load with assign=True): re-pack.
+        # Rows the lazy optimizer still owes steps to are brought up to date in the OLD arena first (the replaced table
+        # is not in it any more, the others are); the moment arenas survive a same-shape re-pack with every row
+        # stamped current, and are dropped (rebuilt by the optimizer) when the shape changed.
+        if self._lazy is not None:
+            self._lazy.flush(self)
         with torch.no_grad():
             tabs = self._tables()
-            arena = torch.cat([p.detach().reshape(p.shape[0], -1) for p in tabs], dim=0).contiguous()
+            arena = torch.cat([p.detach().to(device=a.device, dtype=a.dtype).reshape(p.shape[0], -1) for p in tabs],
+                              dim=0).contiguous()
         self.embedding_dim = arena.shape[1]
         self._point_at(arena)
         self._grad_arena, self._touched, self._grad_clean = None, None, True
         self._rows_sig_cache = None
+        if self._lazy is not None and self._lazy.m.shape != arena.shape:
+            self._lazy = None
 
     @property
     def arena(self) -> torch.Tensor:

@@ -17,6 +17,7 @@ All other parameters go through one multi-tensor dense launch.  `fuse_zero_grad=
 the same pass (the model.zero_grad() that follows optimizer.step() in the reference loop,
 model_pipeline.py:57-58).  CPU parameters are not handled here: make_adam builds torch.optim.Adam for those.
 """
+import weakref
 from typing import Dict, List
 
 import torch
@@ -30,16 +31,19 @@ class LazyAdamRows:
     kernel does)."""
     TABLE_CHUNK = 1024
 
-    def __init__(self, store, betas, eps):
+    def __init__(self, store, betas, eps, owner=None, t0: int = 0):
         a = store.arena
         self.m, self.v = torch.zeros_like(a), torch.zeros_like(a)
         self.last = torch.zeros((a.shape[0],), dtype=torch.int32, device=a.device)
         self.betas, self.eps = betas, eps
-        self.t = 0
-        self.flushed_t = 0
-        self._table = torch.zeros((1, 2), dtype=torch.float32, device=a.device)
+        self.owner = owner           # weakref to the FusedAdam this state belongs to
+        self.t = self.flushed_t = t0  # created mid-run (optimizer state loaded, arena re-packed): every row is current
+        # device table of per-step scalars, indexed by ABSOLUTE step: row j = step j's {lr_j/(1-b1^j), 1/sqrt(1-b2^j)};
+        # row 0 is unused.  Rows <= t0 are never read (no row carries a stamp below t0) but must exist: the kernels
+        # index the table with the step number.
+        self._table = torch.zeros((t0 + 1, 2), dtype=torch.float32, device=a.device)
         self._table_lr = None
-        self._table_from = 1
+        self._table_from = t0 + 1
 
     def apply(self, fn):
         self.m, self.v, self.last, self._table = fn(self.m), fn(self.v), fn(self.last), fn(self._table)
@@ -49,11 +53,16 @@ class LazyAdamRows:
         cap = self._table.shape[0] - 1
         if t_new <= cap and (self._table_lr == lr or t_new < self._table_from):
             return
+        assert cap >= t_new - 1, f"lazy Adam step table has {cap + 1} rows, step {t_new} needs rows up to {t_new - 1}"
         hi = t_new + self.TABLE_CHUNK
         rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s) for s in range(t_new, hi + 1)]
         new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
         self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
         self._table_lr, self._table_from = lr, t_new
+
+    def _check_table(self, t_target):
+        if self._table.shape[0] <= t_target:
+            raise RuntimeError(f"lazy Adam: step table has {self._table.shape[0]} rows but step {t_target} is needed")
 
     def _sorted_touched(self, store):
         sk = store._touched
@@ -65,22 +74,26 @@ class LazyAdamRows:
 
     def replay(self, store, sorted_keys):
         if self.t > 0:
+            self._check_table(self.t)
             hip.lazy_adam_rows(sorted_keys, store.embedding_dim, store.arena, None, self.m, self.v, self.last,
                                self._table, self.t, False, False, self.betas[0], self.betas[1], self.eps)
 
-    def step(self, store, lr):
+    def step(self, store, lr, zero_grad: bool = True):
         t_new = self.t + 1
         self._ensure_table(t_new, lr)
+        self._check_table(t_new)
         sk = self._sorted_touched(store)
         if sk is not None and sk.numel():
             hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
-                               self._table, t_new, True, True, self.betas[0], self.betas[1], self.eps)
+                               self._table, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps)
         self.t = t_new
-        store.grads_were_zeroed()
+        if zero_grad:  # FusedAdam(fuse_zero_grad=True): the gradient rows were cleared inside the step
+            store.grads_were_zeroed()
 
     def flush(self, store):
         if self.flushed_t == self.t:
             return
+        self._check_table(self.t)
         hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
                             self._table, self.t, self.betas[0], self.betas[1], self.eps)
         self.flushed_t = self.t
@@ -155,16 +168,23 @@ class FusedAdam(torch.optim.Optimizer):
                 use_lazy = self.lazy_tables
                 if use_lazy:
                     lz = store._lazy
+                    mine = lz is not None and lz.owner is not None and lz.owner() is self
+                    if lz is not None and not mine:
+                        # the state another optimizer left on the layer (an earlier fit() on the same model): bring the
+                        # rows to that optimizer's last step, then start over like a fresh torch.optim.Adam does
+                        store.flush_lazy()
+                        lz = None
                     if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
-                        lz = store._lazy = LazyAdamRows(store, (b1, b2), eps)
-                        lz.t = lz.flushed_t = step - 1
+                        lz = store._lazy = LazyAdamRows(store, (b1, b2), eps, owner=weakref.ref(self), t0=step - 1)
+                        self._adopt_loaded_state(store, lz.m, lz.v, lz)
                         self._expose_state(store, lz.m, lz.v)
-                    lz.step(store, lr)
+                    lz.step(store, lr, zero_grad=self.fuse_zero_grad)
                     continue
                 st = self._arena_state.get(sid)
                 if st is None or st["m"].shape != store.arena.shape or st["m"].device != store.arena.device:
                     st = {"m": torch.zeros_like(store.arena), "v": torch.zeros_like(store.arena)}
                     self._arena_state[sid] = st
+                    self._adopt_loaded_state(store, st["m"], st["v"], None)
                     self._expose_state(store, st["m"], st["v"])
                 ps.append(store.arena.view(-1))
                 gs.append(store.grad_arena.view(-1))
@@ -175,6 +195,32 @@ class FusedAdam(torch.optim.Optimizer):
             if ps:
                 hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
         return loss
+
+    def _adopt_loaded_state(self, store, m, v, lz):
+        """Moments that load_state_dict() put into self.state for the table Parameters (optimizer resume) are copied
+        into the freshly created moment arenas; with the lazy execution every row that has a moment is stamped
+        current at the loaded step (rows without one stay at 0: a zero-gradient step is the identity for them)."""
+        off, any_loaded = 0, False
+        for p in store.table_parameters():
+            r = p.shape[0]
+            st = self.state.get(p, None)
+            if st and "exp_avg" in st and st["exp_avg"].shape == p.shape and st["exp_avg"].data_ptr() != m[off:off + r].data_ptr():
+                m[off:off + r].copy_(st["exp_avg"])
+                v[off:off + r].copy_(st["exp_avg_sq"])
+                any_loaded = True
+            off += r
+        if any_loaded and lz is not None and lz.t > 0:
+            live = (m != 0).any(dim=1) | (v != 0).any(dim=1)
+            lz.last.copy_(live.to(torch.int32) * lz.t)
+
+    def load_state_dict(self, state_dict):
+        """torch semantics; the moments of arena-backed tables are adopted by the arena state at the next step()."""
+        self.flush()
+        super().load_state_dict(state_dict)
+        for store in list(self._stores.values()):
+            store._lazy = None  # rebuilt from the loaded moments (and the loaded step count) at the next step()
+        self._arena_state.clear()
+        self._plans.clear()
 
     def _expose_state(self, store, m, v):
         """per-table views of the moment arenas, so optimizer.state / state_dict() look like torch.optim.Adam's"""

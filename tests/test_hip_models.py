@@ -263,3 +263,257 @@ def test_sync_batchnorm_on_hip_single_rank():
             torch.testing.assert_close(outs[1][2][k], v, rtol=1e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+# ---- BASELINE config 4 (MMOE: 16 sparse x D=40 + 9 dense -> h=649, 4 experts x 128, towers [256,128], 2 tasks) ----------
+def _mmoe_config4(scale=64, dropouts=(0.0, 0.0)):
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from rec_pangu_amd.models.multi_task import MMOE
+    enc = bench.mmoe_enc_dict(scale)
+    torch.manual_seed(3)
+    model = MMOE(num_task=2, n_expert=4, embedding_dim=40, mmoe_hidden_dim=128, hidden_dim=[256, 128],
+                 dropouts=list(dropouts), enc_dict=enc)
+    return bench, enc, model
+
+
+def test_mmoe_config4_shape_midsize_vs_oracle():
+    """The whole model at BASELINE config 4's shape, B = 4096, TRAIN mode (batch-statistics BatchNorm in the towers,
+    dropout 0 so that the comparison is deterministic): both task predictions, the two-task loss and every gradient
+    against the CPU oracle (oracle/ref_ops.py::mmoe) on the same weights and the same unregistered gates."""
+    bench, enc, model = _mmoe_config4()
+    model.train()
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    gates = [g.clone() for g in model.gates]
+    gates_bias = [g.clone() for g in model.gates_bias]
+    B = 4096
+    batch = bench.synth_batch(enc, B, 5, "cpu")
+    ref = R.mmoe(sd, gates, gates_bias, enc, batch, 2, training=True)
+    ref["loss"].backward()
+    model = model.to(DEV)
+    out = model(_to_dev(batch))
+    out["loss"].backward()
+    for k in ("task1_pred", "task2_pred", "loss"):
+        torch.testing.assert_close(out[k].detach().cpu(), ref[k].detach(), rtol=0, atol=1e-4, msg=lambda m: f"{k}: {m}")
+    for k, p in model.named_parameters():
+        rg = sd[k].grad
+        if rg is None:
+            continue
+        # (Linear biases in front of a train-mode BatchNorm have a zero true gradient: both sides are rounding noise)
+        tol = 1e-4 * max(1e-3, float(rg.abs().max()))
+        got = torch.zeros_like(rg) if p.grad is None else p.grad.cpu()
+        assert (got - rg).abs().max() <= tol, f"grad {k}: {(got - rg).abs().max()} > {tol}"
+
+
+def test_mmoe_config4_full_size_properties():
+    """Config 4 at its full batch (65536), where no CPU oracle run is affordable — two size-independent properties:
+    (a) EVAL mode (running statistics): samples are independent, so the full batch equals its two halves run apart,
+        the loss is their mean and the gradients are the mean of the halves' gradients;
+    (b) TRAIN mode couples the batch through BatchNorm: the full-batch step must equal the same batch fed as two
+        halves to two models sharing statistics — which is what SyncBatchNorm1d computes; on one GPU we check the
+        equivalent statement that BatchNorm statistics of the full batch equal the pooled statistics of the halves:
+        running_mean/var after one train step on the full batch == the pooled mean / unbiased variance of the tower
+        inputs computed from the halves' own (mean, var, n)."""
+    bench, enc, model = _mmoe_config4(scale=16)
+    model = model.to(DEV)
+    B = 65536
+    full = bench.synth_batch(enc, B, 11, DEV)
+    halves = [{k: v[:B // 2] for k, v in full.items()}, {k: v[B // 2:] for k, v in full.items()}]
+
+    def run(batch):
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        out["loss"].backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        return [out[f"task{i}_pred"].detach().clone() for i in (1, 2)], float(out["loss"].detach()), grads
+
+    model.eval()  # (a)
+    pf, lf, gf = run(full)
+    p0, l0, g0 = run(halves[0])
+    p1, l1, g1 = run(halves[1])
+    for i in range(2):
+        torch.testing.assert_close(pf[i], torch.cat([p0[i], p1[i]]), rtol=1e-5, atol=1e-6)
+    assert abs(lf - 0.5 * (l0 + l1)) <= 1e-5 * max(1.0, abs(lf))
+    for k in gf:
+        ref = 0.5 * (g0[k] + g1[k])
+        tol = 2e-4 * max(1e-6, float(ref.abs().max()))
+        assert float((gf[k] - ref).abs().max()) <= tol, f"eval split: {k}: {float((gf[k] - ref).abs().max())} > {tol}"
+
+    # (b) train-mode statistics: full batch vs pooled halves
+    def bn_stats(batch):
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.reset_running_stats()
+                m.momentum = 1.0  # running_* = this batch's statistics
+        model.train()
+        with torch.no_grad():
+            model(batch)
+        return {n: (m.running_mean.clone(), m.running_var.clone()) for n, m in model.named_modules()
+                if isinstance(m, torch.nn.BatchNorm1d) and n.endswith("ctr_batchnorm_0")}
+
+    sf, s0, s1 = bn_stats(full), bn_stats(halves[0]), bn_stats(halves[1])
+    n = B // 2
+    for name in sf:
+        m0, v0 = s0[name]
+        m1, v1 = s1[name]
+        mean = 0.5 * (m0 + m1)
+        # unbiased variances of the halves -> pooled unbiased variance of the union
+        ss = (n - 1) * (v0 + v1) + n * ((m0 - mean) ** 2 + (m1 - mean) ** 2)
+        var = ss / (2 * n - 1)
+        torch.testing.assert_close(sf[name][0], mean, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sf[name][1], var, rtol=1e-4, atol=1e-5)
+
+
+# ---- a4: set_weights / set_pretrained_weights on the HIP device, with the lazy optimizer active ----------------------
+def test_set_weights_on_hip_with_lazy_adam():
+    """embedding.py:36-47 / base_model.py:61-90 on a HIP-resident model that has already trained with the exact lazy
+    Adam: (1) a replaced (trainable) table is re-packed into the arena, the rows of the other tables keep the values
+    the DENSE optimizer would have given them (their owed steps are flushed before the re-pack), and training goes
+    on; (2) a frozen table never moves and the other tables still train; (3) set_pretrained_weights' one-row-short
+    matrix (the reference's quirk) changes the arena size: the optimizer state follows and a lookup of the OOV id of
+    that column raises like the reference's nn.Embedding would."""
+    import numpy as np
+    from rec_pangu_amd.optim import make_adam, FusedAdam
+    g = load_golden("model_deepfm.npz")
+    batch = _to_dev(g["batch"])
+    other = {k: (v.flip(0) if v.dtype.is_floating_point else torch.zeros_like(v)) for k, v in batch.items()}
+
+    def train(model, opt, batches):
+        for b in batches:
+            model(b)["loss"].backward()
+            opt.step()
+            model.zero_grad()
+
+    # reference run: the same sequence with the DENSE execution of the optimizer
+    finals = {}
+    for lazy in (False, True):
+        model = build("deepfm").to(DEV)
+        opt = FusedAdam(model.parameters(), lr=1e-2, fuse_zero_grad=True, lazy_tables=lazy)
+        train(model, opt, [batch, other, other])           # rows of `batch` now owe two zero-gradient steps (lazy)
+        new_c3 = torch.full((51, 8), 0.25)                   # C3: vocab 50 + 1 rows; a CPU tensor, like a user would pass
+        model.embedding_layer.set_weights("C3", new_c3.clone(), trainable=True)
+        out = model(batch)                                   # re-packs (flushes owed steps first), then looks rows up
+        assert model.embedding_layer.arena.is_cuda
+        tabs = {c: model.embedding_layer.embedding_layer[c].weight for c in model.embedding_layer.emb_feature}
+        assert tabs["C3"].data_ptr() != new_c3.data_ptr() and tabs["C3"].is_cuda
+        finals[lazy] = {"pred": out["pred"].detach().clone(),
+                        "tables": {c: t.detach().clone() for c, t in tabs.items()}}
+        # training goes on with a fresh optimizer (what a second RankTrainer.fit does)
+        opt2 = make_adam(model, 1e-2)
+        out["loss"].backward()
+        opt2.step()
+        model.zero_grad()
+        train(model, opt2, [other])
+        sd = model.state_dict()
+        assert not torch.equal(sd["embedding_layer.embedding_layer.C3.weight"].cpu(), new_c3), "replaced table must train"
+        finals[lazy]["after"] = {k: v.clone() for k, v in sd.items()}
+    assert torch.equal(finals[False]["pred"], finals[True]["pred"])
+    for c in finals[False]["tables"]:
+        assert torch.equal(finals[False]["tables"][c], finals[True]["tables"][c]), f"table {c} after the re-pack"
+    for k in finals[False]["after"]:
+        assert torch.equal(finals[False]["after"][k], finals[True]["after"][k]), f"{k} after training on"
+
+    # (2) frozen table
+    model = build("deepfm").to(DEV)
+    frozen = torch.randn(8, 8, generator=torch.Generator().manual_seed(3))  # C1: vocab 7 + 1
+    model.embedding_layer.set_weights("C1", frozen.clone(), trainable=False)
+    opt = make_adam(model, 1e-2)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    train(model, opt, [batch, other, batch])
+    sd = model.state_dict()
+    assert torch.equal(sd["embedding_layer.embedding_layer.C1.weight"].cpu(), frozen), "a frozen table must not move"
+    assert not torch.equal(sd["embedding_layer.embedding_layer.C3.weight"], before["embedding_layer.embedding_layer.C3.weight"])
+    assert not model.embedding_layer.embedding_layer["C1"].weight.requires_grad
+
+    # (3) set_pretrained_weights: vocab_size rows (one short of vocab_size + 1), base_model.py:79
+    model = build("deepfm").to(DEV)
+    opt = make_adam(model, 1e-2)
+    train(model, opt, [batch])
+    rows0 = model.embedding_layer.arena.shape[0]
+    enc = dict(model.enc_dict)
+    enc["C2"] = {"a": 0, "b": 1, "c": 2, "vocab_size": 3}
+    model.enc_dict = model.embedding_layer.enc_dict = enc
+    np.random.seed(0)
+    model.set_pretrained_weights("C2", {"a": np.ones(8), "c": np.full(8, 2.0)}, trainable=True)
+    ok = {k: v.clone() for k, v in batch.items()}
+    ok["C2"] = ok["C2"].clamp(max=2)
+    opt = make_adam(model, 1e-2)
+    train(model, opt, [ok, ok])
+    assert model.embedding_layer.arena.shape[0] == rows0 - 1
+    w = model.state_dict()["embedding_layer.embedding_layer.C2.weight"]
+    assert w.shape == (3, 8)
+    bad = {k: v.clone() for k, v in ok.items()}
+    bad["C2"][0] = 3  # the OOV id has no row any more (the reference's quirk)
+    with pytest.raises(IndexError):
+        model(bad)
+
+
+def test_fused_adam_resume_and_second_optimizer():
+    """optimizer.state_dict() -> new FusedAdam.load_state_dict() continues bit-identically (moments of the arena-backed
+    tables and the step count included), also when the lazy state is (re)created at a step > 1 (the per-step scalar
+    table is indexed by absolute step); a SECOND optimizer on the same model starts from zero moments like a fresh
+    torch.optim.Adam (it must not inherit the first one's lazy state)."""
+    from rec_pangu_amd.optim import FusedAdam
+    g = load_golden("model_deepfm.npz")
+    batch = _to_dev(g["batch"])
+    other = {k: (v.flip(0) if v.dtype.is_floating_point else torch.zeros_like(v)) for k, v in batch.items()}
+    seq = [batch, other, other, batch, other, batch, batch]
+
+    def train(model, opt, batches):
+        for b in batches:
+            model(b)["loss"].backward()
+            opt.step()
+            model.zero_grad()
+
+    def fresh(lazy):
+        m = build("deepfm").to(DEV)
+        return m, FusedAdam(m.parameters(), lr=1e-2, fuse_zero_grad=True, lazy_tables=lazy)
+
+    for lazy in (True, False):
+        m_ref, o_ref = fresh(lazy)
+        train(m_ref, o_ref, seq)
+        m1, o1 = fresh(lazy)
+        train(m1, o1, seq[:4])
+        ck_model = {k: v.clone() for k, v in m1.state_dict().items()}
+        ck_opt = o1.state_dict()
+        ck_opt = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                            for k, st in ck_opt["state"].items()}, "param_groups": ck_opt["param_groups"]}
+        m2, o2 = fresh(lazy)
+        m2.load_state_dict(ck_model)
+        o2.load_state_dict(ck_opt)
+        train(m2, o2, seq[4:])
+        a, b = m_ref.state_dict(), m2.state_dict()
+        for k in a:
+            assert torch.equal(a[k], b[k]), f"lazy={lazy}: {k} differs after resume"
+        sa, sb = o_ref.state_dict()["state"], o2.state_dict()["state"]
+        for k in sa:
+            assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]), k
+
+    # second optimizer on a model that already trained lazily == a dense-executed second optimizer
+    outs = {}
+    for lazy in (True, False):
+        m, o = fresh(lazy)
+        train(m, o, seq[:3])
+        o_second = FusedAdam(m.parameters(), lr=3e-3, fuse_zero_grad=True, lazy_tables=lazy)
+        train(m, o_second, seq[3:6])
+        outs[lazy] = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in outs[True]:
+        assert torch.equal(outs[True][k], outs[False][k]), f"second optimizer: {k}"
+
+
+def test_fused_adam_without_fused_zero_grad_keeps_gradients():
+    """FusedAdam(lazy_tables=True, fuse_zero_grad=False) leaves the gradients in place after step() (torch
+    semantics: post-step inspection, accumulation across steps without zero_grad)."""
+    from rec_pangu_amd.optim import FusedAdam
+    g = load_golden("model_deepfm.npz")
+    batch = _to_dev(g["batch"])
+    model = build("deepfm").to(DEV)
+    opt = FusedAdam(model.parameters(), lr=1e-2, fuse_zero_grad=False, lazy_tables=True)
+    model(batch)["loss"].backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    opt.step()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.equal(p.grad, g1[k]), f"{k}: gradient changed by step()"
+    assert any(float(v.abs().max()) > 0 for k, v in g1.items() if "embedding_layer" in k)

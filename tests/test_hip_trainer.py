@@ -78,3 +78,83 @@ def test_multitask_trainer_on_hip(tmp_path):
     assert list(res["model_name"]) == names
     assert {"test_task1_roc_auc_score", "test_task2_log_loss"} <= set(res.columns)
     assert np.isfinite(res["test_task1_log_loss"]).all()
+
+
+def test_device_batch_loader_on_hip_through_rank_trainer(tmp_path):
+    """the encoded columns live on the HIP device and every batch is a dict of device slices.  The
+    shuffled loader consumes the global RNG like torch's DataLoader + RandomSampler, so RankTrainer.fit fed by it sees
+    the reference run's batches in the reference run's order and must land on its metrics and final weights — with
+    batches that never leave the device."""
+    from rec_pangu_amd.dataset import DeviceBatchLoader
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.trainer import RankTrainer
+    meta, train_loader, valid_loader, test_loader, enc, test_df = _loaders_in_reference_order()
+    ref = json.load(open(os.path.join(GOLDEN, "trainer.json")))
+    g = load_golden("trainer.npz")
+    bs = train_loader.batch_size
+    dl_train = DeviceBatchLoader(train_loader.dataset, bs, shuffle=True, device=DEV)
+    dl_valid = DeviceBatchLoader(valid_loader.dataset, valid_loader.batch_size, shuffle=False, device=DEV)
+    dl_test = DeviceBatchLoader(test_loader.dataset, test_loader.batch_size, shuffle=False, device=DEV)
+    torch.manual_seed(5)
+    first = next(iter(dl_train))
+    assert all(v.is_cuda for v in first.values())
+    torch.manual_seed(5)
+    host = next(iter(train_loader))
+    for k in host:
+        assert torch.equal(first[k].cpu(), host[k]), f"batch column {k} differs from the DataLoader's"
+    torch.manual_seed(ref["seed"])
+    model = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc)
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    valid_metric = trainer.fit(model, dl_train, dl_valid, epoch=ref["epoch"], lr=ref["lr"], device=DEV)
+    for k, v in ref["valid_metric"].items():
+        assert abs(valid_metric[k] - v) <= 2e-4, (k, valid_metric[k], v)
+    sd = model.state_dict()
+    for k, v in g["final"].items():
+        tol = 2e-4 * max(1e-2, float(v.abs().max()))
+        assert (sd[k].cpu() - v).abs().max() <= tol, k
+    test_metric = trainer.evaluate_model(model, dl_test, device=DEV)
+    for k, v in ref["test_metric"].items():
+        assert abs(test_metric[k] - v) <= 2e-4, (k, test_metric[k], v)
+    p_dl = trainer.predict_dataloader(model, dl_test, device=DEV)
+    np.testing.assert_allclose(np.asarray(p_dl), g["pred_dataloader"].numpy(), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_pinned_batch_loader_feeds_the_same_batches(shuffle, tmp_path):
+    """The host-fed path (columns in pinned host memory, double-buffered asynchronous copies on a side stream): the
+    same batch dicts as torch's DataLoader in the same order, on the device, also when the consumer is slower or
+    faster than the copies; and a RankTrainer.fit through it equals the fit through the device-resident loader."""
+    from rec_pangu_amd.dataset import DeviceBatchLoader, PinnedBatchLoader
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.trainer import RankTrainer
+    meta, train_loader, valid_loader, test_loader, enc, test_df = _loaders_in_reference_order()
+    ds = train_loader.dataset
+    ref_loader = torch.utils.data.DataLoader(ds, batch_size=24, shuffle=shuffle, num_workers=0)
+    pinned = PinnedBatchLoader(ds, 24, shuffle=shuffle, device=DEV, depth=2)
+    assert len(pinned) == len(ref_loader)
+    for epoch in range(2):
+        torch.manual_seed(11 + epoch)
+        want = [b for b in ref_loader]
+        torch.manual_seed(11 + epoch)
+        got = []
+        for i, b in enumerate(pinned):
+            assert all(v.is_cuda for v in b.values())
+            got.append({k: v.clone() for k, v in b.items()})  # (feature columns are views of recycled buffers)
+            if i % 2:
+                torch.cuda._sleep(2_000_000)  # a slow consumer: the next copies must not overwrite what it reads
+        assert len(got) == len(want)
+        for x, y in zip(want, got):
+            assert list(x) == list(y)
+            for k in x:
+                assert x[k].dtype == y[k].dtype and torch.equal(x[k], y[k].cpu()), k
+    finals = []
+    for cls in (DeviceBatchLoader, PinnedBatchLoader):
+        torch.manual_seed(3)
+        model = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc)
+        tl = cls(ds, 32, shuffle=True, device=DEV)
+        vl = cls(valid_loader.dataset, 32, shuffle=False, device=DEV)
+        m = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path)).fit(model, tl, vl, epoch=2, lr=1e-2, device=DEV)
+        finals.append((m, {k: v.clone() for k, v in model.state_dict().items()}))
+    assert finals[0][0] == finals[1][0]
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k

@@ -172,3 +172,74 @@ def test_device_batch_loader_yields_the_dataloader_batches(tmp_path):
     model = DeepFM(embedding_dim=4, hidden_units=[8], enc_dict=enc)
     m = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path)).fit(model, shuffled, fast, epoch=1, lr=1e-3)
     assert set(m) == {"roc_auc_score", "log_loss"}
+
+
+def test_device_batch_loader_reproduces_the_reference_run(tmp_path):
+    """With shuffle=True and no explicit generator DeviceBatchLoader consumes the global RNG exactly like torch's
+    DataLoader + RandomSampler (one base seed per iter(), one sampler seed + randperm per shuffled epoch), so a
+    RankTrainer.fit fed by it reproduces the reference's captured 2-epoch run: same batches in the same order, same
+    metrics, same final weights."""
+    from rec_pangu_amd.dataset import DeviceBatchLoader
+    meta, train_loader, valid_loader, test_loader, enc, _ = _loaders_in_reference_order()
+    torch.manual_seed(7)
+    a = [b for b in train_loader] + [b for b in valid_loader] + [b for b in train_loader]
+    torch.manual_seed(7)
+    ft = DeviceBatchLoader(train_loader.dataset, train_loader.batch_size, shuffle=True)
+    fv = DeviceBatchLoader(valid_loader.dataset, valid_loader.batch_size, shuffle=False)
+    b = [x for x in ft] + [x for x in fv] + [x for x in ft]
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    ref = json.load(open(os.path.join(GOLDEN, "trainer.json")))
+    g = load_golden("trainer.npz")
+    torch.manual_seed(ref["seed"])
+    model = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=enc)
+    valid_metric = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path)).fit(
+        model, ft, fv, epoch=ref["epoch"], lr=ref["lr"], device=torch.device("cpu"))
+    assert valid_metric == ref["valid_metric"]
+    for k, v in g["final"].items():
+        torch.testing.assert_close(model.state_dict()[k], v, rtol=1e-4, atol=1e-6)
+
+
+def test_baseline_config1_shape_on_cpu(tmp_path):
+    """BASELINE.json configs[0] as stated: DeepFM on a synthetic CSV-like frame with 13 dense + 26 sparse columns,
+    vocabularies <= 1e4, emb_dim = 16, bsz = 512, through get_dataloader -> RankTrainer.fit on the CPU (plumbing, no
+    GPU).  Checks the shapes that configuration implies, the first training batch against the CPU oracle on the same
+    weights, and that two epochs run through the reference's loop (metrics keys, checkpoints, a falling loss)."""
+    from oracle import ref_ops as R
+    rng = np.random.default_rng(0)
+    n = 3000
+    card = [int(c) for c in rng.integers(3, 10000, size=26)]
+    frame = {f"I{i + 1}": rng.gamma(2.0, 3.0, size=n).astype(np.float32) for i in range(13)}
+    for j, c in enumerate(card):
+        # Zipf-ish ids as strings (like Criteo's hashed categories); ids 0..c-1, the tail rarely seen
+        frame[f"C{j + 1}"] = np.char.add("v", np.minimum(rng.zipf(1.3, size=n) - 1, c - 1).astype(str))
+    z = 0.4 * (frame["I1"] - 6) / 4 + (np.char.equal(frame["C1"], "v0")).astype(np.float32) - 0.8
+    frame["label"] = (rng.random(n) < 1 / (1 + np.exp(-z))).astype(np.float32)
+    df = pd.DataFrame(frame)
+    schema = {"sparse_cols": [f"C{j + 1}" for j in range(26)], "dense_cols": [f"I{i + 1}" for i in range(13)],
+              "label_col": "label", "task_type": "ranking"}
+    train_loader, valid_loader, test_loader, enc = get_dataloader(df[:2048].copy(), df[2048:2560].copy(),
+                                                                  df[2560:].copy(), schema, batch_size=512)
+    assert sum("vocab_size" in v for v in enc.values()) == 26 and sum("min" in v for v in enc.values()) == 13
+    assert max(v["vocab_size"] for v in enc.values() if "vocab_size" in v) <= 10000
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=16, hidden_units=[64, 64, 64], enc_dict=enc)
+    assert model.dnn_input_dim == 26 * 16 + 13
+    torch.manual_seed(1)
+    b0 = next(iter(train_loader))
+    assert b0["C1"].shape == (512,) and b0["C1"].dtype == torch.int64 and b0["I1"].dtype == torch.float32
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = R.deepfm(sd, enc, b0)
+    out = model(b0)
+    torch.testing.assert_close(out["pred"], ref["pred"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(out["loss"], ref["loss"], rtol=0, atol=1e-6)
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    first = trainer.evaluate_model(model, valid_loader)
+    metric = trainer.fit(model, train_loader, valid_loader, epoch=2, lr=1e-3, device=torch.device("cpu"))
+    assert set(metric) == {"roc_auc_score", "log_loss"}
+    assert sorted(os.listdir(tmp_path)) == ["model_e_1.pth", "model_e_2.pth"]
+    assert metric["log_loss"] < first["log_loss"], (first, metric)
+    preds = trainer.predict_dataloader(model, test_loader)
+    assert len(preds) == len(df) - 2560 and all(0.0 <= p <= 1.0 for p in preds)
