@@ -91,13 +91,30 @@ class RankTrainer:
         torch.save(payload, os.path.join(model_ckpt_dir, filename))
         logger.info(f'Model Saved to {model_ckpt_dir}')
 
+    @staticmethod
+    def _is_sharded(model) -> bool:
+        return any(type(m).__name__ == "ShardedEmbeddingLayer" for m in model.modules())
+
+    def _save_sharded(self, model, enc_dict, model_ckpt_dir, filename):
+        """Row-sharded tables (rec_pangu_amd.sharded): every rank writes its shard, rank 0 merges them into the same
+        {'model': <reference state_dict keys>[, 'enc_dict']} file the reference writes (rec_pangu_amd.checkpoint)."""
+        from .checkpoint import save_checkpoint
+        save_checkpoint(model, enc_dict, model_ckpt_dir, filename=filename)
+        logger.info(f'Model Saved to {model_ckpt_dir}')
+
     def save_model(self, model, model_ckpt_dir: str):
+        if self._is_sharded(model):
+            return self._save_sharded(model, None, model_ckpt_dir, 'model.pth')
         self._save({'model': model.state_dict()}, model_ckpt_dir, 'model.pth')
 
     def save_all(self, model, enc_dict: dict, model_ckpt_dir: str):
+        if self._is_sharded(model):
+            return self._save_sharded(model, enc_dict, model_ckpt_dir, 'model.pth')
         self._save({'model': model.state_dict(), 'enc_dict': enc_dict}, model_ckpt_dir, 'model.pth')
 
     def save_train_model(self, model, model_ckpt_dir: str, model_str: str):
+        if self._is_sharded(model):
+            return self._save_sharded(model, None, model_ckpt_dir, f'model_{model_str}.pth')
         self._save({'model': model.state_dict()}, model_ckpt_dir, f'model_{model_str}.pth')
 
     # ---- evaluation / inference (trainer.py:166-236) --------------------------------------------

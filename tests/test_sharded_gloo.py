@@ -213,3 +213,111 @@ def test_mmoe_batchnorm_two_ranks_equal_single_process():
             assert (v - sd[k].detach()).abs().max() <= 2 * 2 * 1e-2 + 1e-6
             continue
         torch.testing.assert_close(v, sd[k].detach(), rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+
+
+# ---- sharded checkpoints in the reference layout, with optimizer state ---------------------------------
+def _ckpt_worker(rank, world, port, ckpt_dir, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from rec_pangu_amd.sharded import build_sharded_model, allreduce_dense_grads, ShardedEmbeddingLayer
+        from rec_pangu_amd.checkpoint import save_checkpoint, load_checkpoint
+        from rec_pangu_amd.trainer import RankTrainer
+        name = "xdeepfm"  # two sharded layers (D-wide tables + the LR_Layer's 1-wide ones)
+        g = load_golden(f"model_{name}.npz")
+        B = g["batch"]["label"].shape[0]
+        b = B // world
+        local = {k: v[rank * b:(rank + 1) * b].clone() for k, v in g["batch"].items()}
+        other = {k: (v.flip(0) if v.dtype.is_floating_point else (v * 0 + 1)) for k, v in local.items()}
+
+        def make(seed_shift=0):
+            m = build_sharded_model(lambda: _build(name), world, rank)
+            if seed_shift:  # different starting weights: a load must overwrite everything
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.add_(0.1 * seed_shift)
+            # (_build leaves xDeepFM in eval mode: its MLP's default dropout would make two runs incomparable)
+            return m, torch.optim.Adam(m.parameters(), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+
+        def train(m, opt, batches):
+            for bt in batches:
+                m(bt)["loss"].backward()
+                allreduce_dense_grads(m)
+                opt.step()
+                m.zero_grad()
+
+        def snapshot(m):
+            with torch.no_grad():
+                pred = m(local, is_training=False)["pred"].clone()
+            return {"pred": pred, "params": {k: p.detach().clone() for k, p in m.named_parameters()}}
+
+        seq = [local, other, other, local]
+        m_ref, o_ref = make()
+        train(m_ref, o_ref, seq)                      # the uninterrupted run
+        m1, o1 = make()
+        train(m1, o1, seq[:2])
+        save_checkpoint(m1, small_enc_dict(), ckpt_dir, optimizer=o1)
+        mid = snapshot(m1)
+        m2, o2 = make(seed_shift=1)                   # "new process": different weights, fresh optimizer
+        extra = load_checkpoint(m2, ckpt_dir, optimizer=o2)
+        assert extra["enc_dict"] == small_enc_dict()
+        loaded = snapshot(m2)
+        for k in mid["params"]:
+            assert torch.equal(mid["params"][k], loaded["params"][k]), f"load: {k}"
+        train(m2, o2, seq[2:])
+        a, c = snapshot(m_ref), snapshot(m2)
+        for k in a["params"]:
+            assert torch.equal(a["params"][k], c["params"][k]), f"resume differs from the uninterrupted run: {k}"
+        assert torch.equal(a["pred"], c["pred"])
+        # RankTrainer.save_all on a sharded model writes the reference layout too (rank 0 merges)
+        RankTrainer(num_task=1).save_all(m_ref, small_enc_dict(), os.path.join(ckpt_dir, "final"))
+        ret[rank] = {"mid_pred": mid["pred"], "final_pred": a["pred"],
+                     "n_sharded": sum(isinstance(x, ShardedEmbeddingLayer) for x in m_ref.modules())}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_checkpoint_reference_layout_resume_and_reshard(tmp_path):
+    """world-2 save -> (a) the merged model.pth has exactly the reference's state_dict keys and loads into a
+    single-process model whose predictions on the global batch equal the two ranks' predictions; (b) save / reload /
+    continue equals the uninterrupted run bit for bit (weights, Adam moments, step count: asserted in the workers);
+    (c) the same files re-shard to another world size (1) and the optimizer file carries per-table moments."""
+    from rec_pangu_amd.checkpoint import load_checkpoint
+    from rec_pangu_amd.sharded import build_sharded_model
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ckpt_dir = str(tmp_path / "ck")
+    mp.spawn(_ckpt_worker, args=(world, _free_port(), ckpt_dir, ret), nprocs=world, join=True)
+    assert len(ret) == world and ret[0]["n_sharded"] == 2
+    g = load_golden("model_xdeepfm.npz")
+    assert sorted(f for f in os.listdir(ckpt_dir) if f.endswith(".pth")) == [
+        "model.pth", "optimizer.pth", "shard_000_of_002.pth", "shard_001_of_002.pth"]
+    saved = torch.load(os.path.join(ckpt_dir, "model.pth"), weights_only=False)
+    assert sorted(saved.keys()) == ["enc_dict", "model"]
+    plain = _build("xdeepfm")
+    assert list(saved["model"].keys()) == list(plain.state_dict().keys()), "reference state_dict keys, in order"
+    plain.load_state_dict(saved["model"])  # examples/ranking/inference_example.py:29-37
+    plain.eval()
+    with torch.no_grad():
+        pred = plain({k: v.clone() for k, v in g["batch"].items()}, is_training=False)["pred"]
+    torch.testing.assert_close(torch.cat([ret[r]["mid_pred"] for r in range(world)]), pred, rtol=1e-5, atol=1e-6)
+    final = torch.load(os.path.join(ckpt_dir, "final", "model.pth"), weights_only=False)
+    plain.load_state_dict(final["model"])
+    with torch.no_grad():
+        pred = plain({k: v.clone() for k, v in g["batch"].items()}, is_training=False)["pred"]
+    torch.testing.assert_close(torch.cat([ret[r]["final_pred"] for r in range(world)]), pred, rtol=1e-5, atol=1e-6)
+    # (c) re-shard to world 1 (no process group needed to load), moments included
+    one = build_sharded_model(lambda: _build("xdeepfm"), 1, 0)
+    opt = torch.optim.Adam(one.parameters(), lr=1e-2)
+    load_checkpoint(one, ckpt_dir, optimizer=opt)
+    osd = torch.load(os.path.join(ckpt_dir, "optimizer.pth"), weights_only=False)
+    assert osd["step"] == 2
+    for lname in ("embedding_layer", "lr_layer.emb_layer"):
+        lay = one.get_submodule(lname)
+        full = torch.cat([saved["model"][f"{lname}.embedding_layer.{c}.weight"] for c in lay.emb_feature])
+        assert torch.equal(lay.local_arena.detach(), full)
+        m_full = torch.cat([osd["state"][f"{lname}.embedding_layer.{c}.weight"]["exp_avg"] for c in lay.emb_feature])
+        assert torch.equal(opt.state[lay.local_arena]["exp_avg"], m_full) and float(m_full.abs().max()) > 0
