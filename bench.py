@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; v_mfma_f32_32x32x16_bf16)
 HBM_COPY_GBS = 6300.0  # device-to-device copy ceiling measured on this part
 VALU_PEAK_TLANE = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T fp32 lane-instructions / s
-REPLAY_VALU_OPS = 6 + 2 * 5.0 / 3.0  # per zero-gradient element-step: 6 fma/mul + sqrt + rcp (5/3 slot each)
+REPLAY_VALU_OPS = 5 + 5.0 / 3.0  # per zero-gradient element-step: 5 fma/mul + one v_rcp_f32 (5/3 of a plain VALU slot)
 
 
 def criteo_enc_dict(scale=1):
@@ -495,8 +495,8 @@ def main():
                              "valu_issue_slots_per_element_step": REPLAY_VALU_OPS,
                              "achieved_Tlane_ops_per_s": round(ops / 1e12, 2), "peak": VALU_PEAK_TLANE,
                              "frac": round(ops / 1e12 / VALU_PEAK_TLANE, 4),
-                             "note": "the replay is a serial fp32 chain per element (2 transcendentals at 5/3 of a "
-                                     "plain VALU slot + 6 fma/mul per skipped step): VALU-bound, not HBM-bound"}
+                             "note": "the replay is a serial fp32 chain per element (5 fma/mul + one reciprocal at 5/3 of a "
+                                     "plain VALU slot per skipped step): VALU-bound, not HBM-bound"}
         return r
 
     kernels = {}

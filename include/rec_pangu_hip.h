@@ -317,7 +317,11 @@ int rp_sigmoid_bce_bwd(const float *pred, const float *label, const float *gloss
 
 /* ---- K11: fused Adam (torch.optim.Adam single-tensor operation order) -----------------------
  * replaces trainer.py:75 + model_pipeline.py:57-58 (optimizer.step(); model.zero_grad()).
- * n_tensors <= RP_MAX_FIELDS per call; zero_grad=1 also clears g (the fused zero_grad).       */
+ * n_tensors <= RP_MAX_FIELDS per call; zero_grad=1 also clears g (the fused zero_grad).
+ * The second-moment arrays (`v_ptrs`, and `v` of the lazy entry points below) hold s = sqrt(v), not v: Adam only uses
+ * sqrt(v), and a zero-gradient step is then s *= sqrt(b2) (one multiply, no transcendental) — chosen per element on
+ * g == 0 by the one update function all these kernels share, so dense and lazy execution stay bit-identical.  The
+ * host side squares s when it exports torch.optim.Adam-style state (rec_pangu_amd/optim.py).  */
 int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
                  const int64_t *sizes, int n_tensors, float lr, float beta1, float beta2, float eps,
                  int64_t step, int zero_grad, rp_stream_t stream);
@@ -333,8 +337,10 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  *                       last+1 .. t_target(-1); if real_step also apply step t_target with g = grad row
  *                       (and clear it if zero_grad); last[row] = t_target
  *   rp_lazy_adam_flush  replay every row up to t_target (before a checkpoint / state_dict / eval of raw tables)
- * Any D >= 1: 16-byte vector rows when D % 4 == 0 and the arenas are 16-byte aligned, scalar lanes otherwise (D = 1:
- * the LR_Layer's tables). */
+ * Any D >= 1.  Pure replays (real_step = 0) and the flush of rows wider than 16 floats run ONE ROW PER WAVE (the chain
+ * length differs per row: side by side in a wave every row would wait for the longest), candidates strided over the
+ * waves so that every wave sees the same mix of tables; the real step and narrow rows (D = 1: the LR_Layer's tables)
+ * use 16-byte vector lanes when D % 4 == 0 and the arenas are 16-byte aligned, scalar lanes otherwise. */
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
 int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,

@@ -45,12 +45,17 @@ def _world(group):
     return 1, 0
 
 
+SQRT_KEY = "exp_avg_sq_sqrt"  # FusedAdam keeps sqrt(second moment) (rec_pangu_amd/optim.py); torch.optim.Adam the moment
+
+
 def _table_state(optimizer, param):
-    """(exp_avg, exp_avg_sq) of one parameter, whatever optimizer holds it (torch.optim.Adam / FusedAdam)."""
+    """{'exp_avg': ..., 'exp_avg_sq' | 'exp_avg_sq_sqrt': ...} of one parameter: the optimizer's NATIVE second-moment
+    form is what gets saved, so that a resume with the same optimizer type is bit-exact; load converts when needed."""
     st = optimizer.state.get(param, None)
     if not st or "exp_avg" not in st:
         return None
-    return st["exp_avg"], st["exp_avg_sq"]
+    key = SQRT_KEY if SQRT_KEY in st else "exp_avg_sq"
+    return {"exp_avg": st["exp_avg"].detach().cpu(), key: st[key].detach().cpu()}
 
 
 def _step_of(optimizer) -> int:
@@ -93,14 +98,14 @@ def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, o
         for name, lay in layers.items():
             ts = _table_state(optimizer, lay.local_arena)
             if ts is not None:
-                opt["tables"][name] = {"exp_avg": ts[0].detach().cpu(), "exp_avg_sq": ts[1].detach().cpu()}
+                opt["tables"][name] = ts
         if rank == 0:
             for k, p in named.items():
                 if k in arena_keys:
                     continue
                 ts = _table_state(optimizer, p)
                 if ts is not None:
-                    opt["dense"][k] = {"exp_avg": ts[0].detach().cpu(), "exp_avg_sq": ts[1].detach().cpu()}
+                    opt["dense"][k] = ts
         payload["optimizer"] = opt
     torch.save(payload, shard_file(ckpt_dir, rank, world))
     if world > 1:
@@ -144,16 +149,17 @@ def merge_shards(ckpt_dir: str, world: int, enc_dict: Optional[dict], filename: 
         for r in rows[:-1]:
             base.append(base[-1] + r)
         parts = [s["layers"][lname]["local_arena"] for s in shards]
-        mparts = vparts = None
+        mparts = vparts = vkey = None
         if has_opt and lname in head["optimizer"]["tables"]:
+            vkey = SQRT_KEY if SQRT_KEY in head["optimizer"]["tables"][lname] else "exp_avg_sq"
             mparts = [s["optimizer"]["tables"][lname]["exp_avg"] for s in shards]
-            vparts = [s["optimizer"]["tables"][lname]["exp_avg_sq"] for s in shards]
+            vparts = [s["optimizer"]["tables"][lname][vkey] for s in shards]
         for f, col in enumerate(info["emb_feature"]):
             k = f"{lname}.embedding_layer.{col}.weight" if lname else f"embedding_layer.{col}.weight"
             model_sd[k] = _merge_table(parts, f, rows, base, D, world, parts[0].dtype)
             if mparts is not None:
                 opt_state[k] = {"exp_avg": _merge_table(mparts, f, rows, base, D, world, mparts[0].dtype),
-                                "exp_avg_sq": _merge_table(vparts, f, rows, base, D, world, vparts[0].dtype)}
+                                vkey: _merge_table(vparts, f, rows, base, D, world, vparts[0].dtype)}
     ckpt = {"model": model_sd}
     if enc_dict is not None:
         ckpt["enc_dict"] = enc_dict
@@ -163,12 +169,22 @@ def merge_shards(ckpt_dir: str, world: int, enc_dict: Optional[dict], filename: 
                     "state": opt_state}, os.path.join(ckpt_dir, "optimizer.pth"))
 
 
-def _install_moments(optimizer, param, exp_avg, exp_avg_sq, step: int):
+def _second_moment(saved: dict, want_sqrt: bool):
+    """the saved second moment in the form the loading optimizer keeps (exact when the forms agree)"""
+    if want_sqrt:
+        return saved[SQRT_KEY] if SQRT_KEY in saved else saved["exp_avg_sq"].sqrt()
+    return saved["exp_avg_sq"] if "exp_avg_sq" in saved else saved[SQRT_KEY] * saved[SQRT_KEY]
+
+
+def _install_moments(optimizer, param, exp_avg, second, step: int):
     from .optim import FusedAdam
     st = optimizer.state[param]
     st["exp_avg"] = exp_avg.to(device=param.device, dtype=param.dtype).clone()
-    st["exp_avg_sq"] = exp_avg_sq.to(device=param.device, dtype=param.dtype).clone()
-    if not isinstance(optimizer, FusedAdam):  # torch.optim.Adam keeps a per-parameter step tensor
+    if isinstance(optimizer, FusedAdam):
+        st.pop("exp_avg_sq", None)
+        st[SQRT_KEY] = second.to(device=param.device, dtype=param.dtype).clone()
+    else:  # torch.optim.Adam keeps the moment itself and a per-parameter step tensor
+        st["exp_avg_sq"] = second.to(device=param.device, dtype=param.dtype).clone()
         st["step"] = torch.tensor(float(step))
 
 
@@ -220,6 +236,7 @@ def load_checkpoint(model: nn.Module, ckpt_dir: str, optimizer=None, group=None,
             optimizer._arena_state.clear()
             optimizer._plans.clear()
         named = dict(model.named_parameters())
+        want_sqrt = hasattr(optimizer, "SQRT_KEY")
         for k, p in named.items():
             lname = k[:-len(".local_arena")] if k.endswith(".local_arena") else None
             if lname is not None and lname in layers:
@@ -234,7 +251,7 @@ def load_checkpoint(model: nn.Module, ckpt_dir: str, optimizer=None, group=None,
                         continue
                     any_state = True
                     first, lrow = lay._table_slice(f)
-                    sm, sv = st["exp_avg"][first::lay.world], st["exp_avg_sq"][first::lay.world]
+                    sm, sv = st["exp_avg"][first::lay.world], _second_moment(st, want_sqrt)[first::lay.world]
                     m[lrow:lrow + sm.shape[0]].copy_(sm)
                     v[lrow:lrow + sv.shape[0]].copy_(sv)
                 if any_state:
@@ -243,5 +260,5 @@ def load_checkpoint(model: nn.Module, ckpt_dir: str, optimizer=None, group=None,
                         lay._lazy = None
             elif k in opt_ck["state"]:
                 st = opt_ck["state"][k]
-                _install_moments(optimizer, p, st["exp_avg"], st["exp_avg_sq"], step)
+                _install_moments(optimizer, p, st["exp_avg"], _second_moment(st, want_sqrt), step)
     return {k: v for k, v in ckpt.items() if k != "model"}

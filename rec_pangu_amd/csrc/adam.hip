@@ -39,32 +39,45 @@ __device__ __forceinline__ f32x4 rp_rcp_fast(f32x4 x) {
                  __builtin_amdgcn_rcpf(x.w)};
 }
 
-// inv_bc2_sqrt = 1 / sqrt(1 - b2^t)
+// The second moment is kept as its SQUARE ROOT  s = sqrt(v)  (the `v` arrays of this file hold s).  Adam only ever
+// uses sqrt(v), and for a zero gradient  v <- b2 v  is  s <- sqrt(b2) s : one multiply instead of a multiply and a
+// transcendental — the lazy replay of skipped (zero-gradient) steps is bound by exactly this arithmetic.  With a
+// gradient  s <- sqrt(b2 s^2 + (1 - b2) g^2).  The choice is made PER ELEMENT on g == 0, by the one function every
+// kernel of this file calls, so "dense every step" and "lazy replay later" execute the same operations on the same
+// values: bit-identical.  Against torch.optim.Adam (which stores v) each step differs by <= 1 ulp in s.
+// Exported optimizer state squares s again (rec_pangu_amd/optim.py).
+// inv_bc2_sqrt = 1 / sqrt(1 - b2^t);  sqrt_b2 = (float)sqrt((double)b2)
+__device__ __forceinline__ float rp_sel_zero(float g, float a, float b) { return g == 0.f ? a : b; }
+__device__ __forceinline__ f32x4 rp_sel_zero(f32x4 g, f32x4 a, f32x4 b) {
+    return f32x4{g.x == 0.f ? a.x : b.x, g.y == 0.f ? a.y : b.y, g.z == 0.f ? a.z : b.z, g.w == 0.f ? a.w : b.w};
+}
+
 template <typename T>
-__device__ __forceinline__ void adam1(T &p, const T g, T &m, T &v, float one_m_b1, float b2, float one_m_b2,
-                                      float step_size, float inv_bc2_sqrt, float eps) {
+__device__ __forceinline__ void adam1(T &p, const T g, T &m, T &s, float one_m_b1, float b2, float sqrt_b2,
+                                      float one_m_b2, float step_size, float inv_bc2_sqrt, float eps) {
     const T c1 = rp_splat(one_m_b1, p), c2 = rp_splat(one_m_b2, p), ns = rp_splat(-step_size, p);
     m = rp_fma(g - m, c1, m);                      // m + (g - m)(1 - b1)
-    const T vb = v * b2;                           // rounded once
-    v = rp_fma(c2 * g, g, vb);                     // b2 v + ((1 - b2) g) g
-    const T denom = rp_fma(rp_sqrt_fast(v), rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
+    const T vb = (s * s) * b2;                     // b2 v, v = s^2
+    const T sg = rp_sqrt_fast(rp_fma(c2 * g, g, vb));  // sqrt(b2 v + ((1 - b2) g) g)
+    s = rp_sel_zero(g, s * sqrt_b2, sg);           // zero gradient: sqrt(b2) s, exactly what the replay computes
+    const T denom = rp_fma(s, rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
     p = rp_fma(ns, m * rp_rcp_fast(denom), p);     // p - step_size * (m / denom)
 }
 
-// a zero-gradient step (the lazy replay): the same function with g = 0 folded by hand — (0 - m)(1 - b1) + m and
-// b2 v + 0 round exactly as the general form does, so the result is bit-identical to adam1(p, 0, m, v, ...)
+// a zero-gradient step (the lazy replay): adam1(p, 0, m, s, ...) with the g == 0 branches folded by hand —
+// (0 - m)(1 - b1) + m rounds exactly as the general form does, and s takes the sqrt(b2) s branch
 template <typename T>
-__device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &v, float one_m_b1, float b2, float step_size,
+__device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &s, float one_m_b1, float sqrt_b2, float step_size,
                                                 float inv_bc2_sqrt, float eps) {
     const T c1 = rp_splat(one_m_b1, p), ns = rp_splat(-step_size, p);
     m = rp_fma(-m, c1, m);
-    v = v * b2;
-    const T denom = rp_fma(rp_sqrt_fast(v), rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
+    s = s * sqrt_b2;
+    const T denom = rp_fma(s, rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
     p = rp_fma(ns, m * rp_rcp_fast(denom), p);
 }
 
 template <bool ZERO_G>
-__global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, float b2, float one_m_b2,
+__global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, float b2, float sqrt_b2, float one_m_b2,
                                                    float step_size, float bc2_sqrt, float eps) {
     const int ti = blockIdx.y;
     float *__restrict__ P = a.p[ti];
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
         f32x4 p = reinterpret_cast<f32x4 *>(P)[e];
         const f32x4 g = reinterpret_cast<const f32x4 *>(G)[e];
         f32x4 m = reinterpret_cast<f32x4 *>(Mo)[e], v = reinterpret_cast<f32x4 *>(Vo)[e];
-        adam1<f32x4>(p, g, m, v, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps);
+        adam1<f32x4>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, step_size, bc2_sqrt, eps);
         reinterpret_cast<f32x4 *>(P)[e] = p;
         reinterpret_cast<f32x4 *>(Mo)[e] = m;
         reinterpret_cast<f32x4 *>(Vo)[e] = v;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
     for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         float p = P[e], m = Mo[e], v = Vo[e];
         const float g = G[e];
-        adam1<float>(p, g, m, v, one_m_b1, b2, one_m_b2, step_size, bc2_sqrt, eps);
+        adam1<float>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, step_size, bc2_sqrt, eps);
         P[e] = p;
         Mo[e] = m;
         Vo[e] = v;
@@ -126,11 +139,12 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
     dim3 grid((unsigned)bx, (unsigned)n_tensors);
     hipStream_t s = (hipStream_t)stream;
     const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
+    const float sqrt_b2 = (float)std::sqrt((double)beta2);
     if (zero_grad)
-        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, beta2, one_m_b2, step_size,
+        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, step_size,
                            bc2_sqrt, eps);
     else
-        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, beta2, one_m_b2, step_size,
+        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, step_size,
                            bc2_sqrt, eps);
     RP_LAUNCH_CHECK("adam_step");
     return RP_OK;
@@ -151,7 +165,7 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
 // (unique rows, no write race).
 // ------------------------------------------------------------------------------------------------
 struct LazyCfg {
-    float one_m_b1, b2, one_m_b2, eps;
+    float one_m_b1, b2, sqrt_b2, one_m_b2, eps;
 };
 
 template <int TPR, typename T>
@@ -180,13 +194,13 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
 #pragma unroll 4
             for (int j = l0 + 1; j <= t_catch; ++j) {
                 const float2 s = sc[j];
-                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.b2, s.x, s.y, c.eps);
+                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
             }
         }
         if (real_step) {
             const T g = *reinterpret_cast<const T *>(G + off);
             const float2 s = sc[t_target];
-            adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.one_m_b2, s.x, s.y, c.eps);
+            adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.sqrt_b2, c.one_m_b2, s.x, s.y, c.eps);
             if (zero_grad) *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
         }
         *reinterpret_cast<T *>(P + off) = p;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
 #pragma unroll 4
                     for (int j = l0[u] + 1; j <= t_target; ++j) {
                         const float2 s = sc[j];
-                        adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.b2, s.x, s.y, c.eps);
+                        adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
                     }
                     const int64_t off = rows[u] * D + cidx;
                     *reinterpret_cast<T *>(P + off) = p[u];
@@ -307,7 +321,7 @@ __device__ __forceinline__ void lazy_replay_candidates(bool need, int row, int l
         for (int j = l + 1; j <= t_target; ++j) {
             const float2 s = sc[j];  // uniform address: scalar load
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) adam1_zero_grad<float>(p[e], m[e], v[e], c.one_m_b1, c.b2, s.x, s.y, c.eps);
+            for (int e = 0; e < EPL; ++e) adam1_zero_grad<float>(p[e], m[e], v[e], c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
         }
         const int64_t off = (int64_t)r * D;
 #pragma unroll
@@ -426,7 +440,7 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
     RP_REQUIRE(t_target >= (real_step ? 1 : 0) && t_target < INT32_MAX, "lazy_adam_rows: bad step");
     if (n == 0) return RP_OK;
-    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps};
+    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)std::sqrt((double)beta2), (float)(1.0 - (double)beta2), eps};
     const int tpr = lazy_tpr(D, vw);
     const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
@@ -460,7 +474,7 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     RP_REQUIRE(D >= 1, "lazy_adam_flush: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v)) ? 4 : 1;
     if (rows == 0 || t_target <= 0) return RP_OK;
-    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps};
+    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)std::sqrt((double)beta2), (float)(1.0 - (double)beta2), eps};
     const int tpr = lazy_tpr(D, vw);
     int64_t nb = rp_cdiv(rows, 256 / tpr);
     if (nb > 65536) nb = 65536;

@@ -121,9 +121,22 @@ class FusedAdam(torch.optim.Optimizer):
         for store in self._stores.values():
             store.flush_lazy()
 
+    # The kernels keep the second moment as its square root (adam.hip: a zero-gradient step is then one multiply, which
+    # is what the lazy replay is bound by).  Live state: 'exp_avg', 'exp_avg_sq_sqrt'.  state_dict() adds the squared
+    # 'exp_avg_sq' torch.optim.Adam would hold (same keys, comparable / loadable there) and keeps the native tensor so
+    # that a FusedAdam resume is bit-exact; load_state_dict() accepts either.
+    SQRT_KEY = "exp_avg_sq_sqrt"
+
     def state_dict(self):
         self.flush()
-        return super().state_dict()
+        sd = super().state_dict()
+        out_state = {}
+        for k, st in sd["state"].items():
+            st = dict(st)
+            if self.SQRT_KEY in st:
+                st["exp_avg_sq"] = st[self.SQRT_KEY] * st[self.SQRT_KEY]
+            out_state[k] = st
+        return {"state": out_state, "param_groups": sd["param_groups"]}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -158,11 +171,11 @@ class FusedAdam(torch.optim.Optimizer):
                         continue
                 st = self.state[p]
                 if not st:
-                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                    st["exp_avg"], st[self.SQRT_KEY] = torch.zeros_like(p), torch.zeros_like(p)
                 ps.append(p.data)
                 gs.append(p.grad)
                 ms.append(st["exp_avg"])
-                vs.append(st["exp_avg_sq"])
+                vs.append(st[self.SQRT_KEY])
             for sid, store in stores.items():
                 self._stores[sid] = store
                 use_lazy = self.lazy_tables
@@ -206,7 +219,7 @@ class FusedAdam(torch.optim.Optimizer):
             st = self.state.get(p, None)
             if st and "exp_avg" in st and st["exp_avg"].shape == p.shape and st["exp_avg"].data_ptr() != m[off:off + r].data_ptr():
                 m[off:off + r].copy_(st["exp_avg"])
-                v[off:off + r].copy_(st["exp_avg_sq"])
+                v[off:off + r].copy_(st[self.SQRT_KEY])
                 any_loaded = True
             off += r
         if any_loaded and lz is not None and lz.t > 0:
@@ -217,6 +230,12 @@ class FusedAdam(torch.optim.Optimizer):
         """torch semantics; the moments of arena-backed tables are adopted by the arena state at the next step()."""
         self.flush()
         super().load_state_dict(state_dict)
+        for st in self.state.values():  # torch.optim.Adam layout -> native (sqrt of the second moment)
+            if self.SQRT_KEY in st:
+                st.pop("exp_avg_sq", None)
+            elif "exp_avg_sq" in st:
+                st[self.SQRT_KEY] = st.pop("exp_avg_sq").sqrt()
+            st.pop("step", None)
         for store in list(self._stores.values()):
             store._lazy = None  # rebuilt from the loaded moments (and the loaded step count) at the next step()
         self._arena_state.clear()
@@ -228,7 +247,8 @@ class FusedAdam(torch.optim.Optimizer):
         for p in store.table_parameters():
             r = p.shape[0]
             self.state[p]["exp_avg"] = m[off:off + r]
-            self.state[p]["exp_avg_sq"] = v[off:off + r]
+            self.state[p].pop("exp_avg_sq", None)
+            self.state[p][self.SQRT_KEY] = v[off:off + r]
             off += r
 
 
