@@ -302,6 +302,21 @@ int rp_batchnorm_apply(const float *x, int64_t ldx, const float *mean, const flo
 int rp_batchnorm_apply_bwd(const float *dy, int64_t lddy, const float *rstd, const float *gamma, float *dx,
                            int64_t lddx, int64_t M, int N, rp_stream_t stream);
 
+/* building blocks of a BatchNorm1d whose batch statistics span several ranks (SyncBatchNorm1d of rec_pangu_amd/sharded.py;
+ * mmoe.py:54 on the global batch).  The all-reduce between the stages is the caller's.
+ *   rp_batchnorm_colsum     out[n] = sum_m x[m,n]  (center NULL)  |  sum_m (x[m,n] - center[n])^2  (center given)
+ *   rp_batchnorm_bwd_sums   dbeta[n] = sum_m dy, dgamma[n] = sum_m dy * xhat  (xhat from the given mean / rstd)
+ *   rp_batchnorm_bwd_apply  dx = gamma * rstd * (dy - mean_dy - xhat * mean_dyx) with the given (global) means
+ * workspace: rp_batchnorm_workspace_bytes(M, N). */
+int rp_batchnorm_colsum(const float *x, int64_t ldx, const float *center, float *out, int64_t M, int N, void *workspace,
+                        size_t workspace_bytes, rp_stream_t stream);
+int rp_batchnorm_bwd_sums(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
+                          const float *rstd, float *dgamma, float *dbeta, int64_t M, int N, void *workspace,
+                          size_t workspace_bytes, rp_stream_t stream);
+int rp_batchnorm_bwd_apply(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
+                           const float *rstd, const float *gamma, const float *mean_dy, const float *mean_dyx,
+                           float *dx, int64_t lddx, int64_t M, int N, rp_stream_t stream);
+
 /* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
  * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
  *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)
@@ -365,6 +380,13 @@ int rp_route_workspace_bytes(int64_t n, int world, size_t *bytes);
 int rp_route_build(void *workspace, size_t workspace_bytes, const int32_t *sorted_keys, const int32_t *sorted_pos,
                    int64_t n, int world, int lbits, int32_t *slot_sorted, int64_t *slot_of_pair, int64_t *uniq_rows,
                    int64_t *counts, rp_stream_t stream);
+/* fixed-capacity form of the exchange (no host-side split sizes, hence no host sync per step): rewrites the compact
+ * slots of rp_route_build as owner * capacity + index within the owner (slot_sorted in place, slot_of_pair) and fills
+ * rows_padded[world * capacity] (zero-filled by the caller: unused slots ask for local row 0 and receive a zero
+ * gradient).  More than `capacity` unique requests for one owner: bit 1 of *err_flag is set, the step is invalid. */
+int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int world, int lbits,
+                 int64_t capacity, const int64_t *counts, int32_t *slot_sorted, int64_t *slot_of_pair,
+                 int64_t *rows_padded, int32_t *err_flag, rp_stream_t stream);
 
 #ifdef __cplusplus
 }

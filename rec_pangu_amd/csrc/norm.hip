@@ -360,3 +360,67 @@ extern "C" int rp_batchnorm_apply_bwd(const float *dy, int64_t lddy, const float
     RP_LAUNCH_CHECK("batchnorm_apply_bwd");
     return RP_OK;
 }
+
+
+// ---- building blocks of a BatchNorm whose statistics span several ranks (rec_pangu_amd/sharded.py SyncBatchNorm1d):
+// the local column sums come out of the same two-stage deterministic reductions, the all-reduce between the stages is
+// the caller's (RCCL), and the element-wise passes take the GLOBAL statistics.
+//   rp_batchnorm_colsum     out[n] = sum_m x[m,n]                    (center == NULL)
+//                           out[n] = sum_m (x[m,n] - center[n])^2     (center given: variance around the global mean)
+//   rp_batchnorm_bwd_sums   dbeta[n] = sum_m dy, dgamma[n] = sum_m dy * xhat   (xhat from the given mean / rstd)
+//   rp_batchnorm_bwd_apply  dx = gamma * rstd * (dy - mean_dy - xhat * mean_dyx)  with the given (global) means
+extern "C" int rp_batchnorm_colsum(const float *x, int64_t ldx, const float *center, float *out, int64_t M, int N,
+                                   void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(x && out && workspace && M >= 1 && N >= 1 && ldx >= N, "batchnorm_colsum: bad argument");
+    size_t need = 0;
+    rp_batchnorm_workspace_bytes(M, N, &need);
+    RP_REQUIRE(workspace_bytes >= need, "batchnorm_colsum: workspace %zu < %zu", workspace_bytes, need);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const BnPlan p = bn_plan(M, N);
+    dim3 pg((unsigned)p.nblk, (unsigned)p.ncolblk), fg((unsigned)rp_cdiv(N, 16));
+    hipStream_t s = (hipStream_t)stream;
+    if (center == nullptr)
+        hipLaunchKernelGGL((bn_partial_kernel<0>), pg, dim3(256), 0, s, x, ldx, nullptr, 0, nullptr, nullptr, M, N, p.ncl,
+                           p.rows, P);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<1>), pg, dim3(256), 0, s, x, ldx, nullptr, 0, center, nullptr, M, N, p.ncl,
+                           p.rows, P);
+    RP_LAUNCH_CHECK("batchnorm colsum partial");
+    hipLaunchKernelGGL(bn_finish_kernel, fg, dim3(256), 0, s, P, p.nblk, N, 1.f, 0.f, 0, out, nullptr, nullptr, nullptr);
+    RP_LAUNCH_CHECK("batchnorm colsum");
+    return RP_OK;
+}
+
+extern "C" int rp_batchnorm_bwd_sums(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
+                                     const float *rstd, float *dgamma, float *dbeta, int64_t M, int N, void *workspace,
+                                     size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(x && dy && mean && rstd && dgamma && dbeta && workspace && M >= 1 && N >= 1 && ldx >= N && lddy >= N,
+               "batchnorm_bwd_sums: bad argument");
+    size_t need = 0;
+    rp_batchnorm_workspace_bytes(M, N, &need);
+    RP_REQUIRE(workspace_bytes >= need, "batchnorm_bwd_sums: workspace %zu < %zu", workspace_bytes, need);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const BnPlan p = bn_plan(M, N);
+    float *mdy = P + (size_t)p.nblk * 2 * N, *mdyx = mdy + N;  // (the local means: not used by the caller)
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((bn_partial_kernel<2>), dim3((unsigned)p.nblk, (unsigned)p.ncolblk), dim3(256), 0, s, x, ldx, dy,
+                       lddy, mean, rstd, M, N, p.ncl, p.rows, P);
+    RP_LAUNCH_CHECK("batchnorm bwd partial");
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((unsigned)rp_cdiv(N, 16)), dim3(256), 0, s, P, p.nblk, N, 1.f / (float)M,
+                       0.f, 2, dbeta, dgamma, mdy, mdyx);
+    RP_LAUNCH_CHECK("batchnorm bwd sums");
+    return RP_OK;
+}
+
+extern "C" int rp_batchnorm_bwd_apply(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
+                                      const float *rstd, const float *gamma, const float *mean_dy,
+                                      const float *mean_dyx, float *dx, int64_t lddx, int64_t M, int N,
+                                      rp_stream_t stream) {
+    RP_REQUIRE(x && dy && mean && rstd && mean_dy && mean_dyx && dx && M >= 1 && N >= 1 && ldx >= N && lddy >= N &&
+               lddx >= N, "batchnorm_bwd_apply: bad argument");
+    const BnPlan p = bn_plan(M, N);
+    hipLaunchKernelGGL((bn_elem_kernel<1>), bn_elem_grid(M, p), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, mean,
+                       rstd, gamma, nullptr, mean_dy, mean_dyx, dx, lddx, M, N, p.ncl);
+    RP_LAUNCH_CHECK("batchnorm bwd apply");
+    return RP_OK;
+}

@@ -148,3 +148,55 @@ extern "C" int rp_route_build(void *workspace, size_t workspace_bytes, const int
     rp_count_launch();
     return RP_OK;
 }
+
+
+// Fixed-capacity form of one exchange (no host-side split sizes -> no host sync per step): every owner gets exactly
+// `capacity` request slots.  Rewrites the compact unique-request slots of rp_route_build as
+//     slot' = owner * capacity + (slot - first slot of that owner)
+// in slot_sorted (in place) and slot_of_pair, and writes the local rows to ask for into rows_padded[world * capacity]
+// (the caller zero-fills it: unused slots ask for local row 0, whose gradient contribution is then exactly zero).
+// An owner with more than `capacity` unique requests sets bit 1 of *err_flag (the requests beyond the capacity are
+// dropped: the caller must treat the step as failed and enlarge the capacity).
+__global__ __launch_bounds__(256) void route_pad_kernel(const int32_t *__restrict__ sk, const int32_t *__restrict__ sp,
+                                                        int64_t n, int world, int lbits, int64_t capacity,
+                                                        const int64_t *__restrict__ counts,
+                                                        int32_t *__restrict__ slot_sorted,
+                                                        int64_t *__restrict__ slot_of_pair,
+                                                        int64_t *__restrict__ rows_padded,
+                                                        int32_t *__restrict__ err_flag) {
+    __shared__ int64_t start[RP_MAX_FIELDS + 1];
+    if (threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (int o = 0; o < world; ++o) {
+            start[o] = acc;
+            if (counts[o] > capacity) *err_flag = (*err_flag) | 2;
+            acc += counts[o];
+        }
+    }
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t key = sk[j];
+    const int owner = key >> lbits;
+    int64_t within = (int64_t)slot_sorted[j] - start[owner];
+    const bool fits = within < capacity;
+    if (!fits) within = capacity - 1;  // dropped (flagged above): stay inside the buffer
+    const int64_t slot = (int64_t)owner * capacity + within;
+    slot_sorted[j] = (int32_t)slot;
+    slot_of_pair[sp[j]] = slot;
+    if (fits && (j == 0 || sk[j - 1] != key)) rows_padded[slot] = (int64_t)(key & ((1 << lbits) - 1));
+}
+
+extern "C" int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int world, int lbits,
+                            int64_t capacity, const int64_t *counts, int32_t *slot_sorted, int64_t *slot_of_pair,
+                            int64_t *rows_padded, int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && counts && slot_sorted && slot_of_pair && rows_padded && err_flag,
+               "route_pad: null pointer");
+    RP_REQUIRE(n >= 1 && n < INT32_MAX && world >= 1 && world <= RP_MAX_FIELDS && lbits >= 1 && lbits <= 30,
+               "route_pad: bad n/world/lbits");
+    RP_REQUIRE(capacity >= 1 && (int64_t)world * capacity < INT32_MAX, "route_pad: bad capacity");
+    hipLaunchKernelGGL(route_pad_kernel, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, sorted_keys,
+                       sorted_pos, n, world, lbits, capacity, counts, slot_sorted, slot_of_pair, rows_padded, err_flag);
+    RP_LAUNCH_CHECK("route_pad");
+    return RP_OK;
+}

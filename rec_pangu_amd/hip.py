@@ -82,6 +82,9 @@ _SIGNATURES = {
                                          _vp]),
     "rp_batchnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rp_batchnorm_apply_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_batchnorm_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "rp_batchnorm_bwd_sums": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "rp_batchnorm_bwd_apply": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
@@ -90,6 +93,7 @@ _SIGNATURES = {
     "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
                                     _vp]),
@@ -929,6 +933,52 @@ def route_build(sorted_keys, sorted_pos, world: int, lbits: int):
                                     lbits, slot_sorted.data_ptr(), slot_of_pair.data_ptr(), uniq_rows.data_ptr(),
                                     counts.data_ptr(), _stream()), "rp_route_build")
     return slot_sorted, slot_of_pair, uniq_rows, counts
+
+
+def route_pad(sorted_keys, sorted_pos, world: int, lbits: int, capacity: int, counts, slot_sorted, slot_of_pair, err_flag):
+    """fixed-capacity form of a route (rp_route_pad): slot_sorted / slot_of_pair are rewritten in place / overwritten;
+    -> rows_padded int64 [world * capacity] (local rows to ask each owner for, unused slots 0)."""
+    rows_padded = torch.zeros((world * capacity,), dtype=torch.int64, device=sorted_keys.device)
+    with _Timed("route_pad"):
+        _check(lib().rp_route_pad(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), world, lbits, capacity,
+                                  counts.data_ptr(), slot_sorted.data_ptr(), slot_of_pair.data_ptr(),
+                                  rows_padded.data_ptr(), err_flag.data_ptr(), _stream()), "rp_route_pad")
+    return rows_padded
+
+
+def batchnorm_colsum(x, center=None):
+    """column sums of x, or of (x - center)^2 (rp_batchnorm_colsum) -> [N]"""
+    _req(x, torch.float32, "x")
+    M, N = x.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    ws, nb = _bn_ws(M, N, x.device)
+    with _Timed("batchnorm_colsum", f"{M}x{N}", 4 * M * N):
+        _check(lib().rp_batchnorm_colsum(x.data_ptr(), _rowmajor(x, "x"), _ptr(center), out.data_ptr(), M, N, ws.data_ptr(),
+                                         nb, _stream()), "rp_batchnorm_colsum")
+    return out
+
+
+def batchnorm_bwd_sums(x, dy, mean, rstd):
+    """-> (dgamma [N] = sum dy * xhat, dbeta [N] = sum dy) over the local rows (rp_batchnorm_bwd_sums)"""
+    M, N = x.shape
+    dgamma, dbeta = (torch.empty((N,), dtype=torch.float32, device=x.device) for _ in range(2))
+    ws, nb = _bn_ws(M, N, x.device)
+    with _Timed("batchnorm_bwd_sums", f"{M}x{N}", 8 * M * N):
+        _check(lib().rp_batchnorm_bwd_sums(x.data_ptr(), _rowmajor(x, "x"), dy.data_ptr(), _rowmajor(dy, "dy"),
+                                           mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, N,
+                                           ws.data_ptr(), nb, _stream()), "rp_batchnorm_bwd_sums")
+    return dgamma, dbeta
+
+
+def batchnorm_bwd_apply(x, dy, mean, rstd, gamma, mean_dy, mean_dyx):
+    M, N = x.shape
+    dx = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _Timed("batchnorm_bwd_apply", f"{M}x{N}", 12 * M * N):
+        _check(lib().rp_batchnorm_bwd_apply(x.data_ptr(), _rowmajor(x, "x"), dy.data_ptr(), _rowmajor(dy, "dy"),
+                                            mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), mean_dy.data_ptr(),
+                                            mean_dyx.data_ptr(), dx.data_ptr(), N, M, N, _stream()),
+               "rp_batchnorm_bwd_apply")
+    return dx
 
 
 def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int):

@@ -60,10 +60,21 @@ class _Route:
             from . import hip
             idx = keys
             n = len(idx) * idx[0].numel()
-            comp = hip.shard_keys(layer._row_base, layer._row_count, idx, world, lbits, layer._err_flag(idx[0].device))
+            err = layer._err_flag(idx[0].device)
+            comp = hip.shard_keys(layer._row_base, layer._row_count, idx, world, lbits, err)
             sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # rocPRIM radix sort, (key, position) pairs
             self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
             self.pos_sorted = sp
+            self.n_requests = n
+            cap = layer._capacity if layer.check_indices == "deferred" else None
+            if cap is not None:
+                # fixed-capacity exchange: every owner gets `cap` slots, the split sizes are constants and nothing
+                # has to come back to the host (an owner asked for more than cap unique rows sets the error flag,
+                # which raise_if_bad_index() turns into an exception at the deferred check)
+                self.local_rows = hip.route_pad(sk, sp, world, lbits, cap, counts, self.slot_sorted, self.slot_of_pair, err)
+                self.send = self.recv = [cap] * world
+                self.n_unique = self.n_recv = cap * world
+                return
             send_counts = counts[:world]
             recv_counts = torch.empty_like(send_counts)
             dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
@@ -71,7 +82,11 @@ class _Route:
             self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
             self.n_unique, self.n_recv = sum(self.send), sum(self.recv)
             self.local_rows = uniq_rows[:self.n_unique]
-            self.n_requests = n
+            if layer.check_indices == "deferred":
+                # from the next step on: fixed capacity, 25 % above the largest per-owner count any rank saw now
+                m = torch.tensor([max(self.send + self.recv)], dtype=torch.int64, device=sk.device)
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=layer.group)
+                layer._capacity = (int(m.item()) * 5 // 4 + 1024 + 255) // 256 * 256
             return
         comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
         sk, sp = torch.sort(comp, stable=True)
@@ -206,6 +221,7 @@ class ShardedEmbeddingLayer(nn.Module):
         self._lazy = None
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
+        self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 
     def _tag(self):
@@ -260,9 +276,15 @@ class ShardedEmbeddingLayer(nn.Module):
             self._lazy.flush(self)
 
     def raise_if_bad_index(self):
-        if self._err is not None and int(self._err.item()) != 0:
-            self._err.zero_()
-            raise IndexError("index out of range in self")
+        if self._err is not None:
+            code = int(self._err.item())
+            if code != 0:
+                self._err.zero_()
+                if code & 2:
+                    cap, self._capacity = self._capacity, None  # re-measured by the next (exact) exchange
+                    raise RuntimeError(f"row exchange: an owner was asked for more than the fixed capacity of {cap} "
+                                       "unique rows; the steps since the last check dropped requests")
+                raise IndexError("index out of range in self")
 
     def _err_flag(self, device):
         if self._err is None or self._err.device != device:
@@ -380,35 +402,60 @@ class ShardedEmbeddingLayer(nn.Module):
 
 
 class _SyncBatchNormFn(torch.autograd.Function):
-    """BatchNorm1d over the GLOBAL batch (all ranks' local batches): one all-reduce of (sum, sum of squares, count)
-    per feature in forward, one of (sum dy, sum dy*xhat) in backward.  Gradients follow the local-loss convention of
+    """BatchNorm1d over the GLOBAL batch (all ranks' local batches).  Forward: all-reduce of (sum x, count), then of
+    sum (x - mean)^2 (variance around the GLOBAL mean: no E[x^2] - E[x]^2 cancellation); backward: one all-reduce of
+    (sum dy, sum dy * xhat).  On a HIP device the column sums and the element-wise passes are the rp_batchnorm_*
+    kernels (two-stage deterministic reductions), on the CPU torch ops.  Gradients follow the local-loss convention of
     this module (every rank backpropagates its own mean loss; row gradients are scaled 1/G when they travel and dense
     gradients are averaged by allreduce_dense_grads), so the means below are over all N = sum of local batch sizes."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps: float, group):
         C = x.shape[1]
-        stats = torch.cat([x.sum(0), (x * x).sum(0), x.new_tensor([float(x.shape[0])])])
+        hipdev = x.is_cuda
+        if hipdev:
+            from . import hip
+            x = Fh._unit_inner(x)
+            s1 = hip.batchnorm_colsum(x)
+        else:
+            s1 = x.sum(0)
+        stats = torch.cat([s1, x.new_tensor([float(x.shape[0])])])
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
         n = stats[-1]
         mean = stats[:C] / n
-        var = (stats[C:2 * C] / n - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
+        s2 = hip.batchnorm_colsum(x, mean.contiguous()) if hipdev else ((x - mean) ** 2).sum(0)
+        s2 = s2.clone()
+        dist.all_reduce(s2, op=dist.ReduceOp.SUM, group=group)
+        var = s2 / n  # biased, as F.batch_norm normalises with
         invstd = torch.rsqrt(var + eps)
-        xhat = (x - mean) * invstd
-        ctx.group = group
-        ctx.save_for_backward(xhat, invstd, weight, n)
+        ctx.group, ctx.hipdev = group, hipdev
+        if hipdev:
+            y = hip.batchnorm_apply(x, mean.contiguous(), invstd, weight, bias)
+            ctx.save_for_backward(x, mean.contiguous(), invstd, weight, n)
+        else:
+            xhat = (x - mean) * invstd
+            y = xhat * weight + bias
+            ctx.save_for_backward(xhat, None, invstd, weight, n)
         ctx.mark_non_differentiable(mean, var, n)
-        return xhat * weight + bias, mean, var, n
+        return y, mean, var, n
 
     @staticmethod
     def backward(ctx, dy, *_unused):
-        xhat, invstd, weight, n = ctx.saved_tensors
+        x_or_xhat, mean, invstd, weight, n = ctx.saved_tensors
         C = dy.shape[1]
-        dyx = dy * xhat
-        dw, db = dyx.sum(0), dy.sum(0)
+        if ctx.hipdev:
+            from . import hip
+            dy = Fh._unit_inner(dy)
+            dw, db = hip.batchnorm_bwd_sums(x_or_xhat, dy, mean, invstd)
+        else:
+            dw, db = (dy * x_or_xhat).sum(0), dy.sum(0)
         s = torch.cat([db, dw])
         dist.all_reduce(s, op=dist.ReduceOp.SUM, group=ctx.group)
-        dx = (weight * invstd) * (dy - s[:C] / n - xhat * (s[C:] / n))
+        if ctx.hipdev:
+            dx = hip.batchnorm_bwd_apply(x_or_xhat, dy, mean, invstd, weight, (s[:C] / n).contiguous(),
+                                         (s[C:] / n).contiguous())
+        else:
+            dx = (weight * invstd) * (dy - s[:C] / n - x_or_xhat * (s[C:] / n))
         return dx, dw, db, None, None
 
 
@@ -416,7 +463,7 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d whose training-mode statistics span every rank's local batch, so that a model with BatchNorm
     towers (MMOE & co.) trained on G ranks equals the single-process run on the global batch.  Same
     parameters, buffers and state_dict keys as nn.BatchNorm1d; eval mode is the stock layer.  Device-agnostic torch
-    ops (gloo on CPU, RCCL on HIP tensors)."""
+    ops on the CPU (gloo), the rp_batchnorm_* kernels + RCCL on HIP tensors."""
 
     group = None
 

@@ -585,3 +585,52 @@ def test_checkpoint_resume_on_hip(sharded, tmp_path):
     finally:
         if sharded:
             dist.destroy_process_group()
+
+
+def test_sharded_fixed_capacity_exchange_single_rank():
+    """check_indices == 'deferred' switches the row exchange to fixed per-owner capacities after the first (exact) step:
+    no split sizes come back to the host any more.  Under a 1-rank RCCL group the steps must give exactly the numbers
+    of the exact exchange, padding slots included (they ask for local row 0 and return a zero gradient), and an owner
+    asked for more than the capacity is reported at the deferred check."""
+    import socket
+    import torch.distributed as dist
+    from rec_pangu_amd.optim import make_adam
+    from rec_pangu_amd.sharded import shard_model_tables, allreduce_dense_grads, ShardedEmbeddingLayer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    try:
+        g = load_golden("model_deepfm.npz")
+        batch = _to_dev(g["batch"])
+        other = {k: (v.flip(0) if v.dtype.is_floating_point else torch.zeros_like(v)) for k, v in batch.items()}
+        finals = {}
+        for mode in ("sync", "deferred"):
+            model = shard_model_tables(build("deepfm").to(DEV), 1, 0)
+            lay = model.embedding_layer
+            lay.check_indices = mode
+            opt = make_adam(model, 1e-2)
+            preds = []
+            for b in (batch, other, batch, other):
+                out = model(b)
+                preds.append(out["pred"].detach().clone())
+                out["loss"].backward()
+                allreduce_dense_grads(model)
+                opt.step()
+                model.zero_grad()
+            lay.raise_if_bad_index()
+            assert (lay._capacity is not None) == (mode == "deferred")
+            finals[mode] = (preds, {k: v.clone() for k, v in model.state_dict().items()})
+        for a, b in zip(finals["sync"][0], finals["deferred"][0]):
+            assert torch.equal(a, b)
+        for k in finals["sync"][1]:
+            assert torch.equal(finals["sync"][1][k], finals["deferred"][1][k]), k
+        # capacity overflow is detected
+        lay._capacity = 4
+        model(batch)
+        with pytest.raises(RuntimeError, match="fixed capacity"):
+            lay.raise_if_bad_index()
+        assert lay._capacity is None
+    finally:
+        dist.destroy_process_group()
