@@ -317,6 +317,15 @@ int rp_batchnorm_bwd_apply(const float *x, int64_t ldx, const float *dy, int64_t
                            const float *rstd, const float *gamma, const float *mean_dy, const float *mean_dyx,
                            float *dx, int64_t lddx, int64_t M, int N, rp_stream_t stream);
 
+/* ---- Dropout (layers/deep.py:66-68 inside the MLP chain; the multi-task towers, mmoe.py:55) -------------------------
+ * y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10(counter = (element group, offset), key = seed): a
+ * pure function of (seed, offset, element index).  mask: uint8 [M*N] (1 = kept), saved for the backward
+ * dx = dy * keep / (1 - p).  One call consumes ONE offset value (the host advances its generator by one per call). */
+int rp_dropout_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
+                   uint64_t seed, uint64_t offset, rp_stream_t stream);
+int rp_dropout_bwd(const float *dy, int64_t lddy, const uint8_t *mask, float *dx, int64_t lddx, int64_t M, int N, float p,
+                   rp_stream_t stream);
+
 /* ---- K10: logit sum + sigmoid + BCE(mean) ---------------------------------------------------
  * replaces ranking/deepfm.py:61-63 (sigmoid + torch.nn.BCELoss) and multi_task/mmoe.py:127.
  *   z = sum_i z_ptrs[i][b] (n_addends <= 4; pass apply_sigmoid=0 when z is already a probability)

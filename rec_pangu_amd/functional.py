@@ -478,6 +478,32 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d):
 
 
 # ----------------------------------------------------------------------------------------------
+# Dropout (training mode, p > 0)   — layers/deep.py:66-68, the multi-task towers
+# ----------------------------------------------------------------------------------------------
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p: float):
+        x = _unit_inner(x)
+        y, mask = hip.dropout_fwd(x, p)
+        ctx.p = p
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return hip.dropout_bwd(_unit_inner(dy), mask, ctx.p), None
+
+
+def dropout(x, p: float):
+    """y = x * keep / (1 - p) on the HIP kernel (rp_dropout_*); x is [..., N], any leading shape."""
+    if x.dim() == 2:
+        return _Dropout.apply(x, float(p))
+    lead = x.shape[:-1]
+    return _Dropout.apply(x.reshape(-1, x.shape[-1]), float(p)).reshape(*lead, x.shape[-1])
+
+
+# ----------------------------------------------------------------------------------------------
 # K10  sum of logits -> sigmoid -> BCE(mean)   — ranking/deepfm.py:61-63, multi_task/mmoe.py:127
 # ----------------------------------------------------------------------------------------------
 class _SigmoidBCE(torch.autograd.Function):

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "rp_batchnorm_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_sums": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_apply": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_dropout_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp]),
+    "rp_dropout_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
@@ -978,6 +980,48 @@ def batchnorm_bwd_apply(x, dy, mean, rstd, gamma, mean_dy, mean_dyx):
                                             mean.data_ptr(), rstd.data_ptr(), _ptr(gamma), mean_dy.data_ptr(),
                                             mean_dyx.data_ptr(), dx.data_ptr(), N, M, N, _stream()),
                "rp_batchnorm_bwd_apply")
+    return dx
+
+
+_drop_calls = 0
+
+
+def _dropout_seed_offset(device):
+    """(seed, offset) for one dropout call, tied to torch's RNG state: the seed is the device generator's (set by
+    torch.manual_seed), the offset its Philox offset, advanced by 4 per call (the granularity torch accepts) so that
+    other torch random ops interleave consistently.  Falls back to a process-wide call counter if this torch build does
+    not expose generator offsets."""
+    global _drop_calls
+    try:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + 4)
+        return seed & 0xFFFFFFFFFFFFFFFF, off
+    except (AttributeError, RuntimeError):
+        _drop_calls += 1
+        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 4 * _drop_calls
+
+
+def dropout_fwd(x, p: float, seed: Optional[int] = None, offset: Optional[int] = None):
+    """-> (y, mask uint8 [M, N]); seed / offset default to torch's device generator state (advanced)."""
+    _req(x, torch.float32, "x")
+    M, N = x.shape
+    if seed is None:
+        seed, offset = _dropout_seed_offset(x.device)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    mask = torch.empty((M, N), dtype=torch.uint8, device=x.device)
+    with _Timed("dropout_fwd", f"{M}x{N}", 9 * M * N):
+        _check(lib().rp_dropout_fwd(x.data_ptr(), _rowmajor(x, "x"), y.data_ptr(), N, mask.data_ptr(), M, N, p, seed, offset,
+                                    _stream()), "rp_dropout_fwd")
+    return y, mask
+
+
+def dropout_bwd(dy, mask, p: float):
+    M, N = dy.shape
+    dx = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    with _Timed("dropout_bwd", f"{M}x{N}", 9 * M * N):
+        _check(lib().rp_dropout_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), mask.data_ptr(), dx.data_ptr(), N, M, N, p, _stream()),
+               "rp_dropout_bwd")
     return dx
 
 

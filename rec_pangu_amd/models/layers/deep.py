@@ -3,9 +3,9 @@
 The module tree is the reference's (`net` = nn.Sequential of Linear/BatchNorm1d/activation/Dropout
 in the same order, so state_dict keys `net.<i>.{weight,bias}` and the init RNG draws are identical).
 On a HIP device forward() walks `net` and runs every Linear (+ a directly following ReLU) as one
-fp32-MFMA launch with fused bias/ReLU epilogue (rp_linear_fwd); its backward is rp_linear_fwd on the
-transposed weight + rp_linear_wgrad.  Other modules in the chain (Dropout, BatchNorm1d, non-ReLU
-activations — none of which the reference's DeepFM uses) are applied as they are.
+matrix-core launch with fused bias/ReLU epilogue (rp_linear_fwd); its backward is rp_linear_fwd on the
+transposed weight + rp_linear_wgrad.  Dropout runs on rp_dropout_* (training mode; identity otherwise),
+BatchNorm1d on rp_batchnorm_*; non-ReLU activations are applied as they are.
 """
 from typing import List, Union
 
@@ -73,7 +73,13 @@ class MLP(nn.Module):
                 x = Fh.batch_norm(x, m)
                 pending = None
                 i += 1
-            elif isinstance(m, nn.Dropout) and not (self.training and m.p > 0):
+            elif isinstance(m, nn.Dropout):
+                if self.training and 0 < m.p < 1:
+                    x = Fh.dropout(x, m.p)  # rp_dropout_*: Philox mask, saved for the backward
+                    pending = None
+                elif self.training and m.p >= 1:
+                    x = m(x)
+                    pending = None
                 i += 1
             else:
                 x = m(x)

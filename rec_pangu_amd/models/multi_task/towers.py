@@ -6,7 +6,7 @@ mmoe.py:44-56, omoe.py:44-56, mlmmoe.py:52-64, sharebottom.py:40-52):
     loss = sum_t w_t * BCE(p_t (+ p_eps), y_t),   w_t = 1/T
 
 HIP execution: Linear on the fp32-MFMA kernel, BatchNorm1d on rp_batchnorm_*, the final sigmoid fused with
-the BCE in rp_sigmoid_bce_*; Dropout (torch RNG, reference stream) only when training with p > 0.
+the BCE in rp_sigmoid_bce_*; Dropout on rp_dropout_* (Philox mask) when training with p > 0.
 """
 import numpy as np
 import torch
@@ -70,8 +70,11 @@ def run_towers(model: nn.Module, inputs, data, is_training: bool, p_eps: float =
                 break  # fused into the loss / prediction kernel below
             elif isinstance(mod, nn.BatchNorm1d):
                 x_t = Fh.batch_norm(x_t, mod)
-            elif isinstance(mod, nn.Dropout) and not (model.training and mod.p > 0):
-                continue
+            elif isinstance(mod, nn.Dropout):
+                if model.training and 0 < mod.p < 1:
+                    x_t = Fh.dropout(x_t, mod.p)  # rp_dropout_*
+                elif model.training and mod.p >= 1:
+                    x_t = mod(x_t)
             else:
                 x_t = mod(x_t)
         if is_training:

@@ -348,3 +348,83 @@ def test_route_kernels_vs_torch(world, rows, b):
     assert int(counts[world]) == uniq.numel()
     assert torch.equal(counts[:world], torch.bincount(uniq >> lbits, minlength=world))
     assert torch.equal(uniq_rows[:uniq.numel()].cpu(), uniq & ((1 << lbits) - 1))
+
+
+@pytest.mark.parametrize("shape,p", [((4096, 64), 0.1), ((1000, 37), 0.5), ((65536, 256), 0.2), ((3, 5), 0.3)])
+def test_dropout_kernels(shape, p):
+    """rp_dropout_fwd/bwd (nn.Dropout of layers/deep.py:66-68 and the towers): y = x * keep / (1 - p) with a saved
+    mask; exact arithmetic given the mask, the mask a pure function of (seed, offset), keep rate = 1 - p within 5 sigma,
+    different offsets -> different masks, backward = dy * keep / (1 - p); strided (padded) inputs give the same mask."""
+    from rec_pangu_amd import hip
+    M, N = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, N, generator=g).to(DEV) + 3.0  # (no exact zeros)
+    y, mask = hip.dropout_fwd(x, p, seed=1234, offset=8)
+    y2, mask2 = hip.dropout_fwd(x, p, seed=1234, offset=8)
+    assert torch.equal(mask, mask2) and torch.equal(y, y2)
+    scale = 1.0 / (1.0 - p)
+    assert torch.equal(y, torch.where(mask.bool(), x * torch.tensor(scale, dtype=torch.float32), torch.zeros_like(x)))
+    keep = float(mask.float().mean())
+    sigma = (p * (1 - p) / (M * N)) ** 0.5
+    assert abs(keep - (1 - p)) <= 5 * sigma + 1e-9, (keep, 1 - p, sigma)
+    _, mask3 = hip.dropout_fwd(x, p, seed=1234, offset=12)
+    if M * N > 100:
+        assert not torch.equal(mask, mask3)
+    xp = torch.zeros(M, N + 7, device=DEV)
+    xp[:, :N] = x
+    _, mask4 = hip.dropout_fwd(xp[:, :N], p, seed=1234, offset=8)  # unaligned rows: scalar path, same mask
+    assert torch.equal(mask, mask4)
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    dx = hip.dropout_bwd(dy, mask, p)
+    assert torch.equal(dx, torch.where(mask.bool(), dy * torch.tensor(scale, dtype=torch.float32), torch.zeros_like(dy)))
+    # columns are not correlated with rows (a Philox counter bug would show up as a periodic mask)
+    if M >= 1000:
+        col = mask.float().mean(0)
+        assert float((col - (1 - p)).abs().max()) <= 6 * (p * (1 - p) / M) ** 0.5
+
+
+def test_dropout_follows_torch_seed_and_trains_without_aten():
+    """The autograd wrapper takes (seed, offset) from torch's device generator: torch.manual_seed reproduces a training
+    step bit for bit, consecutive calls differ; an xDeepFM / MMOE train step (default dropout 0.1 / 0.2) runs with
+    torch's own dropout disabled (the ATen kernels are not on the path)."""
+    import torch.nn.functional as TF
+    from rec_pangu_amd import functional as Fh
+    from test_host_models import CASES, build
+    from conftest import load_golden
+    x = torch.randn(512, 64, device=DEV, requires_grad=True)
+    torch.manual_seed(5)
+    a = Fh.dropout(x, 0.3)
+    b = Fh.dropout(x, 0.3)
+    torch.manual_seed(5)
+    a2 = Fh.dropout(x, 0.3)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    a.sum().backward()
+    assert torch.equal(x.grad != 0, a != 0)
+
+    def boom(*args, **kw):
+        raise AssertionError("torch's dropout was called on the HIP path")
+
+    saved = (TF.dropout, torch.dropout, torch.nn.functional.dropout)
+    TF.dropout = boom
+    torch.dropout = boom
+    try:
+        for name in ("xdeepfm", "mmoe_eval", "autoint_h2"):
+            g = load_golden(f"model_{name}.npz")
+            model = build(name).to(DEV)
+            model.train()
+            batch = {k: v.to(DEV) for k, v in g["batch"].items()}
+            torch.manual_seed(9)
+            o1 = model(batch)
+            o1["loss"].backward()
+            g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            model.zero_grad()
+            torch.manual_seed(9)
+            o2 = model(batch)
+            o2["loss"].backward()
+            assert torch.equal(o1["loss"], o2["loss"])
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    assert torch.equal(p.grad, g1[k]), k
+            assert torch.isfinite(o1["loss"])
+    finally:
+        TF.dropout, torch.dropout = saved[0], saved[1]
