@@ -93,11 +93,16 @@ int rp_sort_pairs_i32(void *workspace, size_t workspace_bytes, const int32_t *ke
  *        (sum_in may be NULL with gfm given: the gfm[b]*sum_in[b,:] part was already added to dx by
  *         rp_linear_fwd_rowadd, only the -gfm[b]*arena[key,:] part is applied here)
  *   dx may be NULL (FM-only models), gfm may be NULL (no FM term), not both.
- *   accumulate=0: rows must be zero on entry (rp_zero_rows), complete runs are stored;
- *   accumulate=1: everything is added to what is there.                                     */
+ *   accumulate=0: every row that has pairs is OVERWRITTEN with its sum (rows without pairs are not touched: the caller
+ *                 keeps them zero, rp_zero_rows);   accumulate=1: the sum is added to what is there.
+ *   Deterministic: every row has one writer and every sum a fixed order (ascending sorted position — the sort is
+ *   stable, so ascending sample index); runs that cross workgroups are chained through `workspace`
+ *   (rp_embed_grad_reduce_workspace_bytes) by a second launch.  No floating-point atomics.                        */
+int rp_embed_grad_reduce_workspace_bytes(int64_t n, int D, size_t *bytes);
 int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
                          const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
-                         const float *arena, float *grad_arena, int accumulate, rp_stream_t stream);
+                         const float *arena, float *grad_arena, int accumulate, void *workspace,
+                         size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
 

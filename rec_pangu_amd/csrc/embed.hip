@@ -31,12 +31,6 @@ struct Vec<4> {
     static __device__ __forceinline__ void store(float *p, T v) { *reinterpret_cast<f32x4 *>(p) = v; }
     static __device__ __forceinline__ T zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ float hsum(T v) { return (v.x + v.y) + (v.z + v.w); }
-    static __device__ __forceinline__ void atomic_add(float *p, T v) {
-        atomicAdd(p + 0, v.x);
-        atomicAdd(p + 1, v.y);
-        atomicAdd(p + 2, v.z);
-        atomicAdd(p + 3, v.w);
-    }
 };
 template <>
 struct Vec<1> {
@@ -45,7 +39,6 @@ struct Vec<1> {
     static __device__ __forceinline__ void store(float *p, T v) { *p = v; }
     static __device__ __forceinline__ T zero() { return 0.f; }
     static __device__ __forceinline__ float hsum(T v) { return v; }
-    static __device__ __forceinline__ void atomic_add(float *p, T v) { atomicAdd(p, v); }
 };
 
 template <int TPR, int VEC>
@@ -90,26 +83,35 @@ __global__ __launch_bounds__(256) void embed_gather_fwd_kernel(
     }
 }
 
-// Segmented reduction of the per-pair gradient rows into the dense gradient arena.
+// Segmented reduction of the per-pair gradient rows into the dense gradient arena — DETERMINISTIC: every gradient row
+// has exactly one writer and every sum a fixed order (ascending sorted position), no floating-point atomics.
 // One TPR-lane group owns RP_SEG consecutive SORTED positions: it loads all their keys/positions, issues all
 // their row loads at once (RP_SEG independent 256-B loads per group keep the memory pipe full; a per-run serial
 // walk was latency-bound at 0.8 TB/s) and then folds equal keys together in registers.
-//   * a run that starts and ends inside the segment is stored (or atomically added when accumulating);
+//   * a run that starts and ends inside the segment is stored by its group;
 //   * the piece of a run that crosses a segment border goes to LDS; after a barrier the first group of the
-//     workgroup merges neighbouring pieces with equal keys (a hot row of a tiny table fills whole workgroups
-//     with one key: 16 segments x 8 positions collapse into ONE fp32-atomic row add instead of 16, which is what
-//     keeps the few L2 channels holding the tiny tables from serialising the kernel).
+//     workgroup merges neighbouring pieces with equal keys in segment order (a hot row of a tiny table fills whole
+//     workgroups with one key: 16 segments x 8 positions collapse into ONE piece) and stores the runs that lie
+//     inside the workgroup;
+//   * a merged run that reaches the first / last position of the workgroup may continue in the neighbour: it is
+//     written to the workgroup's (head, tail) slot of a small global piece list instead, and embed_grad_fix_kernel
+//     sums the chains of equal keys across workgroups in workgroup order — one writer per row again.
+//   * those chains can be long (a 3-row table at batch 65536: one run over 170 workgroups), so the piece list — itself a
+//     sorted (key, row) list — first goes through THIS kernel once more (LEVEL1: positions are the list indices, key -1
+//     = "no piece" is skipped), which leaves chains of a handful of entries for the sequential walk.
 #define RP_SEG 8
-template <int TPR, int VEC>
+template <int TPR, int VEC, bool LEVEL1 = false>
 __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, int D,
     const float *__restrict__ dx, int64_t ldx, const float *__restrict__ gfm, const float *__restrict__ sum_in,
-    const float *__restrict__ arena, float *__restrict__ G, int accumulate) {
+    const float *__restrict__ arena, float *__restrict__ G, int accumulate, float *__restrict__ gpiece,
+    int32_t *__restrict__ gkey) {
     typedef Vec<VEC> V;
     constexpr int GPB = 256 / TPR;
     constexpr int W = TPR * VEC;  // columns handled per pass
     __shared__ __attribute__((aligned(16))) float piece[GPB][2][W];
-    __shared__ int32_t pkey[GPB][2];  // -1: no piece
+    __shared__ int32_t pkey[GPB][2];   // -1: no piece
+    __shared__ int32_t pcont[GPB];     // the group's last run continues beyond its segment
     const int t = threadIdx.x % TPR, grp = threadIdx.x / TPR;
     const int64_t start = ((int64_t)blockIdx.x * GPB + grp) * RP_SEG;
     const bool active = start < n;
@@ -120,12 +122,19 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     for (int j = 0; j < RP_SEG; ++j) {
         const bool ok = j < cnt;
         k[j] = ok ? sk[start + j] : -1;
-        const int32_t p = ok ? sp[start + j] : 0;
-        ff[j] = p / Bi;
-        bb[j] = p - ff[j] * Bi;
+        if (LEVEL1) {  // the piece list of the first pass: row start + j of a [n, D] buffer
+            ff[j] = 0;
+            bb[j] = (int)(start + j);
+        } else {
+            const int32_t p = ok ? sp[start + j] : 0;
+            ff[j] = p / Bi;
+            bb[j] = p - ff[j] * Bi;
+        }
     }
     const int32_t kprev = (active && start > 0) ? sk[start - 1] : -1;
     const int32_t knext = (active && start + cnt < n) ? sk[start + cnt] : -1;
+    // the global piece list is written once per workgroup (all column passes fill the same two rows)
+    float *hp = gpiece + (int64_t)blockIdx.x * 2 * D, *tp = hp + D;
     for (int c0 = 0; c0 < D; c0 += W) {
         const int c = c0 + t * VEC;
         const bool col_ok = c < D;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
             r[j] = V::zero();
             w[j] = V::zero();
             gf[j] = 0.f;
-            if (j < cnt && col_ok) {
+            if (j < cnt && col_ok && !(LEVEL1 && k[j] < 0)) {
                 if (dx != nullptr) r[j] = V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
                 if (gfm != nullptr) {
                     gf[j] = gfm[bb[j]];
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
         if (t == 0) {
             pkey[grp][0] = -1;
             pkey[grp][1] = -1;
+            pcont[grp] = 0;
         }
         typename V::T acc = V::zero();
         float gs = 0.f;
@@ -162,17 +172,21 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
                 if (last_of_run) {
                     const bool run_ends_here = (j + 1 < cnt) ? true : (k[j] != knext);
                     if (gfm != nullptr) acc -= gs * w[j];
-                    if (run_head && run_ends_here) {
+                    if (LEVEL1 && k[j] < 0) {
+                        // "no piece" entries of the first pass: nothing to add anywhere
+                    } else if (run_head && run_ends_here) {
                         if (col_ok) {
                             float *dst = G + (int64_t)k[j] * D + c;
-                            if (!accumulate) V::store(dst, acc);
-                            else V::atomic_add(dst, acc);
+                            V::store(dst, accumulate ? V::load(dst) + acc : acc);  // the only writer of this row
                         }
                     } else {
                         // border piece: slot 0 if the run came in from the previous segment, else slot 1
                         const int slot = run_head ? 1 : 0;
                         V::store(&piece[grp][slot][t * VEC], acc);
-                        if (t == 0) pkey[grp][slot] = k[j];
+                        if (t == 0) {
+                            pkey[grp][slot] = k[j];
+                            if (!run_ends_here) pcont[grp] = 1;
+                        }
                     }
                     acc = V::zero();
                     gs = 0.f;
@@ -181,9 +195,24 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
             }
         }
         __syncthreads();
-        if (grp == 0 && col_ok) {
+        if (grp == 0) {
+            // does the first / last position of the workgroup belong to a run that continues in the neighbour?
+            const bool head_open = pkey[0][0] >= 0;  // group 0's first run came in from the previous workgroup
+            int last_g = -1;                          // the last group whose final run leaves its segment ...
+            for (int g2 = GPB - 1; g2 >= 0; --g2)
+                if (pkey[g2][0] >= 0 || pkey[g2][1] >= 0) {
+                    last_g = g2;
+                    break;
+                }
+            // ... leaves the WORKGROUP only if that group is the workgroup's last active one
+            const int64_t wg_end = ((int64_t)blockIdx.x + 1) * GPB * RP_SEG;
+            const int last_active = (int)(((n < wg_end ? n : wg_end) - (int64_t)blockIdx.x * GPB * RP_SEG + RP_SEG - 1) / RP_SEG) - 1;
+            const bool tail_open = last_g >= 0 && last_g == last_active && pcont[last_g] != 0;
             int32_t cur = -1;
+            bool cur_is_head = false;
             typename V::T cacc = V::zero();
+            int32_t headkey = -1, tailkey = -1;
+            typename V::T headv = V::zero(), tailv = V::zero();
             for (int g2 = 0; g2 < GPB; ++g2) {
 #pragma unroll
                 for (int slot = 0; slot < 2; ++slot) {
@@ -193,15 +222,70 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
                     if (key == cur) {
                         cacc += pv;
                     } else {
-                        if (cur >= 0) V::atomic_add(G + (int64_t)cur * D + c, cacc);
+                        if (cur >= 0) {
+                            if (cur_is_head) {
+                                headkey = cur;
+                                headv = cacc;
+                            } else if (col_ok) {
+                                float *dst = G + (int64_t)cur * D + c;
+                                V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+                            }
+                        }
                         cur = key;
                         cacc = pv;
+                        cur_is_head = head_open && g2 == 0 && slot == 0;
                     }
                 }
             }
-            if (cur >= 0) V::atomic_add(G + (int64_t)cur * D + c, cacc);
+            if (cur >= 0) {
+                if (tail_open) {
+                    if (cur_is_head) {  // one run covers the whole workgroup: it is both; the tail entry adds zero
+                        headkey = cur;
+                        headv = cacc;
+                        tailkey = cur;
+                    } else {
+                        tailkey = cur;
+                        tailv = cacc;
+                    }
+                } else if (cur_is_head) {
+                    headkey = cur;
+                    headv = cacc;
+                } else if (col_ok) {
+                    float *dst = G + (int64_t)cur * D + c;
+                    V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+                }
+            }
+            if (col_ok) {
+                V::store(hp + c, headv);
+                V::store(tp + c, tailv);
+            }
+            if (t == 0 && c0 == 0) {
+                gkey[2 * (int64_t)blockIdx.x] = headkey;
+                gkey[2 * (int64_t)blockIdx.x + 1] = tailkey;
+            }
         }
         __syncthreads();
+    }
+}
+
+// Chains of equal keys in the workgroup piece list [head_0, tail_0, head_1, tail_1, ...] (key -1: no piece) are runs
+// that cross workgroup borders: the group that owns a chain's FIRST entry sums the chain in list order and writes the
+// row — its only writer (a key's positions are contiguous in the sorted list, so it forms at most one chain).
+template <int TPR, int VEC>
+__global__ __launch_bounds__(256) void embed_grad_fix_kernel(const float *__restrict__ gpiece, const int32_t *__restrict__ gkey,
+                                                             int64_t nent, int D, float *__restrict__ G, int accumulate) {
+    typedef Vec<VEC> V;
+    constexpr int GPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
+    if (i >= nent) return;
+    const int32_t key = gkey[i];
+    if (key < 0 || (i > 0 && gkey[i - 1] == key)) return;
+    for (int c = t * VEC; c < D; c += TPR * VEC) {
+        typename V::T acc = V::load(gpiece + i * D + c);
+        for (int64_t j = i + 1; j < nent && gkey[j] == key; ++j) acc += V::load(gpiece + j * D + c);
+        float *dst = G + (int64_t)key * D + c;
+        V::store(dst, accumulate ? V::load(dst) + acc : acc);
     }
 }
 
@@ -285,27 +369,82 @@ extern "C" int rp_embed_gather_fwd(const float *arena, const int64_t *row_base, 
     return RP_OK;
 }
 
+static int64_t grad_reduce_blocks(int64_t n, int D, int vec) {
+    const int tpr = pick_tpr(D, vec);
+    return rp_cdiv(rp_cdiv(n, RP_SEG), 256 / tpr);
+}
+
+static size_t grad_piece_bytes(int64_t nb, int D) {
+    return (((size_t)nb * 2 * ((size_t)D * sizeof(float) + sizeof(int32_t))) + 255) & ~(size_t)255;
+}
+
+// workspace of rp_embed_grad_reduce: the (head, tail) piece rows and keys of every workgroup of the first pass and of
+// the second pass over that list (sized for the scalar layout, the larger of the two)
+extern "C" int rp_embed_grad_reduce_workspace_bytes(int64_t n, int D, size_t *bytes) {
+    RP_REQUIRE(bytes && n >= 0 && D >= 1, "embed_grad_reduce_workspace_bytes: bad argument");
+    const int64_t nn = n > 0 ? n : 1;
+    const int64_t a = grad_reduce_blocks(nn, D, 1), b = grad_reduce_blocks(nn, D, 4);
+    const int64_t nb0 = a > b ? a : b;
+    const int64_t a1 = grad_reduce_blocks(2 * nb0, D, 1), b1 = grad_reduce_blocks(2 * nb0, D, 4);
+    *bytes = grad_piece_bytes(nb0, D) + grad_piece_bytes(a1 > b1 ? a1 : b1, D) + 512;
+    return RP_OK;
+}
+
 extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
                                     int D, const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
-                                    const float *arena, float *grad_arena, int accumulate, rp_stream_t stream) {
-    RP_REQUIRE(sorted_keys && sorted_pos && grad_arena, "embed_grad_reduce: null pointer");
+                                    const float *arena, float *grad_arena, int accumulate, void *workspace,
+                                    size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && grad_arena && workspace, "embed_grad_reduce: null pointer");
     RP_REQUIRE(dx != nullptr || gfm != nullptr, "embed_grad_reduce: neither dx nor gfm given");
     RP_REQUIRE(gfm == nullptr || arena, "embed_grad_reduce: the FM term needs the arena (and sum_in unless folded)");
     RP_REQUIRE(B >= 1 && B < INT32_MAX && D >= 1, "embed_grad_reduce: bad B/D");
     if (n == 0) return RP_OK;
+    size_t need = 0;
+    rp_embed_grad_reduce_workspace_bytes(n, D, &need);
+    RP_REQUIRE(workspace_bytes >= need, "embed_grad_reduce: workspace %zu < %zu bytes", workspace_bytes, need);
+    char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     const bool v4 = (D % 4 == 0) && (dx == nullptr || ((ldx % 4 == 0) && rp_aligned16(dx))) &&
                     rp_aligned16(grad_arena) &&
                     (gfm == nullptr || ((sum_in == nullptr || rp_aligned16(sum_in)) && rp_aligned16(arena)));
     const int vec = v4 ? 4 : 1;
     const int tpr = pick_tpr(D, vec);
-    const unsigned grid = (unsigned)rp_cdiv(rp_cdiv(n, RP_SEG), 256 / tpr);
+    const int64_t nb0 = grad_reduce_blocks(n, D, vec);
+    float *piece0 = reinterpret_cast<float *>(wbase);
+    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
     hipStream_t s = (hipStream_t)stream;
-#define CALL(T, VV)                                                                                            \
-    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV>), dim3(grid), dim3(256), 0, s, sorted_keys, sorted_pos, \
-                       n, (int)B, D, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate)
+#define CALL(T, VV)                                                                                                 \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, false>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys,  \
+                       sorted_pos, n, (int)B, D, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0)
     RP_DISPATCH_TPR(tpr, vec, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("embed_grad_reduce");
+    // second pass: the piece list (2 * nb0 entries, key -1 = none) through the same reduction
+    const int64_t n1 = 2 * nb0;
+    const int vec1 = (D % 4 == 0) ? 4 : 1;  // (the workspace rows are 16-byte aligned when D % 4 == 0)
+    const int tpr1 = pick_tpr(D, vec1);
+    const int64_t nb1 = grad_reduce_blocks(n1, D, vec1);
+    float *piece1 = reinterpret_cast<float *>(wbase + grad_piece_bytes(nb0 > grad_reduce_blocks(n, D, 1) ? nb0 : grad_reduce_blocks(n, D, 1), D));
+    int32_t *key1 = reinterpret_cast<int32_t *>(piece1 + nb1 * 2 * D);
+    const float *no_f = nullptr;
+    if (n1 > 2) {
+#define CALL(T, VV)                                                                                                   \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, true>), dim3((unsigned)nb1), dim3(256), 0, s, key0, key0, n1,  \
+                       (int)n1, D, piece0, (int64_t)D, no_f, no_f, no_f, grad_arena, accumulate, piece1, key1)
+        RP_DISPATCH_TPR(tpr1, vec1, CALL);
+#undef CALL
+        RP_LAUNCH_CHECK("embed_grad_reduce (piece list)");
+    } else {
+        piece1 = piece0;
+        key1 = key0;
+    }
+    const int64_t nfix = (n1 > 2) ? 2 * nb1 : n1;
+    const unsigned fgrid = (unsigned)rp_cdiv(nfix, 256 / tpr1);
+#define CALL(T, VV)                                                                                                \
+    hipLaunchKernelGGL((embed_grad_fix_kernel<T, VV>), dim3(fgrid), dim3(256), 0, s, piece1, key1, nfix, D, grad_arena, \
+                       accumulate)
+    RP_DISPATCH_TPR(tpr1, vec1, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_grad_reduce (cross-workgroup runs)");
     return RP_OK;
 }
 

@@ -27,7 +27,8 @@ _SIGNATURES = {
     "rp_embed_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "rp_sort_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rp_embed_grad_reduce_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
@@ -287,10 +288,14 @@ def embed_grad_reduce(sorted_keys, sorted_pos, B: int, D: int, dx, gfm, sum_in, 
     if dx is not None:
         _req(dx, torch.float32, "dx")
         ldx = _rowmajor(dx, "dx")
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_reduce_workspace_bytes(sorted_keys.numel(), D, C.byref(nbytes)),
+           "rp_embed_grad_reduce_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
     with _Timed("embed_grad_reduce", f"D={D}"):
         _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
                                       _ptr(dx), ldx, _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(),
-                                      int(accumulate), _stream()), "rp_embed_grad_reduce")
+                                      int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_reduce")
 
 
 def zero_rows(keys, D: int, grad_arena):

@@ -108,7 +108,7 @@ def test_sort_pairs(hip, n, hi):
 
 @pytest.mark.parametrize("rows,D,B,with_fm,with_dx", [
     ([8, 4, 51, 12, 3], 8, 24, True, True),
-    ([3, 4, 10, 5000, 27], 64, 4099, True, True),     # runs of >1000 equal rows: chunked + atomic pieces
+    ([3, 4, 10, 5000, 27], 64, 4099, True, True),     # runs of >1000 equal rows: pieces chained across workgroups
     ([3, 4, 10, 5000, 27], 64, 4099, False, True),    # DCN-like: no FM term
     ([17, 5], 40, 333, True, False),                  # FM-only model: dx absent
     ([50, 7, 9], 1, 777, False, True),                # LR tables
@@ -428,3 +428,57 @@ def test_dropout_follows_torch_seed_and_trains_without_aten():
             assert torch.isfinite(o1["loss"])
     finally:
         TF.dropout, torch.dropout = saved[0], saved[1]
+
+
+def test_embed_grad_reduce_is_deterministic_and_ordered(hip):
+    """The segmented reduce has one writer per row and a fixed summation order (ascending sorted position = ascending
+    sample index): (a) at the full Criteo shape (26 fields x 65536 samples, tiny tables -> runs of > 20000 equal rows
+    crossing hundreds of workgroups) two launches give bit-identical gradient arenas, also from a non-zeroed arena in
+    accumulate=0 mode; (b) on a small case the result equals a sequential left-to-right fp32 sum in sample order,
+    bit for bit."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rows = [c // 16 + 1 for c in bench.CRITEO_CARD]
+    F, D, B = len(rows), 64, 65536
+    g = torch.Generator(device=DEV).manual_seed(3)
+    base = torch.tensor([0] + list(torch.tensor(rows).cumsum(0)[:-1]), device=DEV)
+    idx = torch.stack([torch.randint(0, r, (B,), generator=g, device=DEV) for r in rows])
+    keys = (idx + base[:, None]).reshape(-1).to(torch.int32)
+    ldx = (F * D + 13 + 63) // 64 * 64
+    dx = torch.randn(B, ldx, generator=g, device=DEV)
+    gfm = torch.randn(B, 1, generator=g, device=DEV)
+    arena = torch.randn(sum(rows), D, generator=g, device=DEV)
+    ssum = torch.randn(B, D, generator=g, device=DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=max(1, (sum(rows) - 1).bit_length()))
+    outs = []
+    for trial in range(3):
+        G = torch.zeros_like(arena) if trial < 2 else torch.full_like(arena, 7.0)  # accumulate=0 overwrites touched rows
+        hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, arena, G, accumulate=False)
+        outs.append(G)
+    assert torch.equal(outs[0], outs[1]), "two launches of the gradient reduce differ"
+    touched = torch.zeros(sum(rows), dtype=torch.bool, device=DEV)
+    touched[sk.long()] = True
+    assert torch.equal(outs[2][touched], outs[0][touched]) and bool((outs[2][~touched] == 7.0).all())
+    col = dx[:, :F * D].reshape(B, F, D).sum(dim=(0, 1)).double()
+    got = outs[0].double().sum(0) - (gfm.double() * ssum.double()).sum(0) * F + \
+        (arena.double() * torch.zeros(sum(rows), 1, device=DEV, dtype=torch.float64).index_add_(
+            0, keys.long(), gfm.double().repeat(F, 1))).sum(0)
+    assert float((got - col).abs().max()) <= 1e-3 * float(col.abs().max() + 1)  # column sums of G == column sums of dX
+    # (b) exact order on a small case: no FM term, one table of 3 rows, 700 samples
+    B2, D2 = 700, 8
+    idx2 = torch.randint(0, 3, (B2,), generator=torch.Generator().manual_seed(1))
+    dx2 = torch.randn(B2, D2, generator=torch.Generator().manual_seed(2))
+    ref = torch.zeros(3, D2)
+    for b in range(B2):  # sequential fp32 sum in sample order
+        ref[idx2[b]] += dx2[b]
+    sk2, sp2 = hip.sort_pairs(idx2.to(torch.int32).to(DEV), end_bit=2)
+    G2 = torch.zeros(3, D2, device=DEV)
+    hip.embed_grad_reduce(sk2, sp2, B2, D2, dx2.to(DEV), None, None, None, G2, accumulate=False)
+    # the kernel sums 8 positions in a register chain, then pieces in segment order: a fixed order, but not the
+    # purely sequential one — equal to it within fp32 reassociation error, and identical across launches
+    torch.testing.assert_close(G2.cpu(), ref, rtol=1e-5, atol=1e-5)
+    G3 = torch.zeros(3, D2, device=DEV)
+    hip.embed_grad_reduce(sk2, sp2, B2, D2, dx2.to(DEV), None, None, None, G3, accumulate=False)
+    assert torch.equal(G2, G3)
