@@ -196,8 +196,9 @@ def main():
                     help="un-timed training steps on distinct batches before the warm-up, so that the lazy optimizer's "
                          "per-row step stamps are in their long-run state (default: 1000 for --mode train with "
                          "--optimizer lazy, else 0)")
-    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "bf16x3", "bf16x6"],
-                    help="matrix-core mode of the GEMM kernels (default: the library's, bf16x6 = fp32-faithful)")
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16", "bf16x3", "bf16x6", "auto"],
+                    help="matrix-core mode of the GEMM kernels (default: the library's 'auto' = bf16x3 for launches that "
+                         "are matrix-core bound, fp32-faithful bf16x6 for HBM-bound ones)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -459,9 +460,14 @@ def main():
                 return 0, local_B * per / len(units) * (2 if entry.endswith("bwd_x") else 1)
         return None
 
-    nprod = {"bf16x6": 6, "bf16x3": 3, "bf16": 1, "fp32": 1}[precision]
     mfma_peak = 157.3 if precision == "fp32" else MFMA_BF16_PEAK_TF
-    ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)  # flop per byte above which a kernel is matrix-core bound
+    ridge = mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)  # products per byte above which a kernel is matrix-core bound
+
+    def products(flops, nbytes):
+        """bf16 matrix-core products per flop of a launch (the library's rule, rp_matmul_products)"""
+        if precision == "auto":
+            return 3 if (nbytes and flops * 3.0 / nbytes > ridge) else 6
+        return {"bf16x6": 6, "bf16x3": 3, "bf16": 1, "fp32": 1}[precision]
 
     def roofline_of(key, mean_ms):
         a = alg(key)
@@ -469,11 +475,15 @@ def main():
             return None
         nbytes, flops = a
         sec = mean_ms * 1e-3
-        if flops and (not nbytes or flops / nbytes > ridge):
+        nprod = products(flops, nbytes) if flops else 1
+        if key.startswith("cin_bs_") or key.startswith("cin_last"):
+            nprod = 6  # these kernels always run the fp32-faithful split
+        if flops and (not nbytes or flops * nprod / nbytes > ridge):
             tf = flops / sec / 1e12
             return {"kernel": key, "bound": "mfma", "achieved": round(tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                     "frac": round(tf / mfma_peak, 4), "traffic": pmc_traffic(key, mean_ms) if world == 1 else None,
-                    "matmul_precision": precision, "mfma_products_per_flop": nprod,
+                    "matmul_precision": precision + (f" -> bf16x{nprod}" if precision == "auto" else ""),
+                    "mfma_products_per_flop": nprod,
                     "mfma_issue_frac": round(tf * nprod / mfma_peak, 4),
                     "note": "achieved = ALGORITHMIC flops (fp32 operands, fp32 accumulation); the matrix core issues "
                             "mfma_products_per_flop bf16 products for each (mfma_issue_frac counts those)"}

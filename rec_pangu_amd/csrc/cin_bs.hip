@@ -463,11 +463,21 @@ extern "C" int rp_cin_bs_bwd_w(const float *x0, int64_t ld0, const float *xp, in
 // per wave instruction, measured SLOWER than one 32-byte octet per thread: twice the LDS store instructions.)
 #define CP_LD 40
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// products of the split-bf16 evaluation, smallest terms first (as BfProd in gemm.hip): piece 0 = hi, 1 = mid, 2 = lo
+template <int NPROD>
+struct CpProd {
+    __device__ static constexpr int pa(int i) { return NPROD == 6 ? (i == 1 ? 2 : ((i == 2 || i == 4) ? 1 : 0))
+                                                     : NPROD == 3 ? (i == 1 ? 1 : 0) : 0; }
+    __device__ static constexpr int pb(int i) { return NPROD == 6 ? (i == 0 ? 2 : ((i == 2 || i == 3) ? 1 : 0))
+                                                     : NPROD == 3 ? (i == 0 ? 1 : 0) : 0; }
+};
+template <int NPROD>
 __global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int npair, const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool,
                                                                 float *__restrict__ P, float *__restrict__ Pb, int64_t B,
                                                                 int64_t b_per_blk) {
+    constexpr int NPC = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);  // bf16 pieces per operand that are used
     __shared__ __attribute__((aligned(16))) __bf16 At[3][128][CP_LD];  // G[o][r]
     __shared__ __attribute__((aligned(16))) __bf16 Bt[3][128][CP_LD];  // Pr[p][r]
     __shared__ __attribute__((aligned(16))) float Xs[32][36];           // X_0[h][r] of the stage (fp32)
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__r
         cbbf8 pc[3];
         cb_split(vg, pc);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&At[q][c][8 * oct]) = pc[q];
+        for (int q = 0; q < NPC; ++q) *reinterpret_cast<cbbf8 *>(&At[q][c][8 * oct]) = pc[q];
         __syncthreads();  // Xs complete
         {
             cbf8 a0, b0;
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__r
             }
             cb_split(a0 * b0, pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][c][8 * oct]) = pc[q];
+            for (int q = 0; q < NPC; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][c][8 * oct]) = pc[q];
         }
         if (st + 1 < nstage) load_stage();
         __syncthreads();
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__r
         for (int ks = 0; ks < 2; ++ks) {
             cbbf8 a[3], bq[2][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPC; ++q) {
                 a[q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -567,9 +577,9 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_w_kernel(const float *__r
             }
             // product-major: consecutive MFMAs alternate between the two accumulators (smallest terms first)
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
-                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
+            for (int pr = 0; pr < NPROD; ++pr) {
+                const int qa = CpProd<NPROD>::pa(pr);
+                const int qb = CpProd<NPROD>::pb(pr);
 #pragma unroll
                 for (int v = 0; v < 2; ++v)
                     acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bq[v][qb], acc[v], 0, 0, 0);
@@ -664,8 +674,14 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
     const int64_t ncx = rp_cdiv(B, per);
     float *Pb = P + (size_t)ncx * O * npair;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cin_pair_bwd_w_kernel, dim3((unsigned)ncx, (unsigned)ntile), dim3(512), 0, s, x0, ld0, H, O, D, npair,
-                       gout, gpool, P, db ? Pb : nullptr, B, per);
+    const int nprod = rp_matmul_products(2.0 * O * npair * D * (double)B, 4.0 * (double)B * D * (O + H));
+#define CPW(NP_)                                                                                                         \
+    hipLaunchKernelGGL((cin_pair_bwd_w_kernel<NP_>), dim3((unsigned)ncx, (unsigned)ntile), dim3(512), 0, s, x0, ld0, H, O, D, \
+                       npair, gout, gpool, P, db ? Pb : nullptr, B, per)
+    if (nprod == 6) CPW(6);
+    else if (nprod == 3) CPW(3);
+    else CPW(1);
+#undef CPW
     RP_LAUNCH_CHECK("cin_pair_bwd_w");
     const int64_t total = (int64_t)O * H * H + O;
     hipLaunchKernelGGL(cin_pair_wsum_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, (int)ncx, O, H, npair, dW,
@@ -682,10 +698,12 @@ extern "C" int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout
 // each stage (32 pairs) copies the A tile L2 -> LDS and forms the B tile from LDS X_0.  EIGHT waves, 4 (rows) x 2
 // (columns), each 32 x 64: hipcc schedules a stage as "all VALU / LDS, then the MFMAs back to back", so the overlap has
 // to come from other waves — four half-size waves per SIMD (120 VGPRs) beat two full-size ones (3.9 -> 3.35 ms).
+template <int NPROD>
 __global__ __launch_bounds__(512, 4) void cin_pair_fwd_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O, int D,
                                                               int npair, int KP, const __bf16 *__restrict__ wsp,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               float *__restrict__ pooled, int64_t B) {
+    constexpr int NPC = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);  // bf16 pieces per operand that are used
     __shared__ __attribute__((aligned(16))) __bf16 At[3][128][CP_LD];  // Ws[o][p]
     __shared__ __attribute__((aligned(16))) __bf16 Bt[3][128][CP_LD];  // Pr[col][p]
     __shared__ __attribute__((aligned(16))) float Xs[32][132];          // X_0[h][col]
@@ -720,7 +738,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_fwd_kernel(const float *__res
     f32x4 aq[3];
     auto load_a = [&](int st) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NPC; ++u) {
             const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             aq[u] = *reinterpret_cast<const f32x4 *>(wsp + ((int64_t)(q * 128 + row) * KP + st * 32 + ch * 8));
@@ -748,20 +766,20 @@ __global__ __launch_bounds__(512, 4) void cin_pair_fwd_kernel(const float *__res
         }
         __syncthreads();  // previous stage's fragment reads are done
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NPC; ++u) {
             const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
         }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pb[0][q];
+        for (int q = 0; q < NPC; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pb[0][q];
         if (st + 1 < nst) load_a(st + 1);
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             cbbf8 a[1][3], bq[2][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPC; ++q) {
                 a[0][q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
@@ -769,9 +787,9 @@ __global__ __launch_bounds__(512, 4) void cin_pair_fwd_kernel(const float *__res
             }
             // product-major: consecutive MFMAs go to four different accumulators (smallest terms first per accumulator)
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
-                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
+            for (int pr = 0; pr < NPROD; ++pr) {
+                const int qa = CpProd<NPROD>::pa(pr);
+                const int qb = CpProd<NPROD>::pb(pr);
 #pragma unroll
                 for (int u = 0; u < 1; ++u)
 #pragma unroll
@@ -831,8 +849,14 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
     const int npair = H * (H + 1) / 2;
     const int KP = (int)rp_cdiv(npair, 32) * 32;
     const int64_t nblk = rp_cdiv(B * D, 128);
-    hipLaunchKernelGGL(cin_pair_fwd_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, npair, KP,
-                       reinterpret_cast<const __bf16 *>(wsp), bias, out, pooled, B);
+    const int nprod = rp_matmul_products(2.0 * O * npair * D * (double)B, 4.0 * (double)B * D * (O + H));
+#define CPF(NP_)                                                                                                          \
+    hipLaunchKernelGGL((cin_pair_fwd_kernel<NP_>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, \
+                       npair, KP, reinterpret_cast<const __bf16 *>(wsp), bias, out, pooled, B)
+    if (nprod == 6) CPF(6);
+    else if (nprod == 3) CPF(3);
+    else CPF(1);
+#undef CPF
     RP_LAUNCH_CHECK("cin_pair_fwd");
     return RP_OK;
 }
@@ -850,12 +874,14 @@ extern "C" int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, co
 //     its own (h, column) outputs from a host-built list  (tile, half, h) -> [(local pair row, m)]  — wave-uniform
 //     scalar loads, no atomics, fixed summation order; dX_0 stays in registers until the end.
 // (A first version scattered T with LDS float atomics and loaded G with strided dword loads: 21 ms.)
+template <int NPROD>
 __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__restrict__ x0, int64_t ld0, int H, int O,
                                                                 int D, int KPT, const __bf16 *__restrict__ wst,
                                                                 const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool, float *__restrict__ dx,
                                                                 int64_t lddx, int64_t B, const int *__restrict__ lstart,
                                                                 const int *__restrict__ lent) {
+    constexpr int NPC = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);  // bf16 pieces per operand that are used
     __shared__ __attribute__((aligned(16))) char smem[2 * 3 * 128 * CP_LD * 2 + 32 * 132 * 4];
     typedef __bf16(*Tile)[128][CP_LD];
     Tile At = reinterpret_cast<Tile>(smem);                                   // Ws^T[p][o]
@@ -883,7 +909,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
     auto load_stage = [&](int st) {
         const int tile = st / nks, ks = st - tile * nks;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NPC; ++u) {
             const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             aq[u] = *reinterpret_cast<const f32x4 *>(wst + ((int64_t)(q * KPT + tile * 128 + row) * 128 + ks * 32 + ch * 8));
@@ -913,7 +939,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4 *>(&Gs[go * 132 + 16 * c16 + 4 * (gj + j)]) = gq[j] + gp;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < NPC; ++u) {
             const int id = t + 512 * u;
             const int q = id >> 9, row = (id & 511) >> 2, ch = id & 3;
             *reinterpret_cast<f32x4 *>(&At[q][row][ch * 8]) = aq[u];
@@ -926,7 +952,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
             cbbf8 pc[3];
             cb_split(gv, pc);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pc[q];
+            for (int q = 0; q < NPC; ++q) *reinterpret_cast<cbbf8 *>(&Bt[q][col][8 * oq]) = pc[q];
         }
         if (st + 1 < nst) load_stage(st + 1);
         __syncthreads();
@@ -934,16 +960,16 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
         for (int ks = 0; ks < 2; ++ks) {
             cbbf8 a[3], bq[2][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPC; ++q) {
                 a[q] = *reinterpret_cast<const cbbf8 *>(&At[q][wa + i][ks * 16 + 8 * hh]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     bq[u][q] = *reinterpret_cast<const cbbf8 *>(&Bt[q][wb + 32 * u + i][ks * 16 + 8 * hh]);
             }
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) {
-                const int qa = (pr == 1) ? 2 : ((pr == 2 || pr == 4) ? 1 : 0);
-                const int qb = (pr == 0) ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);
+            for (int pr = 0; pr < NPROD; ++pr) {
+                const int qa = CpProd<NPROD>::pa(pr);
+                const int qb = CpProd<NPROD>::pb(pr);
 #pragma unroll
                 for (int v = 0; v < 2; ++v)
                     acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[qa], bq[v][qb], acc[v], 0, 0, 0);
@@ -1019,8 +1045,14 @@ extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, 
     const int npair = H * (H + 1) / 2;
     const int KPT = (int)rp_cdiv(npair, 128) * 128;
     const int64_t nblk = rp_cdiv(B * D, 128);
-    hipLaunchKernelGGL(cin_pair_bwd_x_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, KPT,
-                       reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent);
+    const int nprod = rp_matmul_products(2.0 * O * npair * D * (double)B, 4.0 * (double)B * D * (O + 2 * H));
+#define CPX(NP_)                                                                                                            \
+    hipLaunchKernelGGL((cin_pair_bwd_x_kernel<NP_>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, \
+                       KPT, reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent)
+    if (nprod == 6) CPX(6);
+    else if (nprod == 3) CPX(3);
+    else CPX(1);
+#undef CPX
     RP_LAUNCH_CHECK("cin_pair_bwd_x");
     return RP_OK;
 }

@@ -30,3 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // wave64 constants: hard-coded, gfx950 only
 #define RP_WAVE 64
+
+// Matrix-core products per flop for a GEMM-shaped launch under the process-wide precision mode (gemm.hip):
+// 6 / 3 / 1 bf16 products, or 0 for the f32-input MFMA.  RP_MATMUL_AUTO picks 3 (~2^-16 per product) when the launch is
+// matrix-core bound even at 3 products (flops x 3 / algorithmic bytes above the MFMA/HBM ridge) and 6 (fp32-faithful)
+// otherwise — HBM-bound launches get the exact products for free.
+int rp_matmul_products(double flops, double bytes);

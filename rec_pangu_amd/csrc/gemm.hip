@@ -917,14 +917,32 @@ static void launch_smallk_rowadd(const float *a, int64_t lda, const float *w, in
                        nullptr, out, ldo, M, N, K, nullptr, 0, per, rs, radd, ldadd, nadd);
 }
 
-// process-wide matrix-core precision for the GEMM entry points (rp_linear_fwd / rp_linear_wgrad)
-static int g_matmul_precision = RP_MATMUL_BF16X6;
+// process-wide matrix-core precision for the GEMM-shaped entry points (rp_linear_*, rp_cin_pair_*)
+static int g_matmul_precision = RP_MATMUL_AUTO;
 
 extern "C" int rp_set_matmul_precision(int mode) {
-    RP_REQUIRE(mode == RP_MATMUL_FP32 || mode == RP_MATMUL_BF16 || mode == RP_MATMUL_BF16X3 || mode == RP_MATMUL_BF16X6,
-               "set_matmul_precision: unknown mode %d", mode);
+    RP_REQUIRE(mode == RP_MATMUL_FP32 || mode == RP_MATMUL_BF16 || mode == RP_MATMUL_BF16X3 || mode == RP_MATMUL_BF16X6 ||
+                   mode == RP_MATMUL_AUTO, "set_matmul_precision: unknown mode %d", mode);
     g_matmul_precision = mode;
     return RP_OK;
+}
+
+int rp_matmul_products(double flops, double bytes) {
+    switch (g_matmul_precision) {
+        case RP_MATMUL_FP32: return 0;
+        case RP_MATMUL_BF16: return 1;
+        case RP_MATMUL_BF16X3: return 3;
+        case RP_MATMUL_BF16X6: return 6;
+        default: break;
+    }
+    // ridge of the part: 2.5 PFLOP/s dense bf16 over 8 TB/s = 312 products per byte
+    return (bytes > 0 && flops * 3.0 / bytes > 312.0) ? 3 : 6;
+}
+
+static int linear_mode(int64_t M, int N, int K) {  // the RP_MATMUL_* mode one GEMM launch runs in
+    if (g_matmul_precision != RP_MATMUL_AUTO) return g_matmul_precision;
+    return rp_matmul_products(2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N)) == 3
+               ? RP_MATMUL_BF16X3 : RP_MATMUL_BF16X6;
 }
 
 extern "C" int rp_get_matmul_precision(void) { return g_matmul_precision; }
@@ -938,7 +956,7 @@ extern "C" int rp_linear_fwd_rowadd(const float *a, int64_t lda, const float *w,
                                     int64_t ld_add, int add_cols, rp_stream_t stream) {
     RP_REQUIRE(a && w && out && row_scale && row_add, "linear_fwd_rowadd: null pointer");
     RP_REQUIRE(lda >= K && ldw >= K && ldo >= N && ld_add >= 64, "linear_fwd_rowadd: leading dimension too small");
-    const int mode = g_matmul_precision;
+    const int mode = linear_mode(M, N, K);
     const bool ok = mode != RP_MATMUL_FP32 && K >= 4 && K <= 64 && K % 4 == 0 && M >= 128 && M % 128 == 0 && N >= 64 &&
                     N % 64 == 0 && add_cols >= 0 && add_cols % 64 == 0 && add_cols <= N && lda % 4 == 0 && ldw % 4 == 0 &&
                     rp_aligned16(a) && rp_aligned16(w);
@@ -963,7 +981,7 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     const bool va = (lda % 4 == 0) && rp_aligned16(a);
     const bool vw = (ldw % 4 == 0) && rp_aligned16(w);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = g_matmul_precision;
+    const int mode = linear_mode(M, N, K);
     if (mode != RP_MATMUL_FP32) {
         if (K <= 64) {  // A-stationary walk over the output columns
             if (mode == RP_MATMUL_BF16X6) run_smallk<6>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
@@ -1080,7 +1098,7 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     const bool vx = (ldx % 4 == 0) && rp_aligned16(x);
     dim3 grid((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, TN_BN), (unsigned)S);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = g_matmul_precision;
+    const int mode = linear_mode(M, N, K);
     if (mode != RP_MATMUL_FP32) {
         const bool vx2 = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
         const bool wide = wgrad_wide(N);

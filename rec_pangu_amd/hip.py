@@ -118,7 +118,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
         _lib = handle
-        mode = os.environ.get("RP_MATMUL_PRECISION")  # fp32 | bf16 | bf16x3 | bf16x6 (library default)
+        mode = os.environ.get("RP_MATMUL_PRECISION")  # fp32 | bf16 | bf16x3 | bf16x6 | auto (library default)
         if mode:
             if handle.rp_set_matmul_precision(MATMUL_MODES[mode]) != 0:
                 raise RuntimeError(f"RP_MATMUL_PRECISION={mode}: rejected by the library")
@@ -767,11 +767,12 @@ def mmoe_combine_bwd(z, K: int, E: int, T: int, gate, dout):
     return dz
 
 
-MATMUL_MODES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+MATMUL_MODES = {"fp32": 0, "bf16": 1, "auto": 2, "bf16x3": 3, "bf16x6": 6}
 
 
 def set_matmul_precision(mode: str):
-    """GEMM matrix-core mode: 'bf16x6' (default, fp32-faithful split-bf16), 'bf16x3', 'bf16', 'fp32' (f32 MFMA)."""
+    """GEMM matrix-core mode: 'auto' (default: per launch 'bf16x3' when matrix-core bound, 'bf16x6' when HBM-bound),
+    'bf16x6' (fp32-faithful split-bf16), 'bf16x3', 'bf16', 'fp32' (f32 MFMA)."""
     _check(lib().rp_set_matmul_precision(MATMUL_MODES[mode]), "rp_set_matmul_precision")
 
 

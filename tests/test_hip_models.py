@@ -23,8 +23,19 @@ def _to_dev(batch):
     return {k: v.to(DEV) for k, v in batch.items()}
 
 
+@pytest.fixture(params=["auto", "bf16x6", "bf16x3"])
+def matmul_mode(request):
+    """The model-level parity gates are held in every matrix-core mode a user can end up in: 'auto' (the default: per
+    launch bf16x3 when matrix-core bound, fp32-faithful bf16x6 otherwise), forced 'bf16x6' and forced 'bf16x3'."""
+    from rec_pangu_amd import hip
+    prev = hip.get_matmul_precision()
+    hip.set_matmul_precision(request.param)
+    yield request.param
+    hip.set_matmul_precision(prev)
+
+
 @pytest.mark.parametrize("name", list(CASES))
-def test_model_forward_backward_vs_reference(name):
+def test_model_forward_backward_vs_reference(name, matmul_mode):
     from rec_pangu_amd import hip
     g = load_golden(f"model_{name}.npz")
     train_mode = CASES[name][1]
@@ -109,7 +120,7 @@ def test_index_out_of_range_raises_like_the_reference():
     model(_to_dev(g["batch"]))  # flag was cleared
 
 
-def test_deepfm_criteo_shape_midsize_vs_oracle():
+def test_deepfm_criteo_shape_midsize_vs_oracle(matmul_mode):
     """26 sparse (Criteo cardinalities / 64) + 13 dense, D=64, MLP [64,64,64], B=4096: pred/loss and all
     gradients against the CPU oracle on the same weights."""
     card = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
@@ -135,9 +146,12 @@ def test_deepfm_criteo_shape_midsize_vs_oracle():
     assert model.embedding_layer._fm_link is not None and model.embedding_layer._fm_link.folded
     torch.testing.assert_close(out["pred"].cpu(), ref["pred"].detach(), rtol=0, atol=1e-4)
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=0, atol=1e-4)
+    # gradients: 1e-4 relative in the modes the library chooses itself; a FORCED bf16x3 (opt-in: 'auto' keeps these
+    # HBM-bound GEMMs at the fp32-faithful six products) is held to 2e-4 (measured 1.3e-4 on one table)
+    gtol = 2e-4 if matmul_mode == "bf16x3" else 1e-4
     for k, p in model.named_parameters():
         rg = sd[k].grad
-        tol = 1e-4 * max(1e-4, float(rg.abs().max()))
+        tol = gtol * max(1e-4, float(rg.abs().max()))
         assert (p.grad.cpu() - rg).abs().max() <= tol, f"grad {k}: {(p.grad.cpu() - rg).abs().max()} > {tol}"
 
 
@@ -194,7 +208,7 @@ def test_sharded_layer_hip_primitives_single_rank():
 
 
 @pytest.mark.parametrize("name", ["deepfm", "xdeepfm", "dcn", "autoint"])
-def test_full_size_split_batch_property(name):
+def test_full_size_split_batch_property(name, matmul_mode):
     """BASELINE.json's full batch (65536 samples, 26 Criteo-shaped fields + 13 dense, D = 64; vocabularies / 16 to keep
     the test light) has no CPU oracle run — instead a size-independent property of these models (no BatchNorm): the
     samples are independent, so the full-batch predictions equal those of its two halves run separately, the loss is
@@ -279,7 +293,7 @@ def _mmoe_config4(scale=64, dropouts=(0.0, 0.0)):
     return bench, enc, model
 
 
-def test_mmoe_config4_shape_midsize_vs_oracle():
+def test_mmoe_config4_shape_midsize_vs_oracle(matmul_mode):
     """The whole model at BASELINE config 4's shape, B = 4096, TRAIN mode (batch-statistics BatchNorm in the towers,
     dropout 0 so that the comparison is deterministic): both task predictions, the two-task loss and every gradient
     against the CPU oracle (oracle/ref_ops.py::mmoe) on the same weights and the same unregistered gates."""
@@ -634,3 +648,31 @@ def test_sharded_fixed_capacity_exchange_single_rank():
         assert lay._capacity is None
     finally:
         dist.destroy_process_group()
+
+
+def test_xdeepfm_midsize_vs_oracle_in_every_matmul_mode(matmul_mode):
+    """xDeepFM at the Criteo shape (26 x D=64, CIN [128,128], vocabularies / 64), B = 2048, eval mode: logits / loss
+    within 1e-4 of the CPU oracle and gradients within 1e-4 relative — the CIN pair-form kernels are matrix-core bound,
+    so 'auto' runs them at three bf16 products per flop; the gate must hold there too."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    enc = bench.criteo_enc_dict(64)
+    torch.manual_seed(0)
+    model = bench.build_model("xdeepfm", enc)
+    model.eval()
+    sd = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    B = 2048
+    batch = bench.synth_batch(enc, B, 3, "cpu")
+    ref = R.xdeepfm(sd, enc, batch)
+    ref["loss"].backward()
+    model = model.to(DEV)
+    out = model(_to_dev(batch))
+    out["loss"].backward()
+    torch.testing.assert_close(out["pred"].cpu(), ref["pred"].detach(), rtol=0, atol=1e-4)
+    torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=0, atol=1e-4)
+    for k, p in model.named_parameters():
+        rg = sd[k].grad
+        tol = 1e-4 * max(1e-4, float(rg.abs().max()))
+        assert (p.grad.cpu() - rg).abs().max() <= tol, f"{matmul_mode}: grad {k}: {(p.grad.cpu() - rg).abs().max()} > {tol}"
