@@ -23,6 +23,7 @@
 //   second kernel sums them in fixed order (deterministic, no float atomics).  Column sums of dY
 //   (the bias gradient) ride along in the blocks of the first k tile.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 64
@@ -423,6 +424,202 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_fwd_bf16_kernel(const flo
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + arow0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= M) continue;
+                float v = acc[mi][ni][r] + bv;
+                if (act == RP_ACT_RELU)
+                    v = v > 0.f ? v : 0.f;
+                else if (act == RP_ACT_MASK)
+                    v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+                C[m * ldc + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT for WIDE layers (matrix-core bound: N >= 256, long K):  256 x 128 workgroup tiles, EIGHT waves of 64 x 64.
+//
+// What bounds the 128 x 128 / 32 x 64-wave kernel above on these shapes is LDS read bandwidth, not the matrix core: a
+// 32 x 64 wave tile reads 3 fragments per 2 MFMA tiles, 96 KB of ds_read_b128 per 32-deep k-tile and workgroup against
+// 768 matrix-core cycles.  Here a wave owns 64 x 64 (2 x 2 MFMA tiles): 4 fragment reads feed 4 tiles, 0.67 KB of LDS
+// reads per MFMA instead of 1 KB, and per k-tile a CU spends 1024 LDS cycles against 1536 matrix-core cycles.
+//   * LDS is double buffered, ONE (LDS-only) barrier per k-tile: tile t+1 is converted and written while tile t is on
+//     the matrix core; global loads run three tiles ahead through a register ring (counted vmcnt waits: the main loop is
+//     straight-line code with unguarded loads, the K tail and the last tiles run a guarded epilogue).
+//     (Measured at [65536, 1677] x [1024, 1677], bf16x3: 0.82 ms = 274 TFLOP/s algorithmic against 1.17 ms on the
+//     128 x 128 kernel; SQ counters: the matrix pipe is busy 40 % of the kernel at the ~2.0 GHz it clocks to, a wave
+//     spends 33 % of its cycles issuing (~220 instructions per k-tile, 24 of them MFMAs), 39 % stalled on the busy
+//     pipe and 28 % parked at the barrier / on waitcnt.  Running the two waves of a SIMD in opposite stage / compute
+//     order ("ping-pong") spilled registers and lost 4 %; plain column-fastest tile order loses 6 %, M-fastest 20 %.)
+//   * workgroup -> tile mapping is XCD-aware: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs
+//     (each with its own 4 MB L2); ids are remapped so that one XCD walks all column blocks of an M block back to back
+//     and the [256, K] activation slab (the operand that does not fit) is fetched from HBM once and then served by
+//     that XCD's L2, instead of once per column block.
+// Instantiated for the split modes with two pieces or fewer (bf16x3 / bf16: 120 KB of LDS; six products would need
+// 180 KB double buffered and keep the kernel above).
+template <int NPROD>
+__global__ __launch_bounds__(512) void linear_fwd_bf16_wide_kernel(const float *__restrict__ A, int64_t lda,
+                                                                    const float *__restrict__ W, int64_t ldw,
+                                                                    const float *__restrict__ bias, float *__restrict__ C,
+                                                                    int64_t ldc, int64_t M, int N, int K, int act,
+                                                                    const float *__restrict__ aux, int64_t ldaux,
+                                                                    int mblocks, int nblocks) {
+    constexpr int NP = BfProd<NPROD>::NP;
+    static_assert(NP <= 2, "double-buffered 256 x 128 tiles fit the LDS with at most two pieces per operand");
+    constexpr int WBM = 256, WBN = 128;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NP][WBM][BF_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NP][WBN][BF_LD];
+    const int t = threadIdx.x;
+    // XCD-aware mapping: id = xcd + 8 * j;  the 8 * nblocks ids {xcd + 8 * (g * nblocks + n)} of group g run the
+    // column blocks n of M block (8 g + xcd) one after the other on XCD `xcd`
+    int mb, nb;
+    {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int g = j / nblocks;
+        nb = j - g * nblocks;
+        mb = g * 8 + xcd;
+        if (mb >= mblocks) return;  // (the grid is padded to whole groups)
+    }
+    const int64_t m0 = (int64_t)mb * WBM;
+    const int n0 = nb * WBN;
+    const int lr = t >> 3, lc = (t & 7) * 4;   // staging: 64 rows per pass, 8 threads (32 floats) per row
+    const int w = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
+    const int wm = w & 3, wn = w >> 2;         // 4 (rows) x 2 (columns) waves of 64 x 64
+    const int arow0 = 64 * wm, bcol0 = 64 * wn;
+
+    const float *a_row[4];
+    const float *w_row[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_row[j] = A + (m0 + lr + 64 * j) * lda + lc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int n = n0 + lr + 64 * j;
+        if (n >= N) n = N - 1;  // clamped, never stored (keeps the loads unguarded)
+        w_row[j] = W + (int64_t)n * ldw + lc;
+    }
+    f32x4 ra[3][4], rw[3][2];
+    auto load_full = [&](int kt, f32x4 (&da)[4], f32x4 (&dw)[2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) da[j] = *reinterpret_cast<const f32x4 *>(a_row[j] + kt * BK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dw[j] = *reinterpret_cast<const f32x4 *>(w_row[j] + kt * BK);
+    };
+    auto load_guard = [&](int kt, f32x4 (&da)[4], f32x4 (&dw)[2]) {
+        const int k0 = kt * BK + lc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) da[j] = load4_guard(a_row[j] + kt * BK, K - k0, true);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dw[j] = load4_guard(w_row[j] + kt * BK, K - k0, true);
+    };
+    auto stage = [&](int buf, const f32x4 (&sa)[4], const f32x4 (&sw)[2]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 pc[NP];
+            bf_split4<NP>(sa[j], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&As[buf][q][lr + 64 * j][lc]) = pc[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16x4 pc[NP];
+            bf_split4<NP>(sw[j], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&Ws[buf][q][lr + 64 * j][lc]) = pc[q];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][NP], b[2][NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    a[mi][q] = *reinterpret_cast<const bf16x8 *>(&As[buf][q][arow0 + 32 * mi + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    b[ni][q] = *reinterpret_cast<const bf16x8 *>(&Ws[buf][q][bcol0 + 32 * ni + i][ks * 16 + 8 * h]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < NPROD; ++pr)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][BfProd<NPROD>::pa(pr)],
+                                                                              b[ni][BfProd<NPROD>::pb(pr)], acc[mi][ni], 0, 0, 0);
+        }
+    };
+#define RP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    const int nk = (K + BK - 1) / BK;
+    const int nkf = K / BK;  // k-tiles that need no column guard
+    // ring slot of tile kt: kt % 3.  Prologue: tiles 0..2 in flight, tile 0 staged.
+    int kt = 0;
+    if (nkf >= 6) {
+        load_full(0, ra[0], rw[0]);
+        load_full(1, ra[1], rw[1]);
+        load_full(2, ra[2], rw[2]);
+        stage(0, ra[0], rw[0]);
+        load_full(3, ra[0], rw[0]);
+        RP_LDS_BARRIER();
+        // steady state, unrolled by 6 (ring of 3 x double buffer of 2): at the top of step kt the LDS buffer kt & 1
+        // holds tile kt, the ring holds tiles kt+1, kt+2, kt+3
+        const int nmain = (nkf - 4) / 6 * 6;  // steps that can prefetch tile kt + 4 unguarded
+        for (; kt < nmain; kt += 6) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int slot = (u + 1) % 3;             // ring slot of tile kt + u + 1
+                stage((u + 1) & 1, ra[slot], rw[slot]);
+                load_full(kt + u + 4, ra[slot], rw[slot]);
+                compute(u & 1);
+                RP_LDS_BARRIER();
+            }
+        }
+        // drain: tiles kt .. nk-1; tiles kt+1 .. kt+3 are in the ring (full tiles), later ones are loaded guarded
+        // (kt is a multiple of 6 here, so LDS buffer parity and ring slots restart at 0)
+        for (int u = 0; kt + u < nk; ++u) {
+            const int nxt = kt + u + 1;
+            if (nxt < nk) {
+                const int slot = nxt % 3;
+                if (u >= 3) {  // not in the ring any more
+                    if (slot == 0) load_guard(nxt, ra[0], rw[0]);
+                    else if (slot == 1) load_guard(nxt, ra[1], rw[1]);
+                    else load_guard(nxt, ra[2], rw[2]);
+                }
+                if (slot == 0) stage(nxt & 1, ra[0], rw[0]);
+                else if (slot == 1) stage(nxt & 1, ra[1], rw[1]);
+                else stage(nxt & 1, ra[2], rw[2]);
+            }
+            compute((kt + u) & 1);
+            RP_LDS_BARRIER();
+        }
+    } else {
+        for (; kt < nk; ++kt) {
+            load_guard(kt, ra[0], rw[0]);
+            RP_LDS_BARRIER();
+            stage(0, ra[0], rw[0]);
+            RP_LDS_BARRIER();
+            compute(0);
+        }
+    }
+#undef RP_LDS_BARRIER
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + bcol0 + 32 * ni + i;
+        if (n0 + bcol0 + 32 * ni >= N) continue;  // wave-uniform (N is a multiple of 32 on this path)
+        const float bv = (bias != nullptr) ? bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + arow0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[mi][ni][r] + bv;
                 if (act == RP_ACT_RELU)
                     v = v > 0.f ? v : 0.f;
@@ -939,6 +1136,8 @@ int rp_matmul_products(double flops, double bytes) {
     return (bytes > 0 && flops * 3.0 / bytes > 312.0) ? 3 : 6;
 }
 
+static int g_wide_kernel = 1;  // RP_WIDE_KERNEL=0 in the environment: fall back to the 128 x 128 kernel (A/B measurements)
+
 static int linear_mode(int64_t M, int N, int K) {  // the RP_MATMUL_* mode one GEMM launch runs in
     if (g_matmul_precision != RP_MATMUL_AUTO) return g_matmul_precision;
     return rp_matmul_products(2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N)) == 3
@@ -946,6 +1145,15 @@ static int linear_mode(int64_t M, int N, int K) {  // the RP_MATMUL_* mode one G
 }
 
 extern "C" int rp_get_matmul_precision(void) { return g_matmul_precision; }
+
+namespace {
+struct WideKernelEnv {
+    WideKernelEnv() {
+        const char *e = getenv("RP_WIDE_KERNEL");
+        if (e && e[0] == '0') g_wide_kernel = 0;
+    }
+} g_wide_kernel_env;
+}  // namespace
 
 // out[M,N] = a[M,K] . w[N,K]^T  +  row_scale[m] * row_add[m, n % 64] for n < add_cols       (no bias, no activation)
 // Restricted to what the DeepFM dgrad needs and the straight-line short-K kernel covers: K <= 64 and a multiple of 4,
@@ -999,6 +1207,21 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
             if (rc != RP_OK) return rc;
             return rp_linear_fwd(a, lda, w + (int64_t)Nb * ldw, ldw, bias ? bias + Nb : nullptr, out + Nb, ldo, M, N - Nb, K,
                                  act, aux ? aux + Nb : nullptr, ldaux, stream);
+        }
+        // wide, matrix-core-bound layers in a two-piece mode: 256 x 128 tiles, 64 x 64 wave tiles, double-buffered LDS
+        if ((mode == RP_MATMUL_BF16X3 || mode == RP_MATMUL_BF16) && g_wide_kernel && N >= 256 && N % 32 == 0 && M % 256 == 0 &&
+            K >= 192 && va && vw && rp_cdiv(N, 128) * (M / 256) >= 512) {
+            const int mblocks = (int)(M / 256), nblocks = (int)rp_cdiv(N, 128);
+            const int groups = (int)rp_cdiv(mblocks, 8);
+            dim3 gridw((unsigned)(groups * 8 * nblocks));
+            if (mode == RP_MATMUL_BF16X3)
+                hipLaunchKernelGGL((linear_fwd_bf16_wide_kernel<3>), gridw, dim3(512), 0, s, a, lda, w, ldw, bias, out, ldo, M, N, K,
+                                   act, aux, ldaux, mblocks, nblocks);
+            else
+                hipLaunchKernelGGL((linear_fwd_bf16_wide_kernel<1>), gridw, dim3(512), 0, s, a, lda, w, ldw, bias, out, ldo, M, N, K,
+                                   act, aux, ldaux, mblocks, nblocks);
+            RP_LAUNCH_CHECK("linear_fwd (bf16 split, wide)");
+            return RP_OK;
         }
         // tile shape: 128 x 128 (eight waves of 32 x 64) for wide outputs; 128 x 64 otherwise — with eight waves when that grid
         // would give the 256 CUs fewer than ~4 workgroups each

@@ -169,7 +169,7 @@ def test_linear_fwd(hip, M, N, K, lda_pad, act, mode):
         _linear_fwd_case(hip, M, N, K, lda_pad, act, *{"fp32": (1e-5, 2e-5), "bf16x6": (1e-5, 2e-5),
                                                        "bf16x3": (1e-4, 2e-4), "bf16": (5e-2, 5e-2)}[mode])
     finally:
-        hip.set_matmul_precision("bf16x6")
+        hip.set_matmul_precision("auto")
 
 
 def _linear_fwd_case(hip, M, N, K, lda_pad, act, rtol, atol):
@@ -200,7 +200,7 @@ def test_linear_wgrad(hip, M, N, K, ldx_pad, mode):
     try:
         _linear_wgrad_case(hip, M, N, K, ldx_pad, {"fp32": 1.0, "bf16x6": 1.0, "bf16x3": 20.0, "bf16": 3000.0}[mode])
     finally:
-        hip.set_matmul_precision("bf16x6")
+        hip.set_matmul_precision("auto")
 
 
 def _linear_wgrad_case(hip, M, N, K, ldx_pad, slack):
@@ -482,3 +482,41 @@ def test_embed_grad_reduce_is_deterministic_and_ordered(hip):
     G3 = torch.zeros(3, D2, device=DEV)
     hip.embed_grad_reduce(sk2, sp2, B2, D2, dx2.to(DEV), None, None, None, G3, accumulate=False)
     assert torch.equal(G2, G3)
+
+
+@pytest.mark.parametrize("M,N,K,lda_pad", [(65536, 1024, 1677, 1728), (65536, 384, 205, 208), (65536, 256, 192, 192),
+                                           (131072, 512, 649, 704)])
+@pytest.mark.parametrize("mode", ["bf16x3", "auto", "bf16"])
+def test_linear_fwd_wide_kernel(hip, M, N, K, lda_pad, mode):
+    """The 256 x 128 / 64 x 64-wave kernel that serves wide, matrix-core-bound layers in the two-piece modes (XCD-aware
+    tile order, double-buffered LDS, register ring three k-tiles deep): full tiles, a partial last column block
+    (N = 384), a K tail that is not a multiple of 32 (1677, 205, 649), a K with exactly six k-tiles (192: the shortest
+    pipelined case); bias + ReLU and the mask epilogue, against an fp64 product on the device."""
+    hip.set_matmul_precision(mode)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(M + N + K)
+        a = torch.zeros(M, lda_pad, device=DEV)
+        a[:, :K] = torch.randn(M, K, generator=g, device=DEV)
+        w = torch.randn(N, K, generator=g, device=DEV) / K ** 0.5
+        wp = torch.zeros(N, (K + 3) // 4 * 4, device=DEV)
+        wp[:, :K] = w
+        b = torch.randn(N, generator=g, device=DEV)
+        rtol, atol = {"bf16x3": (1e-4, 2e-4), "auto": (1e-4, 2e-4), "bf16": (5e-2, 5e-2)}[mode]
+        rows = torch.randint(0, M, (4096,), generator=g, device=DEV)  # fp64 reference on a sample of rows (+ the ends)
+        rows[:256] = torch.arange(256, device=DEV)
+        rows[-256:] = torch.arange(M - 256, M, device=DEV)
+        ref = a[rows, :K].double() @ w.double().t() + b.double()
+        n0 = hip.launch_count()
+        out = hip.linear_fwd(a, wp[:, :K], b, hip.ACT_RELU, K=K)
+        assert hip.launch_count() == n0 + 1
+        torch.testing.assert_close(out[rows].double(), ref.relu(), rtol=rtol, atol=atol)
+        aux = torch.randn(M, N, generator=g, device=DEV)
+        out2 = hip.linear_fwd(a, wp[:, :K], None, hip.ACT_MASK, aux=aux, K=K)
+        ref2 = (a[rows, :K].double() @ w.double().t()) * (aux[rows] > 0)
+        torch.testing.assert_close(out2[rows].double(), ref2, rtol=rtol, atol=atol)
+        # every output element was written (no tile skipped by the XCD-aware workgroup -> tile mapping)
+        out3 = torch.full((M, N), float("nan"), device=DEV)
+        hip.linear_fwd(a, wp[:, :K], b, hip.ACT_NONE, K=K, out=out3)
+        assert not bool(torch.isnan(out3).any())
+    finally:
+        hip.set_matmul_precision("auto")
