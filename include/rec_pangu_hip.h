@@ -108,6 +108,19 @@ int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, 
                          const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
                          const float *arena, float *grad_arena, int accumulate, void *workspace,
                          size_t workspace_bytes, rp_stream_t stream);
+/* The same reduce FUSED with the dgrad of the Linear that consumes the gathered rows (DeepFM's dnn.net.0, deep.py:62-72 +
+ * embedding.py:62): the dX row of pair (f, b) is dh[b, 0:64] . W1[:, f*64:(f+1)*64], formed on the matrix core
+ * (split-bf16, six products) inside the reduce, so the [B, F*D] gradient of the MLP input is never written or read.
+ *   dh  [B, 64]            gradient w.r.t. the layer's pre-activation (lddh floats per row)
+ *   wt  [>= F*64, 64]      the layer's weight transposed (rp_transpose): row f*64+d = column f*64+d of W1 [64, K]
+ *   dx  optional           sum of the gradients of x's other consumers, added per pair (NULL: none)
+ * rp_embed_grad_gemm_fits: D == 64, a 64-wide layer, row strides multiples of 4 floats; otherwise RP_ERR_UNSUPPORTED
+ * (compose rp_linear_fwd + rp_embed_grad_reduce).  Workspace: rp_embed_grad_reduce_workspace_bytes(n, D). */
+int rp_embed_grad_gemm_fits(int D, int hidden, int64_t lddh, int64_t ldwt);
+int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D, const float *dh,
+                       int64_t lddh, const float *wt, int64_t ldwt, const float *dx, int64_t ldx, const float *gfm,
+                       const float *sum_in, const float *arena, float *grad_arena, int accumulate, void *workspace,
+                       size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
 

@@ -14,6 +14,7 @@
 // so FM costs no extra HBM traffic.  HBM-bound: algorithmic bytes/sample =
 // F*(D*4 + 8) read + (F*D+ND)*4 written.
 #include "common.h"
+#include "bfsplit.h"
 
 struct IdxPtrs {
     const int64_t *p[RP_MAX_FIELDS];
@@ -268,6 +269,250 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gather backward FUSED with the dgrad of the Linear that consumes the gathered rows (DeepFM: dnn.net.0).
+//
+// Unfused, the first layer's dgrad writes dX[B, F*D] (436 MB at Criteo shape) and the segmented reduce reads it back
+// one row per (sample, field) pair.  But the row of pair p = (f, b) is just  dH[b, :] . W1[:, f*D:(f+1)*D]  with
+// dH = gradient w.r.t. the layer's pre-activation ([B, 64], 16.7 MB: L2/MALL resident): this kernel forms the 128
+// dX rows of a workgroup's 128 sorted positions on the matrix core (A = the gathered dH rows, straight from global
+// memory into MFMA fragments; B = the field's 64 x 64 slice of W1^T through LDS; split-bf16, six products: fp32-
+// faithful), parks them in LDS and runs the SAME deterministic segmented reduce over them.  dX never exists.
+// An optional `dx` (the sum of the gradients of x's OTHER consumers, e.g. a CIN branch) is added per pair.
+// Positions are field-major, so a 128-position tile lies in one field except at the F-1 field borders, where it runs
+// one matrix pass per field with the other field's rows masked out.
+// ------------------------------------------------------------------------------------------------
+#define EG_LD 72  // bf16 row of 64 + 8 pad: 144 B = 9 x 16 B (odd) -> conflict-free ds_read_b128 fragment reads
+#define EG_CT 68  // fp32 row of the C tile
+__global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
+    const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
+    int64_t lddh, const float *__restrict__ wt, int64_t ldwt, const float *__restrict__ dx, int64_t ldx,
+    const float *__restrict__ gfm, const float *__restrict__ sum_in, const float *__restrict__ arena,
+    float *__restrict__ G, int accumulate, float *__restrict__ gpiece, int32_t *__restrict__ gkey) {
+    typedef Vec<4> V;
+    constexpr int D = 64, TPR = 16, VEC = 4, GPB = 16, W = 64;
+    constexpr int SM_B = 3 * 64 * EG_LD * 2, SM_C = 128 * EG_CT * 4;
+    __shared__ __attribute__((aligned(16))) char smem[SM_B > SM_C ? SM_B : SM_C];
+    __shared__ __attribute__((aligned(16))) float piece[GPB][2][W];
+    __shared__ int32_t pkey[GPB][2];
+    __shared__ int32_t pcont[GPB];
+    typedef __bf16(*BTile)[64][EG_LD];
+    BTile Bt = reinterpret_cast<BTile>(smem);                 // [3][64 d][64 n (+pad)]: W1^T slice of one field, pieces
+    float(*Ct)[EG_CT] = reinterpret_cast<float(*)[EG_CT]>(smem);  // [128][64 (+pad)]: the tile's dX rows (after the MFMAs)
+    const int t = threadIdx.x % TPR, grp = threadIdx.x / TPR;
+    const int64_t wg0 = (int64_t)blockIdx.x * GPB * RP_SEG;
+    // ---- the tile's dX rows on the matrix core (kept register-lean: three workgroups per CU have to overlap the
+    //      gather latencies of this phase with the matrix / reduce phases of the others) ----------------------------
+    {
+        const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
+        const int64_t prow = wg0 + 32 * wv + i;  // this lane's row of the tile (A operand: lane = row, 8 k per lane)
+        const bool rok = prow < n;
+        const int32_t pp = rok ? sp[prow] : 0;
+        const int fr = pp / Bi, br = pp - fr * Bi;
+        const int64_t plast = (wg0 + 127 < n ? wg0 + 127 : n - 1);
+        const int f_lo = __builtin_amdgcn_readfirstlane(sp[wg0] / Bi), f_hi = __builtin_amdgcn_readfirstlane(sp[plast] / Bi);
+        // the gathered dH row of this lane: 4 k-steps x 8 floats, loaded up front (the longest latency of the kernel)
+        f32x4 araw[4][2];
+        const float *asrc = dh + (int64_t)br * lddh + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            araw[ks][0] = *reinterpret_cast<const f32x4 *>(asrc + ks * 16);
+            araw[ks][1] = *reinterpret_cast<const f32x4 *>(asrc + ks * 16 + 4);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        const int wd = threadIdx.x >> 2, wc = (threadIdx.x & 3) * 16;  // staging: row d of the slice, 16 floats from wc
+        for (int f = f_lo; f <= f_hi; ++f) {
+            if (f != f_lo) __syncthreads();  // the previous field's fragment reads are done
+            {
+                const float *src = wt + ((int64_t)f * D + wd) * ldwt + wc;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + 8 * u), v1 = *reinterpret_cast<const f32x4 *>(src + 8 * u + 4);
+                    f32x8 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = v0[e];
+                        v[4 + e] = v1[e];
+                    }
+                    bf16x8 pc[3];
+                    bf_split8<3>(v, pc);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&Bt[q][wd][wc + 8 * u]) = pc[q];
+                }
+            }
+            __syncthreads();
+            // rows of another field (only in a tile that spans a field border) and rows beyond n contribute zero
+            const float keep = (rok && fr == f) ? 1.f : 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = araw[ks][0][e] * keep;
+                    v[4 + e] = araw[ks][1][e] * keep;
+                }
+                bf16x8 a[3];
+                bf_split8<3>(v, a);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(&Bt[q][nt * 32 + i][ks * 16 + 8 * h]);
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], b[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with Bt: the same LDS now takes the C tile
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ct[32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h][nt * 32 + i] = acc[nt][r];
+        __syncthreads();
+    }
+    // keys / positions of this group's segment (loaded after the matrix phase: they would only occupy registers there)
+    const int64_t start = wg0 + (int64_t)grp * RP_SEG;
+    const bool active = start < n;
+    const int cnt = active ? (int)((n - start) < RP_SEG ? (n - start) : RP_SEG) : 0;
+    int32_t k[RP_SEG];
+    int bb[RP_SEG], ff[RP_SEG];
+#pragma unroll
+    for (int j = 0; j < RP_SEG; ++j) {
+        const bool ok = j < cnt;
+        k[j] = ok ? sk[start + j] : -1;
+        const int32_t p = ok ? sp[start + j] : 0;
+        ff[j] = p / Bi;
+        bb[j] = p - ff[j] * Bi;
+    }
+    const int32_t kprev = (active && start > 0) ? sk[start - 1] : -1;
+    const int32_t knext = (active && start + cnt < n) ? sk[start + cnt] : -1;
+    // ---- the deterministic segmented reduce of embed_grad_reduce_kernel over those rows (D = 64: one column pass) ----
+    float *hp = gpiece + (int64_t)blockIdx.x * 2 * D, *tp = hp + D;
+    const int c = t * VEC;
+    typename V::T r[RP_SEG], w[RP_SEG];
+    float gf[RP_SEG];
+#pragma unroll
+    for (int j = 0; j < RP_SEG; ++j) {
+        r[j] = V::zero();
+        w[j] = V::zero();
+        gf[j] = 0.f;
+        if (j < cnt) {
+            r[j] = V::load(&Ct[grp * RP_SEG + j][c]);
+            if (dx != nullptr) r[j] += V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
+            if (gfm != nullptr) {
+                gf[j] = gfm[bb[j]];
+                if (sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);
+                if (j + 1 >= cnt || k[j + 1] != k[j]) w[j] = V::load(arena + (int64_t)k[j] * D + c);
+            }
+        }
+    }
+    if (t == 0) {
+        pkey[grp][0] = -1;
+        pkey[grp][1] = -1;
+        pcont[grp] = 0;
+    }
+    typename V::T acc = V::zero();
+    float gs = 0.f;
+    bool run_head = (k[0] != kprev);
+#pragma unroll
+    for (int j = 0; j < RP_SEG; ++j) {
+        if (j < cnt) {
+            acc += r[j];
+            gs += gf[j];
+            const bool last_of_run = (j + 1 < cnt) ? (k[j + 1] != k[j]) : true;
+            if (last_of_run) {
+                const bool run_ends_here = (j + 1 < cnt) ? true : (k[j] != knext);
+                if (gfm != nullptr) acc -= gs * w[j];
+                if (run_head && run_ends_here) {
+                    float *dst = G + (int64_t)k[j] * D + c;
+                    V::store(dst, accumulate ? V::load(dst) + acc : acc);  // the only writer of this row
+                } else {
+                    const int slot = run_head ? 1 : 0;
+                    V::store(&piece[grp][slot][t * VEC], acc);
+                    if (t == 0) {
+                        pkey[grp][slot] = k[j];
+                        if (!run_ends_here) pcont[grp] = 1;
+                    }
+                }
+                acc = V::zero();
+                gs = 0.f;
+                run_head = true;
+            }
+        }
+    }
+    __syncthreads();
+    if (grp == 0) {
+        const bool head_open = pkey[0][0] >= 0;
+        int last_g = -1;
+        for (int g2 = GPB - 1; g2 >= 0; --g2)
+            if (pkey[g2][0] >= 0 || pkey[g2][1] >= 0) {
+                last_g = g2;
+                break;
+            }
+        const int64_t wg_end = wg0 + GPB * RP_SEG;
+        const int last_active = (int)(((n < wg_end ? n : wg_end) - wg0 + RP_SEG - 1) / RP_SEG) - 1;
+        const bool tail_open = last_g >= 0 && last_g == last_active && pcont[last_g] != 0;
+        int32_t cur = -1;
+        bool cur_is_head = false;
+        typename V::T cacc = V::zero();
+        int32_t headkey = -1, tailkey = -1;
+        typename V::T headv = V::zero(), tailv = V::zero();
+        for (int g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+            for (int slot = 0; slot < 2; ++slot) {
+                const int32_t key = pkey[g2][slot];
+                if (key < 0) continue;
+                const typename V::T pv = V::load(&piece[g2][slot][t * VEC]);
+                if (key == cur) {
+                    cacc += pv;
+                } else {
+                    if (cur >= 0) {
+                        if (cur_is_head) {
+                            headkey = cur;
+                            headv = cacc;
+                        } else {
+                            float *dst = G + (int64_t)cur * D + c;
+                            V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+                        }
+                    }
+                    cur = key;
+                    cacc = pv;
+                    cur_is_head = head_open && g2 == 0 && slot == 0;
+                }
+            }
+        }
+        if (cur >= 0) {
+            if (tail_open) {
+                if (cur_is_head) {
+                    headkey = cur;
+                    headv = cacc;
+                    tailkey = cur;
+                } else {
+                    tailkey = cur;
+                    tailv = cacc;
+                }
+            } else if (cur_is_head) {
+                headkey = cur;
+                headv = cacc;
+            } else {
+                float *dst = G + (int64_t)cur * D + c;
+                V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+            }
+        }
+        V::store(hp + c, headv);
+        V::store(tp + c, tailv);
+        if (t == 0) {
+            gkey[2 * (int64_t)blockIdx.x] = headkey;
+            gkey[2 * (int64_t)blockIdx.x + 1] = tailkey;
+        }
+    }
+}
+
 // Chains of equal keys in the workgroup piece list [head_0, tail_0, head_1, tail_1, ...] (key -1: no piece) are runs
 // that cross workgroup borders: the group that owns a chain's FIRST entry sums the chain in list order and writes the
 // row — its only writer (a key's positions are contiguous in the sorted list, so it forms at most one chain).
@@ -390,6 +635,40 @@ extern "C" int rp_embed_grad_reduce_workspace_bytes(int64_t n, int D, size_t *by
     return RP_OK;
 }
 
+// second pass over the piece list of the first one (2 * nb0 entries, key -1 = none) through the same reduction, then
+// the sequential walk over what is left (shared by rp_embed_grad_reduce and rp_embed_grad_gemm)
+static int grad_reduce_finish(int64_t n, int D, int64_t nb0, char *wbase, float *piece0, int32_t *key0, float *grad_arena,
+                              int accumulate, hipStream_t s) {
+    const int64_t n1 = 2 * nb0;
+    const int vec1 = (D % 4 == 0) ? 4 : 1;  // (the workspace rows are 16-byte aligned when D % 4 == 0)
+    const int tpr1 = pick_tpr(D, vec1);
+    const int64_t nb1 = grad_reduce_blocks(n1, D, vec1);
+    const int64_t a0 = grad_reduce_blocks(n, D, 1), b0 = grad_reduce_blocks(n, D, 4);
+    float *piece1 = reinterpret_cast<float *>(wbase + grad_piece_bytes(a0 > b0 ? a0 : b0, D));
+    int32_t *key1 = reinterpret_cast<int32_t *>(piece1 + nb1 * 2 * D);
+    const float *no_f = nullptr;
+    if (n1 > 2) {
+#define CALL(T, VV)                                                                                                   \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, true>), dim3((unsigned)nb1), dim3(256), 0, s, key0, key0, n1,  \
+                       (int)n1, D, piece0, (int64_t)D, no_f, no_f, no_f, grad_arena, accumulate, piece1, key1)
+        RP_DISPATCH_TPR(tpr1, vec1, CALL);
+#undef CALL
+        RP_LAUNCH_CHECK("embed_grad_reduce (piece list)");
+    } else {
+        piece1 = piece0;
+        key1 = key0;
+    }
+    const int64_t nfix = (n1 > 2) ? 2 * nb1 : n1;
+    const unsigned fgrid = (unsigned)rp_cdiv(nfix, 256 / tpr1);
+#define CALL(T, VV)                                                                                                \
+    hipLaunchKernelGGL((embed_grad_fix_kernel<T, VV>), dim3(fgrid), dim3(256), 0, s, piece1, key1, nfix, D, grad_arena, \
+                       accumulate)
+    RP_DISPATCH_TPR(tpr1, vec1, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_grad_reduce (cross-workgroup runs)");
+    return RP_OK;
+}
+
 extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
                                     int D, const float *dx, int64_t ldx, const float *gfm, const float *sum_in,
                                     const float *arena, float *grad_arena, int accumulate, void *workspace,
@@ -418,34 +697,43 @@ extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *s
     RP_DISPATCH_TPR(tpr, vec, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("embed_grad_reduce");
-    // second pass: the piece list (2 * nb0 entries, key -1 = none) through the same reduction
-    const int64_t n1 = 2 * nb0;
-    const int vec1 = (D % 4 == 0) ? 4 : 1;  // (the workspace rows are 16-byte aligned when D % 4 == 0)
-    const int tpr1 = pick_tpr(D, vec1);
-    const int64_t nb1 = grad_reduce_blocks(n1, D, vec1);
-    float *piece1 = reinterpret_cast<float *>(wbase + grad_piece_bytes(nb0 > grad_reduce_blocks(n, D, 1) ? nb0 : grad_reduce_blocks(n, D, 1), D));
-    int32_t *key1 = reinterpret_cast<int32_t *>(piece1 + nb1 * 2 * D);
-    const float *no_f = nullptr;
-    if (n1 > 2) {
-#define CALL(T, VV)                                                                                                   \
-    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, true>), dim3((unsigned)nb1), dim3(256), 0, s, key0, key0, n1,  \
-                       (int)n1, D, piece0, (int64_t)D, no_f, no_f, no_f, grad_arena, accumulate, piece1, key1)
-        RP_DISPATCH_TPR(tpr1, vec1, CALL);
-#undef CALL
-        RP_LAUNCH_CHECK("embed_grad_reduce (piece list)");
-    } else {
-        piece1 = piece0;
-        key1 = key0;
-    }
-    const int64_t nfix = (n1 > 2) ? 2 * nb1 : n1;
-    const unsigned fgrid = (unsigned)rp_cdiv(nfix, 256 / tpr1);
-#define CALL(T, VV)                                                                                                \
-    hipLaunchKernelGGL((embed_grad_fix_kernel<T, VV>), dim3(fgrid), dim3(256), 0, s, piece1, key1, nfix, D, grad_arena, \
-                       accumulate)
-    RP_DISPATCH_TPR(tpr1, vec1, CALL);
-#undef CALL
-    RP_LAUNCH_CHECK("embed_grad_reduce (cross-workgroup runs)");
-    return RP_OK;
+    return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+}
+
+// What the fused form needs: D == 64 rows, a 64-wide first layer, 16-byte aligned operands.
+extern "C" int rp_embed_grad_gemm_fits(int D, int hidden, int64_t lddh, int64_t ldwt) {
+    return (D == 64 && hidden == 64 && lddh % 4 == 0 && ldwt % 4 == 0) ? 1 : 0;
+}
+
+// grad_arena[key] (+)= sum over pairs p = (f, b) with that key of
+//       dh[b, 0:64] . wt[f*64:(f+1)*64, 0:64]^T   (= the rows dX[b, f*64:(f+1)*64] of the consuming Linear's dgrad)
+//     + (dx ? dx[b, f*64:(f+1)*64] : 0)  +  (gfm ? gfm[b] * (sum_in[b,:] - arena[key,:]) : 0)
+// wt = W1^T, [>= F*64 rows, 64]: row f*64+d is column f*64+d of the layer's weight [64, K].  Same determinism,
+// accumulate semantics and workspace as rp_embed_grad_reduce.
+extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
+                                  const float *dh, int64_t lddh, const float *wt, int64_t ldwt, const float *dx,
+                                  int64_t ldx, const float *gfm, const float *sum_in, const float *arena,
+                                  float *grad_arena, int accumulate, void *workspace, size_t workspace_bytes,
+                                  rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && dh && wt && grad_arena && workspace, "embed_grad_gemm: null pointer");
+    RP_REQUIRE(gfm == nullptr || arena, "embed_grad_gemm: the FM term needs the arena");
+    RP_REQUIRE(B >= 1 && B < INT32_MAX, "embed_grad_gemm: bad B");
+    if (!rp_embed_grad_gemm_fits(D, 64, lddh, ldwt) || !rp_aligned16(dh) || !rp_aligned16(wt) || !rp_aligned16(grad_arena) ||
+        (dx && (!rp_aligned16(dx) || ldx % 4 != 0)) || (sum_in && !rp_aligned16(sum_in)) || (arena && !rp_aligned16(arena)))
+        return rp_fail(RP_ERR_UNSUPPORTED, "embed_grad_gemm: needs D = 64, a 64-wide layer and 16-byte aligned operands");
+    if (n == 0) return RP_OK;
+    size_t need = 0;
+    rp_embed_grad_reduce_workspace_bytes(n, D, &need);
+    RP_REQUIRE(workspace_bytes >= need, "embed_grad_gemm: workspace %zu < %zu bytes", workspace_bytes, need);
+    char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t nb0 = grad_reduce_blocks(n, D, 4);
+    float *piece0 = reinterpret_cast<float *>(wbase);
+    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(embed_grad_gemm_kernel, dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B, dh, lddh,
+                       wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
+    RP_LAUNCH_CHECK("embed_grad_gemm");
+    return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }
 
 extern "C" int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream) {

@@ -218,49 +218,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float *
 // for A and B alike (the contraction is a sum, so any k pairing shared by both operands is valid).
 // LDS rows hold 32 bf16 + 8 pad (80 B = 5 x 16 B, odd) so the ds_read_b128 fragment reads are conflict-free.
 // ================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-
-#define BF_LD 40
-
-template <int NPROD>
-struct BfProd {
-    static constexpr int NP = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);
-    // smallest terms first
-    __device__ static constexpr int pa(int i) { return NPROD == 6 ? (i == 0 ? 0 : i == 1 ? 2 : i == 2 ? 1 : i == 3 ? 0 : i == 4 ? 1 : 0)
-                                                     : NPROD == 3 ? (i == 0 ? 0 : i == 1 ? 1 : 0) : 0; }
-    __device__ static constexpr int pb(int i) { return NPROD == 6 ? (i == 0 ? 2 : i == 1 ? 0 : i == 2 ? 1 : i == 3 ? 1 : i == 4 ? 0 : 0)
-                                                     : NPROD == 3 ? (i == 0 ? 1 : i == 1 ? 0 : 0) : 0; }
-};
-
-template <int NP>
-__device__ __forceinline__ void bf_split4(f32x4 v, bf16x4 (&p)[NP]) {
-    p[0] = __builtin_convertvector(v, bf16x4);
-    if (NP > 1) {
-        v -= __builtin_convertvector(p[0], f32x4);
-        p[1] = __builtin_convertvector(v, bf16x4);
-    }
-    if (NP > 2) {
-        v -= __builtin_convertvector(p[1], f32x4);
-        p[2] = __builtin_convertvector(v, bf16x4);
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void bf_split8(f32x8 v, bf16x8 (&p)[NP]) {
-    p[0] = __builtin_convertvector(v, bf16x8);
-    if (NP > 1) {
-        v -= __builtin_convertvector(p[0], f32x8);
-        p[1] = __builtin_convertvector(v, bf16x8);
-    }
-    if (NP > 2) {
-        v -= __builtin_convertvector(p[1], f32x8);
-        p[2] = __builtin_convertvector(v, bf16x8);
-    }
-}
+#include "bfsplit.h"
 
 // NT:  out[M,N] = act(A[M,K] . W[N,K]^T + bias).  Block tile (32*WM) x 64 x 32, 4 waves:
 //   WM = 4: wave w owns rows 32w.. and both 32-column halves;   WM = 2: waves are 2 (rows) x 2 (column halves) — used

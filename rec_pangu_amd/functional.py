@@ -39,10 +39,13 @@ class FMFold:
     embedding gradient, g_fm[b] * S[b, :] added to every field's slice of dX[b], is folded into the dgrad GEMM that
     produces dX (rp_linear_fwd_rowadd) instead of being applied per (sample, field) pair in the segmented reduce.
     `dfm` is recorded by _GradTap (tap_fm_grad) when the loss backward produces it, before any Linear runs."""
-    __slots__ = ("ssum", "ncols", "dfm", "folded")
+    __slots__ = ("ssum", "ncols", "dfm", "folded", "dgrad", "D", "fused")
 
-    def __init__(self, ssum, ncols):
+    def __init__(self, ssum, ncols, D=0):
         self.ssum, self.ncols, self.dfm, self.folded = ssum, ncols, None, False
+        # (dH, W^T) of the first Linear when its dgrad is left to the gather backward (rp_embed_grad_gemm): dX is then
+        # never materialised; the Linear returns a stride-0 zero in its place
+        self.dgrad, self.D, self.fused = None, D, False
 
 
 class _GradTap(torch.autograd.Function):
@@ -107,8 +110,18 @@ class _LinearAct(torch.autograd.Function):
             # [ldx, N]: the dgrad GEMM is the same NT kernel on W^T; zero rows beyond K make it write the zeros of
             # x's padding columns itself (a strided fill of those columns costs more than the whole GEMM)
             wt = hip.transpose(weight, rows_out=x.shape[1])
-            dx = torch.empty_like(x)
             lk = ctx.fm_link
+            if lk is not None and lk.D == 64 and weight.shape[0] == 64 and hip.get_matmul_precision() != "fp32" \
+                    and hip.embed_grad_gemm_fits(lk.D, weight.shape[0], dpre, wt):
+                # the consumer of this gradient is the embedding gather: its backward forms the dX rows it needs from
+                # (dH, W^T) on the matrix core, inside the segmented reduce.  What flows back through autograd is a
+                # stride-0 zero of the right shape (other consumers of x add their gradients to it as usual).
+                lk.dgrad = (dpre, wt)
+                dx = torch.zeros((1, 1), dtype=x.dtype, device=x.device).expand(x.shape[0], x.shape[1])
+                if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                    dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
+                return dx, dw, db, None, None, None, None
+            dx = torch.empty_like(x)
             if lk is not None and lk.dfm is not None and lk.ssum is not None and hip.linear_fwd_rowadd(
                     dpre, wt, lk.dfm.reshape(-1).contiguous(), lk.ssum, lk.ncols, dx):
                 lk.folded = True  # the gather backward now only applies the -g_fm * v part
@@ -573,7 +586,9 @@ class _EmbedGather(torch.autograd.Function):
                                                  want_fm, want_fm and need_grad, need_grad and pre is None,
                                                  store.err_flag)
         ctx.store, ctx.want_fm, ctx.B = store, want_fm, idx[0].shape[0]
-        ctx.link = store._fm_link = FMFold(ssum, len(idx) * store.embedding_dim) if (want_fm and need_grad) else None
+        # link to the first Linear that consumes x (DeepFM passes it on as `fm_link`): FM fold / fused dgrad
+        ctx.link = store._fm_link = FMFold(ssum, len(idx) * store.embedding_dim, store.embedding_dim) \
+            if (need_grad and meta is None) else None
         ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
         if pre is not None:
             keys = pre[0] if need_grad else None
@@ -586,12 +601,18 @@ class _EmbedGather(torch.autograd.Function):
     def backward(ctx, dx, dfm=None):
         keys, ssum = ctx.saved_tensors
         store = ctx.store
+        fused = None
+        if ctx.link is not None and ctx.link.dgrad is not None:
+            fused, ctx.link.dgrad = ctx.link.dgrad, None
+            ctx.link.fused = True
+            if dx is not None and dx.dim() == 2 and dx.stride(0) == 0 and dx.stride(1) == 0:
+                dx = None  # the placeholder of the fused Linear: no other consumer of x contributed
         if dx is not None:
             dx = _unit_inner(dx)
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
         if ctx.link is not None and ctx.link.folded:
             ssum = None  # g_fm * S is already inside dx (rp_linear_fwd_rowadd)
-        store.accumulate_grad(keys, ctx.B, dx, gfm, ssum, presorted=ctx.presorted)
+        store.accumulate_grad(keys, ctx.B, dx, gfm, ssum, presorted=ctx.presorted, fused=fused)
         return (None,) * (6 + len(store.emb_feature))
 
 

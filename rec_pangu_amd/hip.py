@@ -29,6 +29,9 @@ _SIGNATURES = {
     "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
     "rp_embed_grad_reduce_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "rp_embed_grad_gemm_fits": (C.c_int, [_i32, _i32, _i64, _i64]),
+    "rp_embed_grad_gemm": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
+                                     _vp, _sz, _vp]),
     "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
@@ -296,6 +299,28 @@ def embed_grad_reduce(sorted_keys, sorted_pos, B: int, D: int, dx, gfm, sum_in, 
         _check(lib().rp_embed_grad_reduce(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
                                       _ptr(dx), ldx, _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(),
                                       int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_reduce")
+
+
+def embed_grad_gemm_fits(D: int, hidden: int, dh, wt) -> bool:
+    return bool(lib().rp_embed_grad_gemm_fits(D, hidden, _rowmajor(dh, "dh"), _rowmajor(wt, "wt"))) \
+        and dh.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
+
+
+def embed_grad_gemm(sorted_keys, sorted_pos, B: int, D: int, dh, wt, dx, gfm, sum_in, arena, grad_arena, accumulate: bool):
+    """rp_embed_grad_gemm: the segmented reduce with the consuming Linear's dgrad formed inside (dh [B,64], wt = W1^T)."""
+    _req(grad_arena, torch.float32, "grad_arena")
+    _req(dh, torch.float32, "dh")
+    _req(wt, torch.float32, "wt")
+    ldx = _rowmajor(dx, "dx") if dx is not None else 0
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_reduce_workspace_bytes(sorted_keys.numel(), D, C.byref(nbytes)),
+           "rp_embed_grad_reduce_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+    with _Timed("embed_grad_gemm", f"D={D}"):
+        _check(lib().rp_embed_grad_gemm(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
+                                        dh.data_ptr(), _rowmajor(dh, "dh"), wt.data_ptr(), _rowmajor(wt, "wt"), _ptr(dx), ldx,
+                                        _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(), int(accumulate),
+                                        ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_gemm")
 
 
 def zero_rows(keys, D: int, grad_arena):

@@ -226,7 +226,7 @@ class EmbeddingLayer(nn.Module):
         if self._lazy is not None:
             self._lazy.flush(self)
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None):
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -249,8 +249,12 @@ class EmbeddingLayer(nn.Module):
             sk, sp = presorted
         else:
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
-        hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
-                              accumulate=not self._grad_clean)
+        if fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
+            hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
+                                accumulate=not self._grad_clean)
+        else:
+            hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
+                                  accumulate=not self._grad_clean)
         if self._touched is None:
             self._touched, self._touched_unsorted = sk, False
         else:  # several backward passes before one optimiser step: the union is no longer sorted

@@ -520,3 +520,61 @@ def test_linear_fwd_wide_kernel(hip, M, N, K, lda_pad, mode):
         assert not bool(torch.isnan(out3).any())
     finally:
         hip.set_matmul_precision("auto")
+
+
+@pytest.mark.parametrize("rows,B,with_fm,with_dx,accumulate", [
+    ([8, 4, 51, 12, 3], 24, True, False, False),
+    ([3, 4, 10, 5000, 27], 4099, True, False, False),   # tiles that span field borders; runs of > 1000 equal rows
+    ([3, 4, 10, 5000, 27], 4099, False, True, True),    # extra per-pair gradient (another consumer of x), accumulate mode
+    ([50000, 7], 65536, True, True, False),             # full batch: mostly unique rows + one hot table
+])
+def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
+    """rp_embed_grad_gemm (the segmented reduce with the consuming Linear's dgrad formed inside, on the matrix core) against
+    the unfused pair rp_linear_fwd (dX = dH . W) + rp_embed_grad_reduce in the fp32-faithful mode, and against an fp64
+    reference: the same gradient arena within fp32 rounding; bit-identical between two launches."""
+    hip.set_matmul_precision("bf16x6")
+    try:
+        D, H = 64, 64
+        g = torch.Generator().manual_seed(B + len(rows))
+        F = len(rows)
+        arena, base = _tables(rows, D, g)
+        idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+        K = F * D + 5
+        ldx = (K + 63) // 64 * 64
+        W1 = torch.randn(H, K, generator=g) / K ** 0.5
+        dh = torch.randn(B, H, generator=g) * 1e-3
+        dx_extra = torch.randn(B, ldx, generator=g) * 1e-3 if with_dx else None
+        gfm = torch.randn(B, 1, generator=g) * 1e-3 if with_fm else None
+        ssum = torch.randn(B, D, generator=g) if with_fm else None
+        keys = torch.cat([base[f] + idx[f] for f in range(F)]).to(torch.int32).to(DEV)
+        sk, sp = hip.sort_pairs(keys, end_bit=max(1, (sum(rows) - 1).bit_length()))
+        dev = lambda t_: None if t_ is None else t_.to(DEV)
+        wt = hip.transpose(dev(W1), rows_out=ldx)                      # [ldx, 64]
+        # unfused: dX = dH . W1 (+ extra), then the reduce
+        dxf = hip.linear_fwd(dev(dh), wt, None, hip.ACT_NONE)          # [B, ldx]
+        if with_dx:
+            dxf = dxf + dev(dx_extra)
+        G0 = torch.full((sum(rows), D), 0.5, device=DEV) if accumulate else torch.zeros(sum(rows), D, device=DEV)
+        G1 = G0.clone()
+        G2 = G0.clone()
+        hip.embed_grad_reduce(sk, sp, B, D, dxf, dev(gfm), dev(ssum), dev(arena), G0, accumulate=accumulate)
+        assert hip.embed_grad_gemm_fits(D, H, dev(dh), wt)
+        hip.embed_grad_gemm(sk, sp, B, D, dev(dh), wt, dev(dx_extra), dev(gfm), dev(ssum), dev(arena), G1, accumulate=accumulate)
+        hip.embed_grad_gemm(sk, sp, B, D, dev(dh), wt, dev(dx_extra), dev(gfm), dev(ssum), dev(arena), G2, accumulate=accumulate)
+        assert torch.equal(G1, G2), "two launches differ"
+        # fp64 reference
+        dX = dh.double() @ W1.double()[:, :F * D]
+        if with_dx:
+            dX = dX + dx_extra.double()[:, :F * D]
+        ref = torch.full((sum(rows), D), 0.5 if accumulate else 0.0, dtype=torch.float64)
+        for f in range(F):
+            rows_f = (base[f] + idx[f]).long()
+            contrib = dX[:, f * D:(f + 1) * D]
+            if with_fm:
+                contrib = contrib + gfm.double() * (ssum.double() - arena.double()[rows_f])
+            ref.index_add_(0, rows_f, contrib)
+        scale = float((ref - (0.5 if accumulate else 0.0)).abs().max())
+        assert float((G1.cpu().double() - ref).abs().max()) <= 2e-5 * max(scale, 1e-6)
+        assert float((G1 - G0).abs().max()) <= 2e-5 * max(scale, 1e-6)
+    finally:
+        hip.set_matmul_precision("auto")

@@ -142,16 +142,23 @@ def test_deepfm_criteo_shape_midsize_vs_oracle(matmul_mode):
     model = model.to(DEV)
     out = model(_to_dev(batch))
     out["loss"].backward()
-    # at this shape the FM part of the embedding gradient rides in the first Linear's dgrad (rp_linear_fwd_rowadd)
-    assert model.embedding_layer._fm_link is not None and model.embedding_layer._fm_link.folded
+    # at this shape (D = 64, 64-wide first layer) the first Linear's dgrad is formed inside the gather backward
+    # (rp_embed_grad_gemm: dX is never materialised); in the exact-fp32 mode the FM part rides in the dgrad GEMM instead
+    lk = model.embedding_layer._fm_link
+    assert lk is not None and (lk.fused or lk.folded)
     torch.testing.assert_close(out["pred"].cpu(), ref["pred"].detach(), rtol=0, atol=1e-4)
     torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=0, atol=1e-4)
     # gradients: 1e-4 relative in the modes the library chooses itself; a FORCED bf16x3 (opt-in: 'auto' keeps these
     # HBM-bound GEMMs at the fp32-faithful six products) is held to 2e-4 (measured 1.3e-4 on one table)
-    gtol = 2e-4 if matmul_mode == "bf16x3" else 1e-4
+    # gradients: 1e-4 relative to each parameter's own largest gradient in the modes the library chooses itself.  A FORCED
+    # bf16x3 (opt-in: 'auto' keeps these HBM-bound GEMMs at the fp32-faithful six products) perturbs the first layer's
+    # pre-activations by ~1e-5: the logit / loss gate above still holds, but a handful of ReLU units within that distance
+    # of zero flip their mask, and each flip moves a weight-gradient row by one whole per-sample term (~1/64 of the row
+    # at B = 4096) — so the gradients of that mode are only held to 2e-3 of the model's largest gradient.
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.named_parameters())
     for k, p in model.named_parameters():
         rg = sd[k].grad
-        tol = gtol * max(1e-4, float(rg.abs().max()))
+        tol = 2e-3 * gmax if matmul_mode == "bf16x3" else 1e-4 * max(1e-4, float(rg.abs().max()))
         assert (p.grad.cpu() - rg).abs().max() <= tol, f"grad {k}: {(p.grad.cpu() - rg).abs().max()} > {tol}"
 
 
