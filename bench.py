@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; v_mfma_f32_32x32x16_bf16)
 HBM_COPY_GBS = 6300.0  # device-to-device copy ceiling measured on this part
 VALU_PEAK_TLANE = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T fp32 lane-instructions / s
-REPLAY_VALU_OPS = 5 + 5.0 / 3.0  # per zero-gradient element-step: 5 fma/mul + one v_rcp_f32 (5/3 of a plain VALU slot)
+REPLAY_VALU_OPS = 4 + 5.0 / 3.0  # per zero-gradient element-step: 4 fma/mul + one v_rcp_f32 (5/3 of a plain VALU slot)
 
 
 def criteo_enc_dict(scale=1):
@@ -405,6 +405,11 @@ def main():
             # into the dgrad: DeepFM at D = 64), gradient row written (+ table row read for FM) per unique row
             fm = has_fm and dd == D
             return ((2 if (fm and D != 64) else 1) * n_pairs + (2 if fm else 1) * n_unique) * rb, 0
+        if entry == "embed_grad_gemm":    # dH row + sum_f v row gathered per pair, W^T slice per 128-pair tile, table row
+            # read (FM) + gradient row written per unique row; the dX rows themselves never touch memory
+            fm = has_fm and dd == D
+            return ((2 if fm else 1) * n_pairs + (2 if fm else 1) * n_unique) * rb + (n_pairs // 128) * 64 * rb, \
+                2.0 * n_pairs * 64 * dd
         if entry == "lazy_adam_rows_step":    # p,m,v read+written, g read + cleared, per unique touched row
             return 8 * n_unique * rb, 0
         if entry == "lazy_adam_rows_replay":  # p,m,v read+written per unique row that is behind (bound: all of them)
@@ -505,7 +510,7 @@ def main():
                              "valu_issue_slots_per_element_step": REPLAY_VALU_OPS,
                              "achieved_Tlane_ops_per_s": round(ops / 1e12, 2), "peak": VALU_PEAK_TLANE,
                              "frac": round(ops / 1e12 / VALU_PEAK_TLANE, 4),
-                             "note": "the replay is a serial fp32 chain per element (5 fma/mul + one reciprocal at 5/3 of a "
+                             "note": "the replay is a serial fp32 chain per element (4 fma/mul + one reciprocal at 5/3 of a "
                                      "plain VALU slot per skipped step): VALU-bound, not HBM-bound"}
         return r
 

@@ -377,8 +377,8 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * Same semantics as rp_adam_step over the whole arena (trainer.py:75: DENSE Adam, every row every step), but a
  * row's zero-gradient steps are replayed in registers when the row is next needed instead of being streamed
  * through HBM every step.  last[row] (int32, 0 = never updated) is the step the stored (p,m,v) are current at;
- * step_scalars is a device float2 table indexed by step: {lr_t/(1-b1^t), sqrt(1-b2^t)} from
- * rp_adam_step_scalars.  The replay runs the dense kernel's update function with g = 0: bit-identical results.
+ * step_scalars is a device float2 table indexed by step: {A_t, B_t} from rp_adam_step_scalars (the eps given
+ * there is the one that counts; the `eps` argument of the entry points below is kept for the record).  The replay runs the dense kernel's update function with g = 0: bit-identical results.
  *   rp_embed_keys       arena-row keys of a batch (same check/flag/clamp as the gather) — needed before the gather
  *   rp_lazy_adam_rows   for every UNIQUE row of `sorted_keys` (sorted; duplicates skipped): replay steps
  *                       last+1 .. t_target(-1); if real_step also apply step t_target with g = grad row
@@ -390,8 +390,9 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * use 16-byte vector lanes when D % 4 == 0 and the arenas are 16-byte aligned, scalar lanes otherwise. */
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
-int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,
-                         float *inv_bc2_sqrt); /* {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)}, computed in double */
+int rp_adam_step_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa,
+                         float *sb); /* {A_t, B_t} = {1/sqrt(1-b2^t), eps} / (-lr/(1-b1^t)), computed in double: the update
+                                      * is p += m * rcp(s * A_t + B_t) (s = sqrt(v)); lr = 0 gives (0, -inf) */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
                       float beta1, float beta2, float eps, rp_stream_t stream);

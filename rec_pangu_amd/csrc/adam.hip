@@ -46,7 +46,12 @@ __device__ __forceinline__ f32x4 rp_rcp_fast(f32x4 x) {
 // kernel of this file calls, so "dense every step" and "lazy replay later" execute the same operations on the same
 // values: bit-identical.  Against torch.optim.Adam (which stores v) each step differs by <= 1 ulp in s.
 // Exported optimizer state squares s again (rec_pangu_amd/optim.py).
-// inv_bc2_sqrt = 1 / sqrt(1 - b2^t);  sqrt_b2 = (float)sqrt((double)b2)
+// The update itself is evaluated as  p += m * rcp(s * A_t + B_t)  with the two per-step scalars
+//     A_t = (1 / sqrt(1 - b2^t)) / (-lr_t / (1 - b1^t)),   B_t = eps / (-lr_t / (1 - b1^t))      (computed in double)
+// i.e. the step size is folded into the denominator: p - step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps) in one fma, one
+// reciprocal and one more fma — one multiply less per element and step than the textbook order, which matters where
+// it is executed 2 G times per training step (the replay).  lr_t = 0: (A, B) = (0, -inf) -> rcp = -0 -> p unchanged.
+// sqrt_b2 = (float)sqrt((double)b2)
 __device__ __forceinline__ float rp_sel_zero(float g, float a, float b) { return g == 0.f ? a : b; }
 __device__ __forceinline__ f32x4 rp_sel_zero(f32x4 g, f32x4 a, f32x4 b) {
     return f32x4{g.x == 0.f ? a.x : b.x, g.y == 0.f ? a.y : b.y, g.z == 0.f ? a.z : b.z, g.w == 0.f ? a.w : b.w};
@@ -54,31 +59,44 @@ __device__ __forceinline__ f32x4 rp_sel_zero(f32x4 g, f32x4 a, f32x4 b) {
 
 template <typename T>
 __device__ __forceinline__ void adam1(T &p, const T g, T &m, T &s, float one_m_b1, float b2, float sqrt_b2,
-                                      float one_m_b2, float step_size, float inv_bc2_sqrt, float eps) {
-    const T c1 = rp_splat(one_m_b1, p), c2 = rp_splat(one_m_b2, p), ns = rp_splat(-step_size, p);
+                                      float one_m_b2, float sa, float sb) {
+    const T c1 = rp_splat(one_m_b1, p), c2 = rp_splat(one_m_b2, p);
     m = rp_fma(g - m, c1, m);                      // m + (g - m)(1 - b1)
     const T vb = (s * s) * b2;                     // b2 v, v = s^2
     const T sg = rp_sqrt_fast(rp_fma(c2 * g, g, vb));  // sqrt(b2 v + ((1 - b2) g) g)
     s = rp_sel_zero(g, s * sqrt_b2, sg);           // zero gradient: sqrt(b2) s, exactly what the replay computes
-    const T denom = rp_fma(s, rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
-    p = rp_fma(ns, m * rp_rcp_fast(denom), p);     // p - step_size * (m / denom)
+    const T denom = rp_fma(s, rp_splat(sa, p), rp_splat(sb, p));  // (sqrt(v) / sqrt(1 - b2^t) + eps) / (-step_size)
+    p = rp_fma(m, rp_rcp_fast(denom), p);                         // p - step_size * m / (sqrt(v)/... + eps)
 }
 
 // a zero-gradient step (the lazy replay): adam1(p, 0, m, s, ...) with the g == 0 branches folded by hand —
 // (0 - m)(1 - b1) + m rounds exactly as the general form does, and s takes the sqrt(b2) s branch
 template <typename T>
-__device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &s, float one_m_b1, float sqrt_b2, float step_size,
-                                                float inv_bc2_sqrt, float eps) {
-    const T c1 = rp_splat(one_m_b1, p), ns = rp_splat(-step_size, p);
+__device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &s, float one_m_b1, float sqrt_b2, float sa, float sb) {
+    const T c1 = rp_splat(one_m_b1, p);
     m = rp_fma(-m, c1, m);
     s = s * sqrt_b2;
-    const T denom = rp_fma(s, rp_splat(inv_bc2_sqrt, p), rp_splat(eps, p));
-    p = rp_fma(ns, m * rp_rcp_fast(denom), p);
+    const T denom = rp_fma(s, rp_splat(sa, p), rp_splat(sb, p));
+    p = rp_fma(m, rp_rcp_fast(denom), p);
+}
+
+// {A_t, B_t} of step t (see adam1): shared by the dense launch and by the step table of the lazy execution
+static void adam_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa, float *sb) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const double ns = -(double)lr / bc1;  // minus the step size
+    if (ns == 0.0) {                      // lr = 0: s * 0 - inf = -inf, rcp = -0, p + m * (-0) = p
+        *sa = 0.f;
+        *sb = -INFINITY;
+        return;
+    }
+    *sa = (float)((1.0 / std::sqrt(bc2)) / ns);
+    *sb = (float)((double)eps / ns);
 }
 
 template <bool ZERO_G>
 __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, float b2, float sqrt_b2, float one_m_b2,
-                                                   float step_size, float bc2_sqrt, float eps) {
+                                                   float sa, float sb) {
     const int ti = blockIdx.y;
     float *__restrict__ P = a.p[ti];
     float *__restrict__ G = a.g[ti];
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
         f32x4 p = reinterpret_cast<f32x4 *>(P)[e];
         const f32x4 g = reinterpret_cast<const f32x4 *>(G)[e];
         f32x4 m = reinterpret_cast<f32x4 *>(Mo)[e], v = reinterpret_cast<f32x4 *>(Vo)[e];
-        adam1<f32x4>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, step_size, bc2_sqrt, eps);
+        adam1<f32x4>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, sa, sb);
         reinterpret_cast<f32x4 *>(P)[e] = p;
         reinterpret_cast<f32x4 *>(Mo)[e] = m;
         reinterpret_cast<f32x4 *>(Vo)[e] = v;
@@ -101,7 +119,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
     for (int64_t e = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         float p = P[e], m = Mo[e], v = Vo[e];
         const float g = G[e];
-        adam1<float>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, step_size, bc2_sqrt, eps);
+        adam1<float>(p, g, m, v, one_m_b1, b2, sqrt_b2, one_m_b2, sa, sb);
         P[e] = p;
         Mo[e] = m;
         Vo[e] = v;
@@ -128,11 +146,8 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
         if (sizes[i] > maxn) maxn = sizes[i];
     }
     if (maxn == 0) return RP_OK;
-    // scalar prep in double, as python floats are in torch.optim.Adam
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)(1.0 / std::sqrt(bc2));  // the kernels multiply by the reciprocal
+    float sa, sb;  // the two per-step scalars, computed in double as python floats are in torch.optim.Adam
+    adam_scalars(lr, beta1, beta2, eps, step, &sa, &sb);
     int64_t bx = rp_cdiv(rp_cdiv(maxn, 4), 256);
     if (bx > 8192) bx = 8192;
     if (bx < 1) bx = 1;
@@ -141,11 +156,9 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
     const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
     const float sqrt_b2 = (float)std::sqrt((double)beta2);
     if (zero_grad)
-        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, step_size,
-                           bc2_sqrt, eps);
+        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, sa, sb);
     else
-        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, step_size,
-                           bc2_sqrt, eps);
+        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, sa, sb);
     RP_LAUNCH_CHECK("adam_step");
     return RP_OK;
 }
@@ -194,13 +207,13 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
 #pragma unroll 4
             for (int j = l0 + 1; j <= t_catch; ++j) {
                 const float2 s = sc[j];
-                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
+                adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
             }
         }
         if (real_step) {
             const T g = *reinterpret_cast<const T *>(G + off);
             const float2 s = sc[t_target];
-            adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.sqrt_b2, c.one_m_b2, s.x, s.y, c.eps);
+            adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.sqrt_b2, c.one_m_b2, s.x, s.y);
             if (zero_grad) *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
         }
         *reinterpret_cast<T *>(P + off) = p;
@@ -249,7 +262,7 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
 #pragma unroll 4
                     for (int j = l0[u] + 1; j <= t_target; ++j) {
                         const float2 s = sc[j];
-                        adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
+                        adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.sqrt_b2, s.x, s.y);
                     }
                     const int64_t off = rows[u] * D + cidx;
                     *reinterpret_cast<T *>(P + off) = p[u];
@@ -321,7 +334,7 @@ __device__ __forceinline__ void lazy_replay_candidates(bool need, int row, int l
         for (int j = l + 1; j <= t_target; ++j) {
             const float2 s = sc[j];  // uniform address: scalar load
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) adam1_zero_grad<float>(p[e], m[e], v[e], c.one_m_b1, c.sqrt_b2, s.x, s.y, c.eps);
+            for (int e = 0; e < EPL; ++e) adam1_zero_grad<float>(p[e], m[e], v[e], c.one_m_b1, c.sqrt_b2, s.x, s.y);
         }
         const int64_t off = (int64_t)r * D;
 #pragma unroll
@@ -421,13 +434,9 @@ static int lazy_tpr(int D, int vw) {
     } while (0)
 
 // host helper shared with the python side: the two per-step scalars exactly as rp_adam_step derives them
-extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, int64_t step, float *step_size,
-                                    float *bc2_sqrt) {
-    RP_REQUIRE(step_size && bc2_sqrt && step >= 1, "adam_step_scalars: bad argument");
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    *step_size = (float)((double)lr / bc1);
-    *bc2_sqrt = (float)(1.0 / std::sqrt(bc2));  // reciprocal: what adam1() multiplies sqrt(v) by
+extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa, float *sb) {
+    RP_REQUIRE(sa && sb && step >= 1, "adam_step_scalars: bad argument");
+    adam_scalars(lr, beta1, beta2, eps, step, sa, sb);
     return RP_OK;
 }
 

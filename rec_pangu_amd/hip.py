@@ -100,7 +100,7 @@ _SIGNATURES = {
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
                                     _vp]),
     "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
@@ -1056,9 +1056,10 @@ def dropout_bwd(dy, mask, p: float):
     return dx
 
 
-def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int):
+def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, eps: float = 1e-8):
+    """the two per-step scalars of the Adam kernels (see rp_adam_step_scalars): one row of the lazy step table"""
     a, b = C.c_float(0), C.c_float(0)
-    _check(lib().rp_adam_step_scalars(lr, beta1, beta2, step, C.byref(a), C.byref(b)), "rp_adam_step_scalars")
+    _check(lib().rp_adam_step_scalars(lr, beta1, beta2, eps, step, C.byref(a), C.byref(b)), "rp_adam_step_scalars")
     return a.value, b.value
 
 

@@ -55,7 +55,7 @@ class LazyAdamRows:
             return
         assert cap >= t_new - 1, f"lazy Adam step table has {cap + 1} rows, step {t_new} needs rows up to {t_new - 1}"
         hi = t_new + self.TABLE_CHUNK
-        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s) for s in range(t_new, hi + 1)]
+        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
         new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
         self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
         self._table_lr, self._table_from = lr, t_new
