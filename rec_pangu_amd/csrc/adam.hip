@@ -9,6 +9,10 @@
 #include "common.h"
 #include <cmath>
 
+#ifndef RP_REPLAY_UNROLL
+#define RP_REPLAY_UNROLL 2  // zero-gradient steps per iteration of the replay loop
+#endif
+
 struct AdamPtrs {
     float *p[RP_MAX_FIELDS];
     float *g[RP_MAX_FIELDS];
@@ -330,7 +334,7 @@ __device__ __forceinline__ void lazy_replay_candidates(bool need, int row, int l
         const int ln = __builtin_amdgcn_readlane(l0, src);
         float pn[EPL], mn[EPL], vn[EPL];
         lazy_load_row<EPL>(P, Mo, Vo, (int64_t)rn * D, lane, D, pn, mn, vn);  // in flight during the replay below
-#pragma unroll 2
+#pragma unroll RP_REPLAY_UNROLL
         for (int j = l + 1; j <= t_target; ++j) {
             const float2 s = sc[j];  // uniform address: scalar load
 #pragma unroll

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librecpangu_hip.so")
+LIB_PATH = os.environ.get("RP_LIB_PATH") or os.path.join(_HERE, "lib", "librecpangu_hip.so")  # (override: A/B builds)
 MAX_FIELDS = 64
 
 ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
