@@ -547,7 +547,7 @@ def main():
 
     if rank == 0:
         opt_txt = ("dense Adam, reference semantics (trainer.py:75), executed lazily: bit-identical to the dense HIP kernel; "
-                   "<= 2e-4 relative vs torch.optim.Adam after 2 steps (v_sqrt_f32 / v_rcp_f32 in the update)"
+                   "<= 2e-4 relative vs torch.optim.Adam after 2 steps (sqrt(v) kept as state, v_rcp_f32 in the update)"
                    if args.optimizer == "lazy" else
                    "dense Adam (reference semantics, every row streamed each step, fused zero_grad)")
         res = {
