@@ -340,6 +340,25 @@ int rp_batchnorm_bwd_apply(const float *x, int64_t ldx, const float *dy, int64_t
                            const float *rstd, const float *gamma, const float *mean_dy, const float *mean_dyx,
                            float *dx, int64_t lddx, int64_t M, int N, rp_stream_t stream);
 
+/* ---- the narrow tail of the MLP as one launch each way (layers/deep.py:62-72 with hidden_units [.., 64, 64], output_dim 1:
+ * DeepFM's dnn.net.{2,4,6}) --------------------------------------------------------------------------------------------
+ *   hin [M, 64] (a ReLU output) -> [Linear 64x64 + ReLU] x n_hidden (1..3) -> Linear 64 -> 1 = logit [M]
+ * rp_mlp_tail_fwd   W_hidden[l] [64 out, 64 in] (ldw[l] floats per row), b_hidden[l] [64] or NULL, h_out[l] [M, 64]: the
+ *                   hidden outputs, saved for the backward; w_out [64], b_out [1] or NULL
+ * rp_mlp_tail_bwd   dz [M] -> dhin [M, lddh] (already masked by hin > 0) and `grads` = dW_0 | .. | db_0 | .. | dw_out | db_out
+ *                   packed (n_hidden*4096 + n_hidden*64 + 64 + 1 floats); acts[0] = hin (ldact0), acts[l] = h_out[l-1];
+ *                   per-workgroup partials through `workspace`, summed in a fixed order (deterministic)
+ * Split-bf16 six-product MFMAs (fp32-faithful) in every precision mode except RP_MATMUL_FP32 (callers compose the plain
+ * entry points there).  rp_mlp_tail_fits: width 64, 1..3 hidden layers, row strides multiples of 4 floats. */
+int rp_mlp_tail_fits(int n_hidden, int width, int64_t ldin);
+int rp_mlp_tail_fwd(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                    const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out, float *logit,
+                    int64_t M, rp_stream_t stream);
+int rp_mlp_tail_bwd_workspace_bytes(int64_t M, int n_hidden, size_t *bytes);
+int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw, const float *const *acts,
+                    int64_t ldact0, const float *w_out, float *dhin, int64_t lddh, float *grads, int64_t M, void *workspace,
+                    size_t workspace_bytes, rp_stream_t stream);
+
 /* ---- Dropout (layers/deep.py:66-68 inside the MLP chain; the multi-task towers, mmoe.py:55) -------------------------
  * y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10(counter = (element group, offset), key = seed): a
  * pure function of (seed, offset, element index).  mask: uint8 [M*N] (1 = kept), saved for the backward

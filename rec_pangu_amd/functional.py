@@ -147,6 +147,42 @@ def linear_act(x, weight, bias=None, act: int = ACT_NONE, fm_link=None, in_link=
     return y if lead is None else y.reshape(*lead, y.shape[-1])
 
 
+class _MLPTail64(torch.autograd.Function):
+    """hin [B,64] (output of a Linear+ReLU) -> [Linear 64x64 + ReLU] x L -> Linear 64 -> 1, ONE launch each way
+    (rp_mlp_tail_fwd / rp_mlp_tail_bwd).  `in_link`: the ReluLink of the producing Linear+ReLU — the gradient that
+    comes out is already masked by hin > 0, so that layer skips its relu_bwd pass."""
+
+    @staticmethod
+    def forward(ctx, hin, in_link, w_out, b_out, *wb):
+        hin = _unit_inner(hin)
+        L = len(wb) // 2
+        Ws = [w.contiguous() for w in wb[:L]]
+        bs = list(wb[L:])
+        logit, hs = hip.mlp_tail_fwd(hin, Ws, bs, w_out.contiguous(), b_out)
+        ctx.L, ctx.in_link, ctx.has_bias = L, in_link, [b is not None for b in bs] + [b_out is not None]
+        ctx.save_for_backward(hin, w_out, *Ws, *hs)
+        return logit
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = ctx.L
+        hin, w_out, *rest = ctx.saved_tensors
+        Ws, hs = rest[:L], rest[L:]
+        dhin, dWs, dbs, dw_out, db_out = hip.mlp_tail_bwd(dz.reshape(-1).contiguous(), list(Ws), [hin] + list(hs),
+                                                           w_out.contiguous())
+        if ctx.in_link is not None:
+            ctx.in_link.dx = dhin
+        dbs = [d if hb else None for d, hb in zip(dbs, ctx.has_bias[:L])]
+        return (dhin, None, dw_out.view_as(w_out), db_out if ctx.has_bias[L] else None, *dWs, *dbs)
+
+
+def mlp_tail64(hin, in_link, hidden, head):
+    """hidden: [(weight [64,64], bias or None), ...] (1..3 layers, each followed by ReLU); head: (weight [1,64], bias)."""
+    Ws = [w for w, _ in hidden]
+    bs = [b for _, b in hidden]
+    return _MLPTail64.apply(hin, in_link, head[0], head[1], *Ws, *bs)
+
+
 # ----------------------------------------------------------------------------------------------
 # K5  CrossNet (+ the fc that follows it in DCN)   — layers/interaction.py:119-141, ranking/dcn.py:64
 # ----------------------------------------------------------------------------------------------

@@ -89,6 +89,10 @@ _SIGNATURES = {
     "rp_batchnorm_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_sums": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_apply": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_mlp_tail_fits": (C.c_int, [_i32, _i32, _i64]),
+    "rp_mlp_tail_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "rp_mlp_tail_bwd_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_mlp_tail_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _vp]),
     "rp_dropout_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp]),
     "rp_dropout_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
@@ -1012,6 +1016,52 @@ def batchnorm_bwd_apply(x, dy, mean, rstd, gamma, mean_dy, mean_dyx):
                                             mean_dyx.data_ptr(), dx.data_ptr(), N, M, N, _stream()),
                "rp_batchnorm_bwd_apply")
     return dx
+
+
+def mlp_tail_fits(n_hidden: int, width: int, hin) -> bool:
+    return bool(lib().rp_mlp_tail_fits(n_hidden, width, _rowmajor(hin, "hin"))) and hin.data_ptr() % 16 == 0
+
+
+def _i64_array(vals):
+    return (C.c_int64 * max(len(vals), 1))(*vals)
+
+
+def _opt_ptr_array(tensors):
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else _ptr(t)
+    return arr
+
+
+def mlp_tail_fwd(hin, Ws, bs, w_out, b_out):
+    """hin [M,64] -> (logit [M,1], hidden outputs [M,64] x len(Ws)) in one launch (rp_mlp_tail_fwd)."""
+    _req(hin, torch.float32, "hin")
+    M, L = hin.shape[0], len(Ws)
+    hs = [torch.empty((M, 64), dtype=torch.float32, device=hin.device) for _ in range(L)]
+    logit = torch.empty((M, 1), dtype=torch.float32, device=hin.device)
+    with _Timed("mlp_tail_fwd", f"{M}x64x{L}", 4 * M * (64 * (L + 1) + 1), 2 * M * (64 * 64 * L + 64)):
+        _check(lib().rp_mlp_tail_fwd(hin.data_ptr(), _rowmajor(hin, "hin"), L, _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]),
+                                     _opt_ptr_array(bs), _ptr_array(hs), w_out.data_ptr(), _ptr(b_out), logit.data_ptr(), M,
+                                     _stream()), "rp_mlp_tail_fwd")
+    return logit, hs
+
+
+def mlp_tail_bwd(dz, Ws, acts, w_out):
+    """-> (dhin [M,64] masked by hin > 0, [dW_l], [db_l], dw_out [1,64], db_out [1]) (rp_mlp_tail_bwd)."""
+    M, L = dz.shape[0], len(Ws)
+    dev = dz.device
+    dhin = torch.empty((M, 64), dtype=torch.float32, device=dev)
+    grads = torch.empty((L * 4096 + L * 64 + 65,), dtype=torch.float32, device=dev)
+    nbytes = _sz(0)
+    _check(lib().rp_mlp_tail_bwd_workspace_bytes(M, L, C.byref(nbytes)), "rp_mlp_tail_bwd_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    with _Timed("mlp_tail_bwd", f"{M}x64x{L}", 4 * M * (64 * (L + 2) + 1), 2 * M * (2 * 64 * 64 * L + 128)):
+        _check(lib().rp_mlp_tail_bwd(dz.data_ptr(), L, _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]),
+                                     _ptr_array(acts), _rowmajor(acts[0], "hin"), w_out.data_ptr(), dhin.data_ptr(), 64,
+                                     grads.data_ptr(), M, ws.data_ptr(), nbytes.value, _stream()), "rp_mlp_tail_bwd")
+    dWs = [grads[l * 4096:(l + 1) * 4096].view(64, 64) for l in range(L)]
+    dbs = [grads[L * 4096 + l * 64:L * 4096 + (l + 1) * 64] for l in range(L)]
+    return dhin, dWs, dbs, grads[L * 4160:L * 4160 + 64].view(1, 64), grads[L * 4160 + 64:L * 4160 + 65]
 
 
 _drop_calls = 0

@@ -53,6 +53,28 @@ class MLP(nn.Module):
             chain.append(get_activation(output_activation))
         self.net = nn.Sequential(*chain)
 
+    @staticmethod
+    def _tail64_start(mods, x):
+        """index of the first module of a trailing  [Linear(64,64), ReLU] x (1..3), Linear(64,1)  chain that directly
+        follows a Linear(., 64) + ReLU (the reference's default hidden_units [64, 64, 64] with output_dim 1 and no
+        dropout / BatchNorm: DeepFM, WDL, NFM), or -1."""
+        from ... import hip
+        n = len(mods)
+        if n < 5 or not isinstance(mods[-1], nn.Linear) or mods[-1].out_features != 1 or mods[-1].in_features != 64:
+            return -1
+        j = n - 1
+        layers = 0
+        while j - 2 >= 0 and isinstance(mods[j - 1], nn.ReLU) and isinstance(mods[j - 2], nn.Linear) \
+                and mods[j - 2].in_features == 64 and mods[j - 2].out_features == 64 and layers < 3:
+            j -= 2
+            layers += 1
+        if layers == 0 or j < 2 or not (isinstance(mods[j - 1], nn.ReLU) and isinstance(mods[j - 2], nn.Linear)
+                                        and mods[j - 2].out_features == 64):
+            return -1
+        if x.dim() != 2 or hip.get_matmul_precision() == "fp32":
+            return -1
+        return j
+
     def forward(self, x, fm_link=None):
         """`fm_link` (DeepFM on HIP): lets the first Linear's dgrad absorb the FM part of the embedding gradient."""
         if not x.is_cuda:
@@ -60,8 +82,13 @@ class MLP(nn.Module):
         mods = list(self.net)
         i = 0
         pending = None  # ReluLink of the Linear+ReLU whose output x currently is (nothing in between)
+        tail_at = self._tail64_start(mods, x)
         while i < len(mods):
             m = mods[i]
+            if i == tail_at and pending is not None:
+                # everything from here on is [Linear 64x64 + ReLU] x L -> Linear 64 -> 1: one launch each way
+                hidden = [(mods[j].weight, mods[j].bias) for j in range(i, len(mods) - 1, 2)]
+                return Fh.mlp_tail64(x, pending, hidden, (mods[-1].weight, mods[-1].bias))
             if isinstance(m, nn.Linear):
                 fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 out_link = Fh.ReluLink() if fuse_relu else None

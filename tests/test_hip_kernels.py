@@ -578,3 +578,51 @@ def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
         assert float((G1 - G0).abs().max()) <= 2e-5 * max(scale, 1e-6)
     finally:
         hip.set_matmul_precision("auto")
+
+
+@pytest.mark.parametrize("M,L", [(65536, 2), (1000, 1), (4099, 3), (128, 2)])
+def test_mlp_tail_fused_vs_fp64(hip, M, L):
+    """rp_mlp_tail_fwd / rp_mlp_tail_bwd (the 64 -> 64 -> .. -> 1 tail of deep.py:62-72 as one launch each way) against an
+    fp64 autograd reference: logits, every saved hidden activation, the gradient w.r.t. the tail's input (masked by its
+    ReLU), all weight / bias gradients; two backward launches are bit-identical (fixed-order partial sums)."""
+    g = torch.Generator().manual_seed(M + L)
+    pre = torch.randn(M, 64, generator=g)
+    hin = pre.relu()                                   # the tail's input is a ReLU output
+    Ws = [torch.randn(64, 64, generator=g) / 8 for _ in range(L)]
+    bs = [torch.randn(64, generator=g) * 0.1 for _ in range(L)]
+    w_out = torch.randn(1, 64, generator=g) / 8
+    b_out = torch.randn(1, generator=g)
+    dz = torch.randn(M, generator=g) / M
+    # fp64 reference
+    p64 = pre.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    b64 = [b.double().requires_grad_(True) for b in bs]
+    wo64, bo64 = w_out.double().requires_grad_(True), b_out.double().requires_grad_(True)
+    a = p64.relu()
+    acts = []
+    for w, b in zip(W64, b64):
+        a = (a @ w.t() + b).relu()
+        acts.append(a)
+    logit = a @ wo64.t() + bo64
+    (logit.reshape(-1) * dz.double()).sum().backward()
+    dev = lambda t_: t_.to(DEV)
+    out, hs = hip.mlp_tail_fwd(dev(hin), [dev(w) for w in Ws], [dev(b) for b in bs], dev(w_out), dev(b_out))
+    torch.testing.assert_close(out.cpu().double(), logit.detach(), rtol=1e-5, atol=2e-5)
+    for got, ref in zip(hs, acts):
+        torch.testing.assert_close(got.cpu().double(), ref.detach(), rtol=1e-5, atol=2e-5)
+    res = [hip.mlp_tail_bwd(dev(dz), [dev(w) for w in Ws], [dev(hin)] + hs, dev(w_out)) for _ in range(2)]
+    dhin, dWs, dbs, dwo, dbo = res[0]
+    for x, y in zip((res[0][0], *res[0][1], *res[0][2], res[0][3], res[0][4]), (res[1][0], *res[1][1], *res[1][2], res[1][3], res[1][4])):
+        assert torch.equal(x, y), "two backward launches differ"
+
+    def close(got, ref, what):
+        scale = float(ref.abs().max())
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * max(scale, 1e-12), f"{what}: {err} vs scale {scale}"
+
+    close(dhin, p64.grad, "d hin (masked)")
+    for l in range(L):
+        close(dWs[l], W64[l].grad, f"dW{l}")
+        close(dbs[l], b64[l].grad, f"db{l}")
+    close(dwo, wo64.grad, "dw_out")
+    close(dbo, bo64.grad, "db_out")
