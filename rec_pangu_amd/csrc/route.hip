@@ -4,7 +4,8 @@
 //   rp_shard_keys   ids of a batch -> composite keys (owner << lbits | local row), range-checked like the gather
 //   rp_route_build  sorted composite keys -> unique-request slots, the rows to ask each owner for, per-owner counts
 #include "common.h"
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 
 struct RouteIdx {
     const int64_t *p[RP_MAX_FIELDS];
@@ -95,7 +96,8 @@ static size_t route_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int route_scan_bytes(int64_t n, size_t *bytes) {
     size_t tb = 0;
-    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr, (int)n, nullptr);
+    hipError_t e = rocprim::inclusive_scan(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n,
+                                           rocprim::plus<int32_t>(), nullptr);
     if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route scan size query: %s", hipGetErrorString(e));
     *bytes = tb;
     return RP_OK;
@@ -138,7 +140,7 @@ extern "C" int rp_route_build(void *workspace, size_t workspace_bytes, const int
     const int64_t nf = n > world + 1 ? n : world + 1;  // the flag launch also clears starts[0..world]
     hipLaunchKernelGGL(route_flags_kernel, dim3((unsigned)rp_cdiv(nf, 256)), dim3(256), 0, s, sorted_keys, n, flags, starts, world);
     RP_LAUNCH_CHECK("route flags");
-    hipError_t e = hipcub::DeviceScan::InclusiveSum(temp, tb, (const int32_t *)flags, incl, (int)n, s);
+    hipError_t e = rocprim::inclusive_scan(temp, tb, (const int32_t *)flags, incl, (size_t)n, rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route_build scan: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, s, sorted_keys, sorted_pos, incl, n,
                        lbits, slot_sorted, slot_of_pair, uniq_rows, starts);
