@@ -149,16 +149,10 @@ int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t lda
  *   X_{l+1} = X_l + (X_l . W[l]) * X_0 + Bv[l];   W, Bv: [L, d] (the L Linear(d,1) weights / biases stacked)
  *   xout [B, ldo] = X_L (NULL to skip);  logit[B] = X_L . wfc + bfc[0] (NULL to skip)
  *   s_out [B, L] = the per-layer scalars X_l . W[l], all the backward needs besides X_0.
- * backward: g_x [B, ldg] = dL/dX_L and/or g_logit [B] = dL/dlogit  ->  dx0 [B, lddx], dW [L,d], dB [L,d],
- * dwfc [d] (per-block partial sums in `workspace`, reduced in fixed order).  d <= 2048, L <= 6.        */
+ * backward: rp_crossnet_bwd_rows below.  d <= 2048, L <= 6.        */
 int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv, const float *wfc,
                     const float *bfc, float *xout, int64_t ldo, float *logit, float *s_out, int64_t B,
                     rp_stream_t stream);
-int rp_crossnet_bwd_workspace_bytes(int64_t B, int d, int L, size_t *bytes);
-int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv, const float *wfc,
-                    const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
-                    int64_t lddx, float *dW, float *dB, float *dwfc, int64_t B, void *workspace,
-                    size_t workspace_bytes, rp_stream_t stream);
 
 /* ---- K6: xDeepFM CIN layer on the fp32 MFMA ------------------------------------------------------
  * replaces layers/interaction.py:164-168 (einsum "bhd,bmd->bhmd" + view + Conv1d(k=1) + sum over d).
@@ -210,8 +204,7 @@ int rp_mmoe_combine_fwd(const float *z, int64_t ldz, int K, int E, int T, float 
 int rp_mmoe_combine_bwd(const float *z, int64_t ldz, int K, int E, int T, const float *gate, const float *dout,
                         float *dz, int64_t lddz, int64_t B, rp_stream_t stream);
 
-/* Streaming CrossNet backward (what rec_pangu_amd uses; rp_crossnet_bwd above is the single-kernel variant that
- * keeps the parameter-gradient partials in registers).  X_l = A_l X_0 + C_l (A_l = 1 + sum_{k<l} s_k per sample,
+/* Streaming CrossNet backward.  X_l = A_l X_0 + C_l (A_l = 1 + sum_{k<l} s_k per sample,
  * C_l = sum_{k<l} b_k per feature), so one wave per row produces dx0 and V[B, 2L+2] =
  * [t_l A_l (l<L) | g_logit A_L | t_l (l<L) | g_logit]; then dW_l = (V^T X_0)[l] + C_l colsum(V)[L+1+l] etc. are one
  * rp_linear_wgrad(V, X_0) plus [L,d]-sized weight-space arithmetic.  d <= 2048.                            */

@@ -144,120 +144,6 @@ __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restri
     }
 }
 
-// partial layout per block: [ dW (L*d) | dB (L*d) | dwfc (d) ]
-template <int MAXL>
-__global__ __launch_bounds__(256) void crossnet_bwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
-                                                           const float *__restrict__ W, const float *__restrict__ Bv,
-                                                           const float *__restrict__ wfc,
-                                                           const float *__restrict__ s_in,
-                                                           const float *__restrict__ g_x, int64_t ldg,
-                                                           const float *__restrict__ g_logit,
-                                                           float *__restrict__ dx0, int64_t lddx,
-                                                           float *__restrict__ partial, int64_t B) {
-    __shared__ float sh[4];
-    const int t = threadIdx.x;
-    float aW[MAXL][CROSS_J], aB[MAXL][CROSS_J], aF[CROSS_J];
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l)
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            aW[l][j] = 0.f;
-            aB[l][j] = 0.f;
-        }
-#pragma unroll
-    for (int j = 0; j < CROSS_J; ++j) aF[j] = 0.f;
-
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        float r0[CROSS_J], g[CROSS_J], gx0[CROSS_J], xl[CROSS_J];
-        const float gl = (g_logit != nullptr) ? g_logit[b] : 0.f;
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            const int e = t + 256 * j;
-            r0[j] = (e < d) ? x0[b * ldx + e] : 0.f;
-            gx0[j] = 0.f;
-        }
-        // X_L (for the fc weight gradient) and dL/dX_L
-        if (g_logit != nullptr) {
-#pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) xl[j] = r0[j];
-            for (int l = 0; l < L; ++l) {
-                const float s = s_in[b * L + l];
-#pragma unroll
-                for (int j = 0; j < CROSS_J; ++j) {
-                    const int e = t + 256 * j;
-                    if (e < d) xl[j] = xl[j] + (s * r0[j] + Bv[(int64_t)l * d + e]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            const int e = t + 256 * j;
-            float v = 0.f;
-            if (e < d) {
-                if (g_x != nullptr) v += g_x[b * ldg + e];
-                if (g_logit != nullptr) {
-                    v += gl * wfc[e];
-                    aF[j] += gl * xl[j];
-                }
-            }
-            g[j] = v;
-        }
-#pragma unroll
-        for (int l = MAXL - 1; l >= 0; --l) {
-            if (l >= L) continue;
-            // recompute X_l from X_0 with the saved scalars
-#pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) xl[j] = r0[j];
-            for (int k = 0; k < l; ++k) {
-                const float s = s_in[b * L + k];
-#pragma unroll
-                for (int j = 0; j < CROSS_J; ++j) {
-                    const int e = t + 256 * j;
-                    if (e < d) xl[j] = xl[j] + (s * r0[j] + Bv[(int64_t)k * d + e]);
-                }
-            }
-            float part = 0.f;
-#pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) part += g[j] * r0[j];
-            const float tl = block_allsum_256(part, sh);  // dL/ds_l
-            const float s = s_in[b * L + l];
-#pragma unroll
-            for (int j = 0; j < CROSS_J; ++j) {
-                const int e = t + 256 * j;
-                if (e < d) {
-                    aB[l][j] += g[j];
-                    aW[l][j] += tl * xl[j];
-                    gx0[j] += s * g[j];
-                    g[j] = g[j] + tl * W[(int64_t)l * d + e];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            const int e = t + 256 * j;
-            if (e < d && dx0 != nullptr) dx0[b * lddx + e] = gx0[j] + g[j];
-        }
-    }
-    float *P = partial + (int64_t)blockIdx.x * (2 * L + 1) * d;
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
-        if (l >= L) continue;
-#pragma unroll
-        for (int j = 0; j < CROSS_J; ++j) {
-            const int e = t + 256 * j;
-            if (e < d) {
-                P[(int64_t)l * d + e] = aW[l][j];
-                P[(int64_t)(L + l) * d + e] = aB[l][j];
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < CROSS_J; ++j) {
-        const int e = t + 256 * j;
-        if (e < d) P[(int64_t)2 * L * d + e] = aF[j];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Backward, streaming form.  CrossNet is low-rank in disguise: by induction X_l = A_l X_0 + C_l with the per-sample
 // scalar A_l = 1 + sum_{k<l} s_k and the per-feature vector C_l = sum_{k<l} b_k.  Hence
@@ -403,21 +289,6 @@ extern "C" int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, 
     return RP_OK;
 }
 
-// out[e] = sum_k partial[k*stride + e], e < count (fixed order -> deterministic)
-__global__ __launch_bounds__(256) void partial_sum_kernel(const float *__restrict__ partial, int nblk, int64_t stride,
-                                                          int64_t count, float *__restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * stride + e];
-    out[e] = s;
-}
-
-static int cross_blocks(int64_t B) {
-    int64_t nb = B < 2048 ? B : 2048;
-    return (int)(nb < 1 ? 1 : nb);
-}
-
 extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv,
                                const float *wfc, const float *bfc, float *xout, int64_t ldo, float *logit,
                                float *s_out, int64_t B, rp_stream_t stream) {
@@ -444,47 +315,5 @@ extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const
     else CF(false, false);
 #undef CF
     RP_LAUNCH_CHECK("crossnet_fwd");
-    return RP_OK;
-}
-
-extern "C" int rp_crossnet_bwd_workspace_bytes(int64_t B, int d, int L, size_t *bytes) {
-    RP_REQUIRE(bytes && d >= 1 && L >= 1, "crossnet_bwd_workspace_bytes: bad argument");
-    *bytes = (size_t)cross_blocks(B) * (2 * L + 1) * d * sizeof(float) + 256;
-    return RP_OK;
-}
-
-extern "C" int rp_crossnet_bwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv,
-                               const float *wfc, const float *s_in, const float *g_x, int64_t ldg,
-                               const float *g_logit, float *dx0, int64_t lddx, float *dW, float *dB, float *dwfc,
-                               int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
-    RP_REQUIRE(x0 && W && Bv && s_in && dW && dB && workspace && B >= 1, "crossnet_bwd: bad argument");
-    RP_REQUIRE(g_x != nullptr || g_logit != nullptr, "crossnet_bwd: no incoming gradient");
-    RP_REQUIRE(g_logit == nullptr || (wfc && dwfc), "crossnet_bwd: logit gradient needs wfc and dwfc");
-    if (d < 1 || d > 256 * CROSS_J || L < 1 || L > CROSS_MAXL)
-        return rp_fail(RP_ERR_UNSUPPORTED, "crossnet: d=%d / L=%d unsupported", d, L);
-    size_t need = 0;
-    rp_crossnet_bwd_workspace_bytes(B, d, L, &need);
-    RP_REQUIRE(workspace_bytes >= need, "crossnet_bwd: workspace %zu < %zu", workspace_bytes, need);
-    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int nb = cross_blocks(B);
-    hipStream_t s = (hipStream_t)stream;
-    if (L <= 3)
-        hipLaunchKernelGGL((crossnet_bwd_kernel<3>), dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in, g_x, ldg,
-                           g_logit, dx0, lddx, P, B);
-    else
-        hipLaunchKernelGGL((crossnet_bwd_kernel<CROSS_MAXL>), dim3(nb), dim3(256), 0, s, x0, ldx, d, L, W, Bv, wfc, s_in,
-                           g_x, ldg, g_logit, dx0, lddx, P, B);
-    RP_LAUNCH_CHECK("crossnet_bwd");
-    const int64_t n = (int64_t)(2 * L + 1) * d;
-    const int64_t ld = (int64_t)L * d;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv(ld, 256)), dim3(256), 0, s, P, nb, n, ld, dW);
-    RP_LAUNCH_CHECK("crossnet_bwd reduce dW");
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv(ld, 256)), dim3(256), 0, s, P + ld, nb, n, ld, dB);
-    RP_LAUNCH_CHECK("crossnet_bwd reduce dB");
-    if (g_logit != nullptr) {
-        hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)rp_cdiv((int64_t)d, 256)), dim3(256), 0, s, P + 2 * ld, nb,
-                           n, (int64_t)d, dwfc);
-        RP_LAUNCH_CHECK("crossnet_bwd reduce dwfc");
-    }
     return RP_OK;
 }

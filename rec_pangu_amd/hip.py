@@ -40,9 +40,6 @@ _SIGNATURES = {
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
-    "rp_crossnet_bwd_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
-    "rp_crossnet_bwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
-                                  _i64, _vp, _sz, _vp]),
     "rp_crossnet_bwd_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "rp_cin_layer_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
     "rp_cin_layer_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
@@ -422,28 +419,6 @@ def crossnet_fwd(x0, d: int, W, Bv, wfc=None, bfc=None, want_x: bool = True):
                                      _ptr(bfc), _ptr(xout), d, _ptr(logit), s.data_ptr(), B, _stream()),
                "rp_crossnet_fwd")
     return xout, logit, s
-
-
-def crossnet_bwd(x0, d: int, W, Bv, wfc, s, g_x, g_logit):
-    """-> dx0 [B, x0.shape[1]] (columns >= d zeroed), dW [L,d], dB [L,d], dwfc [d] or None."""
-    B, L = x0.shape[0], W.shape[0]
-    dev = x0.device
-    dx0 = torch.empty_like(x0)
-    if x0.shape[1] > d:
-        dx0[:, d:].zero_()
-    dW = torch.empty((L, d), dtype=torch.float32, device=dev)
-    dB = torch.empty((L, d), dtype=torch.float32, device=dev)
-    dwfc = torch.empty((d,), dtype=torch.float32, device=dev) if g_logit is not None else None
-    nbytes = _sz(0)
-    _check(lib().rp_crossnet_bwd_workspace_bytes(B, d, L, C.byref(nbytes)), "rp_crossnet_bwd_workspace_bytes")
-    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
-    ldg = _rowmajor(g_x, "g_x") if g_x is not None else 0
-    with _Timed("crossnet_bwd"):
-        _check(lib().rp_crossnet_bwd(x0.data_ptr(), _rowmajor(x0, "x0"), d, L, W.data_ptr(), Bv.data_ptr(), _ptr(wfc),
-                                     s.data_ptr(), _ptr(g_x), ldg, _ptr(g_logit), dx0.data_ptr(),
-                                     _rowmajor(dx0, "dx0"), dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), B, ws.data_ptr(),
-                                     nbytes.value, _stream()), "rp_crossnet_bwd")
-    return dx0, dW, dB, dwfc
 
 
 def crossnet_bwd_rows(x0, d: int, W, wfc, s, g_x, g_logit):

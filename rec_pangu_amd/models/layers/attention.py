@@ -25,15 +25,21 @@ class ScaledDotProductAttention(nn.Module):
         self.softmax = nn.Softmax(dim=2)
 
     def forward(self, W_q, W_k, W_v, scale=None, mask=None):
-        scores = torch.bmm(W_q, W_k.transpose(1, 2))
-        if scale:
-            scores = scores / scale
-        if mask:
-            scores = scores.masked_fill_(mask, -np.inf)
-        attention = self.softmax(scores)
+        attention = attention_weights(W_q, W_k, scale, mask)
         if self.dropout is not None:
             attention = self.dropout(attention)
-        return torch.bmm(attention, W_v), attention
+        return torch.einsum("bts,bsa->bta", attention, W_v), attention
+
+
+def attention_weights(q, k, scale=None, mask=None):
+    """softmax over the key axis of q k^T (divided by `scale` when given; masked positions at -inf) — the one functional
+    form of the score computation both the module above and the composed path of MultiHeadAttention use."""
+    scores = torch.einsum("bta,bsa->bts", q, k)
+    if scale:
+        scores = scores / scale
+    if mask:
+        scores = scores.masked_fill(mask, -np.inf)
+    return torch.softmax(scores, dim=2)
 
 
 class MultiHeadAttention(nn.Module):
@@ -95,26 +101,21 @@ class MultiHeadAttention(nn.Module):
         return out  # [B, T, H*a]
 
     def _compose(self, query, key, value, mask):
-        residual = query
+        """Any configuration the HIP layer does not cover (and every CPU call): the same layer from device ops.  Heads are
+        the reference's RAW view of the projections ([B, T, H*a] -> [B*H, T, a] without a per-head transpose)."""
         B, H, a = query.size(0), self.num_heads, self.attention_dim
-        q = self.W_q(query).view(B * H, -1, a)  # raw view, not a per-head transpose
-        k = self.W_k(key).view(B * H, -1, a)
-        v = self.W_v(value).view(B * H, -1, a)
-        if mask:
-            mask = mask.repeat(H, 1, 1)
-        output, attention = self.dot_product_attention(q, k, v, self.scale, mask)
+        q, k, v = (proj(t).view(B * H, -1, a) for proj, t in ((self.W_q, query), (self.W_k, key), (self.W_v, value)))
+        output, attention = self.dot_product_attention(q, k, v, self.scale, mask.repeat(H, 1, 1) if mask else mask)
         output = output.view(B, -1, self.output_dim)
-        if self.W_res is not None:
-            if self.align_to == "output":
-                residual = self.W_res(residual)
-            elif self.align_to == "input":
-                output = self.W_res(output)
-        if self.dropout is not None:
-            output = self.dropout(output)
-        if self.use_residual:
-            output = output + residual
-        if self.layer_norm is not None:
-            output = self.layer_norm(output)
+        # width alignment of the skip connection: project the input up ("output") or the result back down ("input")
+        residual = query
+        if self.W_res is not None and self.align_to == "output":
+            residual = self.W_res(query)
+        elif self.W_res is not None and self.align_to == "input":
+            output = self.W_res(output)
+        for post in (self.dropout, (lambda o: o + residual) if self.use_residual else None, self.layer_norm):
+            if post is not None:
+                output = post(output)
         return output.relu(), attention
 
     def forward(self, query, key, value, mask=None):

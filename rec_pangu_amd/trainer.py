@@ -42,16 +42,11 @@ class RankTrainer:
         model = model.to(device)
         optimizer = make_adam(model, lr)
 
-        if lr_scheduler_type == 'StepLR':
-            scheduler = lr_scheduler.StepLR(optimizer, **scheduler_params)
-        elif lr_scheduler_type == 'ExponentialLR':
-            scheduler = lr_scheduler.ExponentialLR(optimizer, **scheduler_params)
-        elif lr_scheduler_type == 'CosineAnnealingLR':
-            scheduler = lr_scheduler.CosineAnnealingLR(optimizer, **scheduler_params)
-        elif lr_scheduler_type == "":
-            scheduler = None
-        else:
+        schedulers = {'StepLR': lr_scheduler.StepLR, 'ExponentialLR': lr_scheduler.ExponentialLR,
+                      'CosineAnnealingLR': lr_scheduler.CosineAnnealingLR}
+        if lr_scheduler_type not in schedulers and lr_scheduler_type != "":
             raise ValueError('Unknown scheduler type: {}'.format(lr_scheduler_type))
+        scheduler = schedulers[lr_scheduler_type](optimizer, **scheduler_params) if lr_scheduler_type else None
 
         logger.info('Model Starting Training ')
         best_epoch, best_metric = -1, -1
