@@ -86,6 +86,19 @@ int rp_embed_gather_fwd(const float *arena, const int64_t *row_base, const int64
                         int64_t B, int D, float *x, int64_t ldx, float *fm_out, float *sum_out,
                         int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
 
+/* The gather FUSED with the Linear (+ ReLU) that consumes its output (DeepFM: embedding.py:59-63 + utils.py:122-137 +
+ * deepfm.py:57-58 + interaction.py:38-44 + deep.py:62-72 for dnn.net.0 in ONE launch): the gathered rows go from global
+ * memory into MFMA fragments once and are stored to x (NULL: x is not materialised), summed for the FM term and
+ * multiplied with the field's 64 x 64 slice of W on the matrix core (split-bf16, six products), so x is never re-read.
+ *   W [64, K] (ldw floats per row), K = F*64 + ND;  h1 [B, 64] = relu(x[:, :K] . W^T + bias)
+ * rp_embed_gather_linear_fits: D == 64, a 64-wide layer, ND <= 16 (and F <= 32); otherwise RP_ERR_UNSUPPORTED
+ * (compose rp_embed_gather_fwd + rp_linear_fwd). */
+int rp_embed_gather_linear_fits(int D, int ND, int hidden, int64_t ldx, int64_t ldw);
+int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, const int64_t *row_count,
+                               const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
+                               int D, float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *h1,
+                               float *fm_out, float *sum_out, int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
+
 /* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
  * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
  * interaction.py:38-44.  rp_sort_pairs_i32 sorts (key, position) pairs by key (stable, so

@@ -269,6 +269,245 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     }
 }
 
+#define EG_LD 72  // bf16 row of 64 + 8 pad: 144 B = 9 x 16 B (odd) -> conflict-free ds_read_b128 fragment reads
+#define EG_CT 68  // fp32 row of the C tile
+#define EGL_MAXF 32  // fields the fused gather + Linear forward keeps keys for
+
+// ------------------------------------------------------------------------------------------------
+// Gather FUSED with the Linear that consumes the gathered rows (DeepFM: embedding lookup + dense concat + FM second
+// order + dnn.net.0 with its ReLU — embedding.py:59-63, utils.py:122-137, deepfm.py:57-58, interaction.py:38-44,
+// deep.py:62-72 in one launch).
+//
+// Unfused, the gather writes x[B, F*D+ND] (453 MB at Criteo shape) and the first layer reads it straight back.  Here a
+// workgroup takes 128 samples through all F fields: a wave owns 32 samples, a lane holds half of a sample's row of the
+// current field (lane = (sample, half): the MFMA A layout, so the 32 floats go from global memory into registers once and
+// are used three times — stored to x (the weight gradient still reads it), added into the FM sums, split into bf16 pieces
+// for the matrix core), the field's 64 x 64 slice of W1 goes through a double-buffered LDS tile (one barrier per
+// field), and h1 = relu(x W1^T + b) accumulates over the fields in the MFMA accumulators.  The next field's rows are in
+// flight while the current field is on the matrix core.  Split-bf16, six products (fp32-faithful).
+// ------------------------------------------------------------------------------------------------
+// FULL: every sample of the workgroup exists and x is written — no lane masks around the loads and stores of the field
+// loop, so the in-order vmcnt waits for THIS field's rows are counted and do not wait for the prefetch of the next.
+template <bool FULL>
+__global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
+    const float *__restrict__ arena, const int64_t *__restrict__ row_base, const int64_t *__restrict__ row_count,
+    IdxPtrs idx, int F, DensePtrs dense, int ND, int64_t B, int64_t blk0, float *__restrict__ x, int64_t ldx,
+    const float *__restrict__ W, int64_t ldw, const float *__restrict__ bias, float *__restrict__ h1,
+    float *__restrict__ fm_out, float *__restrict__ sum_out, int32_t *__restrict__ keys_out, int32_t *__restrict__ err_flag) {
+    constexpr int D = 64;
+    __shared__ __attribute__((aligned(16))) __bf16 Wt[2][3][64][EG_LD];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
+    const int64_t blk = blk0 + blockIdx.x;
+    const int64_t b = blk * 128 + 32 * wv + i;
+    const bool bok = FULL || b < B;
+    const int64_t bc = bok ? b : B - 1;
+    const int wd = threadIdx.x >> 2, wc = (threadIdx.x & 3) * 16;  // W staging: row n = wd, 16 floats from wc
+
+    // arena rows of the workgroup's samples, all fields, computed up front into LDS (range check as the plain gather): the
+    // field loop then needs no index loads — an id load in the loop would be the NEWEST vector-memory operation at the
+    // point where its value is needed, and waiting for it (vmcnt(0)) would also wait for every x store just issued
+    __shared__ int32_t Ks[4][32][EGL_MAXF];
+    for (int f = h; f < F; f += 2) {
+        int64_t id = idx.p[f][bc];
+        if (id < 0 || id >= row_count[f]) {
+            if (bok) *err_flag = 1;
+            id = 0;
+        }
+        const int64_t key = row_base[f] + id;
+        Ks[wv][i][f] = (int32_t)key;
+        if (keys_out != nullptr && bok) keys_out[(int64_t)f * B + b] = (int32_t)key;
+    }
+    __syncthreads();
+    auto row_of = [&](int f) -> const float * { return arena + (int64_t)Ks[wv][i][f] * D + 8 * h; };
+    auto load_row = [&](const float *src, f32x8 (&v)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + ks * 16), v1 = *reinterpret_cast<const f32x4 *>(src + ks * 16 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[ks][e] = v0[e];
+                v[ks][4 + e] = v1[e];
+            }
+        }
+    };
+    auto stage_w = [&](int buf, int col0) {  // W[:, col0 .. col0 + 63] -> Wt[buf] pieces ([n][k])
+        const float *src = W + (int64_t)wd * ldw + col0 + wc;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + 8 * u), v1 = *reinterpret_cast<const f32x4 *>(src + 8 * u + 4);
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = v0[e];
+                v[4 + e] = v1[e];
+            }
+            bf16x8 pc[3];
+            bf_split8<3>(v, pc);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&Wt[buf][q][wd][wc + 8 * u]) = pc[q];
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    f32x8 S[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) S[ks][e] = 0.f;
+    float qsum = 0.f;
+    f32x8 av[4], avn[4];
+    load_row(row_of(0), av);
+    for (int f = 0; f < F; ++f) {
+        load_row(row_of(f + 1 < F ? f + 1 : f), avn);  // in flight during this field's matrix work (the last field is
+                                                       // simply read once more: a load behind a branch cannot be counted)
+        stage_w(f & 1, f * D);
+        __syncthreads();  // slice f visible; everyone is past the fragment reads of slice f - 2 (same buffer)
+        float *xr = (FULL || (x != nullptr && bok)) ? x + b * ldx + (int64_t)f * D + 8 * h : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (FULL || xr != nullptr) {
+                *reinterpret_cast<f32x4 *>(xr + ks * 16) = f32x4{av[ks][0], av[ks][1], av[ks][2], av[ks][3]};
+                *reinterpret_cast<f32x4 *>(xr + ks * 16 + 4) = f32x4{av[ks][4], av[ks][5], av[ks][6], av[ks][7]};
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                S[ks][e] += av[ks][e];
+                qsum = __builtin_fmaf(av[ks][e], av[ks][e], qsum);
+            }
+            bf16x8 a[3];
+            bf_split8<3>(av[ks], a);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bf16x8 bq[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8 *>(&Wt[f & 1][q][nt * 32 + i][ks * 16 + 8 * h]);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) av[ks] = avn[ks];
+    }
+    // ---- the dense columns (K tail: ND <= 16 columns right after the F*D embedding columns): one 16-deep k-step
+    if (ND > 0) {
+        const int buf = F & 1;
+        {   // W[:, F*D + k], k < ND, zero padded to 16; guarded (the row may end right after column K - 1)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = (threadIdx.x & 3) * 4 + u;  // k of this element, row n = wd
+                const float v = e < ND ? W[(int64_t)wd * ldw + (int64_t)F * D + e] : 0.f;
+                const __bf16 hi = (__bf16)v;
+                const float r1 = v - (float)hi;
+                const __bf16 mid = (__bf16)r1;
+                Wt[buf][0][wd][e] = hi;
+                Wt[buf][1][wd][e] = mid;
+                Wt[buf][2][wd][e] = (__bf16)(r1 - (float)mid);
+            }
+        }
+        f32x8 dv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * h + e;
+            dv[e] = k < ND ? dense.p[k][bc] : 0.f;
+        }
+        __syncthreads();
+        if (x != nullptr && bok) {
+            float *xd = x + b * ldx + (int64_t)F * D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (8 * h + e < ND) xd[8 * h + e] = dv[e];
+            for (int64_t j = (int64_t)F * D + ND + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;  // zero padding up to ldx
+        }
+        bf16x8 a[3];
+        bf_split8<3>(dv, a);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            bf16x8 bq[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8 *>(&Wt[buf][q][nt * 32 + i][8 * h]);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
+        }
+    } else if (x != nullptr && bok) {
+        for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;
+    }
+    // ---- epilogue: h1 = relu(acc + bias) in the C layout; FM second order and the field sum from the lane's half row
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + i;
+        const float bv = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = blk * 128 + 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (FULL || m < B) h1[m * 64 + n] = fmaxf(acc[nt][r] + bv, 0.f);
+        }
+    }
+    float ssq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq = __builtin_fmaf(S[ks][e], S[ks][e], ssq);
+    float fmv = ssq - qsum;
+    fmv += __shfl_xor(fmv, 32, 64);
+    if (fm_out != nullptr && h == 0 && bok) fm_out[b] = 0.5f * fmv;
+    if (sum_out != nullptr && bok) {
+        float *sr = sum_out + b * D + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            *reinterpret_cast<f32x4 *>(sr + ks * 16) = f32x4{S[ks][0], S[ks][1], S[ks][2], S[ks][3]};
+            *reinterpret_cast<f32x4 *>(sr + ks * 16 + 4) = f32x4{S[ks][4], S[ks][5], S[ks][6], S[ks][7]};
+        }
+    }
+}
+
+extern "C" int rp_embed_gather_linear_fits(int D, int ND, int hidden, int64_t ldx, int64_t ldw) {
+    return (D == 64 && hidden == 64 && ND >= 0 && ND <= 16 && ldx % 4 == 0 && ldw % 4 == 0) ? 1 : 0;  // (and F <= 32)
+}
+
+// x[B, ldx] (NULL: not materialised), h1[B, 64] = relu(x[:, :F*64+ND] . W^T + bias), fm_out / sum_out / keys_out as
+// rp_embed_gather_fwd.  W: [64, K] with ldw floats per row, K = F*64 + ND.
+extern "C" int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, const int64_t *row_count,
+                                          const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                                          int64_t B, int D, float *x, int64_t ldx, const float *W, int64_t ldw,
+                                          const float *bias, float *h1, float *fm_out, float *sum_out, int32_t *keys_out,
+                                          int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(arena && row_base && row_count && idx_ptrs && W && h1 && err_flag, "embed_gather_linear_fwd: null pointer");
+    RP_REQUIRE(F >= 1 && F <= RP_MAX_FIELDS && B >= 0, "embed_gather_linear_fwd: bad F/B");
+    RP_REQUIRE(ND == 0 || dense_ptrs, "embed_gather_linear_fwd: dense_ptrs is null with ND=%d", ND);
+    RP_REQUIRE((int64_t)F * B < (int64_t)INT32_MAX, "embed_gather_linear_fwd: F*B overflows int32 positions");
+    if (F > EGL_MAXF || !rp_embed_gather_linear_fits(D, ND, 64, x ? ldx : 4, ldw) || !rp_aligned16(arena) || !rp_aligned16(W) ||
+        (x && (!rp_aligned16(x) || ldx < (int64_t)F * D + ND)) || ldw < (int64_t)F * D + ND ||
+        (sum_out && !rp_aligned16(sum_out)))
+        return rp_fail(RP_ERR_UNSUPPORTED, "embed_gather_linear_fwd: needs D = 64, a 64-wide layer, ND <= 16, aligned operands");
+    if (B == 0) return RP_OK;
+    IdxPtrs ip;
+    DensePtrs dp;
+    for (int f = 0; f < F; ++f) {
+        RP_REQUIRE(idx_ptrs[f], "embed_gather_linear_fwd: idx_ptrs[%d] is null", f);
+        ip.p[f] = idx_ptrs[f];
+    }
+    for (int j = 0; j < ND; ++j) {
+        RP_REQUIRE(dense_ptrs[j], "embed_gather_linear_fwd: dense_ptrs[%d] is null", j);
+        dp.p[j] = dense_ptrs[j];
+    }
+    const int64_t nfull = (x != nullptr) ? B / 128 : 0;  // workgroups whose 128 samples all exist (x written: no lane masks)
+    const int64_t nblk = rp_cdiv(B, 128);
+    hipStream_t s = (hipStream_t)stream;
+    if (nfull > 0)
+        hipLaunchKernelGGL((embed_gather_linear_kernel<true>), dim3((unsigned)nfull), dim3(256), 0, s, arena, row_base, row_count, ip,
+                           F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag);
+    if (nblk > nfull)
+        hipLaunchKernelGGL((embed_gather_linear_kernel<false>), dim3((unsigned)(nblk - nfull)), dim3(256), 0, s, arena, row_base,
+                           row_count, ip, F, dp, ND, B, nfull, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag);
+    RP_LAUNCH_CHECK("embed_gather_linear_fwd");
+    return RP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Gather backward FUSED with the dgrad of the Linear that consumes the gathered rows (DeepFM: dnn.net.0).
 //
@@ -282,8 +521,6 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
 // Positions are field-major, so a 128-position tile lies in one field except at the F-1 field borders, where it runs
 // one matrix pass per field with the other field's rows masked out.
 // ------------------------------------------------------------------------------------------------
-#define EG_LD 72  // bf16 row of 64 + 8 pad: 144 B = 9 x 16 B (odd) -> conflict-free ds_read_b128 fragment reads
-#define EG_CT 68  // fp32 row of the C tile
 __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
     int64_t lddh, const float *__restrict__ wt, int64_t ldwt, const float *__restrict__ dx, int64_t ldx,

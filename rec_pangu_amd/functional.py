@@ -652,6 +652,53 @@ class _EmbedGather(torch.autograd.Function):
         return (None,) * (6 + len(store.emb_feature))
 
 
+class _EmbedGatherLinear(torch.autograd.Function):
+    """rp_embed_gather_linear_fwd: lookup + dense concat + FM + the first Linear (+ ReLU) of the MLP in one launch; the
+    backward is the weight gradient (x is still written for it) and rp_embed_grad_gemm (dX never exists).  `out_link`: the
+    ReluLink shared with the consumer of h1 (the fused MLP tail hands back a gradient that is already masked)."""
+
+    @staticmethod
+    def forward(ctx, store, idx, dense, ldx: int, weight, bias, out_link, *tables):
+        pre = store._presorted
+        store._presorted = None
+        need_grad = any(ctx.needs_input_grad[7:])
+        w16 = _rows16(weight)
+        x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx, w16,
+                                                            bias, True, need_grad, need_grad and pre is None, store.err_flag)
+        ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, idx[0].shape[0], weight.shape[1], out_link, bias is not None
+        ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
+        if pre is not None:
+            keys = pre[0] if need_grad else None
+        ctx.save_for_backward(keys, ssum, x, h1, weight)
+        store._fm_link = None
+        return h1, fm
+
+    @staticmethod
+    def backward(ctx, dh1, dfm):
+        keys, ssum, x, h1, weight = ctx.saved_tensors
+        store = ctx.store
+        dh1 = _unit_inner(dh1)
+        lk = ctx.out_link
+        masked = lk is not None and lk.dx is not None and lk.dx.data_ptr() == dh1.data_ptr() and lk.dx.shape == dh1.shape
+        if lk is not None:
+            lk.dx = None
+        dpre = dh1 if masked else hip.relu_bwd(dh1, h1)
+        dw = db = None
+        if ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
+            dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
+        if keys is not None:
+            wt = hip.transpose(weight, rows_out=x.shape[1])
+            gfm = dfm.contiguous() if dfm is not None else None
+            store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
+                                  fused=(dpre, wt))
+        return (None, None, None, None, dw, db, None) + (None,) * len(store.emb_feature)
+
+
+def embed_gather_linear(store, idx, dense, ldx: int, weight, bias, out_link):
+    tables = [store.embedding_layer[c].weight for c in store.emb_feature]
+    return _EmbedGatherLinear.apply(store, idx, dense, ldx, weight, bias, out_link, *tables)
+
+
 def embed_gather(store, idx, dense, ldx: int, want_fm: bool, meta=None):
     """`meta` = (row_base, row_count) of the tables `idx` addresses when that is a subset of the store's fields
     (single-field / sequence lookups); None = all fields in order."""

@@ -25,6 +25,9 @@ _SIGNATURES = {
     "rp_last_error": (C.c_char_p, []),
     "rp_launch_count": (C.c_uint64, []),
     "rp_embed_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "rp_embed_gather_linear_fits": (C.c_int, [_i32, _i32, _i32, _i64, _i64]),
+    "rp_embed_gather_linear_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp]),
     "rp_sort_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
     "rp_embed_grad_reduce_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -271,6 +274,40 @@ def embed_gather_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense:
                                      _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, _ptr(fm), _ptr(ssum), _ptr(keys),
                                      err_flag.data_ptr(), _stream()), "rp_embed_gather_fwd")
     return x, fm, ssum, keys
+
+
+def embed_gather_linear_fits(D: int, F: int, ND: int, hidden: int, ldx: int, W) -> bool:
+    return F <= 32 and bool(lib().rp_embed_gather_linear_fits(D, ND, hidden, ldx, _rowmajor(W, "W"))) and W.data_ptr() % 16 == 0
+
+
+def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, W, bias,
+                            want_fm: bool, want_sum: bool, want_keys: bool, err_flag: torch.Tensor):
+    """the gather fused with the 64-wide Linear + ReLU that consumes it -> (x [B, ldx], h1 [B, 64], fm, ssum, keys)"""
+    _req(arena, torch.float32, "arena")
+    _req(W, torch.float32, "W")
+    F, ND = len(idx), len(dense)
+    B, D = idx[0].shape[0], arena.shape[1]
+    for t in idx:
+        _req(t, torch.int64, "index")
+        if t.dim() != 1 or t.shape[0] != B or not t.is_contiguous():
+            raise RuntimeError("index tensors must be contiguous int64 [B]")
+    for t in dense:
+        _req(t, torch.float32, "dense")
+        if t.dim() != 1 or t.shape[0] != B or not t.is_contiguous():
+            raise RuntimeError("dense tensors must be contiguous float32 [B]")
+    dev = arena.device
+    x = torch.empty((B, ldx), dtype=torch.float32, device=dev)
+    h1 = torch.empty((B, 64), dtype=torch.float32, device=dev)
+    fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
+    ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_sum else None
+    keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
+    K = F * D + ND
+    with _Timed("embed_gather_linear_fwd", f"D={D}", B * (F * (D * 4 + 8) + (F * D + ND) * 4 + 64 * 4), 2 * B * K * 64):
+        _check(lib().rp_embed_gather_linear_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
+                                                _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, W.data_ptr(), _rowmajor(W, "W"),
+                                                _ptr(bias), h1.data_ptr(), _ptr(fm), _ptr(ssum), _ptr(keys),
+                                                err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd")
+    return x, h1, fm, ssum, keys
 
 
 def sort_pairs(keys: torch.Tensor, end_bit: int = 32):

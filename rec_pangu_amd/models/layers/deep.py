@@ -75,13 +75,21 @@ class MLP(nn.Module):
             return -1
         return j
 
-    def forward(self, x, fm_link=None):
-        """`fm_link` (DeepFM on HIP): lets the first Linear's dgrad absorb the FM part of the embedding gradient."""
+    def first_linear_relu(self):
+        """the first Linear when it is directly followed by a ReLU (what the fused gather + Linear launch replaces)"""
+        mods = list(self.net)
+        if len(mods) >= 2 and isinstance(mods[0], nn.Linear) and isinstance(mods[1], nn.ReLU):
+            return mods[0]
+        return None
+
+    def forward(self, x, fm_link=None, start: int = 0, pending=None):
+        """`fm_link` (DeepFM on HIP): lets the first Linear's dgrad absorb the FM part of the embedding gradient.
+        `start` / `pending`: continue after the first `start` modules (x is then the output of a Linear+ReLU that ran
+        elsewhere — the fused gather + Linear launch — and `pending` its ReluLink)."""
         if not x.is_cuda:
             return self.net(x)  # BASELINE config 0 (CPU plumbing)
         mods = list(self.net)
-        i = 0
-        pending = None  # ReluLink of the Linear+ReLU whose output x currently is (nothing in between)
+        i = start
         tail_at = self._tail64_start(mods, x)
         while i < len(mods):
             m = mods[i]

@@ -18,6 +18,8 @@ BASELINE.json config 0 ("plumbing, no GPU") and uses plain torch ops.
 import weakref
 from typing import Dict, List, Optional, Union
 
+import os
+
 import torch
 from torch import nn
 
@@ -277,6 +279,39 @@ class EmbeddingLayer(nn.Module):
         """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
         self._ensure_packed()
         return self._gather(self._idx_list(X), None, dense, want_fm, pad_to, src=tuple(X[c] for c in self.emb_feature))
+
+    def gather_linear_fits(self, n_dense: int, linear: nn.Linear, pad_to: int = 64) -> bool:
+        """can lookup + concat + FM + `linear` (+ ReLU) run as the one fused launch (rp_embed_gather_linear_fwd)?"""
+        from ... import hip
+        F, D = len(self.emb_feature), self.embedding_dim
+        d = F * D + n_dense
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        w = linear.weight
+        return (os.environ.get("RP_GATHER_LINEAR", "1") != "0" and self._arena.is_cuda and D == 64 and linear.out_features == 64 and linear.in_features == d
+                and hip.get_matmul_precision() != "fp32"
+                and hip.embed_gather_linear_fits(D, F, n_dense, 64, ldx, Fh._rows16(w)))
+
+    def gather_linear(self, X, dense: List[torch.Tensor], linear: nn.Linear, out_link, pad_to: int = 64):
+        """HIP path: (h1 [B, 64] = relu(linear(cat(emb, dense))), fm [B,1]) in one launch; x is written for the backward
+        but never re-read in the forward."""
+        self._ensure_packed()
+        idx = self._idx_list(X)
+        F, D = len(idx), self.embedding_dim
+        d = F * D + len(dense)
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        dense = [t.float().reshape(-1).contiguous() for t in dense]
+        src = tuple(X[c] for c in self.emb_feature)
+        self._presorted = None
+        if self._lazy is not None and self._lazy.t > 0:
+            keys, sk, sp = self._sorted_keys(idx, self.row_base, self.row_count, src)
+            self._lazy.replay(self, sk)
+            self._presorted = (keys, sk, sp)
+        elif torch.is_grad_enabled():
+            self._presorted = self._sorted_keys(idx, self.row_base, self.row_count, src, lookup_only=True)
+        out = Fh.embed_gather_linear(self, idx, dense, ldx, linear.weight, linear.bias, out_link)
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return out
 
     def _sorted_keys(self, idx, row_base, row_count, src, lookup_only: bool = False):
         """(keys, sorted keys, positions) of this batch's row requests.  Two layers with the same vocabularies fed the

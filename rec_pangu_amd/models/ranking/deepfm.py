@@ -29,7 +29,15 @@ class DeepFM(BaseModel):
 
     def forward(self, data, is_training=True):
         if self.on_hip:
-            x, fm_out = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=True)
+            dense = self._dense_list(data)
+            first = self.dnn.first_linear_relu()
+            fits = getattr(self.embedding_layer, "gather_linear_fits", None)  # table-sharded layer: rows arrive by exchange
+            if first is not None and fits is not None and fits(len(dense), first):
+                # lookup + dense concat + FM second order + dnn.net.0 (+ ReLU) in ONE launch; the rest of the MLP follows
+                link = Fh.ReluLink()
+                h1, fm_out = self.embedding_layer.gather_linear(data, dense, first, link)
+                return self._finish([fm_out, self.dnn(h1, start=2, pending=link)], data, is_training, self.loss_fun)
+            x, fm_out = self.embedding_layer.gather_concat(data, dense, want_fm=True)
             link = getattr(self.embedding_layer, "_fm_link", None)
             if link is None or not fm_out.requires_grad:
                 return self._finish([fm_out, self.dnn(x)], data, is_training, self.loss_fun)

@@ -626,3 +626,66 @@ def test_mlp_tail_fused_vs_fp64(hip, M, L):
         close(dbs[l], b64[l].grad, f"db{l}")
     close(dwo, wo64.grad, "dw_out")
     close(dbo, bo64.grad, "db_out")
+
+
+@pytest.mark.parametrize("rows,ND,B,biased", [
+    ([8, 4, 51, 12, 3], 5, 24, True),          # one partial workgroup
+    ([3, 4, 10, 5000, 27], 13, 4099, True),    # 32 full workgroups + a 3-sample tail, the Criteo dense count
+    ([50, 7], 0, 1024, False),                 # no dense columns, no bias, only full workgroups
+    ([9] * 26, 13, 640, True),                 # Criteo field count
+    ([5] * 32, 16, 300, True),                 # the limits: 32 fields, 16 dense columns
+])
+def test_embed_gather_linear_vs_unfused(hip, rows, ND, B, biased):
+    """rp_embed_gather_linear_fwd (lookup + concat + FM + the 64-wide Linear + ReLU in one launch) against the unfused
+    rp_embed_gather_fwd + rp_linear_fwd in the fp32-faithful mode: x / keys bit-identical to the plain gather, fm / ssum
+    within fp32 rounding, h1 within fp32 rounding of an fp64 reference; an out-of-range index raises the same error flag."""
+    hip.set_matmul_precision("bf16x6")
+    try:
+        D, H = 64, 64
+        g = torch.Generator().manual_seed(B + len(rows))
+        F = len(rows)
+        arena, base = _tables(rows, D, g)
+        idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+        dense = [torch.rand(B, generator=g) for _ in range(ND)]
+        K = F * D + ND
+        ldx = (K + 63) // 64 * 64
+        W = torch.randn(H, K, generator=g) / K ** 0.5
+        bias = torch.randn(H, generator=g) * 0.1 if biased else None
+        dev = lambda t_: None if t_ is None else t_.to(DEV)
+        rb = torch.tensor(base, dtype=torch.int64, device=DEV)
+        rc = torch.tensor(rows, dtype=torch.int64, device=DEV)
+        err = torch.zeros(2, dtype=torch.int32, device=DEV)
+        didx, dd = [dev(t_) for t_ in idx], [dev(t_) for t_ in dense]
+        x0, fm0, s0, k0 = hip.embed_gather_fwd(dev(arena), rb, rc, didx, dd, ldx, True, True, True, err)
+        Wd = dev(W)
+        if Wd.stride(0) % 4:
+            Wp = torch.zeros(H, (K + 3) // 4 * 4, device=DEV)
+            Wp[:, :K] = Wd
+            Wd = Wp[:, :K]
+        assert hip.embed_gather_linear_fits(D, F, ND, H, ldx, Wd)
+        x1, h1, fm1, s1, k1 = hip.embed_gather_linear_fwd(dev(arena), rb, rc, didx, dd, ldx, Wd, dev(bias), True, True, True, err)
+        x2, h2, _, _, _ = hip.embed_gather_linear_fwd(dev(arena), rb, rc, didx, dd, ldx, Wd, dev(bias), True, True, True, err)
+        assert int(err[0]) == 0
+        assert torch.equal(x1[:, :K], x0[:, :K]) and torch.equal(k1, k0), "gathered rows / keys must be bit-exact"
+        torch.testing.assert_close(s1, s0, rtol=1e-5, atol=1e-5)
+        fscale = (x0[:, :F * D].abs().sum(dim=1, keepdim=True) ** 2).clamp(min=1.0) * 1e-6
+        assert bool(((fm1 - fm0).abs() <= fscale + 1e-5).all())
+        assert torch.equal(h1, h2), "two launches differ"
+        xr = torch.cat([arena[base[f] + idx[f]] for f in range(F)] + [d_[:, None] for d_ in dense], dim=1).double()
+        pre = xr @ W.double().T + (bias.double() if biased else 0.0)
+        ref = pre.clamp_min(0)
+        scale = float(pre.abs().max())
+        # a pre-activation within rounding of zero may land on either side: compare where |pre| is clear of it
+        clear = pre.abs() > 1e-5 * scale
+        assert float(((h1.cpu().double() - ref) * clear).abs().max()) <= 2e-5 * scale
+        assert float((h1.cpu().double() - ref).abs().max()) <= 4e-5 * scale
+        # same composed on the device
+        h0 = hip.linear_fwd(x0, Wd, dev(bias), hip.ACT_RELU, K=K)
+        assert float((h1 - h0).abs().max()) <= 4e-5 * scale
+        # an index past its table: flagged, the sample's row reads as zeros like the plain gather
+        bad = [t_.clone() for t_ in didx]
+        bad[1][B // 2] = rows[1] + 3
+        hip.embed_gather_linear_fwd(dev(arena), rb, rc, bad, dd, ldx, Wd, dev(bias), True, False, False, err)
+        assert int(err[0]) != 0
+    finally:
+        hip.set_matmul_precision("auto")
