@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--optimizer", default="lazy", choices=["lazy", "dense"],
                     help="how the reference's dense Adam is executed on the embedding arena: 'lazy' = exact lazy "
                          "replay (bit-identical to the dense HIP kernel), 'dense' = stream every row every step")
+    ap.add_argument("--no-sort-ahead", action="store_true",
+                    help="do not announce the next batch (BaseModel.prefetch): its row sort then runs inside its own step "
+                         "instead of on the side stream beside the previous one")
     ap.add_argument("--pre-roll", type=int, default=-1,
                     help="un-timed training steps on distinct batches before the warm-up, so that the lazy optimizer's "
                          "per-row step stamps are in their long-run state (default: 1000 for --mode train with "
@@ -254,11 +257,13 @@ def main():
     def gen(i):  # a DISTINCT batch per step, generated on the device
         return synth_batch(enc, local_B, 100 + 100003 * rank + i, dev, args.id_dist)
 
-    def step(data):
+    def step(data, nxt=None):
         if args.mode == "forward":
             with torch.no_grad():
                 model(data, is_training=False)
             return
+        if nxt is not None:
+            model.prefetch(nxt)  # the next batch's row sort is started behind this forward, on the side stream
         out = model(data)
         out["loss"].backward()
         if sharded:
@@ -319,12 +324,18 @@ def main():
     n_batches = min(args.steps, 512)  # distinct batches resident for the timed region (8.8 GB of ids at 512)
     batches = [gen(n_seen + args.warmup + i) for i in range(n_batches)]
     n_prof = min(3, args.warmup)
+    # Training loops know their next batch (model_pipeline._one_ahead does the same): announcing it lets its row sort run on
+    # the side stream beside the step in flight.  One sort is started per step, for the step after it; the sort of the
+    # first timed batch is started by the last warm-up step.
+    ahead = args.mode == "train" and not args.no_sort_ahead and not sharded and hasattr(model, "prefetch")
+    wb = [gen(n_seen + i) for i in range(args.warmup)] + [batches[0]]
     for i in range(args.warmup - n_prof):
-        step(gen(n_seen + i))
+        step(wb[i], wb[i + 1] if ahead else None)
     barrier()
     hip.enable_timing(True)
     for i in range(args.warmup - n_prof, args.warmup):
-        step(gen(n_seen + i))
+        step(wb[i], wb[i + 1] if ahead else None)
+    del wb
     barrier()
     prof = hip.timing_summary() if n_prof else None
     hip.enable_timing(False)
@@ -342,7 +353,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         hip.pause_timing(i % ev_stride != 0)
-        step(batches[i % n_batches])
+        step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None)
     hip.pause_timing(False)
     barrier()
     dt = time.perf_counter() - t0
@@ -565,6 +576,7 @@ def main():
                                    + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
                        "global_batch": B, "per_gpu_batch": local_B, "optimizer": opt_txt,
                        "matmul_precision": precision,
+                       "sort_ahead": bool(ahead),
                        "unique_rows_per_batch": n_unique,
                        "parallelism": "single GPU" if not sharded else f"tables row-sharded x{world}, all-to-all lookup"},
             "pre_roll_steps": pre_roll, "cold": cold,

@@ -84,6 +84,9 @@ class PinnedBatchLoader:
         if self.device.type != "cuda":
             raise ValueError("PinnedBatchLoader feeds a HIP device; use DeviceBatchLoader / DataLoader on the CPU")
         self.depth = max(2, int(depth))
+        # batches the consumer holds at once: 1 = done with batch i when it asks for i+1; 2 = a loop that looks one batch
+        # ahead (model_pipeline._one_ahead asks for i+1 BEFORE it runs step i).  Read at the start of each epoch.
+        self.hold = 1
         cols = _columns(dataset)
         self.n = len(dataset)
         # one block per dtype: ids (int64) and everything else (float32), column order = the batch dict's key order
@@ -123,13 +126,15 @@ class PinnedBatchLoader:
         if perm is not None or not self._host:
             self._stage_epoch(perm)
         nb, bs = len(self), self.batch_size
+        hold = max(1, int(self.hold))
+        depth = max(self.depth, hold + 1)
         dev_bufs = [[torch.empty((len(ks), bs), dtype=dt, device=self.device) for dt, ks, _ in self._groups]
-                    for _ in range(self.depth)]
-        copied = [torch.cuda.Event() for _ in range(self.depth)]   # copy of the buffer finished
-        released = [None] * self.depth                             # consumer done with the buffer
+                    for _ in range(depth)]
+        copied = [torch.cuda.Event() for _ in range(depth)]   # copy of the buffer finished
+        released = [None] * depth                             # consumer done with the buffer
 
         def launch(i):
-            slot = i % self.depth
+            slot = i % depth
             with torch.cuda.stream(self._copy_stream):
                 if released[slot] is not None:
                     self._copy_stream.wait_event(released[slot])   # the step that read this buffer has been enqueued
@@ -137,12 +142,12 @@ class PinnedBatchLoader:
                     buf.copy_(self._host[g][i], non_blocking=True)
                 copied[slot].record(self._copy_stream)
 
-        for i in range(min(self.depth - 1, nb)):
+        for i in range(min(depth - hold, nb)):
             launch(i)
         for i in range(nb):
-            if i + self.depth - 1 < nb:
-                launch(i + self.depth - 1)   # keep depth-1 batches in flight ahead of the consumer
-            slot = i % self.depth
+            if i + depth - hold < nb:
+                launch(i + depth - hold)   # keep depth-hold batches in flight ahead of the consumer
+            slot = i % depth
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(copied[slot])
             rows = bs if (i + 1 < nb or self.n % bs == 0 or self.drop_last) else self.n - i * bs
@@ -153,7 +158,9 @@ class PinnedBatchLoader:
                     # are kept by the training loop for the epoch's metrics, so they get their own (tiny) tensor
                     batch[k] = buf[j, :rows].clone() if "label" in k else buf[j, :rows]
             yield {k: batch[k] for k in self._keys}
-            # everything the consumer enqueued for this batch is ahead of this event on its stream
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            released[slot] = ev
+            # asked for the next batch: everything the consumer enqueued for batch i - (hold - 1) is ahead of this event
+            # on its stream
+            if i - (hold - 1) >= 0:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                released[(i - (hold - 1)) % depth] = ev

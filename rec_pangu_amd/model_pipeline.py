@@ -51,6 +51,26 @@ def _check_indices(model):
             m.raise_if_bad_index()
 
 
+def _one_ahead(loader, device, model):
+    """The loader's batches in order, each yielded after the NEXT one has been moved to the device and announced to the
+    model (BaseModel.prefetch: its row sort overlaps the step in flight).  Same batches, same order, same RNG draws."""
+    announce = getattr(model, "prefetch", None)
+    if hasattr(loader, "hold"):
+        loader.hold = 2  # loaders that recycle device buffers (PinnedBatchLoader): two batches are alive at once
+    it = iter(loader)
+    try:
+        cur = _move(next(it), device)
+    except StopIteration:
+        return
+    for nxt in it:
+        nxt = _move(nxt, device)
+        if announce is not None:
+            announce(nxt)
+        yield cur
+        cur = nxt
+    yield cur
+
+
 def train_model(model, train_loader, optimizer, device, metric_list: List[str] = ['roc_auc_score', 'log_loss'],
                 num_task: int = 1, use_wandb: bool = False, log_rounds: int = 100) -> dict:
     model.train()
@@ -59,8 +79,7 @@ def train_model(model, train_loader, optimizer, device, metric_list: List[str] =
     preds = [[] for _ in tasks]
     labels = [[] for _ in tasks]
     start_time = time.time()
-    for idx, data in enumerate(train_loader):
-        data = _move(data, device)
+    for idx, data in enumerate(_one_ahead(train_loader, device, model)):
         output = model(data)
         loss = output['loss']
         loss.backward()

@@ -79,6 +79,13 @@ class BaseModel(nn.Module):
     def on_hip(self) -> bool:
         return self.embedding_layer.arena.is_cuda
 
+    def prefetch(self, data) -> None:
+        """Optional, HIP only: announce the batch of the NEXT step (the same dict of device tensors the next forward will
+        get).  Its row sort starts on a side stream and overlaps the current step (EmbeddingLayer.prefetch_sort)."""
+        fn = getattr(self.embedding_layer, "prefetch_sort", None)
+        if fn is not None and self.on_hip:
+            fn(data)
+
     def _dense_list(self, data):
         return [data[c] for c in dense_columns(self.enc_dict)]
 

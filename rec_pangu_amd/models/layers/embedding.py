@@ -15,18 +15,19 @@ Device dispatch is by where the arena lives: a HIP-resident layer ALWAYS runs th
 (rec_pangu_amd/hip.py raises if the library is missing — no fallback); a CPU-resident layer is
 BASELINE.json config 0 ("plumbing, no GPU") and uses plain torch ops.
 """
+import os
 import weakref
 from typing import Dict, List, Optional, Union
-
-import os
 
 import torch
 from torch import nn
 
 from ... import functional as Fh
 
-# the last (id tensors, versions, arena signature) -> (keys, sorted keys, positions); see EmbeddingLayer._sorted_keys
-_SORT_CACHE = None
+# the last two (id tensors, versions, arena signature) -> (keys, sorted keys, positions)[, side-stream event]: the batch in
+# flight and the one whose sort was started ahead (EmbeddingLayer._sorted_keys / prefetch_sort)
+_SORT_CACHE: list = []
+_SIDE_STREAMS: dict = {}  # device -> the (high-priority) stream sorts started ahead run on
 
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
@@ -309,6 +310,7 @@ class EmbeddingLayer(nn.Module):
         elif torch.is_grad_enabled():
             self._presorted = self._sorted_keys(idx, self.row_base, self.row_count, src, lookup_only=True)
         out = Fh.embed_gather_linear(self, idx, dense, ldx, linear.weight, linear.bias, out_link)
+        self._start_sort_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out
@@ -318,21 +320,68 @@ class EmbeddingLayer(nn.Module):
         same batch (a model's D-wide tables and its LR_Layer's 1-wide ones) ask for the same arena rows: the second one
         reuses the first one's sort.  The cache entry keeps the id tensors alive, so `is` + `_version` identify them."""
         from ... import hip
-        global _SORT_CACHE
         sig = (self._rows_sig(), str(self._arena.device))
-        if src is not None and _SORT_CACHE is not None:
-            c_src, c_ver, c_sig, c_out = _SORT_CACHE
-            if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
-                    and c_ver == tuple(t._version for t in src):
-                return c_out
+        if src is not None:
+            for entry in _SORT_CACHE:
+                c_src, c_ver, c_sig, c_out, c_event = entry
+                if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
+                        and c_ver == tuple(t._version for t in src):
+                    if c_event is not None:  # sorted ahead on the side stream: order this stream behind it
+                        cur = torch.cuda.current_stream(self._arena.device)
+                        cur.wait_event(c_event)
+                        for t in c_out:
+                            t.record_stream(cur)
+                        entry[4] = None
+                    return c_out
         if lookup_only:
             return None
         keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
         sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
         out = (keys, sk, sp)
         if src is not None:
-            _SORT_CACHE = (src, tuple(t._version for t in src), sig, out)
+            self._cache_sort(src, sig, out, None)
         return out
+
+    @staticmethod
+    def _cache_sort(src, sig, out, event):
+        _SORT_CACHE.append([src, tuple(t._version for t in src), sig, out, event])
+        del _SORT_CACHE[:-4]
+
+    def prefetch_sort(self, X) -> None:
+        """Announce the batch of the NEXT step.  Its (arena row, position) sort is started on this layer's side stream
+        right after this layer's next forward has been enqueued, so that it runs beside that step's backward and
+        optimizer kernels: the radix sort is a chain of short latency-bound launches (0.17 ms at Criteo shape on a few %
+        of the chip), the kernels beside it are HBM-bound.  `X` must hold the very tensors the later forward is given
+        (identity is the cache key).  No effect on results: the same kernels on the same inputs, another stream."""
+        if self._arena.is_cuda and all(X[c].device == self._arena.device for c in self.emb_feature):
+            self._ahead = X
+
+    def _start_sort_ahead(self) -> None:
+        from ... import hip
+        X, self._ahead = self.__dict__.get("_ahead"), None
+        if X is None:
+            return
+        src = tuple(X[c] for c in self.emb_feature)
+        sig = (self._rows_sig(), str(self._arena.device))
+        for c_src, c_ver, c_sig, _, _ in _SORT_CACHE:
+            if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
+                    and c_ver == tuple(t._version for t in src):
+                return
+        dev = self._arena.device
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)  # the id tensors (and whatever produced them) are ordered on the caller's stream
+        with torch.cuda.stream(side):
+            idx = self._idx_list(X)
+            keys = hip.embed_keys(self.row_base, self.row_count, idx, self.err_flag)
+            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            event = torch.cuda.Event()
+            event.record(side)
+        for t in src:
+            t.record_stream(side)
+        self._cache_sort(src, sig, (keys, sk, sp), event)
 
     def _rows_sig(self):
         if getattr(self, "_rows_sig_cache", None) is None:
@@ -358,6 +407,7 @@ class EmbeddingLayer(nn.Module):
             # no replay to do (dense Adam / first step): the backward sorts — unless another layer already has
             self._presorted = self._sorted_keys(idx, row_base, row_count, src, lookup_only=True)
         out = Fh.embed_gather(self, idx, dense, ldx, want_fm, meta)
+        self._start_sort_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)

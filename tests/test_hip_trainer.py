@@ -158,3 +158,45 @@ def test_pinned_batch_loader_feeds_the_same_batches(shuffle, tmp_path):
     assert finals[0][0] == finals[1][0]
     for k in finals[0][1]:
         assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+
+
+@pytest.mark.gpu
+def test_sort_ahead_is_bit_identical():
+    require_gpu()
+    """BaseModel.prefetch (the next batch's row sort on the side stream, beside the step in flight) changes no result:
+    ten lazy-Adam steps with every next batch announced == the same ten steps without, bit for bit."""
+    import copy
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    enc = {f"C{i}": {"vocab_size": v} for i, v in enumerate([5, 40, 3000, 17, 90000])}
+    enc.update({f"I{i}": {"min": 0.0, "max": 1.0} for i in range(3)})
+    torch.manual_seed(3)
+    ref = DeepFM(enc_dict=enc, embedding_dim=64, hidden_units=[64, 64])
+    other = copy.deepcopy(ref)
+    g = torch.Generator().manual_seed(5)
+
+    def batch():
+        b = {c: torch.randint(0, enc[c]["vocab_size"] + 1, (2048,), generator=g) for c in enc if c.startswith("C")}
+        b.update({c: torch.rand(2048, generator=g) for c in enc if c.startswith("I")})
+        b["label"] = (torch.rand(2048, generator=g) < 0.3).float()
+        return b
+    host = [batch() for _ in range(10)]
+    outs = []
+    for model, ahead in ((ref, False), (other, True)):
+        model = model.to(dev)
+        opt = FusedAdam(model.parameters(), lr=1e-2)
+        data = [{k: v.to(dev) for k, v in b.items()} for b in host]
+        losses = []
+        for i, b in enumerate(data):
+            if ahead and i + 1 < len(data):
+                model.prefetch(data[i + 1])
+            out = model(b)
+            out["loss"].backward()
+            opt.step()
+            model.zero_grad()
+            losses.append(out["loss"].detach().clone())
+        outs.append((torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
