@@ -327,7 +327,7 @@ def main():
     # Training loops know their next batch (model_pipeline._one_ahead does the same): announcing it lets its row sort run on
     # the side stream beside the step in flight.  One sort is started per step, for the step after it; the sort of the
     # first timed batch is started by the last warm-up step.
-    ahead = args.mode == "train" and not args.no_sort_ahead and not sharded and hasattr(model, "prefetch")
+    ahead = args.mode == "train" and not args.no_sort_ahead and hasattr(model, "prefetch")
     wb = [gen(n_seen + i) for i in range(args.warmup)] + [batches[0]]
     for i in range(args.warmup - n_prof):
         step(wb[i], wb[i + 1] if ahead else None)

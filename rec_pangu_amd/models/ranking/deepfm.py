@@ -31,8 +31,7 @@ class DeepFM(BaseModel):
         if self.on_hip:
             dense = self._dense_list(data)
             first = self.dnn.first_linear_relu()
-            fits = getattr(self.embedding_layer, "gather_linear_fits", None)  # table-sharded layer: rows arrive by exchange
-            if first is not None and fits is not None and fits(len(dense), first):
+            if first is not None and self.embedding_layer.gather_linear_fits(len(dense), first):
                 # lookup + dense concat + FM second order + dnn.net.0 (+ ReLU) in ONE launch; the rest of the MLP follows
                 link = Fh.ReluLink()
                 h1, fm_out = self.embedding_layer.gather_linear(data, dense, first, link)

@@ -110,8 +110,10 @@ class _ShardedRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, layer, keys, local_arena):
-        route = _Route(keys, layer)
         dev = local_arena.device
+        prepared, layer._prepared = layer._prepared, None
+        # (prepared: this batch's route, built ahead on the side stream — ShardedEmbeddingLayer._route_ahead)
+        route = prepared if prepared is not None else _Route(keys, layer)
         recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=dev)
         _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
         served = layer._local_gather(recv_rows)  # [n_recv, D]
@@ -168,6 +170,50 @@ class _RowsToX(torch.autograd.Function):
         return g_rows, None, None, None, None, None, None, None, None, None
 
 
+class _RowsToLinear(torch.autograd.Function):
+    """HIP: _RowsToX fused with the 64-wide Linear + ReLU that consumes x (DeepFM's dnn.net.0), as on the single-GPU
+    path: forward = rp_embed_gather_linear_fwd with the received unique rows as the arena; backward = the weight
+    gradient and rp_embed_grad_gemm (the layer's dgrad formed inside the per-unique-row segmented sum: dX never
+    exists), so what travels back is again one gradient row per unique request."""
+
+    @staticmethod
+    def forward(ctx, rows, slot_of_pair, dense: List[torch.Tensor], slot_sorted, pos_sorted, b: int, F: int, ldx: int,
+                weight, bias, out_link, err_flag):
+        from . import hip
+        n, D = rows.shape
+        dev = rows.device
+        zero = torch.zeros((F,), dtype=torch.int64, device=dev)
+        cnt = torch.full((F,), n, dtype=torch.int64, device=dev)
+        idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
+        x, h1, fm, ssum, _ = hip.embed_gather_linear_fwd(rows, zero, cnt, idx, dense, ldx, Fh._rows16(weight), bias, True,
+                                                         True, False, err_flag)
+        ctx.cfg = (b, D, weight.shape[1], bias is not None, out_link)
+        ctx.save_for_backward(rows, slot_sorted, pos_sorted, ssum, x, h1, weight)
+        return h1, fm
+
+    @staticmethod
+    def backward(ctx, dh1, dfm):
+        from . import hip
+        rows, slot_sorted, pos_sorted, ssum, x, h1, weight = ctx.saved_tensors
+        b, D, K, has_bias, lk = ctx.cfg
+        dh1 = Fh._unit_inner(dh1)
+        masked = lk is not None and lk.dx is not None and lk.dx.data_ptr() == dh1.data_ptr() and lk.dx.shape == dh1.shape
+        if lk is not None:
+            lk.dx = None
+        dpre = dh1 if masked else hip.relu_bwd(dh1, h1)
+        dw = db = None
+        if ctx.needs_input_grad[8] or (has_bias and ctx.needs_input_grad[9]):
+            dw, db = hip.linear_wgrad(dpre, x, K, want_bias=has_bias)
+        g_rows = None
+        if ctx.needs_input_grad[0]:
+            wt = hip.transpose(weight, rows_out=x.shape[1])
+            gfm = dfm.contiguous() if dfm is not None else None
+            g_rows = torch.zeros_like(rows)  # slots no request reads (fixed-capacity padding) carry a zero gradient
+            hip.embed_grad_gemm(slot_sorted, pos_sorted, b, D, dpre, wt, None, gfm, ssum if gfm is not None else None,
+                                rows, g_rows, accumulate=False)
+        return g_rows, None, None, None, None, None, None, None, dw, db, None, None
+
+
 class ShardedEmbeddingLayer(nn.Module):
     """Drop-in for EmbeddingLayer inside a model whose tables are row-sharded over `world` ranks."""
 
@@ -222,6 +268,9 @@ class ShardedEmbeddingLayer(nn.Module):
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
+        self._prepared = None  # _Route of the batch about to be looked up, when it was built ahead
+        self._announced = None  # the batch of the next step (prefetch_sort), until its route is started
+        self._ahead = None      # (id tensors, versions, route, event) of the route being built on the side stream
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 
     def _tag(self):
@@ -307,6 +356,54 @@ class ShardedEmbeddingLayer(nn.Module):
         idx = torch.where(bad, torch.zeros_like(idx), idx)
         return (idx + self._row_base[:, None]).reshape(-1)  # p = f*b + i
 
+    # ---- the part of a lookup that does not depend on the weights, started ahead -----------------------------
+    def prefetch_sort(self, X) -> None:
+        """Announce the batch of the NEXT step (as EmbeddingLayer.prefetch_sort).  With the fixed-capacity exchange active
+        (HIP, check_indices == 'deferred': nothing comes back to the host) its route — range check, composite keys, sort,
+        dedup, padding: nothing that depends on the weights — is built on the side stream behind this layer's next
+        forward.  The collectives stay on the caller's stream: RCCL runs them in issue order, and an id exchange queued
+        behind the side stream's sort would hold up the gradient exchange of the step in flight."""
+        if self.local_arena.is_cuda and all(X[c].device == self.local_arena.device for c in self.emb_feature):
+            self._announced = X
+
+    def _route_ahead(self) -> None:
+        X, self._announced = self._announced, None
+        if X is None:
+            return
+        if self._capacity is None or self.check_indices != "deferred" \
+                or self.lbits + max(1, (self.world - 1).bit_length()) > 31:
+            return
+        from .models.layers.embedding import _SIDE_STREAMS
+        dev = self.local_arena.device
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+        src = tuple(X[c] for c in self.emb_feature)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            prepared = _Route(self._requests(X), self)
+            event = torch.cuda.Event()
+            event.record(side)
+        for t in src:
+            t.record_stream(side)
+        self._ahead = (src, tuple(t._version for t in src), prepared, event)
+
+    def _take_prepared(self, X) -> None:
+        """the forward of batch X begins: use what _route_ahead prepared for exactly these tensors, if anything"""
+        a, self._ahead, self._prepared = self._ahead, None, None
+        if a is None:
+            return
+        src, ver, prepared, event = a
+        cur = tuple(X[c] for c in self.emb_feature)
+        if len(cur) != len(src) or any(x is not y for x, y in zip(cur, src)) or ver != tuple(t._version for t in cur) \
+                or self._capacity is None:
+            return
+        stream = torch.cuda.current_stream(self.local_arena.device)
+        stream.wait_event(event)
+        for t in (prepared.slot_sorted, prepared.slot_of_pair, prepared.pos_sorted, prepared.local_rows):
+            t.record_stream(stream)
+        self._prepared = prepared
+
     # ---- local primitives: HIP kernels on a HIP device, torch ops on CPU ---------------------------
     def _local_gather(self, rows_idx):
         if self.local_arena.is_cuda:
@@ -361,14 +458,44 @@ class ShardedEmbeddingLayer(nn.Module):
         keys = self._requests(X)
         F, D = len(self.emb_feature), self.embedding_dim
         b = keys[0].numel() if isinstance(keys, list) else keys.numel() // F
+        self._take_prepared(X)
         rows, slot_of_pair, slot_sorted, pos_sorted = _ShardedRows.apply(self, keys, self.local_arena)
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
         out = _RowsToX.apply(rows, slot_of_pair, dense, slot_sorted, pos_sorted, b, F, ldx, want_fm, self._err)
+        self._route_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)
+
+    def gather_linear_fits(self, n_dense: int, linear: nn.Linear, pad_to: int = 64) -> bool:
+        """as EmbeddingLayer.gather_linear_fits: can rows->x + FM + `linear` (+ ReLU) run as one fused launch?"""
+        from . import hip
+        F, D = len(self.emb_feature), self.embedding_dim
+        d = F * D + n_dense
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        return (self.local_arena.is_cuda and D == 64 and linear.out_features == 64 and linear.in_features == d
+                and self.lbits + max(1, (self.world - 1).bit_length()) <= 31
+                and hip.get_matmul_precision() != "fp32"
+                and hip.embed_gather_linear_fits(D, F, n_dense, 64, ldx, Fh._rows16(linear.weight)))
+
+    def gather_linear(self, X, dense: List[torch.Tensor], linear: nn.Linear, out_link, pad_to: int = 64):
+        """(h1 [b, 64] = relu(linear(cat(emb, dense))), fm [b, 1]) from the exchanged unique rows, one fused launch"""
+        keys = self._requests(X)
+        F, D = len(self.emb_feature), self.embedding_dim
+        b = keys[0].numel()
+        self._take_prepared(X)
+        rows, slot_of_pair, slot_sorted, pos_sorted = _ShardedRows.apply(self, keys, self.local_arena)
+        d = F * D + len(dense)
+        ldx = (d + pad_to - 1) // pad_to * pad_to
+        dense = [t.float().reshape(-1).contiguous() for t in dense]
+        out = _RowsToLinear.apply(rows, slot_of_pair, dense, slot_sorted, pos_sorted, b, F, ldx, linear.weight, linear.bias,
+                                  out_link, self._err)
+        self._route_ahead()
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return out
 
     def forward(self, X: Dict[str, torch.Tensor], name: Optional[str] = None) -> torch.Tensor:
         if name is not None:
