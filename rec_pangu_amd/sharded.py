@@ -34,8 +34,14 @@ from torch import nn
 from . import functional as Fh
 
 
-def _a2a(out, inp, out_splits, in_splits, group):
+def _a2a(inp, out_splits, in_splits, group, world: int):
+    """all_to_all_single into a fresh tensor; with one rank the exchange is the identity and `inp` itself comes back (no
+    self-copy through an RCCL kernel: 0.12 ms per exchange at Criteo shape)"""
+    if world == 1:
+        return inp
+    out = torch.empty((sum(out_splits),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    return out
 
 
 class _Route:
@@ -114,14 +120,13 @@ class _ShardedRows(torch.autograd.Function):
         prepared, layer._prepared = layer._prepared, None
         # (prepared: this batch's route, built ahead on the side stream — ShardedEmbeddingLayer._route_ahead)
         route = prepared if prepared is not None else _Route(keys, layer)
-        recv_rows = torch.empty((route.n_recv,), dtype=torch.int64, device=dev)
-        _a2a(recv_rows, route.local_rows, route.recv, route.send, layer.group)
+        recv_rows = _a2a(route.local_rows, route.recv, route.send, layer.group, layer.world)
         served = layer._local_gather(recv_rows)  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
-        rows = torch.empty((route.n_unique, local_arena.shape[1]), dtype=local_arena.dtype, device=dev)
-        _a2a(rows, served, route.send, route.recv, layer.group)
+        rows = _a2a(served, route.send, route.recv, layer.group, layer.world)
         ctx.layer, ctx.route = layer, route
+        ctx.scaled, layer._scaled = layer._scaled, None
         ctx.save_for_backward(recv_rows)
         ctx.mark_non_differentiable(route.slot_of_pair, route.slot_sorted, route.pos_sorted)
         return rows, route.slot_of_pair, route.slot_sorted, route.pos_sorted
@@ -130,9 +135,10 @@ class _ShardedRows(torch.autograd.Function):
     def backward(ctx, g_rows, *_unused):
         (recv_rows,) = ctx.saved_tensors
         layer, route = ctx.layer, ctx.route
-        g_rows = g_rows.contiguous() if layer.world == 1 else (g_rows * (1.0 / layer.world)).contiguous()
-        recv_g = torch.empty((route.n_recv, g_rows.shape[1]), dtype=g_rows.dtype, device=g_rows.device)
-        _a2a(recv_g, g_rows, route.recv, route.send, layer.group)
+        # 1/G: the update must equal the 1-GPU update on the global batch (unless the producer already folded it in)
+        prescaled = layer.world == 1 or (ctx.scaled is not None and ctx.scaled[0])
+        g_rows = g_rows.contiguous() if prescaled else (g_rows * (1.0 / layer.world)).contiguous()
+        recv_g = _a2a(g_rows, route.recv, route.send, layer.group, layer.world)
         layer._local_scatter_add(recv_rows, recv_g, presorted=ctx.presorted)
         return None, None, None
 
@@ -178,7 +184,7 @@ class _RowsToLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, slot_of_pair, dense: List[torch.Tensor], slot_sorted, pos_sorted, b: int, F: int, ldx: int,
-                weight, bias, out_link, err_flag):
+                weight, bias, out_link, err_flag, scale: float, scaled):
         from . import hip
         n, D = rows.shape
         dev = rows.device
@@ -187,7 +193,7 @@ class _RowsToLinear(torch.autograd.Function):
         idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
         x, h1, fm, ssum, _ = hip.embed_gather_linear_fwd(rows, zero, cnt, idx, dense, ldx, Fh._rows16(weight), bias, True,
                                                          True, False, err_flag)
-        ctx.cfg = (b, D, weight.shape[1], bias is not None, out_link)
+        ctx.cfg = (b, D, weight.shape[1], bias is not None, out_link, scale, scaled)
         ctx.save_for_backward(rows, slot_sorted, pos_sorted, ssum, x, h1, weight)
         return h1, fm
 
@@ -195,7 +201,7 @@ class _RowsToLinear(torch.autograd.Function):
     def backward(ctx, dh1, dfm):
         from . import hip
         rows, slot_sorted, pos_sorted, ssum, x, h1, weight = ctx.saved_tensors
-        b, D, K, has_bias, lk = ctx.cfg
+        b, D, K, has_bias, lk, scale, scaled = ctx.cfg
         dh1 = Fh._unit_inner(dh1)
         masked = lk is not None and lk.dx is not None and lk.dx.data_ptr() == dh1.data_ptr() and lk.dx.shape == dh1.shape
         if lk is not None:
@@ -208,10 +214,16 @@ class _RowsToLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = hip.transpose(weight, rows_out=x.shape[1])
             gfm = dfm.contiguous() if dfm is not None else None
+            if scale != 1.0:
+                # the 1/G of the row gradients that travel, folded into the two small operands the rows are linear in
+                # (instead of a pass over [n_unique, D] afterwards)
+                dpre = dpre * scale
+                gfm = None if gfm is None else gfm * scale
+                scaled[0] = True
             g_rows = torch.zeros_like(rows)  # slots no request reads (fixed-capacity padding) carry a zero gradient
             hip.embed_grad_gemm(slot_sorted, pos_sorted, b, D, dpre, wt, None, gfm, ssum if gfm is not None else None,
                                 rows, g_rows, accumulate=False)
-        return g_rows, None, None, None, None, None, None, None, dw, db, None, None
+        return g_rows, None, None, None, None, None, None, None, dw, db, None, None, None, None
 
 
 class ShardedEmbeddingLayer(nn.Module):
@@ -269,6 +281,7 @@ class ShardedEmbeddingLayer(nn.Module):
         self._err = None
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
         self._prepared = None  # _Route of the batch about to be looked up, when it was built ahead
+        self._scaled = None     # per-lookup flag shared by _ShardedRows and _RowsToLinear (who applies the 1/G)
         self._announced = None  # the batch of the next step (prefetch_sort), until its route is started
         self._ahead = None      # (id tensors, versions, route, event) of the route being built on the side stream
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
@@ -486,12 +499,13 @@ class ShardedEmbeddingLayer(nn.Module):
         F, D = len(self.emb_feature), self.embedding_dim
         b = keys[0].numel()
         self._take_prepared(X)
+        scaled = self._scaled = [False]  # set by _RowsToLinear.backward once it has applied the 1/G itself
         rows, slot_of_pair, slot_sorted, pos_sorted = _ShardedRows.apply(self, keys, self.local_arena)
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
         out = _RowsToLinear.apply(rows, slot_of_pair, dense, slot_sorted, pos_sorted, b, F, ldx, linear.weight, linear.bias,
-                                  out_link, self._err)
+                                  out_link, self._err, 1.0 / self.world, scaled)
         self._route_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()

@@ -727,6 +727,27 @@ def test_sharded_fused_first_layer_single_rank():
             assert float((p.grad - q.grad).abs().max()) <= 1e-5 * max(1e-6, float(p.grad.abs().max())), k
         plain.zero_grad()
         shard.zero_grad()
+        # the 1/G of the travelling row gradients folded into the small operands (the N > 1 path): same rows x 1/G
+        from rec_pangu_amd.sharded import _RowsToLinear
+        from rec_pangu_amd import hip
+        gen = torch.Generator().manual_seed(4)
+        F, b, n = 26, 512, 3000
+        rows = torch.randn(n, 64, generator=gen).to(DEV)
+        slot = torch.randint(0, n, (F * b,), generator=gen).to(DEV)
+        ss, sp = hip.sort_pairs(slot.to(torch.int32), end_bit=12)
+        dense = [torch.rand(b, generator=gen).to(DEV) for _ in range(13)]
+        err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        lin = shard.dnn.first_linear_relu()
+        gr = []
+        for scale in (1.0, 0.125):
+            r = rows.clone().requires_grad_(True)
+            flag = [False]
+            h1, fm = _RowsToLinear.apply(r, slot, dense, ss, sp, b, F, 1728, lin.weight, lin.bias, None, err, scale, flag)
+            (h1.sum() + (fm * fm).sum()).backward()
+            assert flag[0] == (scale != 1.0)
+            gr.append(r.grad.clone())
+        assert float((gr[1] - 0.125 * gr[0]).abs().max()) <= 1e-6 * float(gr[0].abs().max())
+        shard.zero_grad()
         # three optimiser steps, fixed-capacity exchange from the second step on
         shard.embedding_layer.check_indices = "deferred"
         opts = (make_adam(plain, 1e-2), make_adam(shard, 1e-2))
