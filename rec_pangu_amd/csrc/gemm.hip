@@ -817,7 +817,7 @@ static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw,
 // deterministic second-stage sum, as the f32 kernel; the bias gradient is summed in exact fp32 from the staged
 // registers.
 template <int NPROD, int NA, int PF, bool VEC_X>
-__global__ __launch_bounds__(256, 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
+__global__ __launch_bounds__(256, (NA == 1 && PF == 1) ? 3 : 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                 const float *__restrict__ X, int64_t ldx,
                                                                 float *__restrict__ P, float *__restrict__ Pb,
                                                                 int64_t M, int N, int K, int64_t rows_per_split) {
@@ -1246,6 +1246,8 @@ static void wgrad_plan(int64_t M, int N, int K, int *S, int64_t *rows) {
         }
         s = best;
     }
+    static const int s_env = getenv("RP_WGRAD_S") ? atoi(getenv("RP_WGRAD_S")) : 0;
+    if (s_env > 0) s = s_env;
     int64_t r = rp_cdiv(rp_cdiv(M, s), TN_BM) * TN_BM;
     if (r < TN_BM) r = TN_BM;
     *rows = r;
@@ -1284,15 +1286,18 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
         const bool vx2 = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
         const bool wide = wgrad_wide(N);
         dim3 gridb((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, wide ? 2 * TN_BN : TN_BN), (unsigned)S);
-#define CALLW(NPROD, NA, VX)                                                                                            \
-    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, (NA == 1 ? 1 : 2), VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
+        static const int pf_env = getenv("RP_WGRAD_PF") ? atoi(getenv("RP_WGRAD_PF")) : 1;
+#define CALLW(NPROD, NA, PF, VX)                                                                                        \
+    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, PF, VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
                        N, K, rows)
 #define CALLB(NPROD)                          \
     do {                                      \
-        if (wide && vx2) CALLW(NPROD, 2, true);   \
-        else if (wide) CALLW(NPROD, 2, false);    \
-        else if (vx2) CALLW(NPROD, 1, true);      \
-        else CALLW(NPROD, 1, false);              \
+        if (wide && vx2) CALLW(NPROD, 2, 2, true);   \
+        else if (wide) CALLW(NPROD, 2, 2, false);    \
+        else if (vx2 && pf_env == 3) CALLW(NPROD, 1, 3, true);      \
+        else if (vx2 && pf_env == 2) CALLW(NPROD, 1, 2, true);      \
+        else if (vx2) CALLW(NPROD, 1, 1, true);      \
+        else CALLW(NPROD, 1, 1, false);              \
     } while (0)
         if (mode == RP_MATMUL_BF16X6) CALLB(6);
         else if (mode == RP_MATMUL_BF16X3) CALLB(3);
