@@ -816,8 +816,10 @@ static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw,
 // [n][m] / [k][m] and the MFMA fragments (8 consecutive m per lane) are ds_read_b128.  Split-K over gridDim.z with a
 // deterministic second-stage sum, as the f32 kernel; the bias gradient is summed in exact fp32 from the staged
 // registers.
+// (NA = 1: 168 registers, three workgroups per CU.  Deeper register prefetch (PF = 2, 3: 224 / 246 registers, two per CU)
+//  measured 4 % and 16 % SLOWER at 65536 x 64 x 1677.)
 template <int NPROD, int NA, int PF, bool VEC_X>
-__global__ __launch_bounds__(256, (NA == 1 && PF == 1) ? 3 : 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
+__global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                 const float *__restrict__ X, int64_t ldx,
                                                                 float *__restrict__ P, float *__restrict__ Pb,
                                                                 int64_t M, int N, int K, int64_t rows_per_split) {
@@ -1228,25 +1230,29 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
 static bool wgrad_wide(int N) { return g_matmul_precision != RP_MATMUL_FP32 && N >= 128; }  // 128 x 128 output tiles
 
 static void wgrad_plan(int64_t M, int N, int K, int *S, int64_t *rows) {
-    const int64_t tiles = rp_cdiv(K, TN_BK) * rp_cdiv(N, wgrad_wide(N) ? 2 * TN_BN : TN_BN);
-    // batch splits: enough workgroups to fill the chip (256 CUs x 2 resident), and a count that fills its last wave
-    // of workgroups — 1120 workgroups on 512 slots run as 3 rounds, the last one 19 % full
-    int64_t s = rp_cdiv(1024, tiles);
+    const bool wide = wgrad_wide(N);
+    const int64_t tiles = rp_cdiv(K, TN_BK) * rp_cdiv(N, wide ? 2 * TN_BN : TN_BN);
+    // batch splits: enough workgroups to fill the chip (256 CUs x 3 resident 64-row-tile workgroups, x 2 of the 128-row
+    // ones), in a count that fills its last round of workgroups — 1120 workgroups on 512 slots run as 3 rounds, the last
+    // one 19 % full.  One full round beats two (measured at 65536 x 64 x 1677: 54 splits 0.163 ms, 109 splits 0.168,
+    // 73 splits 0.184), so a larger count must fill its rounds at least 2 % better to be chosen.
+    const int64_t slots = wide ? 512 : 768;
+    int64_t s = rp_cdiv(2 * slots, tiles);
     if (s > 512) s = 512;  // a 64 x 64 layer has ONE output tile: all the parallelism must come from the batch split
-    if (tiles * s > 512) {
+    if (tiles * s > slots) {
         int64_t best = s;
         double best_eff = 0.0;
-        for (int64_t c = rp_cdiv(768, tiles); c <= rp_cdiv(1536, tiles); ++c) {
+        for (int64_t c = rp_cdiv(3 * slots / 4, tiles); c <= rp_cdiv(2 * slots, tiles); ++c) {
             if (c < 1 || c > 512) continue;
-            const double eff = (double)(tiles * c) / (double)(rp_cdiv(tiles * c, 512) * 512);
-            if (eff > best_eff + 1e-9) {
+            const double eff = (double)(tiles * c) / (double)(rp_cdiv(tiles * c, slots) * slots);
+            if (eff > best_eff + 0.02) {
                 best_eff = eff;
                 best = c;
             }
         }
         s = best;
     }
-    static const int s_env = getenv("RP_WGRAD_S") ? atoi(getenv("RP_WGRAD_S")) : 0;
+    static const int s_env = getenv("RP_WGRAD_S") ? atoi(getenv("RP_WGRAD_S")) : 0;  // (profiles/microbench/wgrad_one.py)
     if (s_env > 0) s = s_env;
     int64_t r = rp_cdiv(rp_cdiv(M, s), TN_BM) * TN_BM;
     if (r < TN_BM) r = TN_BM;
@@ -1286,7 +1292,6 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
         const bool vx2 = (ldx % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
         const bool wide = wgrad_wide(N);
         dim3 gridb((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, wide ? 2 * TN_BN : TN_BN), (unsigned)S);
-        static const int pf_env = getenv("RP_WGRAD_PF") ? atoi(getenv("RP_WGRAD_PF")) : 1;
 #define CALLW(NPROD, NA, PF, VX)                                                                                        \
     hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, NA, PF, VX>), gridb, dim3(256), 0, s, dy, lddy, x, ldx, P, Pb, M, \
                        N, K, rows)
@@ -1294,8 +1299,6 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     do {                                      \
         if (wide && vx2) CALLW(NPROD, 2, 2, true);   \
         else if (wide) CALLW(NPROD, 2, 2, false);    \
-        else if (vx2 && pf_env == 3) CALLW(NPROD, 1, 3, true);      \
-        else if (vx2 && pf_env == 2) CALLW(NPROD, 1, 2, true);      \
         else if (vx2) CALLW(NPROD, 1, 1, true);      \
         else CALLW(NPROD, 1, 1, false);              \
     } while (0)
