@@ -27,6 +27,9 @@ __device__ __forceinline__ float rp_fma(float a, float b, float c) { return __bu
 __device__ __forceinline__ f32x4 rp_fma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float rp_splat(float x, float) { return x; }
 __device__ __forceinline__ f32x4 rp_splat(float x, f32x4) { return f32x4{x, x, x, x}; }
+typedef float f32x2a __attribute__((ext_vector_type(2)));  // one v_pk_*_f32 operand: two floats per lane, one issue slot
+__device__ __forceinline__ f32x2a rp_fma(f32x2a a, f32x2a b, f32x2a c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2a rp_splat(float x, f32x2a) { return f32x2a{x, x}; }
 
 // sqrt / reciprocal on the hardware approximations (v_sqrt_f32, v_rcp_f32: 1 ulp): the IEEE-rounded forms expand to
 // ~10 instructions each, and the lazy replay of skipped steps is bound by exactly this arithmetic (one sqrt and one
@@ -38,6 +41,7 @@ __device__ __forceinline__ f32x4 rp_sqrt_fast(f32x4 x) {
                  __builtin_amdgcn_sqrtf(x.w)};
 }
 __device__ __forceinline__ float rp_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ f32x2a rp_rcp_fast(f32x2a x) { return f32x2a{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
 __device__ __forceinline__ f32x4 rp_rcp_fast(f32x4 x) {
     return f32x4{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y), __builtin_amdgcn_rcpf(x.z),
                  __builtin_amdgcn_rcpf(x.w)};
@@ -363,6 +367,105 @@ __device__ __forceinline__ void lazy_replay_candidates(bool need, int row, int l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TWO ROWS PER WAVE-ITERATION on packed fp32 (rows of at most 64 floats: one element of each row per lane).
+//
+// Every replay ends at the same step t_target, so two rows owing kA >= kB steps share their LAST kB steps — same step
+// numbers, same scalars {A_j, B_j} — and those run as v_pk_fma_f32 / v_pk_mul_f32 on the register pair {row A, row B}: four
+// issue slots (+ two v_rcp_f32) for two element-steps instead of eight (+ two).  The kA - kB steps before them run on row A
+// alone.  To make that head short, the wave first SORTS its 64 candidates by the number of steps they owe (bitonic over
+// the lanes: ~170 instructions against ~6000 of replay) and pairs neighbours: with ~45 rows per wave, 97 % of the
+// element-steps are shared ones.  An odd row out is paired with itself (both halves compute and store the same values).
+// Same adam1_zero_grad() per element and step as everywhere else, packed or not: bit-identical to the dense kernel.
+// ------------------------------------------------------------------------------------------------
+template <bool FULL>  // FULL: D == 64, every lane loads and stores its own column
+__device__ __forceinline__ void lazy_replay_pairs(bool need, int row, int l0, int D, float *__restrict__ P,
+                                                  float *__restrict__ Mo, float *__restrict__ Vo,
+                                                  int32_t *__restrict__ last, const float2 *__restrict__ sc, int t_target,
+                                                  const LazyCfg &c) {
+    const int lane = threadIdx.x & 63;
+    const int n_need = __popcll(__ballot(need));
+    if (n_need == 0) return;
+    int key = need ? t_target - l0 : 0;  // steps owed (> 0 exactly for the candidates that need work)
+    int val = row;
+    // bitonic sort of the 64 lanes, DESCENDING by key (payload: the row)
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int pk = __shfl_xor(key, stride, 64);
+            const int pv = __shfl_xor(val, stride, 64);
+            const bool desc = (lane & size) == 0;       // direction of this lane's block (the last merge: all descending)
+            const bool lower = (lane & stride) == 0;
+            const bool take = (lower == desc) ? (pk > key) : (pk < key);  // the lower lane of a descending pair keeps the max
+            key = take ? pk : key;
+            val = take ? pv : val;
+        }
+    }
+    const int npairs = (n_need + 1) >> 1;
+    const int col = FULL ? lane : (lane < D ? lane : D - 1);  // (a lane beyond the row re-reads its last column, never stores)
+    auto pick = [&](int i, int &ra, int &ka, int &rb, int &kb) {
+        const int ia = 2 * i, ib = (2 * i + 1 < n_need) ? 2 * i + 1 : 2 * i;  // odd row out: paired with itself
+        ra = __builtin_amdgcn_readlane(val, ia);
+        ka = __builtin_amdgcn_readlane(key, ia);
+        rb = __builtin_amdgcn_readlane(val, ib);
+        kb = __builtin_amdgcn_readlane(key, ib);
+    };
+    auto load = [&](int ra, int rb, f32x2a &p, f32x2a &m, f32x2a &v) {
+        const int64_t oa = (int64_t)ra * D + col, ob = (int64_t)rb * D + col;
+        p = f32x2a{P[oa], P[ob]};
+        m = f32x2a{Mo[oa], Mo[ob]};
+        v = f32x2a{Vo[oa], Vo[ob]};
+    };
+    int ra, ka, rb, kb;
+    pick(0, ra, ka, rb, kb);
+    f32x2a p, m, v;
+    load(ra, rb, p, m, v);
+    for (int i = 0; i < npairs; ++i) {
+        // the next pair's loads are issued UNCONDITIONALLY (the last pair is simply read once more): see
+        // lazy_replay_candidates
+        const int inext = (i + 1 < npairs) ? i + 1 : i;
+        int rna, kna, rnb, knb;
+        pick(inext, rna, kna, rnb, knb);
+        f32x2a pn, mn, vn;
+        load(rna, rnb, pn, mn, vn);  // in flight during the replay below
+        int j = t_target - ka + 1;
+        const int jshared = t_target - kb + 1;
+#pragma unroll RP_REPLAY_UNROLL
+        for (; j < jshared; ++j) {  // row A alone
+            const float2 s = sc[j];
+            float pa = p.x, ma = m.x, va = v.x;
+            adam1_zero_grad<float>(pa, ma, va, c.one_m_b1, c.sqrt_b2, s.x, s.y);
+            p.x = pa;
+            m.x = ma;
+            v.x = va;
+        }
+#pragma unroll RP_REPLAY_UNROLL
+        for (; j <= t_target; ++j) {  // both rows, packed
+            const float2 s = sc[j];  // uniform address: scalar load
+            adam1_zero_grad<f32x2a>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
+        }
+        if (FULL || lane < D) {
+            const int64_t oa = (int64_t)ra * D + col, ob = (int64_t)rb * D + col;
+            P[oa] = p.x;
+            Mo[oa] = m.x;
+            Vo[oa] = v.x;
+            P[ob] = p.y;
+            Mo[ob] = m.y;
+            Vo[ob] = v.y;
+        }
+        last[ra] = t_target;  // every lane, same address, same value: one dword write and no branch
+        last[rb] = t_target;
+        ra = rna;
+        ka = kna;
+        rb = rnb;
+        kb = knb;
+        p = pn;
+        m = mn;
+        v = vn;
+    }
+}
+
 // candidates = 64 positions of the sorted key list, STRIDED by the number of waves (lane l of wave w looks at position
 // l * n_waves + w): the list is field-major, so 64 consecutive positions belong to one table and all carry that
 // table's revisit gap — the five 2-10 M-row tables of a Criteo-shaped arena hold 95 % of the replay work in 19 % of
@@ -387,7 +490,8 @@ __global__ __launch_bounds__(256) void lazy_replay_wave_kernel(const int32_t *__
             need = l0 > 0 && l0 < t_target;
         }
     }
-    lazy_replay_candidates<EPL, FULL>(need, row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+    if constexpr (EPL == 1) lazy_replay_pairs<FULL>(need, row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+    else lazy_replay_candidates<EPL, FULL>(need, row, l0, D, P, Mo, Vo, last, sc, t_target, c);
 }
 
 // candidates = 64 consecutive arena rows; the grid strides over the arena
@@ -405,7 +509,8 @@ __global__ __launch_bounds__(256) void lazy_flush_wave_kernel(int64_t R, int D, 
             l0 = last[row];
             need = l0 > 0 && l0 < t_target;
         }
-        lazy_replay_candidates<EPL, FULL>(need, (int)row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+        if constexpr (EPL == 1) lazy_replay_pairs<FULL>(need, (int)row, l0, D, P, Mo, Vo, last, sc, t_target, c);
+        else lazy_replay_candidates<EPL, FULL>(need, (int)row, l0, D, P, Mo, Vo, last, sc, t_target, c);
     }
 }
 
