@@ -29,8 +29,12 @@ CRITEO_CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; v_mfma_f32_32x32x16_bf16)
 HBM_COPY_GBS = 6300.0  # device-to-device copy ceiling measured on this part
-VALU_PEAK_TLANE = 39.3  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T fp32 lane-instructions / s
-REPLAY_VALU_OPS = 4 + 5.0 / 3.0  # per zero-gradient element-step: 4 fma/mul + one v_rcp_f32 (5/3 of a plain VALU slot)
+# The replay's arithmetic floor, measured (profiles/microbench/valubench.hip, 8 waves per SIMD, operands in registers,
+# reported in SIMD clocks at the nominal 2.4 GHz): v_fma_f32 2.7, v_pk_fma_f32 7.3, v_rcp_f32 8.0 per wave-instruction; one
+# zero-gradient element-step of a wave (4 fma/mul issued as v_pk_*_f32 over two rows + one v_rcp_f32 per row) 17.2 clocks
+# (19.2 unpacked: rows of more than 64 floats).
+REPLAY_CLK_PER_WAVE_STEP = 17.2
+N_SIMD, NOMINAL_HZ = 1024, 2.4e9
 
 
 def criteo_enc_dict(scale=1):
@@ -516,13 +520,14 @@ def main():
                          frac_vs_measured_copy_peak=round(gbs / HBM_COPY_GBS, 4),
                          note="achieved = rocprofv3 counter bytes (the algorithmic 6 rows x unique is an upper bound)")
             if replay_elem_steps:
-                ops = replay_elem_steps * REPLAY_VALU_OPS / sec
+                floor = replay_elem_steps / 64.0 * REPLAY_CLK_PER_WAVE_STEP / (N_SIMD * NOMINAL_HZ)
                 r["valu"] = {"replayed_element_steps_per_launch": replay_elem_steps,
-                             "valu_issue_slots_per_element_step": REPLAY_VALU_OPS,
-                             "achieved_Tlane_ops_per_s": round(ops / 1e12, 2), "peak": VALU_PEAK_TLANE,
-                             "frac": round(ops / 1e12 / VALU_PEAK_TLANE, 4),
-                             "note": "the replay is a serial fp32 chain per element (4 fma/mul + one reciprocal at 5/3 of a "
-                                     "plain VALU slot per skipped step): VALU-bound, not HBM-bound"}
+                             "simd_clocks_per_wave_element_step": REPLAY_CLK_PER_WAVE_STEP,
+                             "floor_ms": round(floor * 1e3, 4), "achieved_ms": round(sec * 1e3, 4),
+                             "frac": round(floor / sec, 4),
+                             "note": "the replay is a serial fp32 chain per element (4 fma/mul, packed over two rows, + one "
+                                     "v_rcp_f32 per skipped step): bound by VALU issue, not HBM.  floor = the same instruction "
+                                     "mix from registers on all SIMDs (profiles/microbench/valubench.hip)"}
         return r
 
     kernels = {}
