@@ -14,6 +14,7 @@
 // so FM costs no extra HBM traffic.  HBM-bound: algorithmic bytes/sample =
 // F*(D*4 + 8) read + (F*D+ND)*4 written.
 #include "common.h"
+#include <cstdlib>
 #include "bfsplit.h"
 
 struct IdxPtrs {
@@ -279,15 +280,25 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
 // deep.py:62-72 in one launch).
 //
 // Unfused, the gather writes x[B, F*D+ND] (453 MB at Criteo shape) and the first layer reads it straight back.  Here a
-// workgroup takes 128 samples through all F fields: a wave owns 32 samples, a lane holds half of a sample's row of the
-// current field (lane = (sample, half): the MFMA A layout, so the 32 floats go from global memory into registers once and
-// are used three times — stored to x (the weight gradient still reads it), added into the FM sums, split into bf16 pieces
-// for the matrix core), the field's 64 x 64 slice of W1 goes through a double-buffered LDS tile (one barrier per
-// field), and h1 = relu(x W1^T + b) accumulates over the fields in the MFMA accumulators.  The next field's rows are in
-// flight while the current field is on the matrix core.  Split-bf16, six products (fp32-faithful).
-// ------------------------------------------------------------------------------------------------
+// workgroup takes 128 samples through all F fields: the field's rows go from global memory into registers once and are
+// used three times — stored to x (the weight gradient still reads it), added into the FM sums, handed to the matrix core
+// —, the field's 64 x 64 slice of W1 goes through LDS as bf16 pieces, and h1 = relu(x W1^T + b) accumulates over the
+// fields in the MFMA accumulators.  Split-bf16, six products (fp32-faithful).
+//
+// Row traffic is COALESCED, as in the plain gather: 16 lanes x float4 = one 256-byte row per quarter wave, four whole
+// rows per wave-instruction, for the arena loads AND for the x stores; the rows take one trip through LDS (fp32, 272-byte
+// rows: conflict-free ds_write_b128 / ds_read_b128) to reach the MFMA A layout (lane = (sample, k half)).  (A first
+// version loaded and stored straight in the A layout — 16-byte pieces, 64 pieces in 32 different rows per
+// wave-instruction: 0.229 ms against 0.194.)  LDS: rows 34.8 KB + one W slice 27.6 KB + keys 16.9 KB: two workgroups per
+// CU.  Two barriers per field (rows and W slice are single-buffered); the next field's rows and W slice are in flight in
+// registers meanwhile.  All index -> arena-row keys are computed up front into LDS: an id load inside the field loop
+// would be the newest vector-memory operation where its value is needed, and waiting for it (vmcnt(0)) would also wait
+// for the prefetch and for every x store just issued.
 // FULL: every sample of the workgroup exists and x is written — no lane masks around the loads and stores of the field
-// loop, so the in-order vmcnt waits for THIS field's rows are counted and do not wait for the prefetch of the next.
+// loop, so the in-order vmcnt waits are counted.
+// ------------------------------------------------------------------------------------------------
+#define EGL_XLD 68  // floats per staged row (64 + 4 pad)
+#define EGL_KLD 33  // keys per row in LDS (odd: the key fill writes 32 consecutive rows at a fixed field)
 template <bool FULL>
 __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     const float *__restrict__ arena, const int64_t *__restrict__ row_base, const int64_t *__restrict__ row_count,
@@ -295,117 +306,125 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     const float *__restrict__ W, int64_t ldw, const float *__restrict__ bias, float *__restrict__ h1,
     float *__restrict__ fm_out, float *__restrict__ sum_out, int32_t *__restrict__ keys_out, int32_t *__restrict__ err_flag) {
     constexpr int D = 64;
-    __shared__ __attribute__((aligned(16))) __bf16 Wt[2][3][64][EG_LD];
-    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
+    __shared__ __attribute__((aligned(16))) __bf16 Wt[3][64][EG_LD];
+    __shared__ __attribute__((aligned(16))) float Xs[128][EGL_XLD];
+    __shared__ int32_t Ks[128][EGL_KLD];
+    const int t = threadIdx.x;
+    // MFMA side: wave wv owns samples 32 wv .. 32 wv + 31; lane (i, h) = (sample, k half)
+    const int wv = t >> 6, l = t & 63, i = l & 31, h = l >> 5;
     const int64_t blk = blk0 + blockIdx.x;
     const int64_t b = blk * 128 + 32 * wv + i;
     const bool bok = FULL || b < B;
     const int64_t bc = bok ? b : B - 1;
-    const int wd = threadIdx.x >> 2, wc = (threadIdx.x & 3) * 16;  // W staging: row n = wd, 16 floats from wc
+    // row-traffic side: 16 lanes per row (float4 each), rows g + 16 u, u = 0..7
+    const int g = t >> 4, sub = t & 15;
+    const int wd = t >> 2, wc = (t & 3) * 16;  // W staging: row n = wd, 16 floats from wc
 
-    // arena rows of the workgroup's samples, all fields, computed up front into LDS (range check as the plain gather): the
-    // field loop then needs no index loads — an id load in the loop would be the NEWEST vector-memory operation at the
-    // point where its value is needed, and waiting for it (vmcnt(0)) would also wait for every x store just issued
-    __shared__ int32_t Ks[4][32][EGL_MAXF];
-    for (int f = h; f < F; f += 2) {
+    for (int f = h; f < F; f += 2) {  // arena rows of the workgroup's samples, all fields (range check as the plain gather)
         int64_t id = idx.p[f][bc];
         if (id < 0 || id >= row_count[f]) {
             if (bok) *err_flag = 1;
             id = 0;
         }
         const int64_t key = row_base[f] + id;
-        Ks[wv][i][f] = (int32_t)key;
+        Ks[32 * wv + i][f] = (int32_t)key;
         if (keys_out != nullptr && bok) keys_out[(int64_t)f * B + b] = (int32_t)key;
     }
     __syncthreads();
-    auto row_of = [&](int f) -> const float * { return arena + (int64_t)Ks[wv][i][f] * D + 8 * h; };
-    auto load_row = [&](const float *src, f32x8 (&v)[4]) {
+    auto load_rows = [&](int f, f32x4 (&v)[8]) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + ks * 16), v1 = *reinterpret_cast<const f32x4 *>(src + ks * 16 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[ks][e] = v0[e];
-                v[ks][4 + e] = v1[e];
-            }
-        }
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
     };
-    auto stage_w = [&](int buf, int col0) {  // W[:, col0 .. col0 + 63] -> Wt[buf] pieces ([n][k])
+    auto load_w = [&](int col0, f32x4 (&v)[4]) {
         const float *src = W + (int64_t)wd * ldw + col0 + wc;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src + 8 * u), v1 = *reinterpret_cast<const f32x4 *>(src + 8 * u + 4);
-            f32x8 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = v0[e];
-                v[4 + e] = v1[e];
-            }
-            bf16x8 pc[3];
-            bf_split8<3>(v, pc);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8 *>(&Wt[buf][q][wd][wc + 8 * u]) = pc[q];
-        }
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + 4 * u);
     };
     f32x16 acc[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    f32x8 S[4];
+    f32x4 S[8];
+    float q[8];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) S[ks][e] = 0.f;
-    float qsum = 0.f;
-    f32x8 av[4], avn[4];
-    load_row(row_of(0), av);
+    for (int u = 0; u < 8; ++u) {
+        S[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        q[u] = 0.f;
+    }
+    f32x4 cur[8], nxt[8], wq[4], wqn[4];
+    load_rows(0, cur);
+    load_w(0, wq);
     for (int f = 0; f < F; ++f) {
-        load_row(row_of(f + 1 < F ? f + 1 : f), avn);  // in flight during this field's matrix work (the last field is
-                                                       // simply read once more: a load behind a branch cannot be counted)
-        stage_w(f & 1, f * D);
-        __syncthreads();  // slice f visible; everyone is past the fragment reads of slice f - 2 (same buffer)
-        float *xr = (FULL || (x != nullptr && bok)) ? x + b * ldx + (int64_t)f * D + 8 * h : nullptr;
+        const int fn = f + 1 < F ? f + 1 : f;  // (the last field is simply read once more: a load behind a branch cannot be
+        load_rows(fn, nxt);                    //  counted by the in-order vmcnt waits)
+        load_w(fn * D, wqn);
+        __syncthreads();  // everyone is past the fragment reads of field f - 1: Xs and Wt are free
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = g + 16 * u;
+            *reinterpret_cast<f32x4 *>(&Xs[r][4 * sub]) = cur[u];
+            const int64_t br = blk * 128 + r;
+            if (FULL || (x != nullptr && br < B)) *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + 4 * sub) = cur[u];
+            S[u] += cur[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[u] = __builtin_fmaf(cur[u][e], cur[u][e], q[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = wq[2 * u][e];
+                v[4 + e] = wq[2 * u + 1][e];
+            }
+            bf16x8 pc[3];
+            bf_split8<3>(v, pc);
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) *reinterpret_cast<bf16x8 *>(&Wt[qq][wd][wc + 8 * u]) = pc[qq];
+        }
+        __syncthreads();  // rows and W slice of field f visible
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (FULL || xr != nullptr) {
-                *reinterpret_cast<f32x4 *>(xr + ks * 16) = f32x4{av[ks][0], av[ks][1], av[ks][2], av[ks][3]};
-                *reinterpret_cast<f32x4 *>(xr + ks * 16 + 4) = f32x4{av[ks][4], av[ks][5], av[ks][6], av[ks][7]};
-            }
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&Xs[32 * wv + i][ks * 16 + 8 * h]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&Xs[32 * wv + i][ks * 16 + 8 * h + 4]);
+            f32x8 av;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                S[ks][e] += av[ks][e];
-                qsum = __builtin_fmaf(av[ks][e], av[ks][e], qsum);
+            for (int e = 0; e < 4; ++e) {
+                av[e] = v0[e];
+                av[4 + e] = v1[e];
             }
             bf16x8 a[3];
-            bf_split8<3>(av[ks], a);
+            bf_split8<3>(av, a);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 bf16x8 bq[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8 *>(&Wt[f & 1][q][nt * 32 + i][ks * 16 + 8 * h]);
+                for (int qq = 0; qq < 3; ++qq) bq[qq] = *reinterpret_cast<const bf16x8 *>(&Wt[qq][nt * 32 + i][ks * 16 + 8 * h]);
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) av[ks] = avn[ks];
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wq[u] = wqn[u];
     }
     // ---- the dense columns (K tail: ND <= 16 columns right after the F*D embedding columns): one 16-deep k-step
     if (ND > 0) {
-        const int buf = F & 1;
+        __syncthreads();  // the fragment reads of the last field are done
         {   // W[:, F*D + k], k < ND, zero padded to 16; guarded (the row may end right after column K - 1)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = (threadIdx.x & 3) * 4 + u;  // k of this element, row n = wd
+                const int e = (t & 3) * 4 + u;  // k of this element, row n = wd
                 const float v = e < ND ? W[(int64_t)wd * ldw + (int64_t)F * D + e] : 0.f;
                 const __bf16 hi = (__bf16)v;
                 const float r1 = v - (float)hi;
                 const __bf16 mid = (__bf16)r1;
-                Wt[buf][0][wd][e] = hi;
-                Wt[buf][1][wd][e] = mid;
-                Wt[buf][2][wd][e] = (__bf16)(r1 - (float)mid);
+                Wt[0][wd][e] = hi;
+                Wt[1][wd][e] = mid;
+                Wt[2][wd][e] = (__bf16)(r1 - (float)mid);
             }
         }
         f32x8 dv;
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
         for (int nt = 0; nt < 2; ++nt) {
             bf16x8 bq[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) bq[q] = *reinterpret_cast<const bf16x8 *>(&Wt[buf][q][nt * 32 + i][8 * h]);
+            for (int qq = 0; qq < 3; ++qq) bq[qq] = *reinterpret_cast<const bf16x8 *>(&Wt[qq][nt * 32 + i][8 * h]);
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr)
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     } else if (x != nullptr && bok) {
         for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;
     }
-    // ---- epilogue: h1 = relu(acc + bias) in the C layout; FM second order and the field sum from the lane's half row
+    // ---- epilogue: h1 = relu(acc + bias) in the C layout
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = nt * 32 + i;
@@ -447,20 +466,20 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             if (FULL || m < B) h1[m * 64 + n] = fmaxf(acc[nt][r] + bv, 0.f);
         }
     }
-    float ssq = 0.f;
+    // FM second order and the field sum, from the row-traffic layout (16 lanes per sample)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int u = 0; u < 8; ++u) {
+        const int64_t br = blk * 128 + g + 16 * u;
+        float fmv = -q[u];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ssq = __builtin_fmaf(S[ks][e], S[ks][e], ssq);
-    float fmv = ssq - qsum;
-    fmv += __shfl_xor(fmv, 32, 64);
-    if (fm_out != nullptr && h == 0 && bok) fm_out[b] = 0.5f * fmv;
-    if (sum_out != nullptr && bok) {
-        float *sr = sum_out + b * D + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            *reinterpret_cast<f32x4 *>(sr + ks * 16) = f32x4{S[ks][0], S[ks][1], S[ks][2], S[ks][3]};
-            *reinterpret_cast<f32x4 *>(sr + ks * 16 + 4) = f32x4{S[ks][4], S[ks][5], S[ks][6], S[ks][7]};
+        for (int e = 0; e < 4; ++e) fmv = __builtin_fmaf(S[u][e], S[u][e], fmv);
+        fmv += __shfl_xor(fmv, 1, 64);
+        fmv += __shfl_xor(fmv, 2, 64);
+        fmv += __shfl_xor(fmv, 4, 64);
+        fmv += __shfl_xor(fmv, 8, 64);
+        if (FULL || br < B) {
+            if (fm_out != nullptr && sub == 0) fm_out[br] = 0.5f * fmv;
+            if (sum_out != nullptr) *reinterpret_cast<f32x4 *>(sum_out + br * D + 4 * sub) = S[u];
         }
     }
 }
