@@ -424,6 +424,8 @@ def main():
         rb = dd * 4
         nd = ND if dd == D else 0
         if entry == "embed_gather_fwd":   # table rows read + int64 ids read + [B, F*D+ND] fp32 output written
+            if sharded:  # the owner-side gather of the requested unique rows into the send buffer: row read + row written
+                return 2 * n_unique * rb, 0
             return local_B * (F * (rb + 8) + (F * dd + nd) * 4), 0
         if entry == "embed_grad_reduce":  # dX row per pair (+ the sum_f v row per pair unless the FM term is folded
             # into the dgrad: DeepFM at D = 64), gradient row written (+ table row read for FM) per unique row
@@ -565,7 +567,8 @@ def main():
         roofline["share_of_step"] = round(share[dominant] / max(sum(share.values()), 1e-9), 4)
     # north_star's "HBM GB/s on the embedding gather": the plain gather where the model runs it, else the launch it is
     # fused into (DeepFM at D = 64: lookup + concat + FM + first Linear, rp_embed_gather_linear_fwd)
-    gkey = next((k for k in (f"embed_gather_fwd[D={D}]", f"embed_gather_linear_fwd[D={D}]") if k in timing), None)
+    gkeys = (f"embed_gather_fwd[D={D}]", f"embed_gather_linear_fwd[D={D}]")
+    gkey = next((k for k in (gkeys[::-1] if sharded else gkeys) if k in timing), None)
     gather = roofline_of(gkey, timing[gkey][1]) if gkey else None
     gemm = None
     if args.model == "deepfm" and hidden != (64, 64, 64):
