@@ -243,3 +243,37 @@ def test_baseline_config1_shape_on_cpu(tmp_path):
     assert metric["log_loss"] < first["log_loss"], (first, metric)
     preds = trainer.predict_dataloader(model, test_loader)
     assert len(preds) == len(df) - 2560 and all(0.0 <= p <= 1.0 for p in preds)
+
+
+def test_one_ahead_feeds_the_same_batches_and_announces_the_next():
+    """model_pipeline._one_ahead (the look-ahead of train_model): the loader's batches in order, each one yielded only after
+    the NEXT one has been announced to the model (BaseModel.prefetch); loaders that recycle buffers are told to keep two
+    batches alive; a model without `prefetch` (stock torch modules) and an empty loader are fine."""
+    from rec_pangu_amd.model_pipeline import _one_ahead
+
+    class Loader(list):
+        hold = 1
+
+    class Model:
+        def __init__(self):
+            self.log = []
+
+        def prefetch(self, batch):
+            self.log.append(("announce", int(batch["i"])))
+
+    batches = Loader({"i": torch.tensor(i)} for i in range(4))
+    model = Model()
+    seen = []
+    for b in _one_ahead(batches, torch.device("cpu"), model):
+        model.log.append(("step", int(b["i"])))
+        seen.append(int(b["i"]))
+    assert seen == [0, 1, 2, 3]
+    assert batches.hold == 2
+    assert model.log == [("announce", 1), ("step", 0), ("announce", 2), ("step", 1), ("announce", 3), ("step", 2), ("step", 3)]
+    assert [int(b["i"]) for b in _one_ahead([{"i": torch.tensor(7)}], torch.device("cpu"), object())] == [7]
+    assert list(_one_ahead([], torch.device("cpu"), model)) == []
+    # a CPU-resident model ignores the announcement (BASELINE config 0: plumbing, no GPU)
+    enc = {"C1": {"vocab_size": 5}, "I1": {"min": 0.0, "max": 1.0}}
+    cpu_model = DeepFM(enc_dict=enc, embedding_dim=4, hidden_units=[8])
+    cpu_model.prefetch({"C1": torch.zeros(3, dtype=torch.long), "I1": torch.zeros(3)})
+    assert getattr(cpu_model.embedding_layer, "_ahead", None) is None
