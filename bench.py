@@ -337,9 +337,9 @@ def main():
 
     def side_stream(name):
         """rows of the per-kernel table whose launches run on the side stream when the next batch is announced: the key
-        computation and routing, and the pair sort (in the sharded path only one of its two sorts: not excluded there)"""
+        computation and routing, and the pair sort(s)"""
         e = name.split("[")[0]
-        return ahead and (e in AHEAD_ROWS or (e == "sort_pairs_i32" and not sharded))
+        return ahead and (e in AHEAD_ROWS or e == "sort_pairs_i32")
 
     wb = [gen(n_seen + i) for i in range(args.warmup)] + [batches[0]]
     for i in range(args.warmup - n_prof):

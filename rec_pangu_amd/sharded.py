@@ -118,10 +118,14 @@ class _ShardedRows(torch.autograd.Function):
     def forward(ctx, layer, keys, local_arena):
         dev = local_arena.device
         prepared, layer._prepared = layer._prepared, None
-        # (prepared: this batch's route, built ahead on the side stream — ShardedEmbeddingLayer._route_ahead)
-        route = prepared if prepared is not None else _Route(keys, layer)
-        recv_rows = _a2a(route.local_rows, route.recv, route.send, layer.group, layer.world)
-        served = layer._local_gather(recv_rows)  # [n_recv, D]
+        # (prepared: what was done ahead on the side stream for this batch — its route (ShardedEmbeddingLayer._route_ahead)
+        #  and, once the previous step's collectives were enqueued, its id exchange and owner-side sort (_request_ahead))
+        route, recv_rows, served_sorted = prepared if prepared is not None else (None, None, None)
+        if route is None:
+            route = _Route(keys, layer)
+        if recv_rows is None:
+            recv_rows = _a2a(route.local_rows, route.recv, route.send, layer.group, layer.world)
+        served = layer._local_gather(recv_rows, served_sorted)  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
         rows = _a2a(served, route.send, route.recv, layer.group, layer.world)
@@ -280,10 +284,10 @@ class ShardedEmbeddingLayer(nn.Module):
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
-        self._prepared = None  # _Route of the batch about to be looked up, when it was built ahead
+        self._prepared = None  # (route, requested rows, their sort) of the batch about to be looked up, as far as prepared ahead
         self._scaled = None     # per-lookup flag shared by _ShardedRows and _RowsToLinear (who applies the 1/G)
         self._announced = None  # the batch of the next step (prefetch_sort), until its route is started
-        self._ahead = None      # (id tensors, versions, route, event) of the route being built on the side stream
+        self._ahead = None      # (id tensors, versions, route, event[, requested rows, their sort]) prepared on the side stream
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_lazy())
 
     def _tag(self):
@@ -406,19 +410,43 @@ class ShardedEmbeddingLayer(nn.Module):
         a, self._ahead, self._prepared = self._ahead, None, None
         if a is None:
             return
-        src, ver, prepared, event = a
+        src, ver, prepared, event = a[:4]
         cur = tuple(X[c] for c in self.emb_feature)
         if len(cur) != len(src) or any(x is not y for x, y in zip(cur, src)) or ver != tuple(t._version for t in cur) \
                 or self._capacity is None:
             return
         stream = torch.cuda.current_stream(self.local_arena.device)
         stream.wait_event(event)
-        for t in (prepared.slot_sorted, prepared.slot_of_pair, prepared.pos_sorted, prepared.local_rows):
-            t.record_stream(stream)
-        self._prepared = prepared
+        recv_rows, served_sorted = a[4:] if len(a) == 6 else (None, None)
+        for t in (prepared.slot_sorted, prepared.slot_of_pair, prepared.pos_sorted, prepared.local_rows, recv_rows) \
+                + tuple(served_sorted or ()):
+            if t is not None:
+                t.record_stream(stream)
+        self._prepared = (prepared, recv_rows, served_sorted)
+
+    def _request_ahead(self) -> None:
+        """Second half of the look-ahead, called once the current step's collectives are enqueued (allreduce_dense_grads):
+        the id exchange of the announced batch and the owner-side sort of the rows this rank is asked for, on the side
+        stream behind the route.  Issued HERE, not with the route: RCCL runs collectives in issue order, and an id exchange
+        waiting for the side stream must not sit in front of the gradient exchange / all-reduce of the step in flight."""
+        a = self._ahead
+        if a is None or len(a) != 4 or self._capacity is None:
+            return
+        from .models.layers.embedding import _SIDE_STREAMS
+        src, ver, route, _ = a
+        side = _SIDE_STREAMS[self.local_arena.device]
+        with torch.cuda.stream(side):
+            recv_rows = _a2a(route.local_rows, route.recv, route.send, self.group, self.world)
+            served_sorted = None
+            if self._lazy is not None and recv_rows.numel():
+                from . import hip
+                served_sorted = hip.sort_pairs(recv_rows.to(torch.int32), end_bit=self._meta()[3])
+            event = torch.cuda.Event()
+            event.record(side)
+        self._ahead = (src, ver, route, event, recv_rows, served_sorted)
 
     # ---- local primitives: HIP kernels on a HIP device, torch ops on CPU ---------------------------
-    def _local_gather(self, rows_idx):
+    def _local_gather(self, rows_idx, served_sorted=None):
         if self.local_arena.is_cuda:
             from . import hip
             n = rows_idx.numel()
@@ -427,7 +455,8 @@ class ShardedEmbeddingLayer(nn.Module):
             self._served_sorted = None
             if self._lazy is not None and self._lazy.t > 0:
                 # exact lazy dense Adam: rows about to be served first replay the steps they skipped
-                sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
+                sk, sp = served_sorted if served_sorted is not None else \
+                    hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
                 self._lazy.replay(self, sk)
                 self._served_sorted = (sk, sp)
             zero = torch.zeros((1,), dtype=torch.int64, device=rows_idx.device)
@@ -710,13 +739,16 @@ def dense_parameters(model: nn.Module):
 def allreduce_dense_grads(model: nn.Module, group=None):
     """Average the replicated parameters' gradients over the ranks in one flat bucket."""
     ps = [p for p in dense_parameters(model) if p.grad is not None]
-    if not ps:
-        return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat /= dist.get_world_size(group)
-    off = 0
-    for p in ps:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    if ps:
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= dist.get_world_size(group)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    # this step's collectives are all enqueued: the announced next batch may now request its rows (side stream)
+    for m in model.modules():
+        if isinstance(m, ShardedEmbeddingLayer):
+            m._request_ahead()
