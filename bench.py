@@ -364,9 +364,12 @@ def main():
     ev_stride = 4 if (n_prof and args.steps >= 8) else 1  # events on every 4th timed step only
     barrier()
     t0 = time.perf_counter()
+    host_s = 0.0
     for i in range(args.steps):
         hip.pause_timing(i % ev_stride != 0)
+        th = time.perf_counter()
         step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None)
+        host_s += time.perf_counter() - th  # time the host needs to ENQUEUE a step (it runs ahead of the device)
     hip.pause_timing(False)
     barrier()
     dt = time.perf_counter() - t0
@@ -602,6 +605,7 @@ def main():
                        "unique_rows_per_batch": n_unique,
                        "parallelism": "single GPU" if not sharded else f"tables row-sharded x{world}, all-to-all lookup"},
             "pre_roll_steps": pre_roll, "cold": cold,
+            "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
             "roofline": roofline, "roofline_gather": gather, "kernels": kernels,
             "kernels_note": f"per-kernel table: HIP events around every launch during the last {n_prof} warm-up steps; "
                             f"roofline/roofline_gather durations: HIP events inside the timed region, every "
