@@ -23,10 +23,20 @@ static hipError_t sort_dispatch(void *temp, size_t &tb, const int32_t *ki, int32
     return rocprim::radix_sort_pairs<rocprim::default_config>(temp, tb, ki, ko, vi, vo, (size_t)n, 0u, (unsigned)end_bit, s);
 }
 
+// rocPRIM's size query walks its config dispatch and asks the runtime for the device on every call (~0.1 ms of host time,
+// three of them per sort before this cache: more than the host spends on the rest of a DeepFM step's forward)
 static int sort_bytes(int64_t n, size_t *bytes) {
+    static thread_local int64_t cached_n = -1;
+    static thread_local size_t cached_tb = 0;
+    if (n == cached_n) {
+        *bytes = cached_tb;
+        return RP_OK;
+    }
     size_t tb = 0;
     hipError_t e = sort_dispatch(nullptr, tb, nullptr, nullptr, nullptr, nullptr, n, 32, nullptr);
     if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "sort size query: %s", hipGetErrorString(e));
+    cached_n = n;
+    cached_tb = tb;
     *bytes = tb;
     return RP_OK;
 }
