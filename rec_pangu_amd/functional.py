@@ -3,7 +3,7 @@
 Everything here takes HIP-device fp32 tensors; nothing in this module computes on the CPU and
 nothing falls back: a missing librecpangu_hip.so raises from hip.lib().
 """
-from typing import List, Optional, Sequence
+from typing import List, Sequence
 
 import torch
 

@@ -13,7 +13,6 @@ expert weights in weight space — experts' = experts . Lm, bias' = bias . Lm wi
 — and the rest is exactly the MMOE kernels: one MFMA GEMM over [experts' | gates] + the gate-softmax/combine kernel.
 """
 import torch
-from torch import nn
 
 from ... import functional as Fh
 from ..base_model import BaseModel

@@ -8,7 +8,6 @@ Towers are Linear -> BatchNorm1d -> Dropout with no activation in between, then 
 loss = sum_t (1/T) * BCE(p_t + 1e-6, y_t).
 """
 import torch
-from torch import nn
 
 from ... import functional as Fh
 from ..base_model import BaseModel

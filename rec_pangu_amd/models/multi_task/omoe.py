@@ -11,7 +11,6 @@ b_eff = experts_bias . gate, an [h,K,E]x[E] contraction in weight space — and 
 reference's flops produces gate_out.  Gradients reach experts/experts_bias/gate through that contraction.
 """
 import torch
-from torch import nn
 
 from ... import functional as Fh
 from ..base_model import BaseModel

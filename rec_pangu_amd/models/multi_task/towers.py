@@ -9,7 +9,6 @@ HIP execution: Linear on the fp32-MFMA kernel, BatchNorm1d on rp_batchnorm_*, th
 the BCE in rp_sigmoid_bce_*; Dropout on rp_dropout_* (Philox mask) when training with p > 0.
 """
 import numpy as np
-import torch
 from torch import nn
 
 from ... import functional as Fh

@@ -6,7 +6,6 @@ The reference class cannot be constructed: it calls `BaseModel.__init__()` witho
 """
 from typing import Dict
 
-import torch
 from torch import nn
 
 from ..base_model import BaseModel, build_loss
