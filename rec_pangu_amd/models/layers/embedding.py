@@ -27,7 +27,7 @@ from ... import functional as Fh
 # the last two (id tensors, versions, arena signature) -> (keys, sorted keys, positions)[, side-stream event]: the batch in
 # flight and the one whose sort was started ahead (EmbeddingLayer._sorted_keys / prefetch_sort)
 _SORT_CACHE: list = []
-_SIDE_STREAMS: dict = {}  # device -> the (high-priority) stream sorts started ahead run on
+_SIDE_STREAMS: dict = {}  # device -> the stream sorts started ahead run on
 
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
@@ -370,7 +370,7 @@ class EmbeddingLayer(nn.Module):
         dev = self._arena.device
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)  # (a high-priority stream measured no better)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)  # the id tensors (and whatever produced them) are ordered on the caller's stream
         with torch.cuda.stream(side):

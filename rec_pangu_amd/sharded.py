@@ -394,7 +394,7 @@ class ShardedEmbeddingLayer(nn.Module):
         dev = self.local_arena.device
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
         src = tuple(X[c] for c in self.emb_feature)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
