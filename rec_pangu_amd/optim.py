@@ -131,10 +131,15 @@ class FusedAdam(torch.optim.Optimizer):
         self.flush()
         sd = super().state_dict()
         out_state = {}
+        step_of = {}  # state index -> the step count of its group (torch.optim.Adam keeps one 'step' per parameter)
+        for g in sd["param_groups"]:
+            for i in g["params"]:
+                step_of[i] = g.get("_rp_step", 0)
         for k, st in sd["state"].items():
             st = dict(st)
             if self.SQRT_KEY in st:
                 st["exp_avg_sq"] = st[self.SQRT_KEY] * st[self.SQRT_KEY]
+                st["step"] = torch.tensor(float(step_of.get(k, 0)))
             out_state[k] = st
         return {"state": out_state, "param_groups": sd["param_groups"]}
 
@@ -230,6 +235,12 @@ class FusedAdam(torch.optim.Optimizer):
         """torch semantics; the moments of arena-backed tables are adopted by the arena state at the next step()."""
         self.flush()
         super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            # a torch.optim.Adam state_dict carries the step count per parameter, not per group: without it the bias
+            # correction (and the lazy step table) would restart at 1 on warm moments
+            if "_rp_step" not in group:
+                steps = [float(self.state[p]["step"]) for p in group["params"] if "step" in self.state.get(p, {})]
+                group["_rp_step"] = int(max(steps)) if steps else 0
         for st in self.state.values():  # torch.optim.Adam layout -> native (sqrt of the second moment)
             if self.SQRT_KEY in st:
                 st.pop("exp_avg_sq", None)

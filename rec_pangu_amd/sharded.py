@@ -24,6 +24,7 @@ the global batch (loss = mean over B).
 On a HIP device the local work runs on the HIP kernels (fused gather + FM from the received rows,
 sort + segmented reduce for the gradients); on CPU (gloo tests, BASELINE config 0 style) plain torch ops.
 """
+import os
 import weakref
 from typing import Dict, List, Optional
 
@@ -34,13 +35,53 @@ from torch import nn
 from . import functional as Fh
 
 
+_STAGED: dict = {}
+
+
+def _host_staged(t, group) -> bool:
+    """HIP tensors on a gloo group: the collective is staged through host memory.  That is the VIRTUAL multi-rank harness
+    (tests/test_hip_sharded_world2.py: two processes sharing one MI355X, where RCCL refuses two ranks on one device) —
+    every HIP kernel of the sharded path runs exactly as under RCCL, only the wire is swapped."""
+    if not t.is_cuda:
+        return False
+    k = id(group)
+    if k not in _STAGED:
+        _STAGED[k] = dist.get_backend(group) == "gloo"
+    return _STAGED[k]
+
+
+def all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
+    if _host_staged(inp, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(h_out)
+        return
+    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+def all_reduce(t, op=None, group=None):
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return
+    dist.all_reduce(t, op=op, group=group)
+
+
+def _force_a2a() -> bool:
+    """RP_FORCE_A2A=1: a one-rank group still goes through all_to_all_single (RCCL self-copies on HIP tensors), so that
+    1-GPU runs exercise the collective call path itself."""
+    return os.environ.get("RP_FORCE_A2A", "0") == "1"
+
+
 def _a2a(inp, out_splits, in_splits, group, world: int):
     """all_to_all_single into a fresh tensor; with one rank the exchange is the identity and `inp` itself comes back (no
-    self-copy through an RCCL kernel: 0.12 ms per exchange at Criteo shape)"""
-    if world == 1:
+    self-copy through an RCCL kernel: 0.12 ms per exchange at Criteo shape) unless RP_FORCE_A2A=1"""
+    if world == 1 and not _force_a2a():
         return inp
     out = torch.empty((sum(out_splits),) + tuple(inp.shape[1:]), dtype=inp.dtype, device=inp.device)
-    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    all_to_all(out, inp, out_splits, in_splits, group)
     return out
 
 
@@ -72,34 +113,40 @@ class _Route:
             self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
             self.pos_sorted = sp
             self.n_requests = n
-            cap = layer._capacity if layer.check_indices == "deferred" else None
+            # fixed-capacity exchange (check_indices == "deferred"): every owner gets `cap` slots, the split sizes are
+            # constants and nothing comes back to the host.  The capacity was measured on a batch of `_capacity_n`
+            # requests; a LARGER batch (an evaluation batch, a changed loader) takes the exact exchange below and the
+            # capacity grows.  Every rank must see the same local batch size in a step (the choice is made without a
+            # collective).  An owner asked for more than `cap` unique rows by a batch that is not larger sets the error
+            # flag, which raise_if_bad_index() — all-reduced over the ranks — turns into an exception on EVERY rank.
+            cap = layer._capacity if (layer.check_indices == "deferred" and n <= layer._capacity_n) else None
             if cap is not None:
-                # fixed-capacity exchange: every owner gets `cap` slots, the split sizes are constants and nothing
-                # has to come back to the host (an owner asked for more than cap unique rows sets the error flag,
-                # which raise_if_bad_index() turns into an exception at the deferred check)
                 self.local_rows = hip.route_pad(sk, sp, world, lbits, cap, counts, self.slot_sorted, self.slot_of_pair, err)
                 self.send = self.recv = [cap] * world
                 self.n_unique = self.n_recv = cap * world
                 return
             send_counts = counts[:world]
             recv_counts = torch.empty_like(send_counts)
-            dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
+            all_to_all(recv_counts, send_counts, group=layer.group)
             # one host sync per exchange: the collective wants its split sizes on the host
             self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
             self.n_unique, self.n_recv = sum(self.send), sum(self.recv)
             self.local_rows = uniq_rows[:self.n_unique]
             if layer.check_indices == "deferred":
-                # from the next step on: fixed capacity, 25 % above the largest per-owner count any rank saw now
-                m = torch.tensor([max(self.send + self.recv)], dtype=torch.int64, device=sk.device)
-                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=layer.group)
-                layer._capacity = (int(m.item()) * 5 // 4 + 1024 + 255) // 256 * 256
+                # from the next step on: fixed capacity, 25 % above the largest per-owner count any rank saw now (never
+                # below what an earlier measurement gave)
+                m = torch.tensor([max(self.send + self.recv), n], dtype=torch.int64, device=sk.device)
+                all_reduce(m, op=dist.ReduceOp.MAX, group=layer.group)
+                m = m.tolist()
+                layer._capacity = max(layer._capacity or 0, (m[0] * 5 // 4 + 1024 + 255) // 256 * 256)
+                layer._capacity_n = max(layer._capacity_n, m[1])
             return
         comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
         sk, sp = torch.sort(comp, stable=True)
         uniq, inverse = torch.unique_consecutive(sk, return_inverse=True)
         send_counts = torch.bincount((uniq >> lbits).long(), minlength=world)
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=layer.group)
+        all_to_all(recv_counts, send_counts, group=layer.group)
         self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
         self.local_rows = (uniq & ((1 << lbits) - 1)).long().contiguous()
         self.n_unique, self.n_recv = int(uniq.numel()), sum(self.recv)
@@ -284,6 +331,7 @@ class ShardedEmbeddingLayer(nn.Module):
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
+        self._capacity_n = 0   # requests of the (largest) batch the capacity was measured on
         self._prepared = None  # (route, requested rows, their sort) of the batch about to be looked up, as far as prepared ahead
         self._scaled = None     # per-lookup flag shared by _ShardedRows and _RowsToLinear (who applies the 1/G)
         self._announced = None  # the batch of the next step (prefetch_sort), until its route is started
@@ -342,15 +390,28 @@ class ShardedEmbeddingLayer(nn.Module):
             self._lazy.flush(self)
 
     def raise_if_bad_index(self):
+        """Turn the device-side flag into the reference's IndexError (bit 0: id out of range) or a RuntimeError (bit 1: the
+        fixed-capacity exchange overflowed).  With more than one rank the flag is OR-ed over the ranks first, so that
+        every rank raises — and re-measures its capacity — together: a rank that kept going alone would meet its peers
+        in mismatched collectives.  COLLECTIVE for world > 1: every rank must call it at the same point (the forward does
+        in 'sync' mode, the trainer / bench after the epoch in 'deferred' mode)."""
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            self._or_flag(self._err_flag(self.local_arena.device))
         if self._err is not None:
             code = int(self._err.item())
             if code != 0:
                 self._err.zero_()
                 if code & 2:
-                    cap, self._capacity = self._capacity, None  # re-measured by the next (exact) exchange
+                    cap, self._capacity, self._capacity_n = self._capacity, None, 0  # re-measured by the next (exact) exchange
                     raise RuntimeError(f"row exchange: an owner was asked for more than the fixed capacity of {cap} "
                                        "unique rows; the steps since the last check dropped requests")
                 raise IndexError("index out of range in self")
+
+    def _or_flag(self, flag):
+        """bitwise OR of the int32 flag over the ranks: ONE MAX all-reduce over its two bits (every backend has MAX)"""
+        bits = torch.stack([flag & 1, (flag >> 1) & 1]).reshape(-1)
+        all_reduce(bits, op=dist.ReduceOp.MAX, group=self.group)
+        flag.copy_((bits[0] | (bits[1] << 1)).reshape(1))
 
     def _err_flag(self, device):
         if self._err is None or self._err.device != device:
@@ -388,8 +449,9 @@ class ShardedEmbeddingLayer(nn.Module):
         if X is None:
             return
         if self._capacity is None or self.check_indices != "deferred" \
-                or self.lbits + max(1, (self.world - 1).bit_length()) > 31:
-            return
+                or self.lbits + max(1, (self.world - 1).bit_length()) > 31 \
+                or len(self.emb_feature) * X[self.emb_feature[0]].numel() > self._capacity_n:
+            return  # (a batch larger than the one the capacity was measured on takes the exact exchange, in its own step)
         from .models.layers.embedding import _SIDE_STREAMS
         dev = self.local_arena.device
         side = _SIDE_STREAMS.get(dev)
@@ -561,6 +623,8 @@ class ShardedEmbeddingLayer(nn.Module):
         per = (self.total_rows + self.world - 1) // self.world
         mine = torch.zeros((per, self.embedding_dim), dtype=self.local_arena.dtype, device=self.local_arena.device)
         mine[:self.local_arena.shape[0]] = self.local_arena.detach()
+        if _host_staged(mine, self.group):
+            mine = mine.cpu()
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine, group=self.group)
         full = torch.stack(parts, dim=1).reshape(per * self.world, self.embedding_dim)[:self.total_rows]
@@ -590,12 +654,12 @@ class _SyncBatchNormFn(torch.autograd.Function):
         else:
             s1 = x.sum(0)
         stats = torch.cat([s1, x.new_tensor([float(x.shape[0])])])
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(stats, group=group)
         n = stats[-1]
         mean = stats[:C] / n
         s2 = hip.batchnorm_colsum(x, mean.contiguous()) if hipdev else ((x - mean) ** 2).sum(0)
         s2 = s2.clone()
-        dist.all_reduce(s2, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(s2, group=group)
         var = s2 / n  # biased, as F.batch_norm normalises with
         invstd = torch.rsqrt(var + eps)
         ctx.group, ctx.hipdev = group, hipdev
@@ -620,7 +684,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
         else:
             dw, db = (dy * x_or_xhat).sum(0), dy.sum(0)
         s = torch.cat([db, dw])
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=ctx.group)
+        all_reduce(s, group=ctx.group)
         if ctx.hipdev:
             dx = hip.batchnorm_bwd_apply(x_or_xhat, dy, mean, invstd, weight, (s[:C] / n).contiguous(),
                                          (s[C:] / n).contiguous())
@@ -741,7 +805,7 @@ def allreduce_dense_grads(model: nn.Module, group=None):
     ps = [p for p in dense_parameters(model) if p.grad is not None]
     if ps:
         flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(flat, group=group)
         flat /= dist.get_world_size(group)
         off = 0
         for p in ps:

@@ -611,8 +611,11 @@ def test_checkpoint_resume_on_hip(sharded, tmp_path):
             dist.destroy_process_group()
 
 
-def test_sharded_fixed_capacity_exchange_single_rank():
-    """check_indices == 'deferred' switches the row exchange to fixed per-owner capacities after the first (exact) step:
+@pytest.mark.parametrize("force_a2a", [False, True])
+def test_sharded_fixed_capacity_exchange_single_rank(force_a2a, monkeypatch):
+    """(force_a2a: RP_FORCE_A2A=1 — the one-rank group still goes through RCCL's all_to_all_single on HIP tensors, so the
+    collective call path itself — split sizes, padded buffers, stream order — runs on the device.)
+    check_indices == 'deferred' switches the row exchange to fixed per-owner capacities after the first (exact) step:
     no split sizes come back to the host any more.  Under a 1-rank RCCL group the steps must give exactly the numbers
     of the exact exchange, padding slots included (they ask for local row 0 and return a zero gradient), and an owner
     asked for more than the capacity is reported at the deferred check."""
@@ -624,6 +627,7 @@ def test_sharded_fixed_capacity_exchange_single_rank():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    monkeypatch.setenv("RP_FORCE_A2A", "1" if force_a2a else "0")
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
     try:
         g = load_golden("model_deepfm.npz")
@@ -655,9 +659,57 @@ def test_sharded_fixed_capacity_exchange_single_rank():
         model(batch)
         with pytest.raises(RuntimeError, match="fixed capacity"):
             lay.raise_if_bad_index()
-        assert lay._capacity is None
+        assert lay._capacity is None and lay._capacity_n == 0
     finally:
         dist.destroy_process_group()
+
+
+def test_fused_adam_state_round_trips_with_torch_adam():
+    """FusedAdam.load_state_dict accepts torch.optim.Adam's layout INCLUDING its per-parameter step count (the bias
+    correction must continue at step 3, not restart at 1 on warm moments), and FusedAdam.state_dict() is loadable by
+    torch.optim.Adam (per-parameter 'step' present).  Reference optimizer: rec_pangu/trainer.py:75."""
+    from rec_pangu_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    w0 = [torch.randn(40, 24), torch.randn(24)]
+    grads = [[torch.randn_like(w) for w in w0] for _ in range(4)]
+
+    def params():
+        return [torch.nn.Parameter(w.clone().to(DEV)) for w in w0]
+
+    def run(opt, ps, steps):
+        for t in steps:
+            for p, g in zip(ps, grads[t]):
+                p.grad = g.clone().to(DEV)
+            opt.step()
+
+    hp = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)
+    # the uninterrupted torch run
+    pt = params()
+    ot = torch.optim.Adam(pt, **hp)
+    run(ot, pt, range(4))
+    # torch (2 steps) -> FusedAdam (2 steps)
+    pa = params()
+    oa = torch.optim.Adam(pa, **hp)
+    run(oa, pa, range(2))
+    pf = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    of = FusedAdam(pf, **hp)
+    of.load_state_dict(oa.state_dict())
+    assert of.param_groups[0]["_rp_step"] == 2
+    run(of, pf, range(2, 4))
+    for a, b in zip(pf, pt):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    # FusedAdam (2 steps) -> torch (2 steps)
+    pf = params()
+    of = FusedAdam(pf, **hp)
+    run(of, pf, range(2))
+    sd = of.state_dict()
+    assert all(float(st["step"]) == 2.0 for st in sd["state"].values())
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pf]
+    ob = torch.optim.Adam(pb, **hp)
+    ob.load_state_dict(sd)
+    run(ob, pb, range(2, 4))
+    for a, b in zip(pb, pt):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
 def test_xdeepfm_midsize_vs_oracle_in_every_matmul_mode(matmul_mode):

@@ -1,0 +1,223 @@
+"""The N > 1 row-sharded path ON HIP TENSORS with a real second rank, on a one-GPU box: two processes share the MI355X
+(RCCL refuses two ranks on one device, so the group is gloo and `sharded.all_to_all / all_reduce` stage the wire through
+host memory).  Everything else is exactly what runs under RCCL: rp_shard_keys / rp_route_build / rp_route_pad, the
+owner-side gather and lazy-Adam replay, the fused rows -> x + FM + first Linear launch, rp_embed_grad_gemm over the
+(slot, position) sort, the gradient return and the owner-side reduce, the two-instalment look-ahead on the side stream,
+the fixed-capacity exchange with its padding slots, a capacity overflow seen by ONE rank only, and a batch larger than
+the one the capacity was measured on.
+
+Contract (the lookup being sharded is rec_pangu/models/layers/embedding.py:58-63): rows bit-identical to
+the unsharded arena's, predictions / gradients / weights after the optimizer steps equal to the unsharded HIP model on
+the global batch within fp32 reduction-order tolerance."""
+import os
+import socket
+import sys
+import time
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import require_gpu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+WORLD, LOCAL_B, BIG_B, SCALE = 2, 4096, 6144, 64
+N_STEPS = 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _global_batch(enc, i, b=LOCAL_B):
+    import bench
+    return bench.synth_batch(enc, WORLD * b, 500 + i, DEV)
+
+
+def _local(batch, rank, b):
+    return {k: v[rank * b:(rank + 1) * b].contiguous() for k, v in batch.items()}
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    try:
+        import bench
+        from rec_pangu_amd import hip
+        from rec_pangu_amd.optim import make_adam
+        from rec_pangu_amd.sharded import build_sharded_model, allreduce_dense_grads, ShardedEmbeddingLayer
+        hip.lib()
+        enc = bench.criteo_enc_dict(SCALE)
+        model = build_sharded_model(lambda: bench.build_model("deepfm", enc), world, rank, DEV, seed=1)
+        lay = model.embedding_layer
+        assert isinstance(lay, ShardedEmbeddingLayer) and lay.world == 2 and lay.local_arena.is_cuda
+        res = {}
+        n0 = hip.launch_count()
+        # (1) index work: the rows that come back through the exchange are bit-identical copies
+        b0 = _local(_global_batch(enc, 0), rank, LOCAL_B)
+        with torch.no_grad():
+            res["rows"] = lay(b0).cpu()
+        # (2) one backward in the exact ('sync') exchange: predictions, loss, dense + table gradients
+        out = model(b0)
+        out["loss"].backward()
+        allreduce_dense_grads(model)
+        res["pred0"], res["loss0"] = out["pred"].detach().cpu(), out["loss"].detach().cpu()
+        res["dense_grads"] = {k: p.grad.cpu().clone() for k, p in model.named_parameters() if "local_arena" not in k}
+        res["table_grad"] = lay.local_arena.grad.cpu().clone()
+        model.zero_grad()
+        # (3) train steps in 'deferred' mode with the next batch announced: step 1 measures the capacity with the exact
+        #     exchange, the others run fixed-capacity with route / id exchange prepared ahead on the side stream
+        for m in model.modules():
+            if hasattr(m, "check_indices"):
+                m.check_indices = "deferred"
+        opt = make_adam(model, 1e-2)
+        batches = [_local(_global_batch(enc, 1 + i), rank, LOCAL_B) for i in range(N_STEPS)]
+        big = _local(_global_batch(enc, 50, BIG_B), rank, BIG_B)
+        preds = []
+
+        def train_step(b, nxt=None):
+            if nxt is not None:
+                model.prefetch(nxt)
+            o = model(b)
+            o["loss"].backward()
+            allreduce_dense_grads(model)
+            opt.step()
+            model.zero_grad()
+            return o["pred"].detach().cpu()
+
+        caps = []
+        for i, b in enumerate(batches):
+            preds.append(train_step(b, batches[i + 1] if i + 1 < N_STEPS else None))
+            caps.append((lay._capacity, lay._capacity_n))
+        lay.raise_if_bad_index()  # collective; nothing to report
+        assert caps[0][0] is not None and caps[0][1] == 26 * LOCAL_B and caps[-1] == caps[0]
+        res["capacity"] = caps[0]
+        # a batch LARGER than the one the capacity was measured on (an evaluation batch): exact exchange, capacity grows
+        preds.append(train_step(big))
+        assert lay._capacity_n == 26 * BIG_B and lay._capacity >= caps[0][0]
+        res["preds"] = preds
+        res["tables"] = {k: v.cpu() for k, v in lay.full_tables().items()}
+        res["dense"] = {k: p.detach().cpu().clone() for k, p in model.named_parameters() if "local_arena" not in k}
+        # (4) capacity overflow that only rank 0's requests cause (rank 1 asks for 26 distinct rows): the deferred check
+        #     must raise on BOTH ranks and both must re-measure together
+        lay._capacity = 256
+        ob = {k: v.clone() for k, v in batches[0].items()}
+        if rank == 1:
+            for k in ob:
+                if k.startswith("C"):
+                    ob[k].zero_()
+        o = model(ob)
+        o["loss"].backward()
+        allreduce_dense_grads(model)
+        model.zero_grad()
+        local_flag = int(lay._err.item())
+        try:
+            lay.raise_if_bad_index()
+            res["overflow"] = (local_flag, "no error")
+        except RuntimeError as e:
+            res["overflow"] = (local_flag, "raised" if "fixed capacity" in str(e) else str(e))
+        assert lay._capacity is None and lay._capacity_n == 0
+        # recovery: the next steps measure again and are right again
+        rb = [_local(_global_batch(enc, 60 + i), rank, LOCAL_B) for i in range(2)]
+        res["recovery"] = [train_step(rb[0], rb[1]), train_step(rb[1])]
+        lay.raise_if_bad_index()
+        assert lay._capacity is not None
+        res["launches"] = hip.launch_count() - n0
+        torch.cuda.synchronize()
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, args, timeout_s=420):
+    ctx = mp.spawn(fn, args=args, nprocs=WORLD, join=False)
+    t0 = time.time()
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"the {WORLD} ranks did not finish within {timeout_s} s")
+    finally:
+        for p in ctx.processes:  # exactly the processes started here
+            if p.is_alive():
+                p.kill()
+
+
+def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model():
+    require_gpu()
+    import bench
+    from rec_pangu_amd.optim import make_adam
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn(_worker, (WORLD, _free_port(), ret))
+    assert len(ret) == WORLD
+    r = [ret[0], ret[1]]
+    assert all(x["launches"] > 100 for x in r)
+
+    enc = bench.criteo_enc_dict(SCALE)
+    torch.manual_seed(1)
+    with torch.device(DEV):
+        plain = bench.build_model("deepfm", enc)
+    emb = plain.embedding_layer
+    F, D = len(emb.emb_feature), 64
+    # (1) rows through the exchange == arena rows, bit for bit
+    gb = _global_batch(enc, 0)
+    arena = emb.arena.detach()
+    for rank in range(WORLD):
+        lb = _local(gb, rank, LOCAL_B)
+        exp = torch.stack([arena[emb.row_base[f] + lb[c]] for f, c in enumerate(emb.emb_feature)], dim=1)
+        assert torch.equal(r[rank]["rows"], exp.cpu()), f"rank {rank}: exchanged rows are not bit-identical"
+    # (2) one backward on the global batch
+    out = plain(gb)
+    out["loss"].backward()
+    pred = torch.cat([r[0]["pred0"], r[1]["pred0"]])
+    torch.testing.assert_close(pred, out["pred"].detach().cpu(), rtol=0, atol=2e-6)
+    torch.testing.assert_close((r[0]["loss0"] + r[1]["loss0"]) / 2, out["loss"].detach().cpu(), rtol=0, atol=2e-6)
+    ref = {k: p.grad.cpu() for k, p in plain.named_parameters()}
+    for k, g in r[0]["dense_grads"].items():
+        assert torch.equal(g, r[1]["dense_grads"][k]), f"{k}: replicated gradients differ after the all-reduce"
+        assert float((g - ref[k]).abs().max()) <= 1e-5 * max(1e-6, float(ref[k].abs().max())), k
+    full = torch.cat([emb.embedding_layer[c].weight.grad for c in emb.emb_feature]).cpu()
+    for rank in range(WORLD):
+        got = r[rank]["table_grad"]
+        assert float((got - full[rank::WORLD]).abs().max()) <= 1e-5 * float(full.abs().max()), f"rank {rank} table gradient"
+    plain.zero_grad()
+    # (3) the same optimizer steps on the global batches
+    opt = make_adam(plain, 1e-2)
+
+    def step(b):
+        o = plain(b)
+        o["loss"].backward()
+        opt.step()
+        plain.zero_grad()
+        return o["pred"].detach().cpu()
+
+    seq = [_global_batch(enc, 1 + i) for i in range(N_STEPS)] + [_global_batch(enc, 50, BIG_B)]
+    for i, b in enumerate(seq):
+        p = step(b)
+        got = torch.cat([r[0]["preds"][i], r[1]["preds"][i]])
+        torch.testing.assert_close(got, p, rtol=0, atol=2e-6 if i == 0 else 1e-4, msg=lambda m: f"step {i}: {m}")
+    sd = plain.state_dict()
+    for c in emb.emb_feature:
+        want = sd[f"embedding_layer.embedding_layer.{c}.weight"].cpu()
+        for rank in range(WORLD):
+            got = r[rank]["tables"][c]
+            assert float((got - want).abs().max()) <= 2e-5 * max(1e-2, float(want.abs().max())), f"table {c}"
+    for k, v in r[0]["dense"].items():
+        assert torch.equal(v, r[1]["dense"][k]), f"{k}: replicas drifted apart"
+        assert float((v - sd[k].cpu()).abs().max()) <= 5e-5 * max(1e-2, float(sd[k].abs().max())), k
+    # (4) the overflow was caused (and flagged) on rank 0 only, and raised on both
+    assert r[0]["overflow"] == (2, "raised"), r[0]["overflow"]
+    assert r[1]["overflow"] == (0, "raised"), r[1]["overflow"]
+    for i in range(2):
+        p = step(_global_batch(enc, 60 + i))
+        got = torch.cat([r[0]["recovery"][i], r[1]["recovery"][i]])
+        torch.testing.assert_close(got, p, rtol=0, atol=2e-4, msg=lambda m: f"recovery step {i}: {m}")

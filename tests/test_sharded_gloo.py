@@ -65,9 +65,11 @@ def _worker(rank, world, port, name, how, ret):
         model.zero_grad()
         res["tables2"] = {n: m.full_tables() for n, m in layers.items()}
         res["dense2"] = {k: p.detach().clone() for k, p in model.named_parameters() if "local_arena" not in k}
-        # out-of-range ids are reported like the single-process path
+        # out-of-range ids are reported like the single-process path — on EVERY rank, also when only one rank's batch
+        # holds the bad id (the flag is OR-ed over the ranks: a rank that kept going alone would hang its peers)
         bad = {k: v.clone() for k, v in local.items()}
-        bad["C2"][0] = 99
+        if rank == 0:
+            bad["C2"][0] = 99
         try:
             model(bad)
             res["raised"] = False
