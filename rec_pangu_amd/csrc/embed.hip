@@ -538,7 +538,8 @@ extern "C" int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row
 // faithful), parks them in LDS and runs the SAME deterministic segmented reduce over them.  dX never exists.
 // An optional `dx` (the sum of the gradients of x's OTHER consumers, e.g. a CIN branch) is added per pair.
 // Positions are field-major, so a 128-position tile lies in one field except at the F-1 field borders, where it runs
-// one matrix pass per field with the other field's rows masked out.
+// one matrix pass per field with the other field's rows masked out (any other order of the fields inside a tile — the
+// owner borders of the row-sharded path — is handled too, by walking all fields for that tile).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
@@ -581,8 +582,16 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         const int wd = threadIdx.x >> 2, wc = (threadIdx.x & 3) * 16;  // staging: row d of the slice, 16 floats from wc
-        for (int f = f_lo; f <= f_hi; ++f) {
-            if (f != f_lo) __syncthreads();  // the previous field's fragment reads are done
+        // Field-major positions: the tile's fields are f_lo..f_hi.  The row-sharded path sorts by (owner, local row):
+        // field-major only INSIDE an owner, so a tile that spans an owner border holds fields {f_a..F-1} u {0..f_b} (and a
+        // tiny batch any mix).  Such a tile (one per owner border) walks every field and skips the absent ones.
+        const bool wrap = __syncthreads_or(rok && (fr < f_lo || fr > f_hi)) != 0;
+        const int f_from = wrap ? 0 : f_lo, f_to = wrap ? (int)((n - 1) / Bi) : f_hi;
+        bool first_pass = true;
+        for (int f = f_from; f <= f_to; ++f) {
+            if (wrap && !__syncthreads_or(rok && fr == f)) continue;
+            if (!first_pass) __syncthreads();  // the previous field's fragment reads are done
+            first_pass = false;
             {
                 const float *src = wt + ((int64_t)f * D + wd) * ldwt + wc;
 #pragma unroll

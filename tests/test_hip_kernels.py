@@ -522,13 +522,18 @@ def test_linear_fwd_wide_kernel(hip, M, N, K, lda_pad, mode):
         hip.set_matmul_precision("auto")
 
 
-@pytest.mark.parametrize("rows,B,with_fm,with_dx,accumulate", [
-    ([8, 4, 51, 12, 3], 24, True, False, False),
-    ([3, 4, 10, 5000, 27], 4099, True, False, False),   # tiles that span field borders; runs of > 1000 equal rows
-    ([3, 4, 10, 5000, 27], 4099, False, True, True),    # extra per-pair gradient (another consumer of x), accumulate mode
-    ([50000, 7], 65536, True, True, False),             # full batch: mostly unique rows + one hot table
+@pytest.mark.parametrize("rows,B,with_fm,with_dx,accumulate,owners", [
+    ([8, 4, 51, 12, 3], 24, True, False, False, 1),
+    ([3, 4, 10, 5000, 27], 4099, True, False, False, 1),   # tiles that span field borders; runs of > 1000 equal rows
+    ([3, 4, 10, 5000, 27], 4099, False, True, True, 1),    # extra per-pair gradient (another consumer of x), accumulate mode
+    ([50000, 7], 65536, True, True, False, 1),             # full batch: mostly unique rows + one hot table
+    # the row-sharded path's order: rows renumbered owner-major (r -> (r % G) * ceil(R / G) + r // G), so the sorted
+    # positions are field-major only inside an owner and a tile at an owner border holds fields {.., F-1, 0, ..}
+    ([8, 4, 51, 12, 3], 24, True, False, False, 8),        # every owner inside ONE tile
+    ([3, 4, 10, 5000, 27], 4099, True, True, False, 2),
+    ([300, 40, 1000, 5000, 27, 90], 2048, True, False, False, 8),
 ])
-def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
+def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate, owners):
     """rp_embed_grad_gemm (the segmented reduce with the consuming Linear's dgrad formed inside, on the matrix core) against
     the unfused pair rp_linear_fwd (dX = dH . W) + rp_embed_grad_reduce in the fp32-faithful mode, and against an fp64
     reference: the same gradient arena within fp32 rounding; bit-identical between two launches."""
@@ -539,6 +544,13 @@ def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
         F = len(rows)
         arena, base = _tables(rows, D, g)
         idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+        if owners > 1:  # renumber the arena rows owner-major (what the slots of a row-sharded lookup look like)
+            R = sum(rows)
+            per = (R + owners - 1) // owners
+            renum = (torch.arange(R) % owners) * per + torch.arange(R) // owners
+            big = torch.zeros(owners * per, D)
+            big[renum] = arena
+            arena = big
         K = F * D + 5
         ldx = (K + 63) // 64 * 64
         W1 = torch.randn(H, K, generator=g) / K ** 0.5
@@ -546,15 +558,17 @@ def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
         dx_extra = torch.randn(B, ldx, generator=g) * 1e-3 if with_dx else None
         gfm = torch.randn(B, 1, generator=g) * 1e-3 if with_fm else None
         ssum = torch.randn(B, D, generator=g) if with_fm else None
-        keys = torch.cat([base[f] + idx[f] for f in range(F)]).to(torch.int32).to(DEV)
-        sk, sp = hip.sort_pairs(keys, end_bit=max(1, (sum(rows) - 1).bit_length()))
+        row_of = [(base[f] + idx[f]) if owners == 1 else renum[base[f] + idx[f]] for f in range(F)]
+        keys = torch.cat(row_of).to(torch.int32).to(DEV)
+        sk, sp = hip.sort_pairs(keys, end_bit=max(1, (arena.shape[0] - 1).bit_length()))
         dev = lambda t_: None if t_ is None else t_.to(DEV)
         wt = hip.transpose(dev(W1), rows_out=ldx)                      # [ldx, 64]
         # unfused: dX = dH . W1 (+ extra), then the reduce
         dxf = hip.linear_fwd(dev(dh), wt, None, hip.ACT_NONE)          # [B, ldx]
         if with_dx:
             dxf = dxf + dev(dx_extra)
-        G0 = torch.full((sum(rows), D), 0.5, device=DEV) if accumulate else torch.zeros(sum(rows), D, device=DEV)
+        NR = arena.shape[0]
+        G0 = torch.full((NR, D), 0.5, device=DEV) if accumulate else torch.zeros(NR, D, device=DEV)
         G1 = G0.clone()
         G2 = G0.clone()
         hip.embed_grad_reduce(sk, sp, B, D, dxf, dev(gfm), dev(ssum), dev(arena), G0, accumulate=accumulate)
@@ -566,9 +580,9 @@ def test_embed_grad_gemm_vs_unfused(hip, rows, B, with_fm, with_dx, accumulate):
         dX = dh.double() @ W1.double()[:, :F * D]
         if with_dx:
             dX = dX + dx_extra.double()[:, :F * D]
-        ref = torch.full((sum(rows), D), 0.5 if accumulate else 0.0, dtype=torch.float64)
+        ref = torch.full((NR, D), 0.5 if accumulate else 0.0, dtype=torch.float64)
         for f in range(F):
-            rows_f = (base[f] + idx[f]).long()
+            rows_f = row_of[f].long()
             contrib = dX[:, f * D:(f + 1) * D]
             if with_fm:
                 contrib = contrib + gfm.double() * (ssum.double() - arena.double()[rows_f])

@@ -26,6 +26,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 WORLD, LOCAL_B, BIG_B, SCALE = 2, 4096, 6144, 64
 N_STEPS = 4
+# The tables are scaled down from their kaiming initialisation (std 0.18: FM second-order logits of std ~4.5, i.e. many
+# saturated predictions).  With saturated predictions p - y cancels to ~1e-5 +- 1 ulp(p), per-row gradients fall to the
+# size of Adam's eps = 1e-8, and lr * g / (|g| + eps) turns a 1-ulp difference of a logit (reduction order: two half
+# batches vs one) into 1e-4 differences of once-touched rows — measured here, and a property of the reference's own
+# arithmetic, not of the sharding.  Unsaturated, the comparison below is tight.
+TABLE_SCALE = 0.25
 
 
 def _free_port():
@@ -59,6 +65,8 @@ def _worker(rank, world, port, ret):
         enc = bench.criteo_enc_dict(SCALE)
         model = build_sharded_model(lambda: bench.build_model("deepfm", enc), world, rank, DEV, seed=1)
         lay = model.embedding_layer
+        with torch.no_grad():
+            lay.local_arena.mul_(TABLE_SCALE)
         assert isinstance(lay, ShardedEmbeddingLayer) and lay.world == 2 and lay.local_arena.is_cuda
         res = {}
         n0 = hip.launch_count()
@@ -167,6 +175,8 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model():
     with torch.device(DEV):
         plain = bench.build_model("deepfm", enc)
     emb = plain.embedding_layer
+    with torch.no_grad():
+        emb.arena.mul_(TABLE_SCALE)
     F, D = len(emb.emb_feature), 64
     # (1) rows through the exchange == arena rows, bit for bit
     gb = _global_batch(enc, 0)
@@ -204,20 +214,27 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model():
     for i, b in enumerate(seq):
         p = step(b)
         got = torch.cat([r[0]["preds"][i], r[1]["preds"][i]])
-        torch.testing.assert_close(got, p, rtol=0, atol=2e-6 if i == 0 else 1e-4, msg=lambda m: f"step {i}: {m}")
+        torch.testing.assert_close(got, p, rtol=0, atol=2e-6, msg=lambda m: f"step {i}: {m}")
+    # Weights after the 5 Adam steps (lr 1e-2).  Predictions agree to 1 ulp, but Adam divides by |g| + 1e-8: elements
+    # whose gradient is of the size of eps turn reduction-order noise (two half batches vs one) into ~1e-5 differences.
+    # Measured with scratch/diag_world2.py: a ONE-process control that accumulates the gradients of the two half batches
+    # (no exchange at all) differs from the full-batch run by the same 1.0e-5 on the big tables / 1.4e-5 on dnn.net.0.weight
+    # and from this two-rank run by 7e-8 on the dense weights.  So: a bound of 0.5 % of one Adam step on every element,
+    # and all but 1e-4 of the elements within 1e-6.
     sd = plain.state_dict()
     for c in emb.emb_feature:
         want = sd[f"embedding_layer.embedding_layer.{c}.weight"].cpu()
         for rank in range(WORLD):
-            got = r[rank]["tables"][c]
-            assert float((got - want).abs().max()) <= 2e-5 * max(1e-2, float(want.abs().max())), f"table {c}"
+            d = (r[rank]["tables"][c] - want).abs()
+            assert float(d.max()) <= 5e-5, f"table {c}: {float(d.max())}"
+            assert float((d > 1e-6).float().mean()) <= 1e-4, f"table {c}: {float((d > 1e-6).float().mean())} of the elements off"
     for k, v in r[0]["dense"].items():
         assert torch.equal(v, r[1]["dense"][k]), f"{k}: replicas drifted apart"
-        assert float((v - sd[k].cpu()).abs().max()) <= 5e-5 * max(1e-2, float(sd[k].abs().max())), k
+        assert float((v - sd[k].cpu()).abs().max()) <= 5e-5, k
     # (4) the overflow was caused (and flagged) on rank 0 only, and raised on both
     assert r[0]["overflow"] == (2, "raised"), r[0]["overflow"]
     assert r[1]["overflow"] == (0, "raised"), r[1]["overflow"]
     for i in range(2):
         p = step(_global_batch(enc, 60 + i))
         got = torch.cat([r[0]["recovery"][i], r[1]["recovery"][i]])
-        torch.testing.assert_close(got, p, rtol=0, atol=2e-4, msg=lambda m: f"recovery step {i}: {m}")
+        torch.testing.assert_close(got, p, rtol=0, atol=5e-6, msg=lambda m: f"recovery step {i}: {m}")
