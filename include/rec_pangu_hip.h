@@ -403,7 +403,8 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * row's zero-gradient steps are replayed in registers when the row is next needed instead of being streamed
  * through HBM every step.  last[row] (int32, 0 = never updated) is the step the stored (p,m,v) are current at;
  * step_scalars is a device float2 table indexed by step: {A_t, B_t} from rp_adam_step_scalars (the eps given
- * there is the one that counts; the `eps` argument of the entry points below is kept for the record).  The replay runs the dense kernel's update function with g = 0: bit-identical results.
+ * there is the one that counts for the serial replay).  The serial replay runs the dense kernel's update function with
+ * g = 0: bit-identical results.
  *   rp_embed_keys       arena-row keys of a batch (same check/flag/clamp as the gather) — needed before the gather
  *   rp_lazy_adam_rows   for every UNIQUE row of `sorted_keys` (sorted; duplicates skipped): replay steps
  *                       last+1 .. t_target(-1); if real_step also apply step t_target with g = grad row
@@ -420,9 +421,28 @@ int rp_adam_step_scalars(float lr, float beta1, float beta2, float eps, int64_t 
                                       * is p += m * rcp(s * A_t + B_t) (s = sqrt(v)); lr = 0 gives (0, -inf) */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
-                      float beta1, float beta2, float eps, rp_stream_t stream);
+                      float beta1, float beta2, float eps, const float *cf_table, int64_t cf_from, rp_stream_t stream);
 int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last, const float *step_scalars,
-                       int64_t t_target, float beta1, float beta2, float eps, rp_stream_t stream);
+                       int64_t t_target, float beta1, float beta2, float eps, const float *cf_table, int64_t cf_from,
+                       rp_stream_t stream);
+/* CLOSED-FORM replay (cf_table != NULL in the two entry points above; tolerance mode, NULL = the bit-exact serial
+ * replay).  The k zero-gradient steps l+1 .. l+k of an element are  m b1^k,  s r^k  and
+ *     p + m * sum_i w_i / (s a_i + eps),  w_i = -lr_{l+i}/(1-b1^{l+i}) b1^i,  a_i = r^i / sqrt(1-b2^{l+i}),  r = sqrt(b2);
+ * every term is expanded around the w-weighted mean abar of the a_i:  q [N0 + y^2 N2 - y^3 N3 + y^4 N4],
+ * q = 1/(s abar + eps), y = s q, N_n = sum_i w_i (a_i - abar)^n — uniformly convergent in s (|y (a_i - abar)| <=
+ * |a_i/abar - 1|), relative truncation error of the summed update <= 9e-8 once l >= 256 at b2 = 0.999
+ * (scratch/closed_form_replay.py).  Steps up to `cf_from` are still replayed serially; steps cf_from+1 .. t cost one
+ * reciprocal and ~10 fp32 operations per element whatever their number.  Here `eps` counts (it is the eps of the
+ * expansion) and must be the one the step scalars were built with.
+ *   rp_lazy_adam_cf_table  cf_table[k] (8 floats: abar, N0, N2, -N3, N4, b1^k, r^k, 0), 1 <= k <= t_end - cf_from,
+ *                          describes the steps t_end-k+1 .. t_end and is valid for replays that END at t_end
+ *                          (rp_lazy_adam_rows(real_step=0, t_target=t_end), (real_step=1, t_target=t_end+1),
+ *                          rp_lazy_adam_flush(t_target=t_end)); rebuilt on the device, in double, whenever the end step
+ *                          changes.  ns_d: device double2 table indexed by step: {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)}.
+ *   rp_lazy_adam_cf_terms  number of leading terms that carry weight (b1^J < 1e-17) */
+int rp_lazy_adam_cf_terms(float beta1, int *terms);
+int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, float beta1, float beta2, float *cf_table,
+                          rp_stream_t stream);
 
 /* ---- request routing for row-sharded tables (rec_pangu_amd/sharded.py; no reference counterpart: the reference is
  * single-device).  Arena row r lives on rank r % world at local row r / world.

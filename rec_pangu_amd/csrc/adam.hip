@@ -189,13 +189,107 @@ struct LazyCfg {
     float one_m_b1, b2, sqrt_b2, one_m_b2, eps;
 };
 
+// ------------------------------------------------------------------------------------------------
+// CLOSED-FORM replay of k zero-gradient steps (tolerance mode; the serial replay above stays the bit-exact one).
+//
+// k zero-gradient steps l+1 .. l+k of one element starting from (p, m, s):
+//     m_i = m b1^i,   s_i = s r^i  (r = sqrt(b2)),   p_k = p + m * sum_{i=1..k} w_i / (s a_i + eps)
+//     w_i = ns_{l+i} b1^i   (ns_j = -lr_j / (1 - b1^j)),      a_i = r^i / sqrt(1 - b2^{l+i})
+// The a_i of the terms that carry weight (b1^i: a window of ~1/(1-b1) steps) differ by a few per cent once the
+// bias correction has flattened out, so expand every term around the w-weighted mean abar of the a_i:
+//     1 / (s a_i + eps) = q / (1 + y (a_i - abar)),   q = 1 / (s abar + eps),   y = s q  in [0, 1/abar)
+//     sum_i w_i / (s a_i + eps) = q * [N0 + y^2 N2 - y^3 N3 + y^4 N4 - ...],   N_n = sum_i w_i (a_i - abar)^n  (N1 = 0)
+// |y (a_i - abar)| <= |a_i/abar - 1| for EVERY s >= 0 (s -> 0 and s -> inf included): the series converges uniformly in
+// s, with ratio ~2 % when l >= 256 (b2 = 0.999).  Truncated after N4 the relative error of the summed update is
+// <= 9e-8 for l >= 256 and <= 7e-9 for l >= 512 (scratch/closed_form_replay.py, double precision study) — fp32 rounding
+// level.  Steps up to CF_FROM (= 256) are therefore replayed serially, everything after in one evaluation:
+// one v_rcp_f32 and ~10 fp32 operations per element for ANY k.  The per-k coefficients {abar, N0, N2, -N3, N4, b1^k,
+// r^k} come from a device table that rp_lazy_adam_cf_table rebuilds (in double) for the current end step.
+// ------------------------------------------------------------------------------------------------
+struct CfEntry {
+    float abar, n0, n2, n3m, n4, pm, ps, pad;  // n3m = -N3;  pm = b1^k, ps = r^k
+};
+
+template <typename T>
+__device__ __forceinline__ void adam_zero_grad_closed(T &p, T &m, T &s, const CfEntry &e, float eps) {
+    const T q = rp_rcp_fast(rp_fma(s, rp_splat(e.abar, p), rp_splat(eps, p)));
+    const T y = s * q;
+    T poly = rp_fma(y, rp_splat(e.n4, p), rp_splat(e.n3m, p));
+    poly = rp_fma(y, poly, rp_splat(e.n2, p));
+    poly = rp_fma(y * y, poly, rp_splat(e.n0, p));
+    p = rp_fma(m * q, poly, p);
+    m = m * e.pm;
+    s = s * e.ps;
+}
+
+// entry k (1 <= k <= t_end - t_from) describes the steps t_end-k+1 .. t_end;  nsd[j] = {ns_j, 1/sqrt(1 - b2^j)} (double).
+// One WAVE per entry: lane i takes the terms i+1, i+65, ... (at most J ~ 350 carry weight), wave reductions in double in
+// a fixed order — the launch sits on the step's critical path (it needs this step's lr), a serial loop per entry cost 25 us.
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void lazy_cf_table_kernel(const double2 *__restrict__ nsd, int t_end, int t_from,
+                                                            int J, double b1e, double r, CfEntry *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
+    if (k > t_end - t_from) return;  // wave-uniform
+    const int l = t_end - k;
+    const int nterm = k < J ? k : J;  // b1^J is below double rounding: later terms carry no weight
+    const double lb = log(b1e), lr_ = log(r);
+    double w[8], a[8];  // J <= 512 terms: 8 per lane
+    double sw = 0.0, swa = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = lane + 64 * u + 1;
+        w[u] = 0.0;
+        a[u] = 0.0;
+        if (i <= nterm) {
+            const double2 x = nsd[l + i];
+            w[u] = x.x * exp(lb * (double)i);
+            a[u] = x.y * exp(lr_ * (double)i);
+            sw += w[u];
+            swa += w[u] * a[u];
+        }
+    }
+    sw = wave_sum_f64(sw);
+    swa = wave_sum_f64(swa);
+    const double abar = (sw != 0.0) ? swa / sw : 1.0;  // every lr_j = 0: no movement, any abar will do
+    double n2 = 0.0, n3 = 0.0, n4 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const double da = a[u] - abar, da2 = da * da;  // (terms beyond nterm have w = 0)
+        n2 += w[u] * da2;
+        n3 += w[u] * da2 * da;
+        n4 += w[u] * da2 * da2;
+    }
+    n2 = wave_sum_f64(n2);
+    n3 = wave_sum_f64(n3);
+    n4 = wave_sum_f64(n4);
+    if (lane == 0) {
+        CfEntry e;
+        e.abar = (float)abar;
+        e.n0 = (float)sw;
+        e.n2 = (float)n2;
+        e.n3m = (float)(-n3);
+        e.n4 = (float)n4;
+        e.pm = (float)exp(lb * (double)k);
+        e.ps = (float)exp(lr_ * (double)k);
+        e.pad = 0.f;
+        out[k] = e;
+    }
+}
+
 template <int TPR, typename T>
 __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
                                                              float *__restrict__ P, float *__restrict__ G,
                                                              float *__restrict__ Mo, float *__restrict__ Vo,
                                                              int32_t *__restrict__ last,
                                                              const float2 *__restrict__ sc, int t_target,
-                                                             int real_step, int zero_grad, LazyCfg c) {
+                                                             int real_step, int zero_grad, LazyCfg c,
+                                                             const CfEntry *__restrict__ cf, int cf_from) {
     constexpr int GPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
     const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
@@ -212,11 +306,14 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
         T m = *reinterpret_cast<T *>(Mo + off);
         T v = *reinterpret_cast<T *>(Vo + off);
         if (l0 > 0) {
+            const int t_serial = (cf && cf_from < t_catch) ? cf_from : t_catch;  // (exact mode: everything)
 #pragma unroll 4
-            for (int j = l0 + 1; j <= t_catch; ++j) {
+            for (int j = l0 + 1; j <= t_serial; ++j) {
                 const float2 s = sc[j];
                 adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
             }
+            const int lc = l0 > t_serial ? l0 : t_serial;
+            if (lc < t_catch) adam_zero_grad_closed<T>(p, m, v, cf[t_catch - lc], c.eps);
         }
         if (real_step) {
             const T g = *reinterpret_cast<const T *>(G + off);
@@ -236,7 +333,8 @@ template <int TPR, typename T>
 __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, float *__restrict__ P,
                                                               float *__restrict__ Mo, float *__restrict__ Vo,
                                                               int32_t *__restrict__ last,
-                                                              const float2 *__restrict__ sc, int t_target, LazyCfg c) {
+                                                              const float2 *__restrict__ sc, int t_target, LazyCfg c,
+                                                              const CfEntry *__restrict__ cf, int cf_from) {
     constexpr int GPB = 256 / TPR;
     constexpr int VW = sizeof(T) / sizeof(float);
     const int t = threadIdx.x % TPR;
@@ -267,11 +365,14 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (need[u]) {
+                    const int t_serial = (cf && cf_from < t_target) ? cf_from : t_target;
 #pragma unroll 4
-                    for (int j = l0[u] + 1; j <= t_target; ++j) {
+                    for (int j = l0[u] + 1; j <= t_serial; ++j) {
                         const float2 s = sc[j];
                         adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.sqrt_b2, s.x, s.y);
                     }
+                    const int lc = l0[u] > t_serial ? l0[u] : t_serial;
+                    if (lc < t_target) adam_zero_grad_closed<T>(p[u], m[u], v[u], cf[t_target - lc], c.eps);
                     const int64_t off = rows[u] * D + cidx;
                     *reinterpret_cast<T *>(P + off) = p[u];
                     *reinterpret_cast<T *>(Mo + off) = m[u];
@@ -549,10 +650,51 @@ extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, float ep
     return RP_OK;
 }
 
+// the effective decay factors of one zero-gradient step as the kernels execute it in fp32: m <- m - m * fl(1 - b1),
+// s <- s * fl(sqrt(b2)); the closed form uses their exact (double) values so that it tracks the serial replay
+static void cf_decay_factors(float beta1, float beta2, double *b1e, double *r) {
+    *b1e = 1.0 - (double)(float)(1.0 - (double)beta1);
+    *r = (double)(float)std::sqrt((double)beta2);
+}
+
+extern "C" int rp_lazy_adam_cf_terms(float beta1, int *terms) {
+    RP_REQUIRE(terms, "lazy_adam_cf_terms: null pointer");
+    RP_REQUIRE(beta1 > 0.f && beta1 < 1.f, "lazy_adam_cf_terms: beta1 must be inside (0, 1)");
+    double b1e, r;
+    cf_decay_factors(beta1, 0.999f, &b1e, &r);
+    const double j = std::ceil(std::log(1e-17) / std::log(b1e));
+    *terms = j > 1e6 ? 1000000 : (int)j;  // (0.9: 372; the table kernel holds up to 512 terms)
+    return RP_OK;
+}
+
+extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, float beta1, float beta2,
+                                     float *cf_table, rp_stream_t stream) {
+    RP_REQUIRE(ns_d && cf_table, "lazy_adam_cf_table: null pointer");
+    RP_REQUIRE(cf_from >= 1 && t_end < INT32_MAX, "lazy_adam_cf_table: bad step range");
+    RP_REQUIRE((((uintptr_t)ns_d) & 15u) == 0 && (((uintptr_t)cf_table) & 31u) == 0,
+               "lazy_adam_cf_table: tables must be 16 / 32-byte aligned");
+    if (t_end <= cf_from) return RP_OK;
+    int J;
+    if (rp_lazy_adam_cf_terms(beta1, &J) != RP_OK) return RP_ERR_ARG;
+    RP_REQUIRE(J <= 512, "lazy_adam_cf_table: beta1 = %g needs %d terms, the closed form holds 512 (use the serial replay)",
+               (double)beta1, J);
+    double b1e, r;
+    cf_decay_factors(beta1, beta2, &b1e, &r);
+    const unsigned grid = (unsigned)rp_cdiv(t_end - cf_from, 4);  // one wave per entry
+    hipLaunchKernelGGL(lazy_cf_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const double2 *>(ns_d), (int)t_end, (int)cf_from, J, b1e, r,
+                       reinterpret_cast<CfEntry *>(cf_table));
+    RP_LAUNCH_CHECK("lazy_adam_cf_table");
+    return RP_OK;
+}
+
 extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                                  int32_t *last, const float *step_scalars, int64_t t_target, int real_step,
-                                 int zero_grad, float beta1, float beta2, float eps, rp_stream_t stream) {
+                                 int zero_grad, float beta1, float beta2, float eps, const float *cf_table,
+                                 int64_t cf_from, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_rows: null pointer");
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.f && (((uintptr_t)cf_table) & 31u) == 0),
+               "lazy_adam_rows: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     RP_REQUIRE(!real_step || g, "lazy_adam_rows: a real step needs the gradient arena");
     RP_REQUIRE(D >= 1, "lazy_adam_rows: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
@@ -563,7 +705,9 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
     const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
-    if (!real_step && D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {  // pure replay: one row per wave
+    const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
+    // closed form: every row costs the same O(1) work, the launch is an HBM stream -> the vector-lane kernel below
+    if (!cf && !real_step && D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {  // serial replay: one row per wave
         const dim3 gw((unsigned)rp_cdiv(n, 256));
 #define CALLW(EPL, FULL)                                                                                              \
     hipLaunchKernelGGL((lazy_replay_wave_kernel<EPL, FULL>), gw, dim3(256), 0, s, sorted_keys, n, D, p, m, v, last, sc, \
@@ -578,7 +722,7 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
     }
 #define CALL(T, TY)                                                                                                  \
     hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
-                       sc, (int)t_target, real_step, zero_grad, c)
+                       sc, (int)t_target, real_step, zero_grad, c, cf, (int)cf_from)
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_rows");
@@ -587,8 +731,11 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
 
 extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last,
                                   const float *step_scalars, int64_t t_target, float beta1, float beta2, float eps,
-                                  rp_stream_t stream) {
+                                  const float *cf_table, int64_t cf_from, rp_stream_t stream) {
     RP_REQUIRE(p && m && v && last && step_scalars, "lazy_adam_flush: null pointer");
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.f && (((uintptr_t)cf_table) & 31u) == 0),
+               "lazy_adam_flush: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
+    const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
     RP_REQUIRE(D >= 1, "lazy_adam_flush: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v)) ? 4 : 1;
     if (rows == 0 || t_target <= 0) return RP_OK;
@@ -598,7 +745,7 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     if (nb > 65536) nb = 65536;
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
-    if (D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {
+    if (!cf && D >= RP_LAZY_WAVE_MIN_D && D <= RP_LAZY_WAVE_MAX_D) {
         int64_t nw = rp_cdiv(rows, 256);
         if (nw > 65536) nw = 65536;
 #define CALLW(EPL, FULL)                                                                                                   \
@@ -614,7 +761,7 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     }
 #define CALL(T, TY)                                                                                              \
     hipLaunchKernelGGL((lazy_adam_flush_kernel<T, TY>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, m, v, last, sc, \
-                       (int)t_target, c)
+                       (int)t_target, c, cf, (int)cf_from)
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_flush");

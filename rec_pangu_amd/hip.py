@@ -106,8 +106,10 @@ _SIGNATURES = {
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
-                                    _vp]),
-    "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
+                                    _vp, _i64, _vp]),
+    "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "rp_lazy_adam_cf_terms": (C.c_int, [_f32, C.POINTER(C.c_int)]),
+    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -1126,16 +1128,31 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, eps: flo
 
 
 def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int, real_step: bool, zero_grad: bool,
-                   beta1: float, beta2: float, eps: float):
+                   beta1: float, beta2: float, eps: float, cf_table=None, cf_from: int = 0):
+    """cf_table (from lazy_adam_cf_table, built for the end step of this call's replay) selects the closed-form replay
+    of the steps after `cf_from`; None = the bit-exact serial replay"""
     with _Timed("lazy_adam_rows_step" if real_step else "lazy_adam_rows_replay", f"D={D}"):
         _check(lib().rp_lazy_adam_rows(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
                                        m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_target,
-                                       int(real_step), int(zero_grad), beta1, beta2, eps, _stream()),
+                                       int(real_step), int(zero_grad), beta1, beta2, eps, _ptr(cf_table), cf_from,
+                                       _stream()),
                "rp_lazy_adam_rows")
 
 
-def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, beta1: float, beta2: float, eps: float):
+def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, beta1: float, beta2: float, eps: float,
+                    cf_table=None, cf_from: int = 0):
     with _Timed("lazy_adam_flush", f"D={D}"):
         _check(lib().rp_lazy_adam_flush(rows, D, p.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(),
-                                        scalars.data_ptr(), t_target, beta1, beta2, eps, _stream()),
+                                        scalars.data_ptr(), t_target, beta1, beta2, eps, _ptr(cf_table), cf_from,
+                                        _stream()),
                "rp_lazy_adam_flush")
+
+
+def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table):
+    """(re)build the closed-form replay table for replays ending at step t_end (see rp_lazy_adam_cf_table):
+    ns_d [>= t_end + 1, 2] float64 device table by step, cf_table [>= t_end - cf_from + 1, 8] float32 (written in place)"""
+    assert ns_d.dtype == torch.float64 and ns_d.shape[0] > t_end and ns_d.is_contiguous()
+    assert cf_table.dtype == torch.float32 and cf_table.shape[0] >= t_end - cf_from + 1 and cf_table.is_contiguous()
+    with _Timed("lazy_adam_cf_table", f"{max(t_end - cf_from, 0)}"):
+        _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _stream()),
+               "rp_lazy_adam_cf_table")

@@ -17,6 +17,7 @@ All other parameters go through one multi-tensor dense launch.  `fuse_zero_grad=
 the same pass (the model.zero_grad() that follows optimizer.step() in the reference loop,
 model_pipeline.py:57-58).  CPU parameters are not handled here: make_adam builds torch.optim.Adam for those.
 """
+import os
 import weakref
 from typing import Dict, List
 
@@ -26,27 +27,45 @@ from . import hip
 
 
 class LazyAdamRows:
-    """Per-EmbeddingLayer state of the exact lazy dense Adam: moment arenas, per-row `last` step stamps and the
-    device table of per-step scalars {lr_t/(1-b1^t), sqrt(1-b2^t)} (computed by the C library, like the dense
-    kernel does)."""
-    TABLE_CHUNK = 1024
+    """Per-EmbeddingLayer state of the lazy dense Adam: moment arenas, per-row `last` step stamps and the device table
+    of per-step scalars {A_t, B_t} (computed by the C library, like the dense kernel does).
 
-    def __init__(self, store, betas, eps, owner=None, t0: int = 0):
+    replay="exact":  skipped zero-gradient steps are replayed one by one with the dense kernel's own update function:
+                     bit-identical to dense execution (the parity mode);
+    replay="closed": steps after CF_FROM are replayed in ONE evaluation per element whatever their number
+                     (rp_lazy_adam_cf_table / adam.hip: uniformly convergent expansion of the summed updates, relative
+                     truncation error <= 9e-8; the replay launch becomes an HBM stream instead of a VALU-bound serial
+                     chain).  Within 1e-6 relative of the exact replay per replay (tests/test_hip_lazy_adam.py); only
+                     for the reference's hyper-parameters betas = (0.9, 0.999), eps > 0 — anything else replays exactly."""
+    TABLE_CHUNK = 1024
+    CF_FROM = 256
+
+    def __init__(self, store, betas, eps, owner=None, t0: int = 0, replay: str = "exact"):
         a = store.arena
         self.m, self.v = torch.zeros_like(a), torch.zeros_like(a)
         self.last = torch.zeros((a.shape[0],), dtype=torch.int32, device=a.device)
         self.betas, self.eps = betas, eps
         self.owner = owner           # weakref to the FusedAdam this state belongs to
         self.t = self.flushed_t = t0  # created mid-run (optimizer state loaded, arena re-packed): every row is current
-        # device table of per-step scalars, indexed by ABSOLUTE step: row j = step j's {lr_j/(1-b1^j), 1/sqrt(1-b2^j)};
+        # device table of per-step scalars, indexed by ABSOLUTE step: row j = step j's {A_j, B_j};
         # row 0 is unused.  Rows <= t0 are never read (no row carries a stamp below t0) but must exist: the kernels
         # index the table with the step number.
         self._table = torch.zeros((t0 + 1, 2), dtype=torch.float32, device=a.device)
         self._table_lr = None
         self._table_from = t0 + 1
+        assert replay in ("exact", "closed"), replay
+        self.closed = (replay == "closed" and abs(betas[0] - 0.9) < 1e-12 and abs(betas[1] - 0.999) < 1e-12 and eps > 0)
+        # closed-form replay: {ns_j, d_j} = {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)} by step in double, and the per-k
+        # coefficient table valid for replays that end at step `_cf_for` (rebuilt on the device when the end step moves)
+        self._ns_d = torch.zeros((t0 + 1, 2), dtype=torch.float64, device=a.device) if self.closed else None
+        self._cf_from = max(self.CF_FROM, t0)  # no row carries a stamp in (0, t0)
+        self._cf, self._cf_for = None, -1
 
     def apply(self, fn):
         self.m, self.v, self.last, self._table = fn(self.m), fn(self.v), fn(self.last), fn(self._table)
+        if self._ns_d is not None:
+            self._ns_d = fn(self._ns_d)
+        self._cf, self._cf_for = None, -1
 
     def _ensure_table(self, t_new, lr):
         """rows [.., t_new] of the scalar table must exist and row t_new must have been built with `lr`."""
@@ -58,7 +77,24 @@ class LazyAdamRows:
         rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
         new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
         self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
+        if self.closed:
+            j = torch.arange(t_new, hi + 1, dtype=torch.float64)
+            ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
+            d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
+            self._ns_d = torch.cat([self._ns_d[:t_new], torch.stack([ns, d], 1).to(self._ns_d.device)]).contiguous()
         self._table_lr, self._table_from = lr, t_new
+
+    def _cf_args(self, t_end):
+        """closed-form arguments of a replay that ends at step t_end: (table, cf_from), or (None, 0) = exact replay"""
+        if not self.closed or t_end <= self._cf_from:
+            return None, 0
+        if self._cf_for != t_end:
+            need = t_end - self._cf_from + 1
+            if self._cf is None or self._cf.shape[0] < need:
+                self._cf = torch.zeros((need + self.TABLE_CHUNK, 8), dtype=torch.float32, device=self.m.device)
+            hip.lazy_adam_cf_table(self._ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], self._cf)
+            self._cf_for = t_end
+        return self._cf, self._cf_from
 
     def _check_table(self, t_target):
         if self._table.shape[0] <= t_target:
@@ -75,8 +111,9 @@ class LazyAdamRows:
     def replay(self, store, sorted_keys):
         if self.t > 0:
             self._check_table(self.t)
+            cf, cf_from = self._cf_args(self.t)
             hip.lazy_adam_rows(sorted_keys, store.embedding_dim, store.arena, None, self.m, self.v, self.last,
-                               self._table, self.t, False, False, self.betas[0], self.betas[1], self.eps)
+                               self._table, self.t, False, False, self.betas[0], self.betas[1], self.eps, cf, cf_from)
 
     def step(self, store, lr, zero_grad: bool = True):
         t_new = self.t + 1
@@ -84,8 +121,9 @@ class LazyAdamRows:
         self._check_table(t_new)
         sk = self._sorted_touched(store)
         if sk is not None and sk.numel():
+            cf, cf_from = self._cf_args(self.t)  # the catch-up before the real step ends at t_new - 1
             hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
-                               self._table, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps)
+                               self._table, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps, cf, cf_from)
         self.t = t_new
         if zero_grad:  # FusedAdam(fuse_zero_grad=True): the gradient rows were cleared inside the step
             store.grads_were_zeroed()
@@ -94,19 +132,23 @@ class LazyAdamRows:
         if self.flushed_t == self.t:
             return
         self._check_table(self.t)
+        cf, cf_from = self._cf_args(self.t)
         hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
-                            self._table, self.t, self.betas[0], self.betas[1], self.eps)
+                            self._table, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
         self.flushed_t = self.t
 
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, fuse_zero_grad=False,
-                 lazy_tables=False):
+                 lazy_tables=False, replay="exact"):
         if weight_decay != 0:
             raise ValueError("FusedAdam mirrors the reference's optimiser: weight_decay must be 0")
+        if replay not in ("exact", "closed"):
+            raise ValueError("replay must be 'exact' (bit-identical to dense execution) or 'closed' (closed-form replay)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0))
         self.fuse_zero_grad = fuse_zero_grad
         self.lazy_tables = lazy_tables
+        self.replay = replay
         self._arena_state: Dict[int, dict] = {}
         self._stores = {}
         self._plans: Dict[int, list] = {}
@@ -193,7 +235,8 @@ class FusedAdam(torch.optim.Optimizer):
                         store.flush_lazy()
                         lz = None
                     if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
-                        lz = store._lazy = LazyAdamRows(store, (b1, b2), eps, owner=weakref.ref(self), t0=step - 1)
+                        lz = store._lazy = LazyAdamRows(store, (b1, b2), eps, owner=weakref.ref(self), t0=step - 1,
+                                                        replay=self.replay)
                         self._adopt_loaded_state(store, lz.m, lz.v, lz)
                         self._expose_state(store, lz.m, lz.v)
                     lz.step(store, lr, zero_grad=self.fuse_zero_grad)
@@ -263,12 +306,16 @@ class FusedAdam(torch.optim.Optimizer):
             off += r
 
 
-def make_adam(model, lr, lazy_tables=True):
-    """What RankTrainer.fit uses: fused HIP Adam for a HIP-resident model (exact lazy dense Adam on the embedding
-    arenas by default), torch.optim.Adam on CPU (BASELINE config 0).  Hyper-parameters are the reference's
-    (trainer.py:75)."""
+def make_adam(model, lr, lazy_tables=True, replay=None):
+    """What RankTrainer.fit uses: fused HIP Adam for a HIP-resident model (lazy dense Adam on the embedding arenas by
+    default), torch.optim.Adam on CPU (BASELINE config 0).  Hyper-parameters are the reference's (trainer.py:75).
+    replay: how the lazy execution catches a row up — "closed" (default; closed-form replay, <= 1e-6 relative to the
+    serial one per replay, see LazyAdamRows) or "exact" (serial replay, bit-identical to dense execution);
+    the environment variable RP_LAZY_REPLAY overrides the default."""
     params = list(model.parameters())
     if params and params[0].is_cuda:
+        if replay is None:
+            replay = os.environ.get("RP_LAZY_REPLAY", "closed")
         return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, fuse_zero_grad=True,
-                         lazy_tables=lazy_tables)
+                         lazy_tables=lazy_tables, replay=replay)
     return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)

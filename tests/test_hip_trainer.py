@@ -200,3 +200,30 @@ def test_sort_ahead_is_bit_identical():
     assert torch.equal(outs[0][0], outs[1][0])
     for k in outs[0][1]:
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_rank_trainer_fit_on_hip_on_the_reference_sample_data(tmp_path):
+    """the reference's own 100-row example data, 16 + 9 column schema, 2 epochs of DeepFM(emb 16) —
+    tests/golden/sample_run.* (make_golden_r3.py) — through RankTrainer.fit on the HIP path."""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.trainer import RankTrainer
+    from test_trainer_dataset import sample_run_loaders
+    meta, g, train_loader, valid_loader, test_loader, enc = sample_run_loaders()
+    torch.manual_seed(meta["seed"])
+    model = DeepFM(embedding_dim=meta["embedding_dim"], enc_dict=enc)
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    n0 = hip.launch_count()
+    valid_metric = trainer.fit(model, train_loader, valid_loader, epoch=meta["epoch"], lr=meta["lr"], device=DEV)
+    assert hip.launch_count() > n0 + 20
+    for k, v in meta["valid_metric"].items():
+        assert abs(valid_metric[k] - v) <= 2e-4, (k, valid_metric[k], v)
+    sd = model.state_dict()
+    for k, v in g["final"].items():
+        tol = 2e-4 * max(1e-2, float(v.abs().max()))
+        assert (sd[k].cpu() - v).abs().max() <= tol, k
+    test_metric = trainer.evaluate_model(model, test_loader, device=DEV)
+    for k, v in meta["test_metric"].items():
+        assert abs(test_metric[k] - v) <= 2e-4, (k, test_metric[k], v)
+    np.testing.assert_allclose(np.asarray(trainer.predict_dataloader(model, test_loader, device=DEV)),
+                               g["pred_dataloader"].numpy(), rtol=1e-3, atol=1e-5)

@@ -277,3 +277,57 @@ def test_one_ahead_feeds_the_same_batches_and_announces_the_next():
     cpu_model = DeepFM(enc_dict=enc, embedding_dim=4, hidden_units=[8])
     cpu_model.prefetch({"C1": torch.zeros(3, dtype=torch.long), "I1": torch.zeros(3)})
     assert getattr(cpu_model.embedding_layer, "_ahead", None) is None
+
+
+# ---- SURVEY a18's own fixture: the reference's 100-row example data with the 16 + 9 column schema of
+# examples/ranking/run_ranking_example.py:17-24 (tests/golden/sample_run.*, written by make_golden_r3.py) ----------------
+def sample_run_fixture():
+    meta = json.load(open(os.path.join(GOLDEN, "sample_run.json")))
+    fr = meta["frame"]
+    df = pd.DataFrame(fr["data"], columns=fr["columns"], index=fr["index"])
+    a, b, c = meta["splits"]
+    return meta, df[:a], df[:b], df[:c], load_golden("sample_run.npz")
+
+
+def sample_run_loaders():
+    meta, train_df, valid_df, test_df, g = sample_run_fixture()
+    loaders = get_dataloader(train_df, valid_df, test_df, meta["schema"], batch_size=meta["batch_size"])
+    enc = {k: loaders[3][k] for k in meta["enc_order"]}  # the field order the reference run had (B4)
+    return meta, g, loaders[0], loaders[1], loaders[2], enc
+
+
+def test_sample_data_encode_matches_reference():
+    meta, train_df, valid_df, test_df, g = sample_run_fixture()
+    train_loader, valid_loader, test_loader, enc_dict = get_dataloader(train_df, valid_df, test_df, meta["schema"],
+                                                                       batch_size=meta["batch_size"])
+    assert set(enc_dict) == set(meta["enc_dict"])
+    for col, ref in meta["enc_dict"].items():
+        got = {str(k): (int(v) if isinstance(v, (int, np.integer)) else float(v)) for k, v in enc_dict[col].items()}
+        assert got == ref, col
+    for split, loader in (("train", train_loader), ("valid", valid_loader), ("test", test_loader)):
+        cols = {k.split("/", 1)[1]: v for k, v in g["enc"].items() if k.startswith(split + "/")}
+        assert set(cols) == set(loader.dataset.data_dict)
+        for col, ref in cols.items():
+            got = loader.dataset.data_dict[col]
+            assert got.dtype == ref.dtype, (split, col)
+            if ref.dtype == torch.int64:
+                assert torch.equal(got, ref), f"{split}/{col}: ids must be bit-exact"
+            else:
+                torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_rank_trainer_fit_on_the_reference_sample_data(tmp_path):
+    meta, g, train_loader, valid_loader, test_loader, enc = sample_run_loaders()
+    torch.manual_seed(meta["seed"])
+    model = DeepFM(embedding_dim=meta["embedding_dim"], enc_dict=enc)
+    for k, v in g["init"].items():
+        assert torch.equal(model.state_dict()[k], v), k
+    trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path))
+    valid_metric = trainer.fit(model, train_loader, valid_loader, epoch=meta["epoch"], lr=meta["lr"],
+                               device=torch.device("cpu"))
+    assert valid_metric == meta["valid_metric"]
+    for k, v in g["final"].items():
+        torch.testing.assert_close(model.state_dict()[k], v, rtol=1e-4, atol=1e-6)
+    assert trainer.evaluate_model(model, test_loader, device=torch.device("cpu")) == meta["test_metric"]
+    np.testing.assert_allclose(np.asarray(trainer.predict_dataloader(model, test_loader)), g["pred_dataloader"].numpy(),
+                               rtol=1e-4, atol=1e-6)
