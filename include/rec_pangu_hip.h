@@ -15,8 +15,11 @@
  *   - pointers named *_ptrs are HOST arrays of DEVICE pointers (copied into the launch packet).
  *   - return 0 on success, <0 on failure (RP_ERR_*); rp_last_error() gives the message for the
  *     calling thread.  Nothing throws or aborts.
- *   - fp32 storage and arithmetic unless a name says otherwise; matrix products run on the
- *     exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) so results are an fp32 FMA chain like ATen's.
+ *   - fp32 storage, fp32 accumulation.  Matrix products run on the bf16 matrix core (v_mfma_f32_32x32x16_bf16)
+ *     over split-bf16 pieces of the fp32 operands; the number of partial products per flop is the library's
+ *     matmul precision (rp_set_matmul_precision, default RP_MATMUL_AUTO: six products = fp32-faithful for
+ *     HBM-bound launches, three for matrix-core-bound ones; RP_MATMUL_FP32 = the exact-fp32
+ *     v_mfma_f32_32x32x2_f32 reference kernels).
  *   - callable from any host thread (autograd's backward thread included).
  */
 #ifndef REC_PANGU_HIP_H
@@ -387,15 +390,40 @@ int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigm
 int rp_sigmoid_bce_bwd(const float *pred, const float *label, const float *gloss, int64_t B, float p_eps,
                        float weight, int apply_sigmoid, float *dz, rp_stream_t stream);
 
+/* ---- multi-id ("bag") lookups with pooling: the CSR / segmented embedding gather + sum-pool of the north star ----------
+ * replaces EmbeddingLayer.forward(X, name="<col>_seq") (rec_pangu/models/layers/embedding.py:64-71: [B, L] ids ->
+ * [B, L, D]) FOLLOWED BY MaskedSumPooling (layers/sequence.py:38-59: sum over dim 1) or MaskedAveragePooling
+ * (layers/sequence.py:13-36: sum / (count of non-zero ELEMENTS per (b, d) + 1e-16)) — the [B, L, D] tensor never exists.
+ *   ids: int64; dense bags: offsets = NULL, bag b = ids[b*L .. b*L+L); CSR bags: offsets int64 [B+1] into ids.
+ *   The table is rows [row_base, row_base + row_count) of the arena; an id outside [0, row_count) sets *err_flag and
+ *   reads row 0 (the reference raises IndexError).  mode 0 = sum, 1 = masked average.
+ *   out [B, ldo >= D]; inv_out [B, D] (mode 1, for the backward: 1 / (count + 1e-16)) or NULL;
+ *   bag_out int32 [nnz] (CSR, for the backward: the bag of every id) or NULL.
+ * rp_embed_pool_bwd: grad_arena[row] (+)= sum over the ids p of that row of g[bag(p), :] (* scale[bag(p), :]), from the
+ *   (arena row, flat id position) pairs sorted by row (rp_embed_keys with F = 1 over the flat ids, rp_sort_pairs_i32);
+ *   bag(p) = bag_of[p], or p / L when bag_of is NULL.  Deterministic (the segmented reduction of rp_embed_grad_reduce,
+ *   same workspace): a padding id present in every bag is one long run like any hot row.
+ * rp_seq_pool_fwd / _bwd: the same two poolings on an explicit, contiguous [B, L, D] tensor (the drop-in modules). */
+int rp_embed_gather_pool_fwd(const float *arena, int64_t row_base, int64_t row_count, const int64_t *ids,
+                             const int64_t *offsets, int64_t L, int64_t B, int D, int mode, float *out, int64_t ldo,
+                             float *inv_out, int32_t *bag_out, int32_t *err_flag, rp_stream_t stream);
+int rp_embed_pool_bwd(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int D, const float *g, int64_t ldg,
+                      const float *scale, const int32_t *bag_of, int64_t L, float *grad_arena, int accumulate,
+                      void *workspace, size_t workspace_bytes, rp_stream_t stream);
+int rp_seq_pool_fwd(const float *e, int64_t B, int64_t L, int D, int mode, float *out, float *inv_out, rp_stream_t stream);
+int rp_seq_pool_bwd(const float *g, const float *inv, int64_t B, int64_t L, int D, float *de, rp_stream_t stream);
+
 /* ---- K11: fused Adam (torch.optim.Adam single-tensor operation order) -----------------------
  * replaces trainer.py:75 + model_pipeline.py:57-58 (optimizer.step(); model.zero_grad()).
  * n_tensors <= RP_MAX_FIELDS per call; zero_grad=1 also clears g (the fused zero_grad).
+ * lr, betas and eps are DOUBLES, like the python floats torch.optim.Adam computes its bias corrections from (a float
+ * beta2 = 0.999f shifts 1 - beta2^t by 5e-6 relative at t ~ 600).
  * The second-moment arrays (`v_ptrs`, and `v` of the lazy entry points below) hold s = sqrt(v), not v: Adam only uses
  * sqrt(v), and a zero-gradient step is then s *= sqrt(b2) (one multiply, no transcendental) — chosen per element on
  * g == 0 by the one update function all these kernels share, so dense and lazy execution stay bit-identical.  The
  * host side squares s when it exports torch.optim.Adam-style state (rec_pangu_amd/optim.py).  */
 int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
-                 const int64_t *sizes, int n_tensors, float lr, float beta1, float beta2, float eps,
+                 const int64_t *sizes, int n_tensors, double lr, double beta1, double beta2, double eps,
                  int64_t step, int zero_grad, rp_stream_t stream);
 
 /* ---- exact LAZY dense Adam for arena rows -----------------------------------------------------
@@ -416,14 +444,14 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * use 16-byte vector lanes when D % 4 == 0 and the arenas are 16-byte aligned, scalar lanes otherwise. */
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
-int rp_adam_step_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa,
+int rp_adam_step_scalars(double lr, double beta1, double beta2, double eps, int64_t step, float *sa,
                          float *sb); /* {A_t, B_t} = {1/sqrt(1-b2^t), eps} / (-lr/(1-b1^t)), computed in double: the update
                                       * is p += m * rcp(s * A_t + B_t) (s = sqrt(v)); lr = 0 gives (0, -inf) */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
-                      float beta1, float beta2, float eps, const float *cf_table, int64_t cf_from, rp_stream_t stream);
+                      double beta1, double beta2, double eps, const float *cf_table, int64_t cf_from, rp_stream_t stream);
 int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last, const float *step_scalars,
-                       int64_t t_target, float beta1, float beta2, float eps, const float *cf_table, int64_t cf_from,
+                       int64_t t_target, double beta1, double beta2, double eps, const float *cf_table, int64_t cf_from,
                        rp_stream_t stream);
 /* CLOSED-FORM replay (cf_table != NULL in the two entry points above; tolerance mode, NULL = the bit-exact serial
  * replay).  The k zero-gradient steps l+1 .. l+k of an element are  m b1^k,  s r^k  and
@@ -440,8 +468,8 @@ int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_
  *                          rp_lazy_adam_flush(t_target=t_end)); rebuilt on the device, in double, whenever the end step
  *                          changes.  ns_d: device double2 table indexed by step: {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)}.
  *   rp_lazy_adam_cf_terms  number of leading terms that carry weight (b1^J < 1e-17) */
-int rp_lazy_adam_cf_terms(float beta1, int *terms);
-int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, float beta1, float beta2, float *cf_table,
+int rp_lazy_adam_cf_terms(double beta1, int *terms);
+int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2, float *cf_table,
                           rp_stream_t stream);
 
 /* ---- request routing for row-sharded tables (rec_pangu_amd/sharded.py; no reference counterpart: the reference is

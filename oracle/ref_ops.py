@@ -64,6 +64,31 @@ def embedding_by_name(tables: Dict[str, Tensor], data, name: str) -> Tensor:
     return tables[name][data[name].long().view(-1, 1)]
 
 
+def seq_pool(emb_seq: Tensor, mode: str) -> Tensor:
+    """rec_pangu/models/layers/sequence.py:58-59 (MaskedSumPooling: torch.sum(dim=1)) and :30-36
+    (MaskedAveragePooling: sum / (count of non-zero ELEMENTS per (sample, column) + 1e-16)) on [B, L, D]."""
+    s = torch.sum(emb_seq, dim=1)
+    if mode == "sum":
+        return s
+    non_padding_length = (emb_seq != 0).sum(dim=1)
+    return s / (non_padding_length.float() + 1e-16)
+
+
+def embedding_seq_pooled(tables: Dict[str, Tensor], data, name: str, mode: str) -> Tensor:
+    """the `_seq` lookup (embedding.py:64-67) followed by one of the two poolings above -> [B, D]"""
+    return seq_pool(embedding_by_name(tables, data, name), mode)
+
+
+def embedding_bags_pooled(table: Tensor, ids: Tensor, offsets: Tensor, mode: str) -> Tensor:
+    """the same for RAGGED bags in CSR form (bag b = ids[offsets[b]:offsets[b+1]]): what the reference computes for a
+    batch whose rows are padded to the longest bag with an all-zero padding row — restated bag by bag (small cases)."""
+    out = []
+    for b in range(offsets.numel() - 1):
+        e = F.embedding(ids[int(offsets[b]):int(offsets[b + 1])].long(), table)[None]  # [1, len, D]
+        out.append(seq_pool(e, mode)[0] if e.shape[1] else torch.zeros(table.shape[1], dtype=table.dtype))
+    return torch.stack(out)
+
+
 def _tables(sd: Dict[str, Tensor], prefix: str, enc_dict) -> Dict[str, Tensor]:
     return {c: sd[f"{prefix}{c}.weight"] for c in sparse_fields(enc_dict)}
 

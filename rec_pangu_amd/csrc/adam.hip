@@ -89,17 +89,17 @@ __device__ __forceinline__ void adam1_zero_grad(T &p, T &m, T &s, float one_m_b1
 }
 
 // {A_t, B_t} of step t (see adam1): shared by the dense launch and by the step table of the lazy execution
-static void adam_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa, float *sb) {
-    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    const double ns = -(double)lr / bc1;  // minus the step size
+static void adam_scalars(double lr, double beta1, double beta2, double eps, int64_t step, float *sa, float *sb) {
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    const double ns = -lr / bc1;  // minus the step size
     if (ns == 0.0) {                      // lr = 0: s * 0 - inf = -inf, rcp = -0, p + m * (-0) = p
         *sa = 0.f;
         *sb = -INFINITY;
         return;
     }
     *sa = (float)((1.0 / std::sqrt(bc2)) / ns);
-    *sb = (float)((double)eps / ns);
+    *sb = (float)(eps / ns);
 }
 
 template <bool ZERO_G>
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
 }
 
 extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
-                            const int64_t *sizes, int n_tensors, float lr, float beta1, float beta2, float eps,
+                            const int64_t *sizes, int n_tensors, double lr, double beta1, double beta2, double eps,
                             int64_t step, int zero_grad, rp_stream_t stream) {
     RP_REQUIRE(p_ptrs && g_ptrs && m_ptrs && v_ptrs && sizes, "adam_step: null pointer");
     RP_REQUIRE(n_tensors >= 1 && n_tensors <= RP_MAX_FIELDS, "adam_step: n_tensors=%d outside [1,%d]", n_tensors,
@@ -161,12 +161,12 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
     if (bx < 1) bx = 1;
     dim3 grid((unsigned)bx, (unsigned)n_tensors);
     hipStream_t s = (hipStream_t)stream;
-    const float one_m_b1 = (float)(1.0 - (double)beta1), one_m_b2 = (float)(1.0 - (double)beta2);
-    const float sqrt_b2 = (float)std::sqrt((double)beta2);
+    const float one_m_b1 = (float)(1.0 - beta1), one_m_b2 = (float)(1.0 - beta2), b2f = (float)beta2;
+    const float sqrt_b2 = (float)std::sqrt(beta2);
     if (zero_grad)
-        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, sa, sb);
+        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb);
     else
-        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, beta2, sqrt_b2, one_m_b2, sa, sb);
+        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb);
     RP_LAUNCH_CHECK("adam_step");
     return RP_OK;
 }
@@ -644,7 +644,8 @@ static int lazy_tpr(int D, int vw) {
     } while (0)
 
 // host helper shared with the python side: the two per-step scalars exactly as rp_adam_step derives them
-extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, float eps, int64_t step, float *sa, float *sb) {
+extern "C" int rp_adam_step_scalars(double lr, double beta1, double beta2, double eps, int64_t step, float *sa,
+                                    float *sb) {
     RP_REQUIRE(sa && sb && step >= 1, "adam_step_scalars: bad argument");
     adam_scalars(lr, beta1, beta2, eps, step, sa, sb);
     return RP_OK;
@@ -652,22 +653,22 @@ extern "C" int rp_adam_step_scalars(float lr, float beta1, float beta2, float ep
 
 // the effective decay factors of one zero-gradient step as the kernels execute it in fp32: m <- m - m * fl(1 - b1),
 // s <- s * fl(sqrt(b2)); the closed form uses their exact (double) values so that it tracks the serial replay
-static void cf_decay_factors(float beta1, float beta2, double *b1e, double *r) {
-    *b1e = 1.0 - (double)(float)(1.0 - (double)beta1);
-    *r = (double)(float)std::sqrt((double)beta2);
+static void cf_decay_factors(double beta1, double beta2, double *b1e, double *r) {
+    *b1e = 1.0 - (double)(float)(1.0 - beta1);
+    *r = (double)(float)std::sqrt(beta2);
 }
 
-extern "C" int rp_lazy_adam_cf_terms(float beta1, int *terms) {
+extern "C" int rp_lazy_adam_cf_terms(double beta1, int *terms) {
     RP_REQUIRE(terms, "lazy_adam_cf_terms: null pointer");
-    RP_REQUIRE(beta1 > 0.f && beta1 < 1.f, "lazy_adam_cf_terms: beta1 must be inside (0, 1)");
+    RP_REQUIRE(beta1 > 0.0 && beta1 < 1.0, "lazy_adam_cf_terms: beta1 must be inside (0, 1)");
     double b1e, r;
-    cf_decay_factors(beta1, 0.999f, &b1e, &r);
+    cf_decay_factors(beta1, 0.999, &b1e, &r);
     const double j = std::ceil(std::log(1e-17) / std::log(b1e));
     *terms = j > 1e6 ? 1000000 : (int)j;  // (0.9: 372; the table kernel holds up to 512 terms)
     return RP_OK;
 }
 
-extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, float beta1, float beta2,
+extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2,
                                      float *cf_table, rp_stream_t stream) {
     RP_REQUIRE(ns_d && cf_table, "lazy_adam_cf_table: null pointer");
     RP_REQUIRE(cf_from >= 1 && t_end < INT32_MAX, "lazy_adam_cf_table: bad step range");
@@ -690,17 +691,17 @@ extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t 
 
 extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                                  int32_t *last, const float *step_scalars, int64_t t_target, int real_step,
-                                 int zero_grad, float beta1, float beta2, float eps, const float *cf_table,
+                                 int zero_grad, double beta1, double beta2, double eps, const float *cf_table,
                                  int64_t cf_from, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_rows: null pointer");
-    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.f && (((uintptr_t)cf_table) & 31u) == 0),
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
                "lazy_adam_rows: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     RP_REQUIRE(!real_step || g, "lazy_adam_rows: a real step needs the gradient arena");
     RP_REQUIRE(D >= 1, "lazy_adam_rows: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
     RP_REQUIRE(t_target >= (real_step ? 1 : 0) && t_target < INT32_MAX, "lazy_adam_rows: bad step");
     if (n == 0) return RP_OK;
-    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)std::sqrt((double)beta2), (float)(1.0 - (double)beta2), eps};
+    LazyCfg c{(float)(1.0 - beta1), (float)beta2, (float)std::sqrt(beta2), (float)(1.0 - beta2), (float)eps};
     const int tpr = lazy_tpr(D, vw);
     const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
@@ -730,16 +731,16 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
 }
 
 extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last,
-                                  const float *step_scalars, int64_t t_target, float beta1, float beta2, float eps,
+                                  const float *step_scalars, int64_t t_target, double beta1, double beta2, double eps,
                                   const float *cf_table, int64_t cf_from, rp_stream_t stream) {
     RP_REQUIRE(p && m && v && last && step_scalars, "lazy_adam_flush: null pointer");
-    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.f && (((uintptr_t)cf_table) & 31u) == 0),
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
                "lazy_adam_flush: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
     RP_REQUIRE(D >= 1, "lazy_adam_flush: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v)) ? 4 : 1;
     if (rows == 0 || t_target <= 0) return RP_OK;
-    LazyCfg c{(float)(1.0 - (double)beta1), beta2, (float)std::sqrt((double)beta2), (float)(1.0 - (double)beta2), eps};
+    LazyCfg c{(float)(1.0 - beta1), (float)beta2, (float)std::sqrt(beta2), (float)(1.0 - beta2), (float)eps};
     const int tpr = lazy_tpr(D, vw);
     int64_t nb = rp_cdiv(rows, 256 / tpr);
     if (nb > 65536) nb = 65536;

@@ -102,12 +102,15 @@ __global__ __launch_bounds__(256) void embed_gather_fwd_kernel(
 //     sorted (key, row) list — first goes through THIS kernel once more (LEVEL1: positions are the list indices, key -1
 //     = "no piece" is skipped), which leaves chains of a handful of entries for the sequential walk.
 #define RP_SEG 8
-template <int TPR, int VEC, bool LEVEL1 = false>
+// POOL (rp_embed_pool_bwd, the backward of the pooled multi-id lookup of pool.hip): position p is the p-th id of a flat
+// id list, its gradient row is the pooled output's gradient row of the BAG it belongs to — dx[bag, :] (times
+// scale[bag, :] for the masked average) with bag = bag_of[p] (CSR) or p / Bi (dense bags of Bi ids).
+template <int TPR, int VEC, bool LEVEL1 = false, bool POOL = false>
 __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, int D,
     const float *__restrict__ dx, int64_t ldx, const float *__restrict__ gfm, const float *__restrict__ sum_in,
     const float *__restrict__ arena, float *__restrict__ G, int accumulate, float *__restrict__ gpiece,
-    int32_t *__restrict__ gkey) {
+    int32_t *__restrict__ gkey, const int32_t *__restrict__ bag_of = nullptr, const float *__restrict__ scale = nullptr) {
     typedef Vec<VEC> V;
     constexpr int GPB = 256 / TPR;
     constexpr int W = TPR * VEC;  // columns handled per pass
@@ -127,6 +130,10 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
         if (LEVEL1) {  // the piece list of the first pass: row start + j of a [n, D] buffer
             ff[j] = 0;
             bb[j] = (int)(start + j);
+        } else if (POOL) {
+            const int32_t p = ok ? sp[start + j] : 0;
+            ff[j] = 0;
+            bb[j] = bag_of ? (ok ? bag_of[p] : 0) : p / Bi;
         } else {
             const int32_t p = ok ? sp[start + j] : 0;
             ff[j] = p / Bi;
@@ -149,6 +156,7 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
             gf[j] = 0.f;
             if (j < cnt && col_ok && !(LEVEL1 && k[j] < 0)) {
                 if (dx != nullptr) r[j] = V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
+                if (POOL && scale != nullptr) r[j] = r[j] * V::load(scale + (int64_t)bb[j] * D + c);
                 if (gfm != nullptr) {
                     gf[j] = gfm[bb[j]];
                     if (sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);  // else: folded upstream
@@ -962,6 +970,41 @@ extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *s
     RP_DISPATCH_TPR(tpr, vec, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("embed_grad_reduce");
+    return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+}
+
+// Backward of rp_embed_gather_pool_fwd (pool.hip): grad_arena[key] (+)= sum over the ids p with that key of
+// g[bag(p), :] (* scale[bag(p), :]); bag(p) = bag_of[p] (CSR bags) or p / L (dense bags of L ids).  sorted_keys /
+// sorted_pos: the (arena row, flat id position) pairs sorted by row.  Same determinism, accumulate semantics and
+// workspace as rp_embed_grad_reduce — a padding id shared by every bag is one long run, handled by the segmented
+// reduction like any hot row.
+extern "C" int rp_embed_pool_bwd(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int D, const float *g,
+                                 int64_t ldg, const float *scale, const int32_t *bag_of, int64_t L, float *grad_arena,
+                                 int accumulate, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && g && grad_arena && workspace, "embed_pool_bwd: null pointer");
+    RP_REQUIRE(D >= 1 && ldg >= D, "embed_pool_bwd: bad D / ldg");
+    RP_REQUIRE(bag_of != nullptr || (L >= 1 && L < INT32_MAX), "embed_pool_bwd: dense bags need 1 <= L < 2^31");
+    if (n == 0) return RP_OK;
+    size_t need = 0;
+    rp_embed_grad_reduce_workspace_bytes(n, D, &need);
+    RP_REQUIRE(workspace_bytes >= need, "embed_pool_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const bool v4 = (D % 4 == 0) && (ldg % 4 == 0) && rp_aligned16(g) && rp_aligned16(grad_arena) &&
+                    (scale == nullptr || rp_aligned16(scale));
+    const int vec = v4 ? 4 : 1;
+    const int tpr = pick_tpr(D, vec);
+    const int64_t nb0 = grad_reduce_blocks(n, D, vec);
+    float *piece0 = reinterpret_cast<float *>(wbase);
+    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
+    hipStream_t s = (hipStream_t)stream;
+    const float *no_f = nullptr;
+#define CALL(T, VV)                                                                                                      \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, false, true>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, \
+                       sorted_pos, n, (int)(bag_of ? 1 : L), D, g, ldg, no_f, no_f, no_f, grad_arena, accumulate, piece0, \
+                       key0, bag_of, scale)
+    RP_DISPATCH_TPR(tpr, vec, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_pool_bwd");
     return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }
 

@@ -704,3 +704,51 @@ def embed_gather(store, idx, dense, ldx: int, want_fm: bool, meta=None):
     (single-field / sequence lookups); None = all fields in order."""
     tables = [store.embedding_layer[c].weight for c in store.emb_feature]
     return _EmbedGather.apply(store, idx, dense, ldx, want_fm, meta, *tables)
+
+
+# ----------------------------------------------------------------------------------------------
+# pooled multi-id lookup (north_star's CSR / segmented gather + sum-pool): embedding.py:64-71 (`_seq`) followed by
+# layers/sequence.py:13-59 (MaskedAveragePooling / MaskedSumPooling) as ONE launch each way
+# ----------------------------------------------------------------------------------------------
+class _EmbedGatherPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, store, field: int, ids, offsets, L: int, B: int, mode: str, presorted, *tables):
+        need_grad = any(ctx.needs_input_grad[8:])
+        base, count = store.table_range(field)
+        out, inv, bag = hip.embed_gather_pool_fwd(store.arena, base, count, ids, offsets, L, B, mode, store.err_flag,
+                                                  need_grad)
+        ctx.store, ctx.field, ctx.L, ctx.presorted = store, field, L, presorted
+        ctx.save_for_backward(ids, inv, bag)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, inv, bag = ctx.saved_tensors
+        store = ctx.store
+        store.accumulate_grad(None, 0, None, None, None, presorted=ctx.presorted,
+                              pool=(g.contiguous(), inv, bag, ctx.L, ctx.field, ids))
+        return (None,) * (8 + len(store.emb_feature))
+
+
+def embed_gather_pool(store, field: int, ids, offsets, L: int, B: int, mode: str, presorted=None):
+    tables = [store.embedding_layer[c].weight for c in store.emb_feature]
+    return _EmbedGatherPool.apply(store, field, ids, offsets, L, B, mode, presorted, *tables)
+
+
+class _SeqPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, mode: str):
+        out, inv = hip.seq_pool_fwd(e, mode, ctx.needs_input_grad[0])
+        ctx.L = e.shape[1]
+        ctx.save_for_backward(inv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return hip.seq_pool_bwd(g.contiguous(), inv, ctx.L), None
+
+
+def seq_pool(e, mode: str):
+    """MaskedSumPooling ("sum") / MaskedAveragePooling ("average") of an explicit [B, L, D] HIP tensor"""
+    return _SeqPool.apply(e.float().contiguous(), mode)

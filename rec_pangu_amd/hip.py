@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
 _lib = None
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+_f64 = C.c_double
 _SIGNATURES = {
     "rp_version": (C.c_int, []),
     "rp_last_error": (C.c_char_p, []),
@@ -98,18 +99,22 @@ _SIGNATURES = {
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
-    "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _i64, _i32, _vp]),
+    "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp]),
     "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "rp_adam_step_scalars": (C.c_int, [_f32, _f32, _f32, _f32, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32,
+    "rp_adam_step_scalars": (C.c_int, [_f64, _f64, _f64, _f64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _f64, _f64,
                                     _vp, _i64, _vp]),
-    "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _i64, _vp]),
-    "rp_lazy_adam_cf_terms": (C.c_int, [_f32, C.POINTER(C.c_int)]),
-    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64, _vp]),
+    "rp_embed_gather_pool_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rp_embed_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "rp_seq_pool_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "rp_seq_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "rp_lazy_adam_cf_terms": (C.c_int, [_f64, C.POINTER(C.c_int)]),
+    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f64, _f64, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -1156,3 +1161,57 @@ def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: floa
     with _Timed("lazy_adam_cf_table", f"{max(t_end - cf_from, 0)}"):
         _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _stream()),
                "rp_lazy_adam_cf_table")
+
+
+POOL_MODES = {"sum": 0, "average": 1}
+
+
+def embed_gather_pool_fwd(arena, row_base: int, row_count: int, ids, offsets, L: int, B: int, mode: str, err_flag,
+                          want_bwd: bool):
+    """rp_embed_gather_pool_fwd: pooled multi-id lookup of ONE table.  ids: flat int64 [nnz] (dense bags: nnz = B * L,
+    offsets None; CSR: offsets int64 [B + 1]).  Returns (out [B, D], inv [B, D] or None, bag_of int32 [nnz] or None)."""
+    _req(arena, torch.float32, "arena")
+    D = arena.shape[1]
+    out = torch.empty((B, D), dtype=torch.float32, device=arena.device)
+    inv = torch.empty((B, D), dtype=torch.float32, device=arena.device) if (want_bwd and mode == "average") else None
+    bag = torch.empty((ids.numel(),), dtype=torch.int32, device=arena.device) if (want_bwd and offsets is not None) else None
+    nnz = ids.numel()
+    with _Timed("embed_gather_pool_fwd", f"D={D}", nnz * (D * 4 + 8) + B * D * 4):
+        _check(lib().rp_embed_gather_pool_fwd(arena.data_ptr(), row_base, row_count, ids.data_ptr(), _ptr(offsets), L, B, D,
+                                              POOL_MODES[mode], out.data_ptr(), D, _ptr(inv), _ptr(bag), err_flag.data_ptr(),
+                                              _stream()), "rp_embed_gather_pool_fwd")
+    return out, inv, bag
+
+
+def embed_pool_bwd(sorted_keys, sorted_pos, D: int, g, scale, bag_of, L: int, grad_arena, accumulate: bool):
+    _req(grad_arena, torch.float32, "grad_arena")
+    _req(g, torch.float32, "g")
+    n = sorted_keys.numel()
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_reduce_workspace_bytes(n, D, C.byref(nbytes)), "rp_embed_grad_reduce_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+    with _Timed("embed_pool_bwd", f"D={D}", n * (D * 4 + 8)):
+        _check(lib().rp_embed_pool_bwd(sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, D, g.data_ptr(), _rowmajor(g, "g"),
+                                       _ptr(scale), _ptr(bag_of), L, grad_arena.data_ptr(), int(accumulate), ws.data_ptr(),
+                                       nbytes.value, _stream()), "rp_embed_pool_bwd")
+
+
+def seq_pool_fwd(e, mode: str, want_bwd: bool):
+    """MaskedSumPooling / MaskedAveragePooling of an explicit contiguous [B, L, D] tensor -> (out [B, D], inv or None)"""
+    _req(e, torch.float32, "e")
+    B, L, D = e.shape
+    out = torch.empty((B, D), dtype=torch.float32, device=e.device)
+    inv = torch.empty((B, D), dtype=torch.float32, device=e.device) if (want_bwd and mode == "average") else None
+    with _Timed("seq_pool_fwd", f"{B}x{L}x{D}", (B * L * D + B * D) * 4):
+        _check(lib().rp_seq_pool_fwd(e.data_ptr(), B, L, D, POOL_MODES[mode], out.data_ptr(), _ptr(inv), _stream()),
+               "rp_seq_pool_fwd")
+    return out, inv
+
+
+def seq_pool_bwd(g, inv, L: int):
+    _req(g, torch.float32, "g")
+    B, D = g.shape
+    de = torch.empty((B, L, D), dtype=torch.float32, device=g.device)
+    with _Timed("seq_pool_bwd", f"{B}x{L}x{D}", (B * L * D + B * D) * 4):
+        _check(lib().rp_seq_pool_bwd(g.data_ptr(), _ptr(inv), B, L, D, de.data_ptr(), _stream()), "rp_seq_pool_bwd")
+    return de

@@ -5,7 +5,8 @@ from .shallow import LR_Layer
 from .interaction import (InnerProductLayer, FM_Layer, CrossInteractionLayer, CrossNet,
                           CompressedInteractionNet)
 from .attention import ScaledDotProductAttention, MultiHeadAttention, MultiHeadSelfAttention
+from .sequence import MaskedAveragePooling, MaskedSumPooling
 
 __all__ = ["get_activation", "EmbeddingLayer", "MLP", "LR_Layer", "InnerProductLayer", "FM_Layer",
            "CrossInteractionLayer", "CrossNet", "CompressedInteractionNet", "ScaledDotProductAttention",
-           "MultiHeadAttention", "MultiHeadSelfAttention"]
+           "MultiHeadAttention", "MultiHeadSelfAttention", "MaskedAveragePooling", "MaskedSumPooling"]

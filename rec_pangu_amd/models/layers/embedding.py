@@ -15,6 +15,7 @@ Device dispatch is by where the arena lives: a HIP-resident layer ALWAYS runs th
 (rec_pangu_amd/hip.py raises if the library is missing — no fallback); a CPU-resident layer is
 BASELINE.json config 0 ("plumbing, no GPU") and uses plain torch ops.
 """
+import copy
 import os
 import weakref
 from typing import Dict, List, Optional, Union
@@ -116,6 +117,19 @@ class EmbeddingLayer(nn.Module):
         self._arena = arena
         self._dev_meta = None
         self._tag_tables()
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model): nn.Parameter.__deepcopy__ clones every table into a storage of its own, which would
+        tear the tables off the arena — and, with the lazy optimizer active, make the next forward re-pack the arena from
+        table values that still owe their skipped steps while the moment arenas are stamped current.  The clone gets
+        ONE copy of the arena (and of the gradient / moment arenas) and its tables are pointed back into it."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__({k: copy.deepcopy(v, memo) for k, v in self.__dict__.items()})
+        new._point_at(new._arena)  # (same values: the arena copy and the table clones were taken from the same memory)
+        if new._grad_arena is not None and self._grads_are_ours():
+            new._attach_grads()
+        return new
 
     def _apply(self, fn, recurse=True):
         # one move for the whole arena instead of one per table (module.to / .cuda / .float ...)
@@ -229,7 +243,7 @@ class EmbeddingLayer(nn.Module):
         if self._lazy is not None:
             self._lazy.flush(self)
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None):
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -248,11 +262,17 @@ class EmbeddingLayer(nn.Module):
             else:
                 self._grad_arena.zero_()
             self._touched, self._grad_clean = None, True
+        if pool is not None and presorted is None:  # pooled multi-id lookup of one table: keys of its flat id list
+            f = pool[4]
+            keys = hip.embed_keys(self.row_base[f:f + 1], self.row_count[f:f + 1], [pool[5]], self.err_flag)
         if presorted is not None:
             sk, sp = presorted
         else:
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
-        if fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
+        if pool is not None:  # (g [B, D], 1 / count or None, bag of every id or None, ids per dense bag, field, ids)
+            hip.embed_pool_bwd(sk, sp, D, pool[0], pool[1], pool[2], pool[3], self._grad_arena,
+                               accumulate=not self._grad_clean)
+        elif fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
             hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
                                 accumulate=not self._grad_clean)
         else:
@@ -411,6 +431,61 @@ class EmbeddingLayer(nn.Module):
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out if want_fm else (out, None)
+
+    def table_range(self, field: int):
+        """(first arena row, rows) of table `field` as python ints (cached with the row signature)"""
+        sig = self._rows_sig()
+        return sum(sig[:field]), sig[field]
+
+    def lookup_pooled(self, X: Dict[str, torch.Tensor], name: str, pooling: str = "sum",
+                      offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The multi-id lookup of a `_seq` column fused with its pooling: what the reference writes as
+        `MaskedSumPooling()(emb(X, name=name))` / `MaskedAveragePooling()(...)` (embedding.py:64-71 +
+        layers/sequence.py:13-59), without the [B, L, D] intermediate -> [B, D].
+
+        X[name]: [B, L] ids (dense bags, padding ids included, as the reference takes them) or, with `offsets`
+        (int64 [B + 1]), a flat [nnz] id list in CSR form (ragged bags).  pooling: "sum" | "average" (the masked average
+        counts non-zero ELEMENTS per (sample, column), like the reference)."""
+        if pooling not in ("sum", "average"):
+            raise ValueError("pooling must be 'sum' or 'average'")
+        self._ensure_packed()
+        base_name = name.replace("_seq", "") if "seq" in name else name
+        ids = X[name].long()
+        if not self._arena.is_cuda:  # BASELINE config 0 (CPU plumbing): the reference's own composition
+            table = self.embedding_layer[base_name]
+            if offsets is None:
+                e = table(ids if ids.dim() == 2 else ids.view(-1, 1))
+                s = torch.sum(e, dim=1)
+                return s if pooling == "sum" else s / ((e != 0).sum(dim=1).float() + 1e-16)
+            rows = table(ids.view(-1))  # ragged bags: segment sums over the flat id list
+            lens = offsets[1:] - offsets[:-1]
+            bag = torch.repeat_interleave(torch.arange(lens.numel()), lens)
+            s = torch.zeros((lens.numel(), rows.shape[1]), dtype=rows.dtype).index_add(0, bag, rows)
+            if pooling == "sum":
+                return s
+            cnt = torch.zeros_like(s).index_add(0, bag, (rows != 0).to(rows.dtype))
+            return s / (cnt + 1e-16)
+        f = self.emb_feature.index(base_name)
+        if offsets is None:
+            if ids.dim() != 2:
+                ids = ids.view(-1, 1)
+            B, L = ids.shape
+        else:
+            offsets = offsets.long().contiguous()
+            B, L = offsets.numel() - 1, 0
+        flat = ids.reshape(-1).contiguous()
+        presorted = None
+        if self._lazy is not None and self._lazy.t > 0:
+            # lazy dense Adam: the rows this lookup reads first replay the zero-gradient steps they skipped
+            from ... import hip
+            keys = hip.embed_keys(self.row_base[f:f + 1], self.row_count[f:f + 1], [flat], self.err_flag)
+            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            self._lazy.replay(self, sk)
+            presorted = (sk, sp)
+        out = Fh.embed_gather_pool(self, f, flat, offsets, L, B, pooling, presorted)
+        if self.check_indices == "sync":
+            self.raise_if_bad_index()
+        return out
 
     def forward(self, X: Dict[str, torch.Tensor], name: Optional[str] = None) -> torch.Tensor:
         self._ensure_packed()

@@ -53,18 +53,23 @@ class LazyAdamRows:
         self._table = torch.zeros((t0 + 1, 2), dtype=torch.float32, device=a.device)
         self._table_lr = None
         self._table_from = t0 + 1
-        assert replay in ("exact", "closed"), replay
-        self.closed = (replay == "closed" and abs(betas[0] - 0.9) < 1e-12 and abs(betas[1] - 0.999) < 1e-12 and eps > 0)
-        # closed-form replay: {ns_j, d_j} = {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)} by step in double, and the per-k
-        # coefficient table valid for replays that end at step `_cf_for` (rebuilt on the device when the end step moves)
-        self._ns_d = torch.zeros((t0 + 1, 2), dtype=torch.float64, device=a.device) if self.closed else None
+        # closed-form replay: {ns_j, d_j} = {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)} by step in double (kept in either mode, so
+        # that the mode can be switched mid-run), and the per-k coefficient table valid for replays that end at step
+        # `_cf_for` (rebuilt on the device when the end step moves)
+        self._ns_d = torch.zeros((t0 + 1, 2), dtype=torch.float64, device=a.device)
         self._cf_from = max(self.CF_FROM, t0)  # no row carries a stamp in (0, t0)
         self._cf, self._cf_for = None, -1
+        self.set_replay(replay)
+
+    def set_replay(self, replay: str):
+        """switch between the serial ("exact") and the closed-form ("closed") replay; takes effect at the next replay"""
+        assert replay in ("exact", "closed"), replay
+        b = self.betas
+        self.closed = (replay == "closed" and abs(b[0] - 0.9) < 1e-12 and abs(b[1] - 0.999) < 1e-12 and self.eps > 0)
 
     def apply(self, fn):
         self.m, self.v, self.last, self._table = fn(self.m), fn(self.v), fn(self.last), fn(self._table)
-        if self._ns_d is not None:
-            self._ns_d = fn(self._ns_d)
+        self._ns_d = fn(self._ns_d)
         self._cf, self._cf_for = None, -1
 
     def _ensure_table(self, t_new, lr):
@@ -77,11 +82,10 @@ class LazyAdamRows:
         rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
         new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
         self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
-        if self.closed:
-            j = torch.arange(t_new, hi + 1, dtype=torch.float64)
-            ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
-            d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
-            self._ns_d = torch.cat([self._ns_d[:t_new], torch.stack([ns, d], 1).to(self._ns_d.device)]).contiguous()
+        j = torch.arange(t_new, hi + 1, dtype=torch.float64)
+        ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
+        d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
+        self._ns_d = torch.cat([self._ns_d[:t_new], torch.stack([ns, d], 1).to(self._ns_d.device)]).contiguous()
         self._table_lr, self._table_from = lr, t_new
 
     def _cf_args(self, t_end):
@@ -157,6 +161,16 @@ class FusedAdam(torch.optim.Optimizer):
     def _store_of(p):
         ref = getattr(p, "_rp_store", None)
         return None if ref is None else ref()
+
+    def set_replay(self, replay: str):
+        """switch the lazy tables between the serial ("exact", bit-identical to dense execution) and the closed-form
+        ("closed") replay mid-run, e.g. to finish a run in the parity mode"""
+        if replay not in ("exact", "closed"):
+            raise ValueError("replay must be 'exact' or 'closed'")
+        self.replay = replay
+        for store in self._stores.values():
+            if store._lazy is not None:
+                store._lazy.set_replay(replay)
 
     def flush(self):
         """Lazy mode: bring every embedding row to the current step (dense-equivalent state)."""

@@ -153,3 +153,56 @@ def test_embedding_arena_views_survive_moves_and_replacement():
     m(batch)
     assert layer.arena.shape[0] == sum(v + 1 for v in (7, 3, 50, 11, 2)) - 1
     assert torch.equal(layer.embedding_layer["C2"].weight, torch.ones(3, 8))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_lookup_pooled_on_cpu_matches_reference(case):
+    """EmbeddingLayer.lookup_pooled + the drop-in MaskedSumPooling / MaskedAveragePooling modules on CPU (BASELINE config
+    0) against the reference's `_seq` lookup + pooling (tests/golden/pool.npz), dense and CSR bags."""
+    from conftest import load_golden
+    from test_oracle_golden import pool_case
+    from rec_pangu_amd.models.layers import EmbeddingLayer, MaskedAveragePooling, MaskedSumPooling
+    table, seq, modes = pool_case(load_golden("pool.npz"), case)
+    enc = {"C1": {"vocab_size": 7}, "I1": {"min": 0.0, "max": 1.0}, "hist": {"vocab_size": 60}, "C2": {"vocab_size": 3}}
+    emb = EmbeddingLayer(enc, table.shape[1])
+    with torch.no_grad():
+        emb.embedding_layer["hist"].weight.copy_(table)
+    X = {"hist_seq": seq}
+    for mode, (out, cot, grad) in modes.items():
+        pooling = "sum" if mode == "sum" else "average"
+        emb.zero_grad()
+        y = emb.lookup_pooled(X, "hist_seq", pooling)
+        assert torch.equal(y, out)
+        (y * cot).sum().backward()
+        torch.testing.assert_close(emb.embedding_layer["hist"].weight.grad, grad, rtol=1e-6, atol=0)
+        mod = MaskedSumPooling() if mode == "sum" else MaskedAveragePooling()
+        assert torch.equal(mod(emb(X, name="hist_seq")), out)
+        if case != "a":  # CSR bags without the (all-zero) padding ids
+            keep = seq != 0
+            offsets = torch.cat([torch.zeros(1, dtype=torch.long), keep.sum(1).cumsum(0)])
+            y = emb.lookup_pooled({"hist_seq": seq[keep]}, "hist_seq", pooling, offsets=offsets)
+            torch.testing.assert_close(y, out, rtol=1e-6, atol=1e-7)
+
+
+def test_deepcopy_keeps_the_tables_in_one_arena():
+    """copy.deepcopy(model) must not tear the table Parameters off the arena (Parameter.__deepcopy__ clones each one):
+    the clone's tables are views of the clone's own arena, with the original's values, and independent of it."""
+    import copy
+    from rec_pangu_amd.models.ranking import DeepFM
+    enc = {"I1": {"min": 0.0, "max": 1.0}, "C1": {"vocab_size": 7}, "C2": {"vocab_size": 30}}
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=8, hidden_units=[8], enc_dict=enc)
+    twin = copy.deepcopy(model)
+    lay, tl = model.embedding_layer, twin.embedding_layer
+    assert tl.arena.data_ptr() != lay.arena.data_ptr() and torch.equal(tl.arena, lay.arena)
+    off = 0
+    for c in lay.emb_feature:
+        w = tl.embedding_layer[c].weight
+        assert w.data_ptr() == tl.arena.data_ptr() + off * 8 * 4, c
+        assert w._rp_store() is tl
+        off += w.shape[0]
+    with torch.no_grad():
+        tl.arena.add_(1.0)
+    assert torch.equal(tl.embedding_layer["C2"].weight, lay.embedding_layer["C2"].weight + 1.0)
+    b = {"I1": torch.rand(4), "C1": torch.tensor([0, 1, 7, 3]), "C2": torch.tensor([5, 30, 0, 2]), "label": torch.ones(4)}
+    assert not torch.equal(twin(b)["pred"], model(b)["pred"])

@@ -167,3 +167,35 @@ def test_dataset_encode():
     for col in meta["schema"]["dense_cols"]:
         x = R.encode_dense(valid[col].values, enc[col]["min"], enc[col]["max"]).astype(np.float32)
         np.testing.assert_allclose(x, g["valid"][col].numpy(), rtol=1e-6, atol=1e-7)
+
+
+POOL_CASES = ("a", "b", "c")
+
+
+def pool_case(g, case):
+    """(table [61, D], seq [B, L], {mode: (out, cot, grad)}) of one case of tests/golden/pool.npz"""
+    c = g[case]
+    return c["w/embedding_layer.hist.weight"], c["seq"], {m: (c[f"{m}/out"], c[f"{m}/cot"], c[f"{m}/grad"])
+                                                          for m in ("sum", "avg")}
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_seq_pooling(case):
+    """the `_seq` lookup + MaskedSumPooling / MaskedAveragePooling restatement against the reference's outputs and
+    autograd gradients (tests/golden/pool.npz, make_golden_r3.py)"""
+    table, seq, modes = pool_case(load_golden("pool.npz"), case)
+    assert torch.equal(R.embedding_by_name({"hist": table}, {"hist_seq": seq}, "hist_seq"), load_golden("pool.npz")[case]["lookup"])
+    for mode, (out, cot, grad) in modes.items():
+        w = table.clone().requires_grad_(True)
+        y = R.embedding_seq_pooled({"hist": w}, {"hist_seq": seq}, "hist_seq", "sum" if mode == "sum" else "average")
+        assert torch.equal(y, out), mode  # same ATen ops, same order
+        (y * cot).sum().backward()
+        torch.testing.assert_close(w.grad, grad, rtol=1e-6, atol=0)
+    # ragged form: dropping the padding ids (whose row is all zero in cases b, c) gives the same sums / averages
+    if case != "a":
+        keep = seq != 0
+        lens = keep.sum(1)
+        offsets = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)])
+        for mode, (out, _, _) in modes.items():
+            y = R.embedding_bags_pooled(table, seq[keep], offsets, "sum" if mode == "sum" else "average")
+            torch.testing.assert_close(y, out, rtol=1e-6, atol=1e-7)
