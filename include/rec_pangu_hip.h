@@ -424,7 +424,15 @@ int rp_seq_pool_bwd(const float *g, const float *inv, int64_t B, int64_t L, int 
  * host side squares s when it exports torch.optim.Adam-style state (rec_pangu_amd/optim.py).  */
 int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
                  const int64_t *sizes, int n_tensors, double lr, double beta1, double beta2, double eps,
-                 int64_t step, int zero_grad, rp_stream_t stream);
+                 int64_t step, int zero_grad, const float *step_scalars, const int32_t *t_dev, rp_stream_t stream);
+/* DEVICE-RESIDENT STEP COUNTERS (hipGraph replays freeze every launch argument at capture, so the step number cannot be
+ * one).  Wherever an entry point of this section takes `t_dev` (device int32[1] = number of COMPLETED optimizer steps,
+ * NULL = use the host arguments), the kernel reads the step from it: rp_adam_step applies step *t_dev + 1 with the
+ * scalars step_scalars[*t_dev + 1] (the float2 table of rp_adam_step_scalars rows indexed by step; lr / step arguments
+ * ignored), rp_lazy_adam_rows replays to *t_dev (real_step: applies *t_dev + 1), rp_lazy_adam_cf_table builds the table
+ * for t_end = *t_dev (its `t_end` argument then is the CAPACITY the launch grid covers).  rp_counter_add advances a
+ * counter on the stream.  rec_pangu_amd/graph_step.py captures fwd + bwd + optimizer on top of these. */
+int rp_counter_add(int32_t *counter, int32_t delta, rp_stream_t stream);
 
 /* ---- exact LAZY dense Adam for arena rows -----------------------------------------------------
  * Same semantics as rp_adam_step over the whole arena (trainer.py:75: DENSE Adam, every row every step), but a
@@ -449,7 +457,8 @@ int rp_adam_step_scalars(double lr, double beta1, double beta2, double eps, int6
                                       * is p += m * rcp(s * A_t + B_t) (s = sqrt(v)); lr = 0 gives (0, -inf) */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
-                      double beta1, double beta2, double eps, const float *cf_table, int64_t cf_from, rp_stream_t stream);
+                      double beta1, double beta2, double eps, const float *cf_table, int64_t cf_from, const int32_t *t_dev,
+                      rp_stream_t stream);
 int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_t *last, const float *step_scalars,
                        int64_t t_target, double beta1, double beta2, double eps, const float *cf_table, int64_t cf_from,
                        rp_stream_t stream);
@@ -470,7 +479,7 @@ int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_
  *   rp_lazy_adam_cf_terms  number of leading terms that carry weight (b1^J < 1e-17) */
 int rp_lazy_adam_cf_terms(double beta1, int *terms);
 int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2, float *cf_table,
-                          rp_stream_t stream);
+                          const int32_t *t_dev, rp_stream_t stream);
 
 /* ---- request routing for row-sharded tables (rec_pangu_amd/sharded.py; no reference counterpart: the reference is
  * single-device).  Arena row r lives on rank r % world at local row r / world.

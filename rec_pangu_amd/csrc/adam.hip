@@ -102,9 +102,17 @@ static void adam_scalars(double lr, double beta1, double beta2, double eps, int6
     *sb = (float)(eps / ns);
 }
 
+// t_dev != NULL (hipGraph replays: the launch arguments are frozen at capture): the step scalars are read from the
+// device table sc[] at row *t_dev + 1, *t_dev = number of completed steps
 template <bool ZERO_G>
 __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, float b2, float sqrt_b2, float one_m_b2,
-                                                   float sa, float sb) {
+                                                   float sa, float sb, const float2 *__restrict__ sc,
+                                                   const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) {
+        const float2 x = sc[*t_dev + 1];
+        sa = x.x;
+        sb = x.y;
+    }
     const int ti = blockIdx.y;
     float *__restrict__ P = a.p[ti];
     float *__restrict__ G = a.g[ti];
@@ -137,11 +145,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPtrs a, float one_m_b1, f
 
 extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptrs, float *const *v_ptrs,
                             const int64_t *sizes, int n_tensors, double lr, double beta1, double beta2, double eps,
-                            int64_t step, int zero_grad, rp_stream_t stream) {
+                            int64_t step, int zero_grad, const float *step_scalars, const int32_t *t_dev,
+                            rp_stream_t stream) {
+    RP_REQUIRE(t_dev == nullptr || step_scalars != nullptr, "adam_step: a device step counter needs the scalar table");
     RP_REQUIRE(p_ptrs && g_ptrs && m_ptrs && v_ptrs && sizes, "adam_step: null pointer");
     RP_REQUIRE(n_tensors >= 1 && n_tensors <= RP_MAX_FIELDS, "adam_step: n_tensors=%d outside [1,%d]", n_tensors,
                RP_MAX_FIELDS);
-    RP_REQUIRE(step >= 1, "adam_step: step must be >= 1");
+    RP_REQUIRE(step >= 1 || t_dev != nullptr, "adam_step: step must be >= 1");
     AdamPtrs a;
     int64_t maxn = 0;
     for (int i = 0; i < n_tensors; ++i) {
@@ -154,8 +164,8 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
         if (sizes[i] > maxn) maxn = sizes[i];
     }
     if (maxn == 0) return RP_OK;
-    float sa, sb;  // the two per-step scalars, computed in double as python floats are in torch.optim.Adam
-    adam_scalars(lr, beta1, beta2, eps, step, &sa, &sb);
+    float sa = 0.f, sb = 0.f;  // the two per-step scalars, computed in double as python floats are in torch.optim.Adam
+    if (t_dev == nullptr) adam_scalars(lr, beta1, beta2, eps, step, &sa, &sb);
     int64_t bx = rp_cdiv(rp_cdiv(maxn, 4), 256);
     if (bx > 8192) bx = 8192;
     if (bx < 1) bx = 1;
@@ -163,10 +173,11 @@ extern "C" int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *c
     hipStream_t s = (hipStream_t)stream;
     const float one_m_b1 = (float)(1.0 - beta1), one_m_b2 = (float)(1.0 - beta2), b2f = (float)beta2;
     const float sqrt_b2 = (float)std::sqrt(beta2);
+    const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
     if (zero_grad)
-        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb);
+        hipLaunchKernelGGL((adam_kernel<true>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb, sc, t_dev);
     else
-        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb);
+        hipLaunchKernelGGL((adam_kernel<false>), grid, dim3(256), 0, s, a, one_m_b1, b2f, sqrt_b2, one_m_b2, sa, sb, sc, t_dev);
     RP_LAUNCH_CHECK("adam_step");
     return RP_OK;
 }
@@ -232,7 +243,9 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 }
 
 __global__ __launch_bounds__(256) void lazy_cf_table_kernel(const double2 *__restrict__ nsd, int t_end, int t_from,
-                                                            int J, double b1e, double r, CfEntry *__restrict__ out) {
+                                                            int J, double b1e, double r, CfEntry *__restrict__ out,
+                                                            const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) t_end = *t_dev;  // graph replays: the grid covers the table's capacity, waves beyond t_end leave
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
     if (k > t_end - t_from) return;  // wave-uniform
@@ -289,7 +302,9 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
                                                              int32_t *__restrict__ last,
                                                              const float2 *__restrict__ sc, int t_target,
                                                              int real_step, int zero_grad, LazyCfg c,
-                                                             const CfEntry *__restrict__ cf, int cf_from) {
+                                                             const CfEntry *__restrict__ cf, int cf_from,
+                                                             const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) t_target = *t_dev + (real_step ? 1 : 0);  // *t_dev = completed steps (graph replays)
     constexpr int GPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
     const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
@@ -579,7 +594,9 @@ template <int EPL, bool FULL>
 __global__ __launch_bounds__(256) void lazy_replay_wave_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
                                                                float *__restrict__ P, float *__restrict__ Mo,
                                                                float *__restrict__ Vo, int32_t *__restrict__ last,
-                                                               const float2 *__restrict__ sc, int t_target, LazyCfg c) {
+                                                               const float2 *__restrict__ sc, int t_target, LazyCfg c,
+                                                               const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) t_target = *t_dev;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     const int64_t i = (int64_t)(threadIdx.x & 63) * n_waves + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
     int row = 0, l0 = 0;
@@ -669,7 +686,7 @@ extern "C" int rp_lazy_adam_cf_terms(double beta1, int *terms) {
 }
 
 extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2,
-                                     float *cf_table, rp_stream_t stream) {
+                                     float *cf_table, const int32_t *t_dev, rp_stream_t stream) {
     RP_REQUIRE(ns_d && cf_table, "lazy_adam_cf_table: null pointer");
     RP_REQUIRE(cf_from >= 1 && t_end < INT32_MAX, "lazy_adam_cf_table: bad step range");
     RP_REQUIRE((((uintptr_t)ns_d) & 15u) == 0 && (((uintptr_t)cf_table) & 31u) == 0,
@@ -684,7 +701,7 @@ extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t 
     const unsigned grid = (unsigned)rp_cdiv(t_end - cf_from, 4);  // one wave per entry
     hipLaunchKernelGGL(lazy_cf_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const double2 *>(ns_d), (int)t_end, (int)cf_from, J, b1e, r,
-                       reinterpret_cast<CfEntry *>(cf_table));
+                       reinterpret_cast<CfEntry *>(cf_table), t_dev);
     RP_LAUNCH_CHECK("lazy_adam_cf_table");
     return RP_OK;
 }
@@ -692,14 +709,14 @@ extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t 
 extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                                  int32_t *last, const float *step_scalars, int64_t t_target, int real_step,
                                  int zero_grad, double beta1, double beta2, double eps, const float *cf_table,
-                                 int64_t cf_from, rp_stream_t stream) {
+                                 int64_t cf_from, const int32_t *t_dev, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_rows: null pointer");
     RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
                "lazy_adam_rows: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     RP_REQUIRE(!real_step || g, "lazy_adam_rows: a real step needs the gradient arena");
     RP_REQUIRE(D >= 1, "lazy_adam_rows: D must be positive");
     const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
-    RP_REQUIRE(t_target >= (real_step ? 1 : 0) && t_target < INT32_MAX, "lazy_adam_rows: bad step");
+    RP_REQUIRE(t_dev != nullptr || (t_target >= (real_step ? 1 : 0) && t_target < INT32_MAX), "lazy_adam_rows: bad step");
     if (n == 0) return RP_OK;
     LazyCfg c{(float)(1.0 - beta1), (float)beta2, (float)std::sqrt(beta2), (float)(1.0 - beta2), (float)eps};
     const int tpr = lazy_tpr(D, vw);
@@ -712,7 +729,7 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
         const dim3 gw((unsigned)rp_cdiv(n, 256));
 #define CALLW(EPL, FULL)                                                                                              \
     hipLaunchKernelGGL((lazy_replay_wave_kernel<EPL, FULL>), gw, dim3(256), 0, s, sorted_keys, n, D, p, m, v, last, sc, \
-                       (int)t_target, c)
+                       (int)t_target, c, t_dev)
         if (D == 64) CALLW(1, true);
         else if (D < 64) CALLW(1, false);
         else if (D <= 128) CALLW(2, false);
@@ -723,7 +740,7 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
     }
 #define CALL(T, TY)                                                                                                  \
     hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
-                       sc, (int)t_target, real_step, zero_grad, c, cf, (int)cf_from)
+                       sc, (int)t_target, real_step, zero_grad, c, cf, (int)cf_from, t_dev)
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_rows");
@@ -766,5 +783,15 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_flush");
+    return RP_OK;
+}
+
+// *counter += delta on the stream (the device-resident step counters of the hipGraph path)
+__global__ void counter_add_kernel(int32_t *c, int32_t delta) { *c += delta; }
+
+extern "C" int rp_counter_add(int32_t *counter, int32_t delta, rp_stream_t stream) {
+    RP_REQUIRE(counter, "counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    RP_LAUNCH_CHECK("counter_add");
     return RP_OK;
 }

@@ -1,0 +1,159 @@
+"""A whole training step — forward, backward, optimizer step, zero_grad — captured once into a hipGraph and replayed.
+
+Why: the eager step of the headline configuration is 13 kernel launches + 5 rocPRIM launches + memsets behind autograd,
+ctypes and torch.empty: ~1.0 ms of host time per step against ~1.3 ms on the device — and at the per-GPU batch of a
+strong-scaling run (8192) the host IS the step time (1.10 ms eager against 0.32 ms replayed, scratch/probe_graph.py).
+Replaying a captured graph costs the host one launch (~0.1 ms) and the device no inter-kernel gaps of host origin.
+
+What makes a step capturable here:
+  * the STEP NUMBER lives on the device: every launch argument is frozen at capture, so the Adam kernels read the step from
+    StepTables.t_dev (rp_adam_step / rp_lazy_adam_rows / rp_lazy_adam_cf_table with t_dev, rp_counter_add) and the
+    per-step scalar tables are persistent buffers that the host extends in place (optim.StepTables);
+  * STATIC INPUT BUFFERS, two sets: graph P reads the current batch from X[P] and — on the side stream, beside its backward
+    — sorts the NEXT batch, already staged in X[1-P], into the persistent (keys, sorted keys, positions) tensors that
+    graph 1-P will read (EmbeddingLayer.pin_sort / prefetch_sort); the caller's batches are copied in with one
+    multi-tensor copy per dtype;
+  * no host synchronisation inside the step: check_indices = "deferred" (raise_if_bad_index() after the run).
+
+The captured launches are the eager path's own (same kernels, same order, same arguments except the step number's
+source): results are bit-identical to the eager loop (tests/test_hip_graph.py).  Uses torch.cuda.CUDAGraph (= hipGraph
+on ROCm) for the capture and for the allocator's graph-private pool; the first `eager_steps` calls run eagerly so that
+optimizer state, gradient buffers and caches exist before the capture.
+"""
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .models.layers import embedding as _emb
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, optimizer); out = step(batch, next_batch) in the training loop.
+
+    `next_batch` is the batch of the following call (None at the end of an epoch: that step then runs eagerly).  The
+    returned dict holds detached, STATIC tensors ('pred', 'loss', ...) that the next call on the same graph overwrites
+    (do not keep an autograd graph of an earlier eager step alive across the first captured call: its AccumulateGrad nodes
+    are bound to the eager stream).  `post_backward`: a hook run
+    between backward and optimizer step (eager and captured alike)."""
+
+    def __init__(self, model, optimizer, post_backward: Optional[Callable[[], None]] = None, eager_steps: int = 2):
+        if not getattr(model, "on_hip", False):
+            raise RuntimeError("GraphedTrainStep needs a HIP-resident model")
+        if not hasattr(optimizer, "set_device_clock"):
+            raise RuntimeError("GraphedTrainStep needs rec_pangu_amd.optim.FusedAdam (device-resident step counters)")
+        for m in model.modules():
+            if getattr(m, "check_indices", "deferred") != "deferred":
+                raise RuntimeError("GraphedTrainStep: set check_indices = 'deferred' on the embedding layers (a captured "
+                                   "step cannot synchronise with the host; call raise_if_bad_index() after the run)")
+        if not hasattr(model.embedding_layer, "pin_sort"):
+            raise RuntimeError("GraphedTrainStep: row-sharded embedding layers (collectives inside the step) are not captured")
+        self.model, self.opt, self.post_backward = model, optimizer, post_backward
+        self.eager_left = eager_steps
+        self.X = None            # the two static batches
+        self.graphs = [None, None]
+        self.outs = [None, None]
+        self.P = 0
+        self._staged = None      # the caller's batch object whose content X[P] holds (sorted and pinned)
+        self._sig = None
+        self._pool = None
+        self._dev = None         # host mirror of the device counters
+        self.replays = 0
+
+    # ---- pieces --------------------------------------------------------------------------------------------------------
+    def _eager(self, batch, nxt):
+        if nxt is not None:
+            self.model.prefetch(nxt)
+        out = self.model(batch)
+        out["loss"].backward()
+        if self.post_backward is not None:
+            self.post_backward()
+        self.opt.step()
+        self.model.zero_grad()
+        # detached: an autograd graph kept alive by a returned loss would keep its AccumulateGrad nodes (bound to THIS
+        # stream) alive into the capture, which runs on another stream — that cross-stream dependency breaks the capture
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+    def _alloc(self, batch):
+        self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
+        self._keys = list(batch.keys())
+        for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
+            self.model.embedding_layer.pin_sort(x)
+
+    def _copy(self, P, batch):
+        dst = [self.X[P][k] for k in self._keys]
+        src = [batch[k] for k in self._keys]
+        for d, s_ in zip(dst, src):
+            if d.shape != s_.shape or d.dtype != s_.dtype:
+                raise RuntimeError("GraphedTrainStep: every batch must have the shapes and dtypes of the first one "
+                                   "(drop the last, smaller batch of an epoch or run it eagerly)")
+        torch._foreach_copy_(dst, src)
+
+    def _stage_current(self, batch):
+        self._copy(self.P, batch)
+        self.model.embedding_layer.pin_sort(self.X[self.P])
+        self._staged = batch
+
+    def _capture(self, P):
+        counters = self.opt.host_counters()
+        self.opt.set_device_clock(True)
+        self._dev = counters
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, pool=self._pool):
+                self.model.prefetch(self.X[1 - P])
+                out = self.model(self.X[P])
+                out["loss"].backward()
+                if self.post_backward is not None:
+                    self.post_backward()
+                self.opt.step()
+                self.model.zero_grad()
+                cur = torch.cuda.current_stream()
+                for side in _emb._SIDE_STREAMS.values():
+                    cur.wait_stream(side)  # the sort of the next batch is part of this graph
+        finally:
+            # the capture ran the python of one step without executing a kernel: put the host counters back
+            self.opt.set_host_counters(counters)
+            self.opt.set_device_clock(False)
+        if self._pool is None:
+            self._pool = g.pool()
+        self.graphs[P], self.outs[P] = g, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        del out
+
+    def reset(self):
+        """drop the captured graphs (buffers they hold moved, the model or the batch shape changed)"""
+        self.graphs, self.outs, self._pool = [None, None], [None, None], None
+        if self.X is not None:
+            for x in self.X:
+                _emb.EmbeddingLayer.unpin_sorts(x)
+        self.X, self._staged = None, None
+
+    # ---- the step ------------------------------------------------------------------------------------------------------
+    def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
+        if self.eager_left > 0 or next_batch is None:
+            self.eager_left -= 1
+            self._staged = None
+            return self._eager(batch, next_batch)
+        if self.X is None:
+            self._alloc(batch)
+        if self._staged is not batch:      # not the batch announced by the previous call: stage and sort it now
+            self._stage_current(batch)
+        P = self.P
+        self._copy(1 - P, next_batch)
+        sig = self.opt.prepare_step()
+        if sig != self._sig:               # a table a graph points into has moved (capacity doubled, replay mode changed)
+            if self._sig is not None:
+                self.graphs, self.outs, self._pool = [None, None], [None, None], None  # (the pool dies with its graphs)
+            self._sig = sig
+        if self.graphs[P] is None:
+            self._capture(P)
+        counters = self.opt.host_counters()
+        if counters != self._dev:          # eager steps ran in between: bring the device counters to the host's
+            self.opt.set_device_clock(True)
+            self.opt.set_device_clock(False)
+        self.graphs[P].replay()
+        self.opt.advance_host()
+        self._dev = self.opt.host_counters()
+        self.replays += 1
+        self.P, self._staged = 1 - P, next_batch
+        return self.outs[P]

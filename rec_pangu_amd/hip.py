@@ -99,7 +99,8 @@ _SIGNATURES = {
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
-    "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp]),
+    "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp, _vp, _vp]),
+    "rp_counter_add": (C.c_int, [_vp, _i32, _vp]),
     "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -107,14 +108,14 @@ _SIGNATURES = {
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f64, _f64, _f64, _f64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _f64, _f64,
-                                    _vp, _i64, _vp]),
+                                    _vp, _i64, _vp, _vp]),
     "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64, _vp]),
     "rp_embed_gather_pool_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_embed_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "rp_seq_pool_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_seq_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "rp_lazy_adam_cf_terms": (C.c_int, [_f64, C.POINTER(C.c_int)]),
-    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f64, _f64, _vp, _vp]),
+    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f64, _f64, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -317,13 +318,15 @@ def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor],
     return x, h1, fm, ssum, keys
 
 
-def sort_pairs(keys: torch.Tensor, end_bit: int = 32):
+def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None):
+    """out = (sorted keys, positions) to write into (persistent buffers of the hipGraph path), else fresh tensors"""
     _req(keys, torch.int32, "keys")
     n = keys.numel()
     nbytes = _sz(0)
     _check(lib().rp_sort_workspace_bytes(n, C.byref(nbytes)), "rp_sort_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
-    ko, po = torch.empty_like(keys), torch.empty_like(keys)
+    ko, po = out if out is not None else (torch.empty_like(keys), torch.empty_like(keys))
+    assert ko.shape == keys.shape and po.shape == keys.shape and ko.dtype == po.dtype == torch.int32
     with _Timed("sort_pairs_i32"):
         _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
                                    end_bit, _stream()), "rp_sort_pairs_i32")
@@ -937,8 +940,14 @@ def sigmoid_bce_bwd(pred, label, gloss, apply_sigmoid: bool = True, p_eps: float
     return dz
 
 
-def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad: bool):
-    """One fused launch per <=64 tensors; tensors must be contiguous fp32 on the same device."""
+def counter_add(counter, delta: int = 1):
+    """*counter += delta on the current stream (device-resident step counters, see rp_counter_add)"""
+    _check(lib().rp_counter_add(counter.data_ptr(), delta, _stream()), "rp_counter_add")
+
+
+def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad: bool, scalars=None, t_dev=None):
+    """One fused launch per <=64 tensors; tensors must be contiguous fp32 on the same device.  t_dev (device int32[1],
+    completed steps) + scalars (the per-step float2 table): the step number is read on the device (hipGraph replays)."""
     for i in range(0, len(params), MAX_FIELDS):
         ps, gs = params[i:i + MAX_FIELDS], grads[i:i + MAX_FIELDS]
         mm, vv = ms[i:i + MAX_FIELDS], vs[i:i + MAX_FIELDS]
@@ -949,13 +958,15 @@ def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad
         sizes = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
         with _Timed("adam_step"):
             _check(lib().rp_adam_step(_ptr_array(ps), _ptr_array(gs), _ptr_array(mm), _ptr_array(vv), sizes, len(ps), lr,
-                                  beta1, beta2, eps, step, int(zero_grad), _stream()), "rp_adam_step")
+                                  beta1, beta2, eps, step, int(zero_grad), _ptr(scalars), _ptr(t_dev), _stream()),
+                   "rp_adam_step")
 
 
 # ---- exact lazy dense Adam (arena rows) ---------------------------------------------------------------
-def embed_keys(row_base, row_count, idx: List[torch.Tensor], err_flag):
+def embed_keys(row_base, row_count, idx: List[torch.Tensor], err_flag, out=None):
     F, B = len(idx), idx[0].shape[0]
-    keys = torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
+    keys = out if out is not None else torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
+    assert keys.numel() == F * B and keys.dtype == torch.int32
     with _Timed("embed_keys"):
         _check(lib().rp_embed_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, keys.data_ptr(),
                                    err_flag.data_ptr(), _stream()), "rp_embed_keys")
@@ -1092,6 +1103,9 @@ def _dropout_seed_offset(device):
     other torch random ops interleave consistently.  Falls back to a process-wide call counter if this torch build does
     not expose generator offsets."""
     global _drop_calls
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("dropout inside a captured step: its (seed, offset) are launch arguments and would be frozen at "
+                           "capture (every replay would draw the same mask) — run models with active dropout eagerly")
     try:
         gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
         seed, off = gen.initial_seed(), gen.get_offset()
@@ -1133,14 +1147,14 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, eps: flo
 
 
 def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int, real_step: bool, zero_grad: bool,
-                   beta1: float, beta2: float, eps: float, cf_table=None, cf_from: int = 0):
+                   beta1: float, beta2: float, eps: float, cf_table=None, cf_from: int = 0, t_dev=None):
     """cf_table (from lazy_adam_cf_table, built for the end step of this call's replay) selects the closed-form replay
     of the steps after `cf_from`; None = the bit-exact serial replay"""
     with _Timed("lazy_adam_rows_step" if real_step else "lazy_adam_rows_replay", f"D={D}"):
         _check(lib().rp_lazy_adam_rows(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
                                        m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_target,
                                        int(real_step), int(zero_grad), beta1, beta2, eps, _ptr(cf_table), cf_from,
-                                       _stream()),
+                                       _ptr(t_dev), _stream()),
                "rp_lazy_adam_rows")
 
 
@@ -1153,14 +1167,14 @@ def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, be
                "rp_lazy_adam_flush")
 
 
-def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table):
+def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table, t_dev=None):
     """(re)build the closed-form replay table for replays ending at step t_end (see rp_lazy_adam_cf_table):
     ns_d [>= t_end + 1, 2] float64 device table by step, cf_table [>= t_end - cf_from + 1, 8] float32 (written in place)"""
     assert ns_d.dtype == torch.float64 and ns_d.shape[0] > t_end and ns_d.is_contiguous()
     assert cf_table.dtype == torch.float32 and cf_table.shape[0] >= t_end - cf_from + 1 and cf_table.is_contiguous()
     with _Timed("lazy_adam_cf_table", f"{max(t_end - cf_from, 0)}"):
-        _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _stream()),
-               "rp_lazy_adam_cf_table")
+        _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _ptr(t_dev),
+                                           _stream()), "rp_lazy_adam_cf_table")
 
 
 POOL_MODES = {"sum": 0, "average": 1}

@@ -29,6 +29,11 @@ from ... import functional as Fh
 # flight and the one whose sort was started ahead (EmbeddingLayer._sorted_keys / prefetch_sort)
 _SORT_CACHE: list = []
 _SIDE_STREAMS: dict = {}  # device -> the stream sorts started ahead run on
+# PINNED entries (graph_step.GraphedTrainStep): the id tensors are STATIC input buffers that are refilled in place, the
+# (keys, sorted keys, positions) tensors are persistent and re-sorted IN PLACE by prefetch_sort — a captured hipGraph
+# holds all their addresses.  Matched by identity only (a refill bumps the versions), never evicted, no events (the
+# order is the capture's: the side stream is joined before the capture ends).
+_SORT_PINNED: list = []
 
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
@@ -342,6 +347,9 @@ class EmbeddingLayer(nn.Module):
         from ... import hip
         sig = (self._rows_sig(), str(self._arena.device))
         if src is not None:
+            for c_src, c_sig, c_out in _SORT_PINNED:
+                if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)):
+                    return c_out
             for entry in _SORT_CACHE:
                 c_src, c_ver, c_sig, c_out, c_event = entry
                 if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
@@ -383,6 +391,11 @@ class EmbeddingLayer(nn.Module):
             return
         src = tuple(X[c] for c in self.emb_feature)
         sig = (self._rows_sig(), str(self._arena.device))
+        pinned = next((c_out for c_src, c_sig, c_out in _SORT_PINNED
+                       if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src))), None)
+        if pinned is not None:  # static input buffers of a graphed step: re-sort into the persistent tensors
+            self._sort_into(X, pinned, on_side_stream=True)
+            return
         for c_src, c_ver, c_sig, _, _ in _SORT_CACHE:
             if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \
                     and c_ver == tuple(t._version for t in src):
@@ -402,6 +415,45 @@ class EmbeddingLayer(nn.Module):
         for t in src:
             t.record_stream(side)
         self._cache_sort(src, sig, (keys, sk, sp), event)
+
+    def _sort_into(self, X, out, on_side_stream: bool) -> None:
+        from ... import hip
+        keys, sk, sp = out
+        dev = self._arena.device
+        if not on_side_stream:
+            hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
+            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp))
+            return
+        side = _SIDE_STREAMS.get(dev)
+        if side is None:
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
+            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp))
+
+    def pin_sort(self, X) -> None:
+        """graph_step: X holds STATIC id tensors (refilled in place from now on).  Sort their current content into
+        persistent tensors on the current stream and pin the cache entry; later prefetch_sort(X) calls re-sort in place."""
+        src = tuple(X[c] for c in self.emb_feature)
+        sig = (self._rows_sig(), str(self._arena.device))
+        for c_src, c_sig, c_out in _SORT_PINNED:
+            if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)):
+                self._sort_into(X, c_out, on_side_stream=False)
+                return
+        n = sum(t.numel() for t in src)
+        out = tuple(torch.empty((n,), dtype=torch.int32, device=self._arena.device) for _ in range(3))
+        self._sort_into(X, out, on_side_stream=False)
+        _SORT_PINNED.append((src, sig, out))
+
+    @staticmethod
+    def unpin_sorts(X=None) -> None:
+        """drop the pinned entries of the static batch X (all of them when X is None)"""
+        if X is None:
+            del _SORT_PINNED[:]
+        else:
+            ids = {id(t) for t in X.values()}
+            _SORT_PINNED[:] = [e for e in _SORT_PINNED if not any(id(t) in ids for t in e[0])]
 
     def _rows_sig(self):
         if getattr(self, "_rows_sig_cache", None) is None:

@@ -26,17 +26,71 @@ import torch
 from . import hip
 
 
+class StepTables:
+    """The per-step scalars of one Adam clock in PERSISTENT device buffers, indexed by absolute step (row 0 unused):
+    sc [cap, 2] float32 = {A_t, B_t} (rp_adam_step_scalars), ns_d [cap, 2] float64 = {-lr_t/(1-b1^t), 1/sqrt(1-b2^t)}
+    (closed-form replay), t_dev int32[1] = completed steps (read by the kernels when a step runs inside a captured
+    hipGraph, graph_step.py).  Rows are built CHUNK steps ahead with the current lr and rebuilt in place from the
+    current step on when lr changes; steps already taken keep the lr they were taken with.  The buffers only move when
+    the capacity doubles (`generation` counts that: a captured graph holds their addresses)."""
+
+    def __init__(self, betas, eps, device, t0: int = 0, chunk: int = 1024):
+        cap = t0 + 2 + 2 * chunk
+        self.betas, self.eps = betas, eps
+        self.sc = torch.zeros((cap, 2), dtype=torch.float32, device=device)
+        self.ns_d = torch.zeros((cap, 2), dtype=torch.float64, device=device)
+        self.t_dev = torch.full((1,), t0, dtype=torch.int32, device=device)
+        self.filled_to, self.lr, self.lr_from = t0, None, t0 + 1
+        self.generation = 0
+
+    @property
+    def capacity(self) -> int:
+        return self.sc.shape[0]
+
+    def apply(self, fn):
+        self.sc, self.ns_d, self.t_dev = fn(self.sc), fn(self.ns_d), fn(self.t_dev)
+        self.generation += 1
+
+    def covers(self, t_new, lr) -> bool:
+        return t_new <= self.filled_to and (self.lr == lr or t_new < self.lr_from)
+
+    def ensure(self, t_new, lr, chunk: int = 1024):
+        """rows [.., t_new] exist and row t_new has been built with `lr`"""
+        if self.covers(t_new, lr):
+            return
+        assert self.filled_to >= t_new - 1, f"step table filled to {self.filled_to}, step {t_new} needs {t_new - 1}"
+        hi = t_new + chunk
+        if hi >= self.capacity:
+            cap = max(2 * self.capacity, hi + 1 + chunk)
+            for name in ("sc", "ns_d"):
+                old = getattr(self, name)
+                new = torch.zeros((cap, 2), dtype=old.dtype, device=old.device)
+                new[:old.shape[0]].copy_(old)
+                setattr(self, name, new)
+            self.generation += 1
+        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
+        self.sc[t_new:hi + 1].copy_(torch.tensor(rows, dtype=torch.float32))
+        j = torch.arange(t_new, hi + 1, dtype=torch.float64)
+        ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
+        d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
+        self.ns_d[t_new:hi + 1].copy_(torch.stack([ns, d], 1))
+        self.lr, self.lr_from, self.filled_to = lr, t_new, hi
+
+
 class LazyAdamRows:
-    """Per-EmbeddingLayer state of the lazy dense Adam: moment arenas, per-row `last` step stamps and the device table
-    of per-step scalars {A_t, B_t} (computed by the C library, like the dense kernel does).
+    """Per-EmbeddingLayer state of the lazy dense Adam: moment arenas, per-row `last` step stamps and the device tables
+    of per-step scalars (StepTables).
 
     replay="exact":  skipped zero-gradient steps are replayed one by one with the dense kernel's own update function:
                      bit-identical to dense execution (the parity mode);
     replay="closed": steps after CF_FROM are replayed in ONE evaluation per element whatever their number
                      (rp_lazy_adam_cf_table / adam.hip: uniformly convergent expansion of the summed updates, relative
                      truncation error <= 9e-8; the replay launch becomes an HBM stream instead of a VALU-bound serial
-                     chain).  Within 1e-6 relative of the exact replay per replay (tests/test_hip_lazy_adam.py); only
-                     for the reference's hyper-parameters betas = (0.9, 0.999), eps > 0 — anything else replays exactly."""
+                     chain).  Closer to float64 Adam than the serial fp32 replay (tests/test_hip_lazy_adam.py); only
+                     for the reference's hyper-parameters betas = (0.9, 0.999), eps > 0 — anything else replays serially.
+
+    device_clock (set by graph_step.GraphedTrainStep): the kernels read the step number from tabs.t_dev instead of the
+    launch arguments, so that a captured hipGraph can be replayed; the host counter `t` is then advanced by the caller."""
     TABLE_CHUNK = 1024
     CF_FROM = 256
 
@@ -47,19 +101,16 @@ class LazyAdamRows:
         self.betas, self.eps = betas, eps
         self.owner = owner           # weakref to the FusedAdam this state belongs to
         self.t = self.flushed_t = t0  # created mid-run (optimizer state loaded, arena re-packed): every row is current
-        # device table of per-step scalars, indexed by ABSOLUTE step: row j = step j's {A_j, B_j};
-        # row 0 is unused.  Rows <= t0 are never read (no row carries a stamp below t0) but must exist: the kernels
-        # index the table with the step number.
-        self._table = torch.zeros((t0 + 1, 2), dtype=torch.float32, device=a.device)
-        self._table_lr = None
-        self._table_from = t0 + 1
-        # closed-form replay: {ns_j, d_j} = {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)} by step in double (kept in either mode, so
-        # that the mode can be switched mid-run), and the per-k coefficient table valid for replays that end at step
-        # `_cf_for` (rebuilt on the device when the end step moves)
-        self._ns_d = torch.zeros((t0 + 1, 2), dtype=torch.float64, device=a.device)
+        # rows <= t0 of the tables are never read (no row carries a stamp below t0) but exist: the kernels index the
+        # tables with the step number
+        self.tabs = StepTables(betas, eps, a.device, t0, self.TABLE_CHUNK)
         self._cf_from = max(self.CF_FROM, t0)  # no row carries a stamp in (0, t0)
-        self._cf, self._cf_for = None, -1
+        # closed form: the per-k coefficient table valid for replays that end at step `_cf_for`
+        self._cf, self._cf_for, self._cf_gen = None, -1, -1
+        self.device_clock = False
         self.set_replay(replay)
+
+    _table = property(lambda self: self.tabs.sc)
 
     def set_replay(self, replay: str):
         """switch between the serial ("exact") and the closed-form ("closed") replay; takes effect at the next replay"""
@@ -68,41 +119,44 @@ class LazyAdamRows:
         self.closed = (replay == "closed" and abs(b[0] - 0.9) < 1e-12 and abs(b[1] - 0.999) < 1e-12 and self.eps > 0)
 
     def apply(self, fn):
-        self.m, self.v, self.last, self._table = fn(self.m), fn(self.v), fn(self.last), fn(self._table)
-        self._ns_d = fn(self._ns_d)
+        self.m, self.v, self.last = fn(self.m), fn(self.v), fn(self.last)
+        self.tabs.apply(fn)
         self._cf, self._cf_for = None, -1
 
     def _ensure_table(self, t_new, lr):
-        """rows [.., t_new] of the scalar table must exist and row t_new must have been built with `lr`."""
-        cap = self._table.shape[0] - 1
-        if t_new <= cap and (self._table_lr == lr or t_new < self._table_from):
+        if self.device_clock:  # inside a captured step: graph_step prepared the tables before the launch
+            assert self.tabs.covers(t_new, lr), "graphed step: the step tables were not prepared for this step / lr"
             return
-        assert cap >= t_new - 1, f"lazy Adam step table has {cap + 1} rows, step {t_new} needs rows up to {t_new - 1}"
-        hi = t_new + self.TABLE_CHUNK
-        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
-        new = torch.tensor(rows, dtype=torch.float32, device=self._table.device)
-        self._table = torch.cat([self._table[:t_new], new])  # steps < t_new keep the lr they were taken with
-        j = torch.arange(t_new, hi + 1, dtype=torch.float64)
-        ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
-        d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
-        self._ns_d = torch.cat([self._ns_d[:t_new], torch.stack([ns, d], 1).to(self._ns_d.device)]).contiguous()
-        self._table_lr, self._table_from = lr, t_new
+        self.tabs.ensure(t_new, lr, self.TABLE_CHUNK)
 
-    def _cf_args(self, t_end):
-        """closed-form arguments of a replay that ends at step t_end: (table, cf_from), or (None, 0) = exact replay"""
-        if not self.closed or t_end <= self._cf_from:
+    def _cf_buffer(self):
+        if self._cf is None or self._cf_gen != self.tabs.generation or self._cf.shape[0] < self.tabs.capacity:
+            self._cf = torch.zeros((self.tabs.capacity, 8), dtype=torch.float32, device=self.m.device)
+            self._cf_gen, self._cf_for = self.tabs.generation, -1
+        return self._cf
+
+    def _cf_args(self, t_end, build: bool = True):
+        """closed-form arguments of a replay that ends at step t_end: (table, cf_from), or (None, 0) = serial replay"""
+        if not self.closed:
             return None, 0
+        if self.device_clock:  # the table is rebuilt on the device for *t_dev by every replay launch of a step
+            cf = self._cf_buffer()
+            if build:
+                hip.lazy_adam_cf_table(self.tabs.ns_d, self.tabs.capacity - 1, self._cf_from, self.betas[0], self.betas[1],
+                                       cf, t_dev=self.tabs.t_dev)
+                self._cf_for = -1
+            return cf, self._cf_from
+        if t_end <= self._cf_from:
+            return None, 0
+        cf = self._cf_buffer()
         if self._cf_for != t_end:
-            need = t_end - self._cf_from + 1
-            if self._cf is None or self._cf.shape[0] < need:
-                self._cf = torch.zeros((need + self.TABLE_CHUNK, 8), dtype=torch.float32, device=self.m.device)
-            hip.lazy_adam_cf_table(self._ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], self._cf)
+            hip.lazy_adam_cf_table(self.tabs.ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], cf)
             self._cf_for = t_end
-        return self._cf, self._cf_from
+        return cf, self._cf_from
 
     def _check_table(self, t_target):
-        if self._table.shape[0] <= t_target:
-            raise RuntimeError(f"lazy Adam: step table has {self._table.shape[0]} rows but step {t_target} is needed")
+        if self.tabs.filled_to < t_target:
+            raise RuntimeError(f"lazy Adam: step table filled to {self.tabs.filled_to} but step {t_target} is needed")
 
     def _sorted_touched(self, store):
         sk = store._touched
@@ -112,12 +166,16 @@ class LazyAdamRows:
             sk, _ = hip.sort_pairs(sk, end_bit=store._meta()[3])
         return sk
 
+    def _t_dev(self):
+        return self.tabs.t_dev if self.device_clock else None
+
     def replay(self, store, sorted_keys):
         if self.t > 0:
             self._check_table(self.t)
             cf, cf_from = self._cf_args(self.t)
             hip.lazy_adam_rows(sorted_keys, store.embedding_dim, store.arena, None, self.m, self.v, self.last,
-                               self._table, self.t, False, False, self.betas[0], self.betas[1], self.eps, cf, cf_from)
+                               self.tabs.sc, self.t, False, False, self.betas[0], self.betas[1], self.eps, cf, cf_from,
+                               self._t_dev())
 
     def step(self, store, lr, zero_grad: bool = True):
         t_new = self.t + 1
@@ -125,9 +183,12 @@ class LazyAdamRows:
         self._check_table(t_new)
         sk = self._sorted_touched(store)
         if sk is not None and sk.numel():
-            cf, cf_from = self._cf_args(self.t)  # the catch-up before the real step ends at t_new - 1
+            cf, cf_from = self._cf_args(self.t, build=False)  # the catch-up before the real step ends at t_new - 1
             hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
-                               self._table, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps, cf, cf_from)
+                               self.tabs.sc, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps, cf, cf_from,
+                               self._t_dev())
+        if self.device_clock:
+            hip.counter_add(self.tabs.t_dev, 1)
         self.t = t_new
         if zero_grad:  # FusedAdam(fuse_zero_grad=True): the gradient rows were cleared inside the step
             store.grads_were_zeroed()
@@ -136,9 +197,11 @@ class LazyAdamRows:
         if self.flushed_t == self.t:
             return
         self._check_table(self.t)
+        was, self.device_clock = self.device_clock, False  # (never inside a captured step: host arguments)
         cf, cf_from = self._cf_args(self.t)
+        self.device_clock = was
         hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
-                            self._table, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
+                            self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
         self.flushed_t = self.t
 
 
@@ -153,6 +216,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.fuse_zero_grad = fuse_zero_grad
         self.lazy_tables = lazy_tables
         self.replay = replay
+        self._device_clock = False  # graph_step.GraphedTrainStep: the kernels read the step number on the device
+        self._dense_tabs: Dict[int, StepTables] = {}
         self._arena_state: Dict[int, dict] = {}
         self._stores = {}
         self._plans: Dict[int, list] = {}
@@ -268,8 +333,72 @@ class FusedAdam(torch.optim.Optimizer):
                 if self.fuse_zero_grad:
                     store.grads_were_zeroed()
             if ps:
-                hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
+                tabs = self._dense_tabs.get(id(group)) if self._device_clock else None
+                if tabs is not None:
+                    assert tabs.covers(step, lr), "graphed step: the dense step table was not prepared for this step / lr"
+                    hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad, scalars=tabs.sc,
+                                  t_dev=tabs.t_dev)
+                    hip.counter_add(tabs.t_dev, 1)
+                else:
+                    hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
         return loss
+
+    # ---- device-resident step counters (graph_step.GraphedTrainStep) --------------------------------------------------
+    def _lazies(self):
+        return [st._lazy for st in self._stores.values() if st._lazy is not None]
+
+    def set_device_clock(self, on: bool):
+        """on: every kernel of step() (and the lazy replays of the forward) reads the step number from device memory
+        (StepTables.t_dev) — what a captured hipGraph needs.  The host counters stay authoritative for everything outside
+        the captured step; they must be advanced with advance_host() after every replay."""
+        self._device_clock = on
+        for group in self.param_groups:
+            if on:
+                t = group.get("_rp_step", 0)
+                dev = next((p.device for p in group["params"] if p.is_cuda), None)
+                tabs = self._dense_tabs.get(id(group))
+                if tabs is None and dev is not None:
+                    tabs = self._dense_tabs[id(group)] = StepTables(group["betas"], group["eps"], dev, t)
+                if tabs is not None:
+                    tabs.t_dev.fill_(t)
+        for lz in self._lazies():
+            lz.device_clock = on
+            lz.tabs.t_dev.fill_(lz.t)
+
+    def prepare_step(self):
+        """tables of the NEXT step exist for the current lr (host work that cannot run inside a capture); returns a
+        signature that changes when a buffer a captured graph holds has moved"""
+        sig = []
+        for group in self.param_groups:
+            tabs = self._dense_tabs.get(id(group))
+            if tabs is None:
+                dev = next((p.device for p in group["params"] if p.is_cuda), None)
+                if dev is not None:
+                    tabs = self._dense_tabs[id(group)] = StepTables(group["betas"], group["eps"], dev, group.get("_rp_step", 0))
+            if tabs is not None:
+                tabs.ensure(group.get("_rp_step", 0) + 1, group["lr"])
+                sig.append(tabs.generation)
+            for lz in self._lazies():
+                lz.tabs.ensure(lz.t + 1, group["lr"], lz.TABLE_CHUNK)
+                lz._cf_buffer()
+                sig.append((lz.tabs.generation, lz.closed))
+        return tuple(sig)
+
+    def host_counters(self):
+        return [g.get("_rp_step", 0) for g in self.param_groups], [lz.t for lz in self._lazies()]
+
+    def set_host_counters(self, counters):
+        for g, t in zip(self.param_groups, counters[0]):
+            g["_rp_step"] = t
+        for lz, t in zip(self._lazies(), counters[1]):
+            lz.t = t
+
+    def advance_host(self):
+        """one captured step was replayed: the device counters moved, move the host ones"""
+        for g in self.param_groups:
+            g["_rp_step"] = g.get("_rp_step", 0) + 1
+        for lz in self._lazies():
+            lz.t += 1
 
     def _adopt_loaded_state(self, store, m, v, lz):
         """Moments that load_state_dict() put into self.state for the table Parameters (optimizer resume) are copied

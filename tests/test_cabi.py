@@ -43,7 +43,7 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b"null" in lib.rp_last_error()
     rc = lib.rp_embed_gather_fwd(None, None, None, None, 0, None, 0, 1, 1, None, 0, None, None, None, None, None)
     assert rc == -1
-    rc = lib.rp_adam_step(None, None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 1, 0, None)
+    rc = lib.rp_adam_step(None, None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 1, 0, None, None, None)
     assert rc == -1
 
 

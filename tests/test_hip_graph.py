@@ -1,0 +1,170 @@
+"""The captured training step (rec_pangu_amd/graph_step.py: forward + backward + FusedAdam step + zero_grad in one
+hipGraph, device-resident step counters, static double-buffered inputs, next batch's sort inside the graph) against the
+eager loop on the same batches: every prediction, loss, weight and optimizer moment bit-identical."""
+import pytest
+import torch
+
+from conftest import require_gpu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    require_gpu()
+    from rec_pangu_amd import hip
+    hip.lib()
+
+
+def _enc(n_dense, vocabs):
+    enc = {f"I{i}": {"min": 0.0, "max": 1.0} for i in range(n_dense)}
+    enc.update({f"C{i}": {"vocab_size": v} for i, v in enumerate(vocabs)})
+    return enc
+
+
+def _batches(enc, B, n, seed):
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        b = {k: (torch.rand(B, generator=gen) if "min" in v else torch.randint(0, v["vocab_size"] + 1, (B,), generator=gen))
+             for k, v in enc.items()}
+        b["label"] = (torch.rand(B, generator=gen) < 0.3).float()
+        out.append({k: v.to(DEV) for k, v in b.items()})
+    return out
+
+
+def _build(kind, enc):
+    from rec_pangu_amd.models.ranking import DCN, DeepFM
+    torch.manual_seed(0)
+    if kind == "deepfm64":   # D = 64, [64, 64, 64]: the fused gather + Linear forward and the fused gather backward
+        model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+    elif kind == "deepfm16":
+        model = DeepFM(embedding_dim=16, hidden_units=[32, 16], enc_dict=enc)
+    else:
+        model = DCN(embedding_dim=16, hidden_units=[32, 16], enc_dict=enc)
+    model = model.to(DEV)
+    for m in model.modules():
+        if hasattr(m, "check_indices"):
+            m.check_indices = "deferred"
+    return model
+
+
+@pytest.mark.parametrize("kind,replay,steps", [("deepfm64", "closed", 330), ("deepfm64", "exact", 60), ("deepfm16", "closed", 300),
+                                               ("dcn", "closed", 60)])
+def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps):
+    """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
+    in-place extensions of the step tables; the learning rate changes twice on the way)"""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows
+    enc = _enc(5, [3000, 17, 900, 4, 20000, 250])
+    batches = _batches(enc, 384, steps + 1, seed=4)
+    results = {}
+    chunk, LazyAdamRows.TABLE_CHUNK = LazyAdamRows.TABLE_CHUNK, 100
+    try:
+        for mode in ("eager", "graph"):
+            model = _build(kind, enc)
+            opt = FusedAdam(model.parameters(), lr=1e-3, fuse_zero_grad=True, lazy_tables=True, replay=replay)
+            gstep = GraphedTrainStep(model, opt) if mode == "graph" else None
+            preds, losses = [], []
+            for i in range(steps):
+                if i in (40, 200):
+                    for grp in opt.param_groups:
+                        grp["lr"] *= 0.5
+                if gstep is not None:
+                    out = gstep(batches[i], batches[i + 1])
+                else:
+                    model.prefetch(batches[i + 1])
+                    out = model(batches[i])
+                    out["loss"].backward()
+                    opt.step()
+                    model.zero_grad()
+                if i % 7 == 0 or i > steps - 4:
+                    preds.append(out["pred"].detach().clone())
+                    losses.append(out["loss"].detach().clone())
+            if gstep is not None:
+                assert gstep.replays == steps - 2, "every step after the two eager ones must have been a graph replay"
+                assert gstep.graphs[0] is not None and gstep.graphs[1] is not None
+            lz = model.embedding_layer._lazy
+            assert lz.t == steps
+            if mode == "graph":
+                assert int(lz.tabs.t_dev.item()) == steps, "device and host step counters must agree"
+            model.embedding_layer.raise_if_bad_index()
+            sd = {k: v.clone() for k, v in model.state_dict().items()}  # (flushes the lazy rows: host counters must be right)
+            osd = opt.state_dict()
+            results[mode] = (preds, losses, sd, [{k: v.clone() for k, v in st.items() if torch.is_tensor(v)} for st in osd["state"].values()],
+                             [g["_rp_step"] for g in osd["param_groups"]])
+    finally:
+        LazyAdamRows.TABLE_CHUNK = chunk
+        from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+        EmbeddingLayer.unpin_sorts()
+    e, g = results["eager"], results["graph"]
+    for a, b in zip(e[0], g[0]):
+        assert torch.equal(a, b), "predictions differ"
+    for a, b in zip(e[1], g[1]):
+        assert torch.equal(a, b), "losses differ"
+    for k in e[2]:
+        assert torch.equal(e[2][k], g[2][k]), k
+    for sa, sb in zip(e[3], g[3]):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), f"optimizer state {k}"
+    assert e[4] == g[4]
+    assert hip.launch_count() > 0
+
+
+def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch():
+    """a batch that was not announced by the previous call is staged and sorted on the spot; a call without a next batch
+    (end of an epoch) runs eagerly; the run continues on the graphs afterwards — all bit-identical to the eager loop"""
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.optim import FusedAdam
+    from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+    enc = _enc(3, [500, 9, 4000])
+    batches = _batches(enc, 256, 24, seed=9)
+    order = [(i, i + 1) for i in range(8)] + [(8, None)] + [(12, 13), (13, 14), (20, 21), (14, 15), (15, None)]
+    finals = {}
+    try:
+        for mode in ("eager", "graph"):
+            model = _build("deepfm16", enc)
+            opt = FusedAdam(model.parameters(), lr=2e-3, fuse_zero_grad=True, lazy_tables=True, replay="closed")
+            gstep = GraphedTrainStep(model, opt) if mode == "graph" else None
+            for cur, nxt in order:
+                nb = batches[nxt] if nxt is not None else None
+                if gstep is not None:
+                    gstep(batches[cur], nb)
+                else:
+                    if nb is not None:
+                        model.prefetch(nb)
+                    model(batches[cur])["loss"].backward()
+                    opt.step()
+                    model.zero_grad()
+            finals[mode] = {k: v.clone() for k, v in model.state_dict().items()}
+            if gstep is not None:
+                assert gstep.replays == len(order) - 2 - 2
+    finally:
+        EmbeddingLayer.unpin_sorts()
+    for k in finals["eager"]:
+        assert torch.equal(finals["eager"][k], finals["graph"][k]), k
+
+
+def test_graphed_step_refuses_what_it_cannot_capture():
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.optim import FusedAdam
+    enc = _enc(2, [50, 7])
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=8, hidden_units=[8], enc_dict=enc).to(DEV)  # check_indices is still "sync"
+    opt = FusedAdam(model.parameters(), lr=1e-3, fuse_zero_grad=True, lazy_tables=True)
+    with pytest.raises(RuntimeError, match="deferred"):
+        GraphedTrainStep(model, opt)
+    with pytest.raises(RuntimeError, match="FusedAdam"):
+        GraphedTrainStep(model, torch.optim.Adam(model.parameters()))
+    # active dropout: the mask's (seed, offset) are launch arguments and would be frozen at capture
+    from rec_pangu_amd import hip
+    real = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: True
+    try:
+        with pytest.raises(RuntimeError, match="dropout"):
+            hip._dropout_seed_offset(torch.device(DEV))
+    finally:
+        torch.cuda.is_current_stream_capturing = real
