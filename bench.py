@@ -201,6 +201,10 @@ def main():
                     help="how the lazy optimizer catches a row up: 'closed' (library default) = closed-form replay of the "
                          "skipped zero-gradient steps (<= 1e-6 relative to the serial replay per replay, an HBM stream), "
                          "'exact' = serial replay, bit-identical to the dense HIP kernel (VALU-bound)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole training step (fwd + bwd + optimizer + the next batch's sort) from a captured "
+                         "hipGraph (rec_pangu_amd/graph_step.py; bit-identical to the eager step).  auto = on for single-GPU "
+                         "training of the models without active dropout (deepfm, dcn)")
     ap.add_argument("--no-sort-ahead", action="store_true",
                     help="do not announce the next batch (BaseModel.prefetch): its row sort then runs inside its own step "
                          "instead of on the side stream beside the previous one")
@@ -267,10 +271,23 @@ def main():
     def gen(i):  # a DISTINCT batch per step, generated on the device
         return synth_batch(enc, local_B, 100 + 100003 * rank + i, dev, args.id_dist)
 
-    def step(data, nxt=None):
+    # auto: only where the eager step is HOST-bound (small per-GPU batches).  On this runtime a replayed graph costs the
+    # device ~10 us per node more than the same launches issued eagerly (B = 65536: 1.6 ms replayed against 1.26 eager in
+    # the cold state, scratch/probe_graph5.py) — a win at b = 8192, a loss at the headline batch
+    use_graph = args.mode == "train" and not sharded and not args.no_sort_ahead and (
+        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn") and local_B <= 16384))
+    gstep = None
+    if use_graph:
+        from rec_pangu_amd.graph_step import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt)
+
+    def step(data, nxt=None, graphed=False):
         if args.mode == "forward":
             with torch.no_grad():
                 model(data, is_training=False)
+            return
+        if graphed and gstep is not None and nxt is not None:
+            gstep(data, nxt)  # (its first two calls run eagerly; then one capture per static input set; then replays)
             return
         if nxt is not None:
             model.prefetch(nxt)  # the next batch's row sort is started behind this forward, on the side stream
@@ -324,9 +341,12 @@ def main():
                 "note": "first steps after initialisation: the lazy optimizer has nothing to replay yet"}
         del cb
         # ---- (2) pre-roll to the long-run state
+        nb = gen(n_seen)
         for i in range(pre_roll):
-            step(gen(n_seen + i))
-        n_seen += pre_roll
+            cur, nb = nb, gen(n_seen + i + 1)
+            step(cur, nb if gstep is not None else None, graphed=True)
+        del cur, nb
+        n_seen += pre_roll + 1
         barrier()
 
     # ---- (3) warm-up; its last few steps double as the per-kernel profiling pass (a HIP-event pair around EVERY
@@ -370,14 +390,32 @@ def main():
     barrier()
     t0 = time.perf_counter()
     host_s = 0.0
+    if gstep is not None:
+        # replays carry no HIP events (no python runs inside a replay): the durations of the reported kernels come from
+        # eager steps right after the timed region instead (same launches, same state)
+        hip.enable_timing(False)
+        for i in range(3):  # the two captures (one per static input set) stay outside the timed region
+            step(batches[(n_batches - 3 + i) % n_batches], batches[(n_batches - 2 + i) % n_batches], graphed=True)
+        barrier()
+        t0 = time.perf_counter()
+    replays0 = gstep.replays if gstep is not None else 0
     for i in range(args.steps):
         hip.pause_timing(i % ev_stride != 0)
         th = time.perf_counter()
-        step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None)
+        step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None, graphed=True)
         host_s += time.perf_counter() - th  # time the host needs to ENQUEUE a step (it runs ahead of the device)
     hip.pause_timing(False)
     barrier()
     dt = time.perf_counter() - t0
+    if gstep is not None:
+        assert gstep.replays - replays0 == args.steps, "every timed step must have been a graph replay"
+        if prof is not None:
+            hip.enable_timing(True, only=watch)
+        else:
+            hip.enable_timing(True)
+        for i in range(8):
+            step(batches[(args.steps + i) % n_batches], batches[(args.steps + i + 1) % n_batches] if ahead else None)
+        barrier()
     timing = hip.timing_summary()
     meta = hip.timing_meta()
     hip.enable_timing(False)
@@ -412,6 +450,39 @@ def main():
         opt.flush()
         barrier()
         flush_ms = (time.perf_counter() - t1) * 1e3
+
+    # ---- (6) the per-GPU batch of a STRONG-scaling run at G = 8 (b = B / 8): eager against the captured hipGraph.  At this
+    #          size the eager step is host-bound (the host needs ~1 ms to enqueue what the device runs in ~0.4 ms)
+    small = None
+    if (args.mode == "train" and not sharded and world == 1 and args.model in ("deepfm", "dcn") and local_B > 16384
+            and not args.no_sort_ahead and args.graph != "off"):
+        from rec_pangu_amd.graph_step import GraphedTrainStep
+        sb = local_B // 8
+        sbat = [synth_batch(enc, sb, 900000 + i, dev, args.id_dist) for i in range(40)]
+
+        def run(fn, n_warm, n_timed):
+            for i in range(n_warm):
+                fn(sbat[i % 40], sbat[(i + 1) % 40])
+            barrier()
+            t_ = time.perf_counter()
+            h_ = 0.0
+            for i in range(n_warm, n_warm + n_timed):
+                th_ = time.perf_counter()
+                fn(sbat[i % 40], sbat[(i + 1) % 40])
+                h_ += time.perf_counter() - th_
+            barrier()
+            return {"ms_per_step": round((time.perf_counter() - t_) / n_timed * 1e3, 4),
+                    "host_enqueue_ms_per_step": round(h_ / n_timed * 1e3, 4)}
+        eager = run(lambda a, b: step(a, b), 10, 40)
+        gs_small = GraphedTrainStep(model, opt)
+        graph = run(lambda a, b: gs_small(a, b), 10, 40)
+        assert gs_small.replays >= 40
+        small = {"per_gpu_batch": sb, "eager": eager, "hip_graph": graph,
+                 "samples_per_s_hip_graph": round(sb / (graph["ms_per_step"] * 1e-3), 1),
+                 "note": "fwd + bwd + optimizer at the per-GPU batch of a strong-scaling run on 8 GPUs, same model and "
+                         "optimizer state: eager launches against replays of the captured step (bit-identical results)"}
+        barrier()
+        del gs_small
 
     # ---- per-kernel numbers (algorithmic bytes from SURVEY.md 8d) --------------------------------
     F = sum(1 for v in enc.values() if "vocab_size" in v)
@@ -619,17 +690,25 @@ def main():
                        "global_batch": B, "per_gpu_batch": local_B, "optimizer": opt_txt,
                        "matmul_precision": precision, "lazy_replay": replay_mode,
                        "sort_ahead": bool(ahead),
+                       "hip_graph": (f"the timed steps are replays of a captured hipGraph (fwd + bwd + optimizer step + "
+                                     f"zero_grad + the next batch's sort; rec_pangu_amd/graph_step.py, bit-identical to the "
+                                     f"eager step: tests/test_hip_graph.py)" if gstep is not None else None),
                        "unique_rows_per_batch": n_unique,
                        "parallelism": "single GPU" if not sharded else f"tables row-sharded x{world}, all-to-all lookup"},
             "pre_roll_steps": pre_roll, "cold": cold,
             "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
             "roofline": roofline, "roofline_gather": gather, "kernels": kernels,
             "kernels_note": f"per-kernel table: HIP events around every launch during the last {n_prof} warm-up steps; "
-                            f"roofline/roofline_gather durations: HIP events inside the timed region, every "
-                            f"{ev_stride}th step",
+                            + (f"roofline/roofline_gather durations: HIP events around the same launches in 8 eager steps "
+                               f"right after the timed region (a replayed graph runs no python, so no event can bracket one "
+                               f"of its nodes; profiles/ holds the rocprofv3 trace of the replays)" if gstep is not None else
+                               f"roofline/roofline_gather durations: HIP events inside the timed region, every "
+                               f"{ev_stride}th step"),
         }
         if gemm is not None:
             res["roofline_gemm"] = gemm
+        if small is not None:
+            res["strong_scaling_batch"] = small
         if lazy:
             res["lazy_adam"] = {
                 "state": f"long-run: {pre_roll} un-timed pre-roll steps on distinct batches before the warm-up",

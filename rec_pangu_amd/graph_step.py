@@ -9,10 +9,13 @@ What makes a step capturable here:
   * the STEP NUMBER lives on the device: every launch argument is frozen at capture, so the Adam kernels read the step from
     StepTables.t_dev (rp_adam_step / rp_lazy_adam_rows / rp_lazy_adam_cf_table with t_dev, rp_counter_add) and the
     per-step scalar tables are persistent buffers that the host extends in place (optim.StepTables);
-  * STATIC INPUT BUFFERS, two sets: graph P reads the current batch from X[P] and — on the side stream, beside its backward
-    — sorts the NEXT batch, already staged in X[1-P], into the persistent (keys, sorted keys, positions) tensors that
-    graph 1-P will read (EmbeddingLayer.pin_sort / prefetch_sort); the caller's batches are copied in with one
-    multi-tensor copy per dtype;
+  * STATIC INPUT BUFFERS, two sets: graph P reads the current batch from X[P] and its (keys, sorted keys, positions) from
+    persistent tensors (EmbeddingLayer.pin_sort); the NEXT batch is copied into X[1-P] (one multi-tensor copy per dtype)
+    before the launch and sorted at the END of graph P, on the same stream, into the tensors graph 1-P reads.  The sort
+    is NOT overlapped with the step as the eager path does it (side stream): a fork inside one graph is replayed without
+    overlap by this runtime, and a second graph on a second stream (measured 0.49 against 0.52 ms at b = 8192) died with
+    memory access faults whenever the host ran more than a few steps ahead without a device-wide synchronisation
+    (scratch/probe_graph6.py) — one linear graph on one stream has run thousands of unsynchronised steps;
   * no host synchronisation inside the step: check_indices = "deferred" (raise_if_bad_index() after the run).
 
 The captured launches are the eager path's own (same kernels, same order, same arguments except the step number's
@@ -27,6 +30,7 @@ import torch
 from .models.layers import embedding as _emb
 
 
+
 class GraphedTrainStep:
     """step = GraphedTrainStep(model, optimizer); out = step(batch, next_batch) in the training loop.
 
@@ -35,6 +39,15 @@ class GraphedTrainStep:
     (do not keep an autograd graph of an earlier eager step alive across the first captured call: its AccumulateGrad nodes
     are bound to the eager stream).  `post_backward`: a hook run
     between backward and optimizer step (eager and captured alike)."""
+
+    MAX_IN_FLIGHT = 6
+
+    def __del__(self):
+        try:
+            if any(g is not None for g in self.graphs):
+                torch.cuda.synchronize()
+        except Exception:
+            pass
 
     def __init__(self, model, optimizer, post_backward: Optional[Callable[[], None]] = None, eager_steps: int = 2):
         if not getattr(model, "on_hip", False):
@@ -53,6 +66,7 @@ class GraphedTrainStep:
         self.graphs = [None, None]
         self.outs = [None, None]
         self.P = 0
+        self._inflight, self._ev_pool = [], []  # completion events of the replays not yet known to have finished
         self._staged = None      # the caller's batch object whose content X[P] holds (sorted and pinned)
         self._sig = None
         self._pool = None
@@ -73,7 +87,19 @@ class GraphedTrainStep:
         # stream) alive into the capture, which runs on another stream — that cross-stream dependency breaks the capture
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
+    # rocPRIM switches to its onesweep radix sort above ~1 M pairs (global digit counters reset by memset nodes between
+    # the passes).  Replayed from a graph WITHOUT device-wide synchronisations in between, that path ends in memory access
+    # faults within a few hundred steps (B = 40960 x 26 fields = 1.06 M pairs: fault; B = 32768 = 0.85 M pairs: 600 steps
+    # clean; B = 65536 with torch.cuda.synchronize() every 50 steps: 1300 steps clean — scratch/probe_graph6.py).  Captured
+    # steps are the tool for SMALL, host-bound batches anyway (at B = 65536 a replay is slower than the eager launches).
+    MAX_PAIRS = 900_000
+
     def _alloc(self, batch):
+        n_pairs = sum(batch[c].numel() for c in self.model.embedding_layer.emb_feature)
+        if n_pairs > self.MAX_PAIRS:
+            raise RuntimeError(f"GraphedTrainStep: {n_pairs} (sample, field) pairs per batch — above {self.MAX_PAIRS} the "
+                               "row sort takes rocPRIM's onesweep path, which does not survive unsynchronised graph "
+                               "replays on this runtime; run batches of this size eagerly (they are not host-bound)")
         self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
         self._keys = list(batch.keys())
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
@@ -82,10 +108,6 @@ class GraphedTrainStep:
     def _copy(self, P, batch):
         dst = [self.X[P][k] for k in self._keys]
         src = [batch[k] for k in self._keys]
-        for d, s_ in zip(dst, src):
-            if d.shape != s_.shape or d.dtype != s_.dtype:
-                raise RuntimeError("GraphedTrainStep: every batch must have the shapes and dtypes of the first one "
-                                   "(drop the last, smaller batch of an epoch or run it eagerly)")
         torch._foreach_copy_(dst, src)
 
     def _stage_current(self, batch):
@@ -101,16 +123,14 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, pool=self._pool):
-                self.model.prefetch(self.X[1 - P])
-                out = self.model(self.X[P])
+                out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
                 out["loss"].backward()
                 if self.post_backward is not None:
                     self.post_backward()
                 self.opt.step()
                 self.model.zero_grad()
-                cur = torch.cuda.current_stream()
-                for side in _emb._SIDE_STREAMS.values():
-                    cur.wait_stream(side)  # the sort of the next batch is part of this graph
+                # the next batch (already staged in X[1-P] when the graph is launched): keys + sort into its pinned tensors
+                self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
         finally:
             # the capture ran the python of one step without executing a kernel: put the host counters back
             self.opt.set_host_counters(counters)
@@ -120,8 +140,17 @@ class GraphedTrainStep:
         self.graphs[P], self.outs[P] = g, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         del out
 
+    def _pinned(self, Q):
+        src = tuple(self.X[Q][c] for c in self.model.embedding_layer.emb_feature)
+        for c_src, _, c_out in _emb._SORT_PINNED:
+            if len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)):
+                return c_out
+        raise RuntimeError("GraphedTrainStep: the static batch lost its pinned sort buffers")
+
     def reset(self):
         """drop the captured graphs (buffers they hold moved, the model or the batch shape changed)"""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()  # never destroy a graph executable that is still in flight
         self.graphs, self.outs, self._pool = [None, None], [None, None], None
         if self.X is not None:
             for x in self.X:
@@ -129,6 +158,11 @@ class GraphedTrainStep:
         self.X, self._staged = None, None
 
     # ---- the step ------------------------------------------------------------------------------------------------------
+    def _fits(self, batch) -> bool:
+        x = self.X[0]
+        return batch.keys() == x.keys() and all(batch[k].shape == x[k].shape and batch[k].dtype == x[k].dtype and
+                                                batch[k].device == x[k].device for k in x)
+
     def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
         if self.eager_left > 0 or next_batch is None:
             self.eager_left -= 1
@@ -136,6 +170,11 @@ class GraphedTrainStep:
             return self._eager(batch, next_batch)
         if self.X is None:
             self._alloc(batch)
+        if not (self._fits(batch) and self._fits(next_batch)):
+            # another shape than the captured one (the smaller last batch of an epoch, or the batch before it, whose
+            # captured step would sort it): this step runs eagerly
+            self._staged = None
+            return self._eager(batch, next_batch)
         if self._staged is not batch:      # not the batch announced by the previous call: stage and sort it now
             self._stage_current(batch)
         P = self.P
@@ -143,6 +182,9 @@ class GraphedTrainStep:
         sig = self.opt.prepare_step()
         if sig != self._sig:               # a table a graph points into has moved (capacity doubled, replay mode changed)
             if self._sig is not None:
+                # launches of the old graphs may still be in flight (the host runs steps ahead): destroying a graph
+                # executable under them frees the kernel arguments they read (observed: memory aperture violation)
+                torch.cuda.synchronize()
                 self.graphs, self.outs, self._pool = [None, None], [None, None], None  # (the pool dies with its graphs)
             self._sig = sig
         if self.graphs[P] is None:
@@ -151,7 +193,15 @@ class GraphedTrainStep:
         if counters != self._dev:          # eager steps ran in between: bring the device counters to the host's
             self.opt.set_device_clock(True)
             self.opt.set_device_clock(False)
+        # bound how far the host runs ahead (a handful of launches in flight is all the overlap there is to win)
+        if len(self._inflight) >= self.MAX_IN_FLIGHT:
+            done = self._inflight.pop(0)
+            done.synchronize()
+            self._ev_pool.append(done)
         self.graphs[P].replay()
+        ev = self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()
+        ev.record()
+        self._inflight.append(ev)
         self.opt.advance_host()
         self._dev = self.opt.host_counters()
         self.replays += 1

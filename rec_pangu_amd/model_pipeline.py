@@ -51,9 +51,10 @@ def _check_indices(model):
             m.raise_if_bad_index()
 
 
-def _one_ahead(loader, device, model):
+def _one_ahead(loader, device, model, pairs: bool = False):
     """The loader's batches in order, each yielded after the NEXT one has been moved to the device and announced to the
-    model (BaseModel.prefetch: its row sort overlaps the step in flight).  Same batches, same order, same RNG draws."""
+    model (BaseModel.prefetch: its row sort overlaps the step in flight).  Same batches, same order, same RNG draws.
+    pairs: yield (batch, next batch or None) and leave the announcing to the caller (a GraphedTrainStep)."""
     announce = getattr(model, "prefetch", None)
     if hasattr(loader, "hold"):
         loader.hold = 2  # loaders that recycle device buffers (PinnedBatchLoader): two batches are alive at once
@@ -64,15 +65,20 @@ def _one_ahead(loader, device, model):
         return
     for nxt in it:
         nxt = _move(nxt, device)
-        if announce is not None:
+        if announce is not None and not pairs:
             announce(nxt)
-        yield cur
+        yield (cur, nxt) if pairs else cur
         cur = nxt
-    yield cur
+    yield (cur, None) if pairs else cur
 
 
 def train_model(model, train_loader, optimizer, device, metric_list: List[str] = ['roc_auc_score', 'log_loss'],
-                num_task: int = 1, use_wandb: bool = False, log_rounds: int = 100) -> dict:
+                num_task: int = 1, use_wandb: bool = False, log_rounds: int = 100, graphed_step=None) -> dict:
+    """graphed_step: a rec_pangu_amd.graph_step.GraphedTrainStep over (model, optimizer): the steps are then replays of
+    a captured hipGraph (same launches, bit-identical results; batches of another shape — the last one of an epoch —
+    fall back to the eager step)."""
+    if graphed_step is not None:
+        return _train_model_graphed(model, train_loader, device, metric_list, num_task, log_rounds, graphed_step)
     model.train()
     max_iter = int(train_loader.dataset.__len__() / train_loader.batch_size)
     tasks = range(num_task)
@@ -96,6 +102,29 @@ def train_model(model, train_loader, optimizer, device, metric_list: List[str] =
             elapsed = time.time() - start_time
             remaining = round(((elapsed / (idx + 1)) * (max_iter - idx + 1)) / 60, 2)
             logger.info(f'Iter {idx}/{max_iter} Remaining time:{remaining} min Loss:{round(float(loss.detach()), 4)}')
+    _check_indices(model)
+    res = dict()
+    for i in tasks:
+        y, p = _to_host(labels[i]), _to_host(preds[i])
+        for metric in metric_list:
+            key = f'train_{metric}' if num_task == 1 else f'train_task{i + 1}_{metric}'
+            res[key] = _metric(metric, y, p)
+    return res
+
+
+def _train_model_graphed(model, train_loader, device, metric_list, num_task, log_rounds, graphed_step) -> dict:
+    model.train()
+    tasks = range(num_task)
+    preds = [[] for _ in tasks]
+    labels = [[] for _ in tasks]
+    for idx, (data, nxt) in enumerate(_one_ahead(train_loader, device, model, pairs=True)):
+        output = graphed_step(data, nxt)
+        for i in tasks:
+            pk, lk = ('pred', 'label') if num_task == 1 else (f'task{i + 1}_pred', f'task{i + 1}_label')
+            preds[i].append(output[pk].detach().clone())  # (a static tensor of the graph: the next replays overwrite it)
+            labels[i].append(data[lk].detach())
+        if idx % log_rounds == 0:
+            logger.info(f'Iter {idx} Loss:{round(float(output["loss"].detach()), 4)}')
     _check_indices(model)
     res = dict()
     for i in tasks:

@@ -35,12 +35,22 @@ class RankTrainer:
     def fit(self, model, train_loader, valid_loader: Optional = None, epoch: int = 10, lr: float = 1e-3,
             device: torch.device = torch.device('cpu'), use_earlystopping: bool = False, max_patience: int = 999,
             monitor_metric: Optional[str] = None, lr_scheduler_type: str = "",
-            scheduler_params: Optional[dict] = {}):
+            scheduler_params: Optional[dict] = {}, use_hip_graph: bool = False):
+        """The reference's signature (trainer.py:51-54) plus `use_hip_graph`: replay the training steps from a captured
+        hipGraph (graph_step.GraphedTrainStep: HIP models without active dropout; out-of-range ids are then reported at
+        the end of the epoch instead of at the offending step)."""
         if self.use_wandb:
             import wandb
             wandb.init(**self.wandb_config)
         model = model.to(device)
         optimizer = make_adam(model, lr)
+        graphed_step = None
+        if use_hip_graph:
+            from .graph_step import GraphedTrainStep
+            for m in model.modules():
+                if hasattr(m, "check_indices"):
+                    m.check_indices = "deferred"
+            graphed_step = GraphedTrainStep(model, optimizer)
 
         schedulers = {'StepLR': lr_scheduler.StepLR, 'ExponentialLR': lr_scheduler.ExponentialLR,
                       'CosineAnnealingLR': lr_scheduler.CosineAnnealingLR}
@@ -53,7 +63,7 @@ class RankTrainer:
         valid_metric = None
         for i in range(1, epoch + 1):
             train_metric = train_model(model, train_loader, optimizer=optimizer, device=device,
-                                       num_task=self.num_task, use_wandb=self.use_wandb)
+                                       num_task=self.num_task, use_wandb=self.use_wandb, graphed_step=graphed_step)
             if scheduler is not None:
                 scheduler.step()
                 logger.info(f"Epoch {i} LR:{[round(x, 6) for x in scheduler.get_last_lr()]}")

@@ -159,6 +159,14 @@ def test_graphed_step_refuses_what_it_cannot_capture():
         GraphedTrainStep(model, opt)
     with pytest.raises(RuntimeError, match="FusedAdam"):
         GraphedTrainStep(model, torch.optim.Adam(model.parameters()))
+    # batches whose row sort would take rocPRIM's onesweep path (> 0.9 M pairs) are refused: see GraphedTrainStep.MAX_PAIRS
+    for m in model.modules():
+        if hasattr(m, "check_indices"):
+            m.check_indices = "deferred"
+    gs = GraphedTrainStep(model, opt, eager_steps=0)
+    big = _batches(enc, 460000, 2, seed=1)
+    with pytest.raises(RuntimeError, match="onesweep"):
+        gs(big[0], big[1])
     # active dropout: the mask's (seed, offset) are launch arguments and would be frozen at capture
     from rec_pangu_amd import hip
     real = torch.cuda.is_current_stream_capturing

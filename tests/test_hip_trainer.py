@@ -227,3 +227,36 @@ def test_rank_trainer_fit_on_hip_on_the_reference_sample_data(tmp_path):
         assert abs(test_metric[k] - v) <= 2e-4, (k, test_metric[k], v)
     np.testing.assert_allclose(np.asarray(trainer.predict_dataloader(model, test_loader, device=DEV)),
                                g["pred_dataloader"].numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_rank_trainer_fit_with_hip_graph_matches_the_eager_fit(tmp_path):
+    """RankTrainer.fit(use_hip_graph=True): 3 epochs over 10 full batches + a smaller last one (which runs eagerly, as
+    does the batch before it), evaluation and checkpoints between the epochs — weights and metrics equal the eager fit
+    bit for bit."""
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.trainer import RankTrainer
+    from rec_pangu_amd.dataset import get_dataloader
+    from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+    import pandas as pd
+    rng = np.random.RandomState(0)
+    n = 10 * 64 + 23
+    df = pd.DataFrame({"a": rng.randint(0, 500, n).astype(str), "b": rng.randint(0, 7, n).astype(str),
+                       "c": rng.randint(0, 3000, n).astype(str), "x": rng.rand(n), "y": rng.rand(n) * 5,
+                       "click": (rng.rand(n) < 0.3).astype(int)})
+    schema = {"sparse_cols": ["a", "b", "c"], "dense_cols": ["x", "y"], "label_col": "click", "task_type": "ranking"}
+    finals = {}
+    try:
+        for use_graph in (False, True):
+            torch.manual_seed(0)
+            train_loader, valid_loader, _, enc = get_dataloader(df, df[:100].copy(), df[:50].copy(), schema, batch_size=64)
+            torch.manual_seed(1)
+            model = DeepFM(embedding_dim=16, hidden_units=[16, 8], enc_dict=enc)
+            trainer = RankTrainer(num_task=1, model_ckpt_dir=str(tmp_path / f"g{int(use_graph)}"))
+            metric = trainer.fit(model, train_loader, valid_loader, epoch=3, lr=2e-3, device=DEV, lr_scheduler_type="StepLR",
+                                 scheduler_params={"step_size": 1, "gamma": 0.5}, use_hip_graph=use_graph)
+            finals[use_graph] = (metric, {k: v.clone() for k, v in model.state_dict().items()})
+    finally:
+        EmbeddingLayer.unpin_sorts()
+    assert finals[False][0] == finals[True][0]
+    for k, v in finals[False][1].items():
+        assert torch.equal(v, finals[True][1][k]), k
