@@ -29,9 +29,23 @@ def _rows16(w: torch.Tensor) -> torch.Tensor:
     K = w.shape[1]
     if K % 4 == 0 or K <= 64 or not w.is_cuda:
         return w
-    buf = torch.empty((w.shape[0], (K + 3) // 4 * 4), dtype=w.dtype, device=w.device)
-    buf[:, :K].copy_(w)
-    return buf[:, :K]
+    # one staging copy per weight VALUE: the key is torch's version counter plus hip.weight_epoch(), which the fused
+    # optimizer kernels bump (they write parameters through raw pointers, invisibly to torch's counter).  DeepFM's forward
+    # asks twice per step (the "does the fused launch fit" check and the launch itself).
+    key = (w.data_ptr(), w._version, hip.weight_epoch(), torch.cuda.is_current_stream_capturing())
+    hit = getattr(w, "_rp_rows16", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():  # (a cached tensor with a grad_fn would keep the weight's AccumulateGrad node alive)
+        buf = torch.empty((w.shape[0], (K + 3) // 4 * 4), dtype=w.dtype, device=w.device)
+        buf[:, :K].copy_(w)
+        out = buf[:, :K]
+    if not key[3]:  # (inside a stream capture the copy must stay a node of every graph that uses it)
+        try:
+            w._rp_rows16 = (key, out)
+        except AttributeError:
+            pass
+    return out
 
 
 class FMFold:

@@ -27,6 +27,7 @@ from typing import Callable, Dict, Optional
 
 import torch
 
+from . import hip
 from .models.layers import embedding as _emb
 
 
@@ -203,6 +204,7 @@ class GraphedTrainStep:
         ev.record()
         self._inflight.append(ev)
         self.opt.advance_host()
+        hip.bump_weight_epoch()
         self._dev = self.opt.host_counters()
         self.replays += 1
         self.P, self._staged = 1 - P, next_batch

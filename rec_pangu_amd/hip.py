@@ -248,13 +248,24 @@ def timing_meta():
     return dict(_timing_meta)
 
 
+_PTR_ARRAYS: dict = {}  # tuple of device addresses -> the ctypes array holding them (the same lists recur every step)
+
+
 def _ptr_array(tensors: Sequence[torch.Tensor]):
-    arr = (C.c_void_p * max(len(tensors), 1))()
-    for i, t in enumerate(tensors):
-        if not t.is_cuda:  # a host pointer inside a launch packet is a GPU memory fault, not an exception
-            raise RuntimeError(f"Expected all tensors to be on the same device: input {i} is on {t.device} but the "
-                               "model is on the HIP device (move the batch with .to(device))")
-        arr[i] = t.data_ptr()
+    """HOST array of the tensors' device addresses for a `*_ptrs` argument (copied into the launch packet by the
+    library).  Built once per distinct address tuple: the element-wise fill of a ctypes array was the largest single item
+    of the host's time per step (10 calls x up to 39 tensors: ~0.25 ms of a ~1.0 ms enqueue, host_profile.py)."""
+    ptrs = tuple([t.data_ptr() for t in tensors])
+    arr = _PTR_ARRAYS.get(ptrs)
+    if arr is None:
+        for i, t in enumerate(tensors):
+            if not t.is_cuda:  # a host pointer inside a launch packet is a GPU memory fault, not an exception
+                raise RuntimeError(f"Expected all tensors to be on the same device: input {i} is on {t.device} but the "
+                                   "model is on the HIP device (move the batch with .to(device))")
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        if len(_PTR_ARRAYS) >= 512:
+            _PTR_ARRAYS.clear()
+        _PTR_ARRAYS[ptrs] = arr
     return arr
 
 
@@ -940,6 +951,21 @@ def sigmoid_bce_bwd(pred, label, gloss, apply_sigmoid: bool = True, p_eps: float
     return dz
 
 
+_weight_epoch = 0
+
+
+def weight_epoch() -> int:
+    """bumped by every optimizer launch of this module: parameters change through raw pointers there, which torch's
+    tensor version counters do not see (caches of derived weight layouts key on this)"""
+    return _weight_epoch
+
+
+def bump_weight_epoch() -> None:
+    """a captured step was replayed: its optimizer kernels ran without any python"""
+    global _weight_epoch
+    _weight_epoch += 1
+
+
 def counter_add(counter, delta: int = 1):
     """*counter += delta on the current stream (device-resident step counters, see rp_counter_add)"""
     _check(lib().rp_counter_add(counter.data_ptr(), delta, _stream()), "rp_counter_add")
@@ -948,6 +974,8 @@ def counter_add(counter, delta: int = 1):
 def adam_step(params, grads, ms, vs, lr, beta1, beta2, eps, step: int, zero_grad: bool, scalars=None, t_dev=None):
     """One fused launch per <=64 tensors; tensors must be contiguous fp32 on the same device.  t_dev (device int32[1],
     completed steps) + scalars (the per-step float2 table): the step number is read on the device (hipGraph replays)."""
+    global _weight_epoch
+    _weight_epoch += 1
     for i in range(0, len(params), MAX_FIELDS):
         ps, gs = params[i:i + MAX_FIELDS], grads[i:i + MAX_FIELDS]
         mm, vv = ms[i:i + MAX_FIELDS], vs[i:i + MAX_FIELDS]

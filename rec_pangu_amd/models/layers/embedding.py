@@ -299,7 +299,13 @@ class EmbeddingLayer(nn.Module):
             self.embedding_layer[col_name].weight.requires_grad = False
 
     def _idx_list(self, X):
-        return [X[c].long().reshape(-1).contiguous() for c in self.emb_feature]
+        out = []
+        for c in self.emb_feature:
+            t = X[c]
+            if t.dtype is not torch.int64 or t.dim() != 1 or not t.is_contiguous():
+                t = t.long().reshape(-1).contiguous()
+            out.append(t)
+        return out
 
     def gather_concat(self, X, dense: List[torch.Tensor], want_fm: bool, pad_to: int = 64):
         """HIP path: (x [B, ldx], fm [B,1] or None).  x = embeddings (F*D) | dense (ND) | zero pad."""
