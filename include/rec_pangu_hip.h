@@ -239,6 +239,12 @@ int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float
  *           whole gradient in one pass.
  * Limits: rows, contraction <= 32, D in {32, 64} (rp_cin_bs_fits). */
 int rp_cin_bs_fits(int H, int M, int D);
+/* A layer fed by MORE than 32 maps (a middle layer of e.g. cin_layer_units = [128, 128, 128]) is the sum over chunks of
+ * <= 32 maps of such layers: rp_cin_bs_fwd per chunk (xp = the chunk's columns of X_{k-1}, leading dimension M*D),
+ * partial outputs summed with rp_accumulate; in the backward g_out is shared, rp_cin_bs_bwd_x gives the X_0-role
+ * gradient per chunk (accumulated) and the chunk's own X_{k-1}-role gradient (written into its columns), and
+ * rp_cin_bs_bwd_w the chunk's slice of dW (functional._CINChunked).  dst[0:n] += src[0:n]: */
+int rp_accumulate(float *dst, const float *src, int64_t n, rp_stream_t stream);
 int rp_cin_bs_fwd(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const void *wp, const float *bias, int H,
                   int M, int O, int D, float *out, float *pooled, int64_t B, rp_stream_t stream);
 int rp_cin_bs_bwd_x(const float *xk, int64_t ldk, const void *wp, const float *gout, const float *gpool, int R, int Cn,

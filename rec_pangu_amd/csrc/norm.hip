@@ -424,3 +424,27 @@ extern "C" int rp_batchnorm_bwd_apply(const float *x, int64_t ldx, const float *
     RP_LAUNCH_CHECK("batchnorm bwd apply");
     return RP_OK;
 }
+
+// dst[0:n] += src[0:n]  (partial results of launches that cannot accumulate themselves: the map chunks of a CIN layer)
+__global__ __launch_bounds__(256) void accumulate_kernel(float *__restrict__ dst, const float *__restrict__ src, int64_t n4,
+                                                         int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 a = reinterpret_cast<f32x4 *>(dst)[i];
+        const f32x4 b = reinterpret_cast<const f32x4 *>(src)[i];
+        a += b;
+        reinterpret_cast<f32x4 *>(dst)[i] = a;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+extern "C" int rp_accumulate(float *dst, const float *src, int64_t n, rp_stream_t stream) {
+    RP_REQUIRE(dst && src && n >= 0, "accumulate: bad argument");
+    if (n == 0) return RP_OK;
+    const int64_t n4 = (rp_aligned16(dst) && rp_aligned16(src)) ? n / 4 : 0;
+    int64_t nb = rp_cdiv(n4 > 0 ? n4 : n, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, dst, src, n4, n);
+    RP_LAUNCH_CHECK("accumulate");
+    return RP_OK;
+}

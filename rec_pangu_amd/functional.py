@@ -324,6 +324,69 @@ def cin_last(x0, xp, V, H: int, M: int, D: int):
     return _CINLast.apply(x0, xp, V, H, M, D)
 
 
+class _CINChunked(torch.autograd.Function):
+    """A CIN layer whose second factor X_{k-1} is NOT X_0 (a middle layer), fed by any number of maps, on the bf16 matrix
+    core: the sum over chunks of <= 32 maps of rp_cin_bs layers (interaction.py:164-168; include/rec_pangu_hip.h K6).
+    X_k[b,o,:] = sum_c sum_{h, m in c} W[o,h,m] X_0[b,h,:] X_{k-1}[b,m,:] + bias[o]."""
+    CHUNK = 32
+
+    @staticmethod
+    def forward(ctx, x0, xp, W, bias, H: int, M: int, D: int):
+        x0, xp = _unit_inner(x0), _unit_inner(xp)
+        O = W.shape[0]
+        W3 = W.reshape(O, H, M)
+        out = pooled = None
+        for c0 in range(0, M, _CINChunked.CHUNK):
+            c1 = min(M, c0 + _CINChunked.CHUNK)
+            o_c, p_c = hip.cin_bs_fwd(x0, xp[:, c0 * D:c1 * D], hip.bf16_pieces(W3[:, :, c0:c1]), bias if c0 == 0 else None,
+                                      H, c1 - c0, O, D, True, True)
+            if out is None:
+                out, pooled = o_c, p_c
+            else:
+                hip.accumulate(out, o_c)
+                hip.accumulate(pooled, p_c)
+        ctx.cfg = (H, M, D, bias is not None)
+        ctx.save_for_backward(x0, xp, W3)
+        return out, pooled
+
+    @staticmethod
+    def backward(ctx, g_out, g_pool):
+        x0, xp, W3 = ctx.saved_tensors
+        H, M, D, has_bias = ctx.cfg
+        O = W3.shape[0]
+        g_out = None if g_out is None else g_out.contiguous()
+        gp = None if g_pool is None else g_pool.contiguous()  # packed [B, O]
+        dx0 = None
+        dxp = torch.empty((x0.shape[0], M * D), dtype=torch.float32, device=x0.device)
+        dW = torch.empty((O, H, M), dtype=torch.float32, device=x0.device)
+        db = None
+        for c0 in range(0, M, _CINChunked.CHUNK):
+            c1 = min(M, c0 + _CINChunked.CHUNK)
+            mc = c1 - c0
+            xc, Wc = xp[:, c0 * D:c1 * D], W3[:, :, c0:c1]
+            # X_0-role gradient: rows h, contraction over the chunk's maps; X_{k-1}-role: rows m, contraction over h
+            d0 = hip.cin_bs_bwd_x(xc, hip.bf16_pieces(Wc), g_out, gp, H, mc, O, D, like=x0)
+            dx0 = d0 if dx0 is None else hip.accumulate(dx0, d0)
+            hip.cin_bs_bwd_x(x0, hip.bf16_pieces(Wc.transpose(1, 2)), g_out, gp, mc, H, O, D, like=None,
+                             out=dxp[:, c0 * D:c1 * D])
+            dWc, dbc = hip.cin_bs_bwd_w(x0, xc, g_out, gp, H, mc, O, D, has_bias and c0 == 0)
+            dW[:, :, c0:c1] = dWc.view(O, H, mc)
+            if dbc is not None:
+                db = dbc
+        return dx0, dxp, dW.view(O, H * M), db, None, None, None
+
+
+def cin_middle_fits(H: int, D: int, x0, xp) -> bool:
+    """can a middle CIN layer (any number of input maps) run on the chunked bf16 matrix-core form?"""
+    return (hip.get_matmul_precision() != "fp32" and hip.cin_bs_fits(H, min(32, H), D) and x0.stride(0) % 4 == 0
+            and x0.data_ptr() % 16 == 0 and xp.data_ptr() % 16 == 0)
+
+
+def cin_middle(x0, xp, W, bias, H: int, M: int, D: int):
+    """-> (X_k [B, O, D], pooled [B, O]) of a middle CIN layer on the bf16 matrix core (see _CINChunked)"""
+    return _CINChunked.apply(x0, xp, W, bias, H, M, D)
+
+
 def cin_layer(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool = True):
     """One CIN layer on [B, >=H*D] / [B, M*D] row buffers (xp=None: first layer, X_{k-1} = X_0).
     -> (X_k [B,O,D], pooled [B,O]) or pooled alone when want_out is False."""

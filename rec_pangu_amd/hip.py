@@ -101,6 +101,7 @@ _SIGNATURES = {
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
     "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp, _vp, _vp]),
     "rp_counter_add": (C.c_int, [_vp, _i32, _vp]),
+    "rp_accumulate": (C.c_int, [_vp, _vp, _i64, _vp]),
     "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -599,11 +600,22 @@ def cin_bs_fwd(x0, xp, wp, bias, H: int, M: int, O: int, D: int, want_out: bool,
     return out, pooled
 
 
-def cin_bs_bwd_x(xk, wp, g_out, g_pool, R: int, Cn: int, O: int, D: int, like):
-    """-> dx shaped like `like` ([B, >= R*D], zero beyond R*D)."""
+def accumulate(dst, src):
+    """dst += src (contiguous fp32 tensors of one size; rp_accumulate)"""
+    _req(dst, torch.float32, "dst")
+    _req(src, torch.float32, "src")
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    with _Timed("accumulate", None, 12 * dst.numel()):
+        _check(lib().rp_accumulate(dst.data_ptr(), src.data_ptr(), dst.numel(), _stream()), "rp_accumulate")
+    return dst
+
+
+def cin_bs_bwd_x(xk, wp, g_out, g_pool, R: int, Cn: int, O: int, D: int, like, out=None):
+    """-> dx shaped like `like` ([B, >= R*D], zero beyond R*D), or written into `out` ([B, R*D] view, any leading
+    dimension)."""
     B = xk.shape[0]
-    dx = torch.empty_like(like)
-    if like.shape[1] > R * D:
+    dx = out if out is not None else torch.empty_like(like)
+    if out is None and like.shape[1] > R * D:
         dx[:, R * D:].zero_()
     with _Timed("cin_bs_bwd_x"):
         _check(lib().rp_cin_bs_bwd_x(xk.data_ptr(), _rowmajor(xk, "xk"), wp.data_ptr(), _ptr(g_out), _ptr(g_pool), R, Cn, O,

@@ -111,12 +111,18 @@ class CompressedInteractionNet(nn.Module):
         from ... import functional as Fh
         B, H, D = feature_emb.shape
         x0 = feature_emb.reshape(B, H * D)
+        if any(u > 32 for u in self.cin_layer_units[:-2]) and (x0.stride(0) % 4 != 0 or x0.data_ptr() % 16 != 0):
+            x0 = x0.contiguous()  # the chunked bf16 middle layers need 16-byte aligned rows (the models' x buffer has them)
         L = len(self.cin_layer_units)
         xp, M, pooled, n_prev = None, H, [], 0
         for i in range(L - 1):
             conv = self.cin_layer["layer_" + str(i + 1)]
             O = conv.weight.shape[0]
-            X_i, p_i = Fh.cin_layer(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D, want_out=True)
+            if xp is not None and Fh.cin_middle_fits(H, D, x0, xp):
+                # a middle layer (fed by any number of maps) on the bf16 matrix core, 32 maps per launch
+                X_i, p_i = Fh.cin_middle(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D)
+            else:
+                X_i, p_i = Fh.cin_layer(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D, want_out=True)
             pooled.append(p_i)
             xp, M, n_prev = X_i.view(B, O * D), O, n_prev + O
         conv = self.cin_layer["layer_" + str(L)]
@@ -136,15 +142,21 @@ class CompressedInteractionNet(nn.Module):
             logit = logit + Fh.linear_act(torch.cat(pooled, dim=-1), self.fc.weight[:, :n_prev].contiguous(), None)
         return logit + self.fc.bias
 
-    def hip_supported(self, H) -> bool:
-        """What the register-tiled backward covers: <= 32 fields, and every middle layer (not first, not last)
-        fed by at most 32 maps; anything else is composed from device ops in forward()."""
+    def hip_supported(self, H, D=None) -> bool:
+        """<= 32 fields and a single output.  Middle layers (not first, not last) fed by more than 32 maps run on the
+        chunked bf16 form (functional._CINChunked: D in {32, 64}, not in the 'fp32' matrix-core mode); the f32-MFMA
+        kernels of cin.hip cover middle layers of <= 32 maps; anything else is composed from device ops in forward()."""
+        from ... import hip
         units = self.cin_layer_units
-        return H <= 32 and self.fc.weight.shape[0] == 1 and all(u <= 32 for u in units[:-2])
+        if not (H <= 32 and self.fc.weight.shape[0] == 1):
+            return False
+        if all(u <= 32 for u in units[:-2]):
+            return True
+        return hip.get_matmul_precision() != "fp32" and D in (32, 64)
 
     def forward(self, feature_emb):
         B, H, D = feature_emb.shape
-        if feature_emb.is_cuda and self.hip_supported(H):
+        if feature_emb.is_cuda and self.hip_supported(H, D):
             return self._forward_hip(feature_emb)
         X_0, X_i, pooled = feature_emb, feature_emb, []
         for i in range(len(self.cin_layer_units)):

@@ -90,8 +90,11 @@ def test_cin_vs_reference_fixture():
         _close(p.grad.cpu(), c["gw/" + k], rel=2e-4, floor=1e-2, what=f"cin d{k}")
 
 
+# [40, 70, 16] / [128, 128, 128]: middle layers fed by MORE than 32 maps — the chunked bf16 matrix-core form
+# (functional._CINChunked: chunks of 32 + 8, 32 + 32 + 6, 4 x 32 maps), through the misaligned-row fallback here
 @pytest.mark.parametrize("B,H,D,units", [(300, 26, 64, [128, 128]), (257, 26, 64, [16, 16, 16]), (130, 16, 40, [8, 8]),
-                                          (64, 5, 8, [7]), (100, 26, 32, [32, 24, 9])])
+                                          (64, 5, 8, [7]), (100, 26, 32, [32, 24, 9]), (300, 26, 64, [40, 70, 16]),
+                                          (130, 26, 64, [128, 128, 128]), (96, 7, 32, [33, 5])])
 def test_cin_vs_oracle(B, H, D, units):
     from rec_pangu_amd.models.layers import CompressedInteractionNet
     g = torch.Generator().manual_seed(B + H)

@@ -740,6 +740,46 @@ def test_xdeepfm_midsize_vs_oracle_in_every_matmul_mode(matmul_mode):
         assert (p.grad.cpu() - rg).abs().max() <= tol, f"{matmul_mode}: grad {k}: {(p.grad.cpu() - rg).abs().max()} > {tol}"
 
 
+def test_xdeepfm_three_cin_layers_of_128_vs_oracle(matmul_mode):
+    """xDeepFM(cin_layer_units=[128, 128, 128]) at the Criteo shape (26 x D = 64, vocabularies / 64), B = 2048, eval mode,
+    every bf16 matrix-core mode: the MIDDLE layer is fed by 128 maps and runs on the bf16 matrix core in four chunks of 32
+    maps (functional._CINChunked) — logits / loss within 1e-4 of the CPU oracle; gradients within 1e-4
+    relative with six products per flop, 1e-3 where the first layer's pair kernels run three (2^-16 per product, and the
+    third-order terms of a three-layer CIN multiply it up: measured 6e-4 on one table); no f32-MFMA middle-layer kernel
+    and no ATen einsum in the step."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.ranking import xDeepFM
+    enc = bench.criteo_enc_dict(64)
+    torch.manual_seed(0)
+    model = xDeepFM(embedding_dim=64, dnn_hidden_units=[64, 64, 64], cin_layer_units=[128, 128, 128], enc_dict=enc)
+    model.eval()
+    sd = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    B = 2048
+    batch = bench.synth_batch(enc, B, 3, "cpu")
+    ref = R.xdeepfm(sd, enc, batch)
+    ref["loss"].backward()
+    model = model.to(DEV)
+    assert model.cin.hip_supported(26, 64)
+    hip.enable_timing(True)
+    out = model(_to_dev(batch))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    rows = hip.timing_summary()
+    hip.enable_timing(False)
+    assert rows["cin_bs_fwd"][0] == 4 and rows["cin_bs_bwd_x"][0] == 8 and rows["cin_bs_bwd_w"][0] == 4, rows.keys()
+    assert not any(k.startswith("cin_layer_") for k in rows), "the f32-MFMA middle-layer kernels must not be used"
+    torch.testing.assert_close(out["pred"].cpu(), ref["pred"].detach(), rtol=0, atol=1e-4)
+    torch.testing.assert_close(out["loss"].cpu(), ref["loss"].detach(), rtol=0, atol=1e-4)
+    for k, p in model.named_parameters():
+        rg = sd[k].grad
+        tol = (1e-4 if matmul_mode == "bf16x6" else 1e-3) * max(1e-4, float(rg.abs().max()))
+        assert (p.grad.cpu() - rg).abs().max() <= tol, f"{matmul_mode}: grad {k}: {(p.grad.cpu() - rg).abs().max()} > {tol}"
+
+
 def test_sharded_fused_first_layer_single_rank():
     """Criteo-shaped DeepFM (D = 64, 64-wide first layer) row-sharded under a 1-rank RCCL group: the exchanged unique rows
     feed the same fused launches as the single-GPU path (rows -> x + FM + dnn.net.0: rp_embed_gather_linear_fwd; the
