@@ -22,13 +22,18 @@ import sys
 
 OURS = ("adam_kernel", "embed_", "linear_", "wgrad_", "transpose_kernel", "relu_bwd", "sigmoid_bce", "loss_finish",
         "zero_rows", "iota_i32", "cin_", "cross_", "attn_", "mmoe_", "radix_sort", "lazy_", "a2a_", "fm_", "bn_",
-        "trampoline_kernel", "onesweep", "field_sort", "mlp_tail", "dropout", "route_", "shard_", "batchnorm")
+        "trampoline_kernel", "onesweep", "field_sort", "mlp_tail", "dropout", "route_", "shard_", "batchnorm", "counter_add",
+        "accumulate", "pool_")
 LAST = 100
 
 
 def short(name):
+    """kernel name without its parameter list, template arguments kept (they may contain parentheses: `float
+    __vector(4)`), so that instantiations stay apart"""
     n = name.replace("void ", "")
-    return n.split("(")[0][:80]
+    i = n.find(">(")
+    n = n[:i + 1] if i >= 0 else n.split("(")[0]
+    return n[:110]
 
 
 def find(d, suffix):

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256) void lazy_cf_table_kernel(const double2 *__res
     }
 }
 
-template <int TPR, typename T>
+// REAL: the launch applies a real step (a compile-time copy of `real_step`: the replay and the step are then two kernels
+// with two names in a profile, and each drops the other's branches)
+template <int TPR, typename T, bool REAL>
 __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
                                                              float *__restrict__ P, float *__restrict__ G,
                                                              float *__restrict__ Mo, float *__restrict__ Vo,
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
                                                              int real_step, int zero_grad, LazyCfg c,
                                                              const CfEntry *__restrict__ cf, int cf_from,
                                                              const int32_t *__restrict__ t_dev) {
-    if (t_dev != nullptr) t_target = *t_dev + (real_step ? 1 : 0);  // *t_dev = completed steps (graph replays)
+    real_step = REAL ? 1 : 0;
+    if (t_dev != nullptr) t_target = *t_dev + (REAL ? 1 : 0);  // *t_dev = completed steps (graph replays)
     constexpr int GPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
     const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
@@ -738,9 +741,15 @@ extern "C" int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, f
         RP_LAUNCH_CHECK("lazy_adam_rows (replay)");
         return RP_OK;
     }
-#define CALL(T, TY)                                                                                                  \
-    hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
-                       sc, (int)t_target, real_step, zero_grad, c, cf, (int)cf_from, t_dev)
+#define CALL(T, TY)                                                                                                       \
+    do {                                                                                                                  \
+        if (real_step)                                                                                                    \
+            hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY, true>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, \
+                               m, v, last, sc, (int)t_target, 1, zero_grad, c, cf, (int)cf_from, t_dev);                   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((lazy_adam_rows_kernel<T, TY, false>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p,   \
+                               g, m, v, last, sc, (int)t_target, 0, zero_grad, c, cf, (int)cf_from, t_dev);                \
+    } while (0)
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_rows");

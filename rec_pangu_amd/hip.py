@@ -1212,7 +1212,7 @@ def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: floa
     ns_d [>= t_end + 1, 2] float64 device table by step, cf_table [>= t_end - cf_from + 1, 8] float32 (written in place)"""
     assert ns_d.dtype == torch.float64 and ns_d.shape[0] > t_end and ns_d.is_contiguous()
     assert cf_table.dtype == torch.float32 and cf_table.shape[0] >= t_end - cf_from + 1 and cf_table.is_contiguous()
-    with _Timed("lazy_adam_cf_table", f"{max(t_end - cf_from, 0)}"):
+    with _Timed("lazy_adam_cf_table"):
         _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _ptr(t_dev),
                                            _stream()), "rp_lazy_adam_cf_table")
 
