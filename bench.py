@@ -118,6 +118,7 @@ KERNELS_OF = {
     "lazy_adam_flush": ("lazy_flush_wave_kernel", "lazy_adam_flush_kernel"),
     "sort_pairs_i32": ("field_sort", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
+    "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
 }
 
 
@@ -209,6 +210,10 @@ def main():
                     help="replay the whole training step (fwd + bwd + optimizer + the next batch's sort) from a captured "
                          "hipGraph (rec_pangu_amd/graph_step.py; bit-identical to the eager step).  auto = on for single-GPU "
                          "training of the models without active dropout (deepfm, dcn)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: SECONDARY inference line (--mode forward only) — the fused lookup + FM + first layer reads a "
+                         "bf16 snapshot of the tables (half the gather traffic; logits within 3e-2 of the fp32 tables', outside "
+                         "the 1e-4 parity gate; never the headline)")
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the strong-scaling-batch comparison (eager vs hipGraph at batch / 8) after the main run")
     ap.add_argument("--no-sort-ahead", action="store_true",
@@ -260,6 +265,9 @@ def main():
         if hasattr(m, "check_indices"):
             m.check_indices = "deferred"  # no per-step host sync; checked once after the run
     model.train()
+    if args.storage == "bf16":
+        assert args.mode == "forward" and not sharded and args.model == "deepfm", "--storage bf16 is the forward-only DeepFM line"
+        model.embedding_layer.bf16_lookup()
     lazy = args.optimizer == "lazy" and args.mode == "train"
     opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"), replay=args.replay)
     replay_mode = getattr(opt, "replay", None) if lazy else None
@@ -388,7 +396,8 @@ def main():
     if prof is not None:
         ours = {n: c * m for n, (c, m) in prof.items() if not n.startswith("lazy_adam_flush") and not side_stream(n)}
         top = sorted(ours, key=ours.get, reverse=True)[:2]
-        watch = {n.split("[")[0] for n in top} | {"embed_gather_fwd", "embed_gather_linear_fwd", "linear_fwd", "linear_wgrad"}
+        watch = {n.split("[")[0] for n in top} | {"embed_gather_fwd", "embed_gather_linear_fwd", "embed_gather_linear_fwd_bf16",
+                                                    "linear_fwd", "linear_wgrad"}
         hip.enable_timing(True, only=watch)
     else:
         hip.enable_timing(True)
@@ -659,7 +668,7 @@ def main():
         roofline["share_of_step"] = round(share[dominant] / max(sum(share.values()), 1e-9), 4)
     # north_star's "HBM GB/s on the embedding gather": the plain gather where the model runs it, else the launch it is
     # fused into (DeepFM at D = 64: lookup + concat + FM + first Linear, rp_embed_gather_linear_fwd)
-    gkeys = (f"embed_gather_fwd[D={D}]", f"embed_gather_linear_fwd[D={D}]")
+    gkeys = (f"embed_gather_fwd[D={D}]", f"embed_gather_linear_fwd[D={D}]", f"embed_gather_linear_fwd_bf16[D={D}]")
     gkey = next((k for k in (gkeys[::-1] if sharded else gkeys) if k in timing), None)
     gather = roofline_of(gkey, timing[gkey][1]) if gkey else None
     gemm = None
@@ -685,7 +694,8 @@ def main():
                       if args.mode == "train" else f"samples/sec {type(model).__name__} Criteo-shape bsz={local_B}/GPU (forward only)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "data": "synthetic",
+            "dtype": "f32" if args.storage == "fp32" else "bf16 tables (secondary inference line; fp32 accumulation)",
             "config": {"workload": f"{type(model).__name__} ({args.model}), {F} sparse fields (Criteo-Kaggle "
                                    f"cardinalities/{args.vocab_scale}, {n_table_rows} arena rows) x D={D} + {ND} dense, "
                                    f"batch {local_B} per GPU (global {B}), "

@@ -95,12 +95,23 @@ int rp_embed_gather_fwd(const float *arena, const int64_t *row_base, const int64
  * multiplied with the field's 64 x 64 slice of W on the matrix core (split-bf16, six products), so x is never re-read.
  *   W [64, K] (ldw floats per row), K = F*64 + ND;  h1 [B, 64] = relu(x[:, :K] . W^T + bias)
  * rp_embed_gather_linear_fits: D == 64, a 64-wide layer, ND <= 16 (and F <= 32); otherwise RP_ERR_UNSUPPORTED
- * (compose rp_embed_gather_fwd + rp_linear_fwd). */
+ * (compose rp_embed_gather_fwd + rp_linear_fwd).
+ *   xd [B, 64] (instead of x; NULL otherwise): ONLY the dense columns are stored (zero padded to 64) — the layer's weight
+ *   gradient then gathers the embedding rows again itself (rp_linear_wgrad_gather below) and the 4*F*D bytes per sample of
+ *   the x store (436 MB at Criteo shape) are never written. */
 int rp_embed_gather_linear_fits(int D, int ND, int hidden, int64_t ldx, int64_t ldw);
 int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, const int64_t *row_count,
                                const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
                                int D, float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *h1,
-                               float *fm_out, float *sum_out, int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
+                               float *fm_out, float *sum_out, int32_t *keys_out, int32_t *err_flag, float *xd, rp_stream_t stream);
+/* bf16-STORAGE inference (SURVEY D6's secondary mode; the fp32 tables stay the parity path and the training path): the same
+ * launch over a bf16 copy of the arena (rows of D bf16 = 128 bytes at D = 64), fp32 accumulation everywhere, nothing stored
+ * but h1 and the FM term.  The looked-up values differ from the fp32 tables' by bf16 rounding (2^-9 relative per element):
+ * logits within 3e-2 (tests/test_hip_models.py), not within the 1e-4 parity gate. */
+int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
+                                    const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
+                                    int D, const float *W, int64_t ldw, const float *bias, float *h1, float *fm_out,
+                                    int32_t *err_flag, rp_stream_t stream);
 
 /* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
  * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
@@ -153,6 +164,15 @@ int rp_linear_wgrad_workspace_bytes(int64_t M, int N, int K, size_t *bytes);
 int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dw, int64_t lddw,
                     float *db, int64_t M, int N, int K, int accumulate, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
+/* The weight gradient of a layer whose input is the embedding lookup, WITHOUT the stored activation: the first Kg = F*64
+ * columns of X are gathered — X[m, f*64 + j] = arena[keys[f*M + m]*64 + j], keys = the arena rows the forward saved
+ * (rp_embed_gather_linear_fwd keys_out / rp_embed_keys) — the remaining K - Kg <= 64 columns (dense features) come from
+ * xd [M, ldxd].  N == 64, Kg a multiple of 128, bf16 matrix-core modes (rp_linear_wgrad_gather_fits); workspace as
+ * rp_linear_wgrad_workspace_bytes(M, N, K). */
+int rp_linear_wgrad_gather_fits(int64_t M, int N, int K, int Kg);
+int rp_linear_wgrad_gather(const float *dy, int64_t lddy, const float *arena, const int32_t *keys, int Kg, const float *xd,
+                           int64_t ldxd, float *dw, int64_t lddw, float *db, int64_t M, int N, int K, int accumulate,
+                           void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* out[C,R] = in[R,C]^T (weights for the dgrad GEMM); rows C .. C_out-1 of out (C_out >= C) are written as zeros */
 int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, rp_stream_t stream);
 /* y = dy * (act_out > 0), elementwise over [M,N] */

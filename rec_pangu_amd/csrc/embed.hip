@@ -307,12 +307,18 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
 // ------------------------------------------------------------------------------------------------
 #define EGL_XLD 68  // floats per staged row (64 + 4 pad)
 #define EGL_KLD 33  // keys per row in LDS (odd: the key fill writes 32 consecutive rows at a fixed field)
-template <bool FULL>
+// STORE_X = false (with FULL): the gathered rows are NOT written to x — the first layer's weight gradient gathers them
+// again itself (rp_linear_wgrad_gather) — only the dense columns go to the compact buffer xd [B, 64]
+// BF16_ROWS: the arena holds bf16 rows (128 bytes at D = 64: the bf16-STORAGE inference mode, half the gather traffic);
+// a lane reads 4 bf16 (8 bytes) where the fp32 form reads a float4 and widens them — exact — so everything downstream
+// (FM sums in fp32, the split-bf16 products) is unchanged.
+template <bool FULL, bool STORE_X = true, bool BF16_ROWS = false>
 __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     const float *__restrict__ arena, const int64_t *__restrict__ row_base, const int64_t *__restrict__ row_count,
     IdxPtrs idx, int F, DensePtrs dense, int ND, int64_t B, int64_t blk0, float *__restrict__ x, int64_t ldx,
     const float *__restrict__ W, int64_t ldw, const float *__restrict__ bias, float *__restrict__ h1,
-    float *__restrict__ fm_out, float *__restrict__ sum_out, int32_t *__restrict__ keys_out, int32_t *__restrict__ err_flag) {
+    float *__restrict__ fm_out, float *__restrict__ sum_out, int32_t *__restrict__ keys_out, int32_t *__restrict__ err_flag,
+    float *__restrict__ xd) {
     constexpr int D = 64;
     __shared__ __attribute__((aligned(16))) __bf16 Wt[3][64][EG_LD];
     __shared__ __attribute__((aligned(16))) float Xs[128][EGL_XLD];
@@ -341,7 +347,16 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     __syncthreads();
     auto load_rows = [&](int f, f32x4 (&v)[8]) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
+        for (int u = 0; u < 8; ++u) {
+            if (BF16_ROWS) {
+                const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(arena) +
+                                                                  (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
+                v[u] = f32x4{__uint_as_float(w2.x << 16), __uint_as_float(w2.x & 0xffff0000u), __uint_as_float(w2.y << 16),
+                             __uint_as_float(w2.y & 0xffff0000u)};
+            } else {
+                v[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
+            }
+        }
     };
     auto load_w = [&](int col0, f32x4 (&v)[4]) {
         const float *src = W + (int64_t)wd * ldw + col0 + wc;
@@ -373,7 +388,8 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             const int r = g + 16 * u;
             *reinterpret_cast<f32x4 *>(&Xs[r][4 * sub]) = cur[u];
             const int64_t br = blk * 128 + r;
-            if (FULL || (x != nullptr && br < B)) *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + 4 * sub) = cur[u];
+            if (STORE_X && (FULL || (x != nullptr && br < B)))
+                *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + 4 * sub) = cur[u];
             S[u] += cur[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[u] = __builtin_fmaf(cur[u][e], cur[u][e], q[u]);
@@ -443,11 +459,17 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
         }
         __syncthreads();
         if (x != nullptr && bok) {
-            float *xd = x + b * ldx + (int64_t)F * D;
+            float *xt = x + b * ldx + (int64_t)F * D;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (8 * h + e < ND) xd[8 * h + e] = dv[e];
+                if (8 * h + e < ND) xt[8 * h + e] = dv[e];
             for (int64_t j = (int64_t)F * D + ND + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;  // zero padding up to ldx
+        }
+        if (xd != nullptr && bok) {  // the compact copy of the dense columns, zero padded to 64
+            float *xt = xd + b * 64;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xt[8 * h + e] = (8 * h + e < ND) ? dv[e] : 0.f;
+            for (int j = 16 + h; j < 64; j += 2) xt[j] = 0.f;
         }
         bf16x8 a[3];
         bf_split8<3>(dv, a);
@@ -460,8 +482,11 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             for (int pr = 0; pr < 6; ++pr)
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
         }
-    } else if (x != nullptr && bok) {
-        for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;
+    } else {
+        if (x != nullptr && bok)
+            for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;
+        if (xd != nullptr && bok)
+            for (int j = h; j < 64; j += 2) xd[b * 64 + j] = 0.f;
     }
     // ---- epilogue: h1 = relu(acc + bias) in the C layout
 #pragma unroll
@@ -492,6 +517,12 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
     }
 }
 
+static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const int64_t *row_base, const int64_t *row_count,
+                                      const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                                      int64_t B, int D, float *x, int64_t ldx, const float *W, int64_t ldw,
+                                      const float *bias, float *h1, float *fm_out, float *sum_out, int32_t *keys_out,
+                                      int32_t *err_flag, float *xd, rp_stream_t stream);
+
 extern "C" int rp_embed_gather_linear_fits(int D, int ND, int hidden, int64_t ldx, int64_t ldw) {
     return (D == 64 && hidden == 64 && ND >= 0 && ND <= 16 && ldx % 4 == 0 && ldw % 4 == 0) ? 1 : 0;  // (and F <= 32)
 }
@@ -502,8 +533,29 @@ extern "C" int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row
                                           const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
                                           int64_t B, int D, float *x, int64_t ldx, const float *W, int64_t ldw,
                                           const float *bias, float *h1, float *fm_out, float *sum_out, int32_t *keys_out,
-                                          int32_t *err_flag, rp_stream_t stream) {
+                                          int32_t *err_flag, float *xd, rp_stream_t stream) {
+    return embed_gather_linear_launch(arena, false, row_base, row_count, idx_ptrs, F, dense_ptrs, ND, B, D, x, ldx, W, ldw, bias,
+                                      h1, fm_out, sum_out, keys_out, err_flag, xd, stream);
+}
+
+// the same launch over a bf16 copy of the arena (rows of D bf16): inference with bf16-STORED tables, fp32 accumulation.
+// Nothing is stored but h1 and the FM term (x, xd, sum_out, keys_out are for the training path, which keeps fp32 tables).
+extern "C" int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
+                                               const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                                               int64_t B, int D, const float *W, int64_t ldw, const float *bias, float *h1,
+                                               float *fm_out, int32_t *err_flag, rp_stream_t stream) {
+    return embed_gather_linear_launch(reinterpret_cast<const float *>(arena_bf16), true, row_base, row_count, idx_ptrs, F,
+                                      dense_ptrs, ND, B, D, nullptr, 0, W, ldw, bias, h1, fm_out, nullptr, nullptr, err_flag,
+                                      nullptr, stream);
+}
+
+static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const int64_t *row_base, const int64_t *row_count,
+                                      const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
+                                      int64_t B, int D, float *x, int64_t ldx, const float *W, int64_t ldw,
+                                      const float *bias, float *h1, float *fm_out, float *sum_out, int32_t *keys_out,
+                                      int32_t *err_flag, float *xd, rp_stream_t stream) {
     RP_REQUIRE(arena && row_base && row_count && idx_ptrs && W && h1 && err_flag, "embed_gather_linear_fwd: null pointer");
+    RP_REQUIRE(!(x && xd), "embed_gather_linear_fwd: give x (full activation) or xd (dense columns only), not both");
     RP_REQUIRE(F >= 1 && F <= RP_MAX_FIELDS && B >= 0, "embed_gather_linear_fwd: bad F/B");
     RP_REQUIRE(ND == 0 || dense_ptrs, "embed_gather_linear_fwd: dense_ptrs is null with ND=%d", ND);
     RP_REQUIRE((int64_t)F * B < (int64_t)INT32_MAX, "embed_gather_linear_fwd: F*B overflows int32 positions");
@@ -522,15 +574,34 @@ extern "C" int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row
         RP_REQUIRE(dense_ptrs[j], "embed_gather_linear_fwd: dense_ptrs[%d] is null", j);
         dp.p[j] = dense_ptrs[j];
     }
-    const int64_t nfull = (x != nullptr) ? B / 128 : 0;  // workgroups whose 128 samples all exist (x written: no lane masks)
+    // workgroups whose 128 samples all exist run without lane masks (x written, or no row store at all: xd / bf16 rows)
+    const int64_t nfull = (x != nullptr || xd != nullptr || bf16_rows) ? B / 128 : 0;
     const int64_t nblk = rp_cdiv(B, 128);
     hipStream_t s = (hipStream_t)stream;
-    if (nfull > 0)
-        hipLaunchKernelGGL((embed_gather_linear_kernel<true>), dim3((unsigned)nfull), dim3(256), 0, s, arena, row_base, row_count, ip,
-                           F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag);
+    if (bf16_rows) {
+        if (nfull > 0)
+            hipLaunchKernelGGL((embed_gather_linear_kernel<true, false, true>), dim3((unsigned)nfull), dim3(256), 0, s, arena,
+                               row_base, row_count, ip, F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out,
+                               keys_out, err_flag, xd);
+        if (nblk > nfull)
+            hipLaunchKernelGGL((embed_gather_linear_kernel<false, true, true>), dim3((unsigned)(nblk - nfull)), dim3(256), 0, s,
+                               arena, row_base, row_count, ip, F, dp, ND, B, nfull, x, ldx, W, ldw, bias, h1, fm_out, sum_out,
+                               keys_out, err_flag, xd);
+        RP_LAUNCH_CHECK("embed_gather_linear_fwd (bf16 rows)");
+        return RP_OK;
+    }
+    if (nfull > 0 && x != nullptr)
+        hipLaunchKernelGGL((embed_gather_linear_kernel<true, true>), dim3((unsigned)nfull), dim3(256), 0, s, arena, row_base,
+                           row_count, ip, F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag,
+                           xd);
+    else if (nfull > 0)
+        hipLaunchKernelGGL((embed_gather_linear_kernel<true, false>), dim3((unsigned)nfull), dim3(256), 0, s, arena, row_base,
+                           row_count, ip, F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag,
+                           xd);
     if (nblk > nfull)
-        hipLaunchKernelGGL((embed_gather_linear_kernel<false>), dim3((unsigned)(nblk - nfull)), dim3(256), 0, s, arena, row_base,
-                           row_count, ip, F, dp, ND, B, nfull, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out, err_flag);
+        hipLaunchKernelGGL((embed_gather_linear_kernel<false, true>), dim3((unsigned)(nblk - nfull)), dim3(256), 0, s, arena,
+                           row_base, row_count, ip, F, dp, ND, B, nfull, x, ldx, W, ldw, bias, h1, fm_out, sum_out, keys_out,
+                           err_flag, xd);
     RP_LAUNCH_CHECK("embed_gather_linear_fwd");
     return RP_OK;
 }

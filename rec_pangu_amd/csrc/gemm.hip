@@ -818,11 +818,21 @@ static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw,
 // registers.
 // (NA = 1: 168 registers, three workgroups per CU.  Deeper register prefetch (PF = 2, 3: 224 / 246 registers, two per CU)
 //  measured 4 % and 16 % SLOWER at 65536 x 64 x 1677.)
-template <int NPROD, int NA, int PF, bool VEC_X>
+// GATHER (rp_linear_wgrad_gather: the first layer of a model whose input is the embedding lookup): the first Kg = F * 64
+// columns of X are not read from a materialised activation buffer but GATHERED — X[m, f*64 + j] = arena[keys[f*keyB + m]*64
+// + j] with the arena-row keys the forward saved — so the forward never has to store its 436 MB of gathered rows; columns
+// >= Kg (the dense features) come from the compact buffer X (leading dimension ldx, column k - Kg).  A k-tile of 128
+// columns is two fields: lanes c < 32 read the row of field k0/64, the others the next one (two 256-byte segments per
+// wave-instruction, as coalesced as the activation read they replace).  Keys are fetched one stage ahead of the rows
+// they address.
+template <int NPROD, int NA, int PF, bool VEC_X, bool GATHER = false>
 __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                 const float *__restrict__ X, int64_t ldx,
                                                                 float *__restrict__ P, float *__restrict__ Pb,
-                                                                int64_t M, int N, int K, int64_t rows_per_split) {
+                                                                int64_t M, int N, int K, int64_t rows_per_split,
+                                                                const float *__restrict__ arena = nullptr,
+                                                                const int32_t *__restrict__ keys = nullptr,
+                                                                int64_t keyB = 0, int Kg = 0) {
     // output tile (64*NA) n x 128 k; waves 2 (n) x 2 (k), each NA x 2 MFMA tiles (NA = 2 for wide layers: every
     // fragment read from LDS then feeds two MFMA tiles)
     constexpr int NP = BfProd<NPROD>::NP;
@@ -843,6 +853,9 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
 
     float ry[PF][NA][8];
     f32x2 rx[PF][8];
+    const bool gtile = GATHER && (k0 + TN_BK <= Kg);                      // this k-tile is gathered (block-uniform)
+    const int32_t *kcol = GATHER ? keys + (int64_t)(kx >> 6) * keyB : nullptr;  // the keys of this lane's field
+    const int cin = kx & 63;
     auto load_tile = [&](int64_t mm, float (&dy_)[NA][8], f32x2 (&dx_)[8]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -851,7 +864,15 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
 #pragma unroll
             for (int u = 0; u < NA; ++u) dy_[u][r] = (ok && n0 + c + 64 * u < N) ? dY[m * lddy + n0 + c + 64 * u] : 0.f;
             f32x2 v = {0.f, 0.f};
-            if (ok) {
+            if (GATHER && ok) {
+                if (gtile) {
+                    v = *reinterpret_cast<const f32x2 *>(arena + (int64_t)kcol[m] * 64 + cin);
+                } else {  // the dense columns, from the compact buffer
+                    const float *px = X + m * ldx + (kx - Kg);
+                    if (kx < K) v.x = px[0];
+                    if (kx + 1 < K) v.y = px[1];
+                }
+            } else if (ok) {
                 const float *px = X + m * ldx + kx;
                 if (VEC_X && kx + 1 < K) {
                     v = *reinterpret_cast<const f32x2 *>(px);
@@ -866,12 +887,19 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
     // interior tile: unguarded loads -> straight-line main loop -> counted vmcnt waits (see linear_fwd_bf16_kernel)
     const float *yb = dY + (mbeg + 8 * o) * lddy + n0 + c;
     const float *xb = X + (mbeg + 8 * o) * ldx + kx;
+    const int32_t *kb = GATHER ? kcol + mbeg + 8 * o : nullptr;
+    int32_t kreg[8];  // GATHER: the keys of the rows the NEXT load_tile_full fetches
+    auto load_keys = [&](int64_t moff) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) kreg[r] = kb[moff + r];
+    };
     auto load_tile_full = [&](int64_t moff, float (&dy_)[NA][8], f32x2 (&dx_)[8]) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) dy_[u][r] = yb[(moff + r) * lddy + 64 * u];
-            dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
+            if (GATHER) dx_[r] = *reinterpret_cast<const f32x2 *>(arena + (int64_t)kreg[r] * 64 + cin);
+            else dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
         }
     };
 
@@ -944,7 +972,23 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
     const int64_t nst = (mend > mbeg) ? (mend - mbeg + TN_BM - 1) / TN_BM : 0;  // stages of 32 batch rows
     const int64_t nstf = (mend > mbeg) ? (mend - mbeg) / TN_BM : 0;             // ... that are complete
     int64_t sbeg = 0;
-    if (VEC_X && (n0 + BNT <= N) && (k0 + TN_BK <= K) && nstf >= 2 * PF) {
+    if (GATHER && gtile && PF == 1 && (n0 + BNT <= N) && nstf >= 3) {
+        // straight-line main loop as below; the keys of stage s + 2 are requested right after the rows of stage s + 1
+        load_keys(0);
+        load_tile_full(0, ry[0], rx[0]);
+        load_keys(TN_BM);
+        const int64_t nloop = nstf - 2;
+        for (int64_t it = 0; it < nloop; ++it) {
+            stage(ry[0], rx[0]);
+            load_tile_full((it + 1) * TN_BM, ry[0], rx[0]);
+            load_keys((it + 2) * TN_BM);
+            compute();
+        }
+        stage(ry[0], rx[0]);
+        load_tile_full((nloop + 1) * TN_BM, ry[0], rx[0]);
+        compute();
+        sbeg = nloop + 1;
+    } else if (!GATHER && VEC_X && (n0 + BNT <= N) && (k0 + TN_BK <= K) && nstf >= 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) load_tile_full((int64_t)p * TN_BM, ry[p], rx[p]);
         const int64_t nloop = (nstf - PF) / PF;
@@ -1323,6 +1367,50 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, S, N, K, dw,
                        lddw, db, accumulate);
     RP_LAUNCH_CHECK("linear_wgrad reduce");
+    return RP_OK;
+}
+
+// dW[N, K] = dY[M, N]^T . X[M, K] where the first Kg = F * 64 columns of X are the embedding rows of the batch, gathered
+// from the arena through the keys the forward saved (keys[f * M + m] = arena row of field f of sample m) instead of being
+// read from a stored activation buffer, and the remaining K - Kg <= 64 columns (the dense features) come from xd [M, ldxd].
+// N = 64 (the fused first layer), F even, bf16 matrix-core modes only (rp_linear_wgrad_gather_fits).
+extern "C" int rp_linear_wgrad_gather_fits(int64_t M, int N, int K, int Kg) {
+    return (g_matmul_precision != RP_MATMUL_FP32 && N == TN_BN && Kg >= TN_BK && Kg % TN_BK == 0 && K >= Kg &&
+            K - Kg <= 64 && M >= 1) ? 1 : 0;
+}
+
+extern "C" int rp_linear_wgrad_gather(const float *dy, int64_t lddy, const float *arena, const int32_t *keys, int Kg,
+                                      const float *xd, int64_t ldxd, float *dw, int64_t lddw, float *db, int64_t M, int N,
+                                      int K, int accumulate, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(dy && arena && keys && dw && workspace, "linear_wgrad_gather: null pointer");
+    RP_REQUIRE(K == Kg || xd, "linear_wgrad_gather: the dense columns need xd");
+    if (!rp_linear_wgrad_gather_fits(M, N, K, Kg) || !rp_aligned16(arena))
+        return rp_fail(RP_ERR_UNSUPPORTED, "linear_wgrad_gather: needs N = 64, F*64 a multiple of 128, <= 64 dense columns, a "
+                                           "bf16 matrix-core mode");
+    RP_REQUIRE(lddy >= N && lddw >= K && (K == Kg || ldxd >= K - Kg), "linear_wgrad_gather: leading dimension too small");
+    size_t need = 0;
+    rp_linear_wgrad_workspace_bytes(M, N, K, &need);
+    RP_REQUIRE(workspace_bytes >= need, "linear_wgrad_gather: workspace %zu < %zu bytes", workspace_bytes, need);
+    int S;
+    int64_t rows;
+    wgrad_plan(M, N, K, &S, &rows);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float *Pb = P + (size_t)S * N * K;
+    hipStream_t s = (hipStream_t)stream;
+    const int mode = linear_mode(M, N, K);
+    dim3 gridb((unsigned)rp_cdiv(K, TN_BK), 1u, (unsigned)S);
+#define CALLG(NPROD)                                                                                                        \
+    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 1, 1, true, true>), gridb, dim3(256), 0, s, dy, lddy, xd, ldxd, P, Pb, \
+                       M, N, K, rows, arena, keys, M, Kg)
+    if (mode == RP_MATMUL_BF16X6) CALLG(6);
+    else if (mode == RP_MATMUL_BF16X3) CALLG(3);
+    else CALLG(1);
+#undef CALLG
+    RP_LAUNCH_CHECK("linear_wgrad_gather partial");
+    const int64_t total = (int64_t)N * K + N;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, S, N, K, dw, lddw, db,
+                       accumulate);
+    RP_LAUNCH_CHECK("linear_wgrad_gather reduce");
     return RP_OK;
 }
 

@@ -3,6 +3,7 @@
 Everything here takes HIP-device fp32 tensors; nothing in this module computes on the CPU and
 nothing falls back: a missing librecpangu_hip.so raises from hip.lib().
 """
+import os
 from typing import List, Sequence
 
 import torch
@@ -739,13 +740,28 @@ class _EmbedGatherLinear(torch.autograd.Function):
         pre = store._presorted
         store._presorted = None
         need_grad = any(ctx.needs_input_grad[7:])
+        need_w = ctx.needs_input_grad[4] or (bias is not None and ctx.needs_input_grad[5])
         w16 = _rows16(weight)
+        B, K, Kg = idx[0].shape[0], weight.shape[1], len(idx) * store.embedding_dim
+        # x exists only for the weight gradient; inference stores none.  RP_WGRAD_GATHER=1: the weight gradient gathers the
+        # embedding rows itself (rp_linear_wgrad_gather: the arena does not change between this forward and its backward) and
+        # only the dense columns are stored.  Measured at Criteo shape: forward 0.195 -> 0.139 ms, weight gradient 0.148 ->
+        # 0.248 ms (random 256-byte rows, two per wave-instruction, against a streamed activation): a net loss of 0.015 ms per
+        # step, so it is OFF by default (bit-identical either way: tests/test_hip_kernels.py).
+        if not need_w:
+            x_mode = "none"
+        elif os.environ.get("RP_WGRAD_GATHER", "0") == "1" and hip.linear_wgrad_gather_fits(B, 64, K, Kg):
+            x_mode = "dense"
+        else:
+            x_mode = "full"
+        want_keys = (need_grad or x_mode == "dense") and pre is None
         x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx, w16,
-                                                            bias, True, need_grad, need_grad and pre is None, store.err_flag)
-        ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, idx[0].shape[0], weight.shape[1], out_link, bias is not None
+                                                            bias, True, need_grad, want_keys, store.err_flag, x_mode=x_mode)
+        ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, B, K, out_link, bias is not None
+        ctx.ldx, ctx.x_mode, ctx.Kg, ctx.need_tables = ldx, x_mode, Kg, need_grad
         ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
         if pre is not None:
-            keys = pre[0] if need_grad else None
+            keys = pre[0] if (need_grad or x_mode == "dense") else None
         ctx.save_for_backward(keys, ssum, x, h1, weight)
         store._fm_link = None
         return h1, fm
@@ -762,9 +778,12 @@ class _EmbedGatherLinear(torch.autograd.Function):
         dpre = dh1 if masked else hip.relu_bwd(dh1, h1)
         dw = db = None
         if ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5]):
-            dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
-        if keys is not None:
-            wt = hip.transpose(weight, rows_out=x.shape[1])
+            if ctx.x_mode == "dense":  # x holds the dense columns only: the embedding columns are gathered from the arena
+                dw, db = hip.linear_wgrad_gather(dpre, store.arena, keys, ctx.Kg, x, ctx.K, want_bias=ctx.has_bias)
+            else:
+                dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
+        if keys is not None and ctx.need_tables:
+            wt = hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
                                   fused=(dpre, wt))

@@ -28,7 +28,12 @@ _SIGNATURES = {
     "rp_embed_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "rp_embed_gather_linear_fits": (C.c_int, [_i32, _i32, _i32, _i64, _i64]),
     "rp_embed_gather_linear_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
-                                             _vp, _vp, _vp, _vp]),
+                                             _vp, _vp, _vp, _vp, _vp]),
+    "rp_embed_gather_linear_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp,
+                                                  _vp]),
+    "rp_linear_wgrad_gather_fits": (C.c_int, [_i64, _i32, _i32, _i32]),
+    "rp_linear_wgrad_gather": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz,
+                                         _vp]),
     "rp_sort_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
     "rp_embed_grad_reduce_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -301,8 +306,10 @@ def embed_gather_linear_fits(D: int, F: int, ND: int, hidden: int, ldx: int, W) 
 
 
 def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], ldx: int, W, bias,
-                            want_fm: bool, want_sum: bool, want_keys: bool, err_flag: torch.Tensor):
-    """the gather fused with the 64-wide Linear + ReLU that consumes it -> (x [B, ldx], h1 [B, 64], fm, ssum, keys)"""
+                            want_fm: bool, want_sum: bool, want_keys: bool, err_flag: torch.Tensor, x_mode: str = "full"):
+    """the gather fused with the 64-wide Linear + ReLU that consumes it -> (x, h1 [B, 64], fm, ssum, keys).
+    x_mode: "full" = x [B, ldx] is stored; "dense" = only the dense columns, as xd [B, 64] (the weight gradient gathers the
+    embedding rows itself: linear_wgrad_gather); "none" = nothing is stored (inference)."""
     _req(arena, torch.float32, "arena")
     _req(W, torch.float32, "W")
     F, ND = len(idx), len(dense)
@@ -316,18 +323,43 @@ def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor],
         if t.dim() != 1 or t.shape[0] != B or not t.is_contiguous():
             raise RuntimeError("dense tensors must be contiguous float32 [B]")
     dev = arena.device
-    x = torch.empty((B, ldx), dtype=torch.float32, device=dev)
+    assert x_mode in ("full", "dense", "none")
+    x = torch.empty((B, ldx), dtype=torch.float32, device=dev) if x_mode == "full" else None
+    xd = torch.empty((B, 64), dtype=torch.float32, device=dev) if x_mode == "dense" else None
     h1 = torch.empty((B, 64), dtype=torch.float32, device=dev)
     fm = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_fm else None
     ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if want_sum else None
     keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
     K = F * D + ND
+    # algorithmic bytes (rows + ids read, the [B, F*D+ND] output written — counted whether or not the launch
+    # stores it, the figure the gather is priced on) + h1
     with _Timed("embed_gather_linear_fwd", f"D={D}", B * (F * (D * 4 + 8) + (F * D + ND) * 4 + 64 * 4), 2 * B * K * 64):
         _check(lib().rp_embed_gather_linear_fwd(arena.data_ptr(), row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F,
-                                                _ptr_array(dense), ND, B, D, x.data_ptr(), ldx, W.data_ptr(), _rowmajor(W, "W"),
+                                                _ptr_array(dense), ND, B, D, _ptr(x), ldx, W.data_ptr(), _rowmajor(W, "W"),
                                                 _ptr(bias), h1.data_ptr(), _ptr(fm), _ptr(ssum), _ptr(keys),
-                                                err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd")
-    return x, h1, fm, ssum, keys
+                                                err_flag.data_ptr(), _ptr(xd), _stream()), "rp_embed_gather_linear_fwd")
+    return (x if x_mode == "full" else xd), h1, fm, ssum, keys
+
+
+def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], W, bias,
+                                 err_flag: torch.Tensor):
+    """bf16-storage inference: the fused lookup + FM + first Linear over a bf16 copy of the arena -> (h1 [B, 64], fm [B, 1])"""
+    _req(arena_bf16, torch.bfloat16, "arena_bf16")
+    _req(W, torch.float32, "W")
+    F, ND = len(idx), len(dense)
+    B, D = idx[0].shape[0], arena_bf16.shape[1]
+    dev = arena_bf16.device
+    h1 = torch.empty((B, 64), dtype=torch.float32, device=dev)
+    fm = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    K = F * D + ND
+    # algorithmic bytes: SURVEY 8d's bf16 figure — bf16 rows + int64 ids read, the [B, F*D] bf16 output "written" (it is
+    # consumed in registers here) = F * (2 D + 8) + 2 F D per sample (6 864 B at Criteo shape) — plus h1
+    with _Timed("embed_gather_linear_fwd_bf16", f"D={D}", B * (F * (D * 2 + 8) + F * D * 2 + 64 * 4), 2 * B * K * 64):
+        _check(lib().rp_embed_gather_linear_fwd_bf16(arena_bf16.data_ptr(), row_base.data_ptr(), row_count.data_ptr(),
+                                                     _ptr_array(idx), F, _ptr_array(dense), ND, B, D, W.data_ptr(),
+                                                     _rowmajor(W, "W"), _ptr(bias), h1.data_ptr(), fm.data_ptr(),
+                                                     err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd_bf16")
+    return h1, fm
 
 
 def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None):
@@ -439,6 +471,30 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     with _Timed("linear_wgrad", f"{M}x{N}x{K}", 4 * (M * N + M * K + N * K), 2 * M * N * K):
         _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
                                  M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
+    return dw, db
+
+
+def linear_wgrad_gather_fits(M: int, N: int, K: int, Kg: int) -> bool:
+    return bool(lib().rp_linear_wgrad_gather_fits(M, N, K, Kg))
+
+
+def linear_wgrad_gather(dy, arena, keys, Kg: int, xd, K: int, want_bias: bool = True):
+    """dw [N, K] = dy^T @ X with X[:, :Kg] gathered from the arena through `keys` ([F * M] int32, field-major) and
+    X[:, Kg:K] = xd[:, :K - Kg] (rp_linear_wgrad_gather)"""
+    _req(dy, torch.float32, "dy")
+    _req(arena, torch.float32, "arena")
+    _req(keys, torch.int32, "keys")
+    M, N = dy.shape
+    assert keys.numel() == (Kg // 64) * M and arena.shape[1] == 64
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
+    with _Timed("linear_wgrad_gather", f"{M}x{N}x{K}", 4 * (M * N + M * K + N * K), 2 * M * N * K):
+        _check(lib().rp_linear_wgrad_gather(dy.data_ptr(), _rowmajor(dy, "dy"), arena.data_ptr(), keys.data_ptr(), Kg, _ptr(xd),
+                                            _rowmajor(xd, "xd") if xd is not None else 0, dw.data_ptr(), K, _ptr(db), M, N, K,
+                                            0, ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad_gather")
     return dw, db
 
 

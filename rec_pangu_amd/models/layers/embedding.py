@@ -323,11 +323,45 @@ class EmbeddingLayer(nn.Module):
                 and hip.get_matmul_precision() != "fp32"
                 and hip.embed_gather_linear_fits(D, F, n_dense, 64, ldx, Fh._rows16(w)))
 
+    def bf16_lookup(self, enable: bool = True) -> None:
+        """bf16-STORAGE inference (SURVEY D6's secondary mode): snapshot the tables into a bf16 copy of the arena (half the
+        bytes: 4.3 GB at Criteo shape) that no-grad forwards of the fused lookup + first layer then read instead of the fp32
+        arena — half the gather traffic, fp32 accumulation, logits within 3e-2 of the fp32 tables' (bf16 rounding of every
+        looked-up value; outside the 1e-4 parity gate, which the fp32 tables keep).  The snapshot is taken of the CURRENT
+        weights (owed optimizer steps flushed first); training on makes it stale — a forward that would read a stale
+        snapshot raises.  enable=False drops it."""
+        if not enable:
+            self._arena_bf16 = None
+            return
+        self._ensure_packed()
+        self.flush_lazy()
+        self._arena_bf16 = self._arena.detach().to(torch.bfloat16)
+        self._bf16_stamp = (self._arena._version, None if self._lazy is None else self._lazy.t)
+
+    def _bf16_arena_for_inference(self):
+        a = self.__dict__.get("_arena_bf16")
+        if a is None or torch.is_grad_enabled():
+            return None
+        stamp = (self._arena._version, None if self._lazy is None else self._lazy.t)
+        if stamp != self._bf16_stamp or a.device != self._arena.device:
+            raise RuntimeError("the bf16 snapshot of the embedding tables is stale (the model was trained or moved since "
+                               "bf16_lookup()): call bf16_lookup() again, or bf16_lookup(False) to read the fp32 tables")
+        return a
+
     def gather_linear(self, X, dense: List[torch.Tensor], linear: nn.Linear, out_link, pad_to: int = 64):
         """HIP path: (h1 [B, 64] = relu(linear(cat(emb, dense))), fm [B,1]) in one launch; x is written for the backward
         but never re-read in the forward."""
         self._ensure_packed()
         idx = self._idx_list(X)
+        a16 = self._bf16_arena_for_inference()
+        if a16 is not None:
+            from ... import hip
+            dense = [t.float().reshape(-1).contiguous() for t in dense]
+            out = hip.embed_gather_linear_fwd_bf16(a16, self.row_base, self.row_count, idx, dense, Fh._rows16(linear.weight),
+                                                   linear.bias, self.err_flag)
+            if self.check_indices == "sync":
+                self.raise_if_bad_index()
+            return out
         F, D = len(idx), self.embedding_dim
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to

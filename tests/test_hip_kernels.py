@@ -703,3 +703,37 @@ def test_embed_gather_linear_vs_unfused(hip, rows, ND, B, biased):
         assert int(err[0]) != 0
     finally:
         hip.set_matmul_precision("auto")
+
+
+@pytest.mark.parametrize("M,F,ND", [(65536, 26, 13), (4096, 6, 0), (1000, 2, 16), (333, 4, 5)])
+@pytest.mark.parametrize("mode", ["auto", "bf16x6", "bf16x3"])
+def test_linear_wgrad_gather_equals_wgrad_on_the_stored_activation(M, F, ND, mode):
+    """rp_linear_wgrad_gather (the first layer's weight gradient gathering the embedding rows itself, so that the forward
+    need not store them) against rp_linear_wgrad on the materialised [M, F*64 + ND] activation: the same staging, the same
+    split plan, the same summation order — bit-identical, in every bf16 matrix-core mode."""
+    from rec_pangu_amd import hip
+    prev = hip.get_matmul_precision()
+    hip.set_matmul_precision(mode)
+    try:
+        _wgrad_gather_case(hip, M, F, ND)
+    finally:
+        hip.set_matmul_precision(prev)
+
+
+def _wgrad_gather_case(hip, M, F, ND):
+    g = torch.Generator().manual_seed(M + F)
+    R, D, K, Kg = 50000, 64, F * 64 + ND, F * 64
+    arena = torch.randn(R, D, generator=g).to(DEV)
+    keys = torch.randint(0, R, (F * M,), generator=g).to(torch.int32).to(DEV)
+    xd = torch.zeros(M, 64)
+    xd[:, :ND] = torch.rand(M, ND, generator=g)
+    xd = xd.to(DEV)
+    dy = (torch.randn(M, 64, generator=g) * (torch.rand(M, 64, generator=g) < 0.5)).to(DEV)
+    assert hip.linear_wgrad_gather_fits(M, 64, K, Kg) == (F % 2 == 0)
+    ld = (K + 63) // 64 * 64
+    x = torch.zeros(M, ld, device=DEV)
+    x[:, :Kg] = arena[keys.long().view(F, M).t().reshape(-1)].view(M, Kg)
+    x[:, Kg:K] = xd[:, :ND]
+    dw_ref, db_ref = hip.linear_wgrad(dy, x, K)
+    dw, db = hip.linear_wgrad_gather(dy, arena, keys, Kg, xd if ND else None, K)
+    assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
