@@ -345,17 +345,26 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
         if (keys_out != nullptr && bok) keys_out[(int64_t)f * B + b] = (int32_t)key;
     }
     __syncthreads();
+    // fp32 rows: 16 lanes x float4 per 256-byte row, rows g + 16 u (u < 8), v[u] = columns 4 sub .. 4 sub + 3.
+    // bf16 rows: 8 lanes x 16 bytes (8 bf16) per 128-byte row — EIGHT whole rows per wave-instruction, half the load
+    // instructions for half the bytes —, rows g8 + 32 u' (u' < 4); v[2 u'], v[2 u' + 1] = columns 8 s8 .. +3, +4 .. +7.
+    const int g8 = t >> 3, s8 = t & 7;
+    auto row_of = [&](int u) { return BF16_ROWS ? g8 + 32 * (u >> 1) : g + 16 * u; };
+    auto col_of = [&](int u) { return BF16_ROWS ? 8 * s8 + 4 * (u & 1) : 4 * sub; };
     auto load_rows = [&](int f, f32x4 (&v)[8]) {
+        if (BF16_ROWS) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (BF16_ROWS) {
-                const uint2 w2 = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(arena) +
-                                                                  (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
-                v[u] = f32x4{__uint_as_float(w2.x << 16), __uint_as_float(w2.x & 0xffff0000u), __uint_as_float(w2.y << 16),
-                             __uint_as_float(w2.y & 0xffff0000u)};
-            } else {
-                v[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
+            for (int u = 0; u < 4; ++u) {
+                const uint4 w4 = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(arena) +
+                                                                  (int64_t)Ks[g8 + 32 * u][f] * D + 8 * s8);
+                v[2 * u] = f32x4{__uint_as_float(w4.x << 16), __uint_as_float(w4.x & 0xffff0000u),
+                                 __uint_as_float(w4.y << 16), __uint_as_float(w4.y & 0xffff0000u)};
+                v[2 * u + 1] = f32x4{__uint_as_float(w4.z << 16), __uint_as_float(w4.z & 0xffff0000u),
+                                     __uint_as_float(w4.w << 16), __uint_as_float(w4.w & 0xffff0000u)};
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)Ks[g + 16 * u][f] * D + 4 * sub);
         }
     };
     auto load_w = [&](int col0, f32x4 (&v)[4]) {
@@ -385,11 +394,11 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
         __syncthreads();  // everyone is past the fragment reads of field f - 1: Xs and Wt are free
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int r = g + 16 * u;
-            *reinterpret_cast<f32x4 *>(&Xs[r][4 * sub]) = cur[u];
+            const int r = row_of(u);
+            *reinterpret_cast<f32x4 *>(&Xs[r][col_of(u)]) = cur[u];
             const int64_t br = blk * 128 + r;
             if (STORE_X && (FULL || (x != nullptr && br < B)))
-                *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + 4 * sub) = cur[u];
+                *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + col_of(u)) = cur[u];
             S[u] += cur[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[u] = __builtin_fmaf(cur[u][e], cur[u][e], q[u]);
@@ -499,7 +508,25 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             if (FULL || m < B) h1[m * 64 + n] = fmaxf(acc[nt][r] + bv, 0.f);
         }
     }
-    // FM second order and the field sum, from the row-traffic layout (16 lanes per sample)
+    // FM second order and the field sum, from the row-traffic layout (16 lanes per sample; bf16 rows: 8 lanes, two
+    // accumulator quads per sample)
+    if (BF16_ROWS) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t br = blk * 128 + g8 + 32 * u;
+            float fmv = -(q[2 * u] + q[2 * u + 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                fmv = __builtin_fmaf(S[2 * u][e], S[2 * u][e], fmv);
+                fmv = __builtin_fmaf(S[2 * u + 1][e], S[2 * u + 1][e], fmv);
+            }
+            fmv += __shfl_xor(fmv, 1, 64);
+            fmv += __shfl_xor(fmv, 2, 64);
+            fmv += __shfl_xor(fmv, 4, 64);
+            if ((FULL || br < B) && fm_out != nullptr && s8 == 0) fm_out[br] = 0.5f * fmv;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int64_t br = blk * 128 + g + 16 * u;
@@ -574,8 +601,8 @@ static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const 
         RP_REQUIRE(dense_ptrs[j], "embed_gather_linear_fwd: dense_ptrs[%d] is null", j);
         dp.p[j] = dense_ptrs[j];
     }
-    // workgroups whose 128 samples all exist run without lane masks (x written, or no row store at all: xd / bf16 rows)
-    const int64_t nfull = (x != nullptr || xd != nullptr || bf16_rows) ? B / 128 : 0;
+    // workgroups whose 128 samples all exist run without lane masks (x written, or no row store at all)
+    const int64_t nfull = B / 128;
     const int64_t nblk = rp_cdiv(B, 128);
     hipStream_t s = (hipStream_t)stream;
     if (bf16_rows) {
