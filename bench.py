@@ -214,6 +214,9 @@ def main():
                     help="bf16: SECONDARY inference line (--mode forward only) — the fused lookup + FM + first layer reads a "
                          "bf16 snapshot of the tables (half the gather traffic; logits within 3e-2 of the fp32 tables', outside "
                          "the 1e-4 parity gate; never the headline)")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
+                    help="row-sharded runs: bf16 = the looked-up rows and their gradients travel as bf16 (half the xGMI bytes; "
+                         "stated tolerance, tests/test_sharded_gloo.py::test_bf16_wire_mode_two_ranks); fp32 = parity mode")
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the strong-scaling-batch comparison (eager vs hipGraph at batch / 8) after the main run")
     ap.add_argument("--no-sort-ahead", action="store_true",
@@ -264,6 +267,8 @@ def main():
     for m in model.modules():
         if hasattr(m, "check_indices"):
             m.check_indices = "deferred"  # no per-step host sync; checked once after the run
+        if hasattr(m, "wire_dtype") and args.wire == "bf16":
+            m.wire_dtype = torch.bfloat16
     model.train()
     if args.storage == "bf16":
         assert args.mode == "forward" and not sharded and args.model == "deepfm", "--storage bf16 is the forward-only DeepFM line"
@@ -710,7 +715,8 @@ def main():
                                      f"zero_grad + the next batch's sort; rec_pangu_amd/graph_step.py, bit-identical to the "
                                      f"eager step: tests/test_hip_graph.py)" if gstep is not None else None),
                        "unique_rows_per_batch": n_unique,
-                       "parallelism": "single GPU" if not sharded else f"tables row-sharded x{world}, all-to-all lookup"},
+                       "parallelism": "single GPU" if not sharded else
+                       f"tables row-sharded x{world}, all-to-all lookup ({args.wire} rows on the wire)"},
             "pre_roll_steps": pre_roll, "cold": cold,
             "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
             "roofline": roofline, "roofline_gather": gather, "kernels": kernels,

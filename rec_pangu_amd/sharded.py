@@ -85,6 +85,24 @@ def _a2a(inp, out_splits, in_splits, group, world: int):
     return out
 
 
+_WIRE_BYTES = [0]  # payload bytes handed to the row / row-gradient exchanges since the last reset (tests, bench)
+
+
+def _a2a_rows(rows, out_splits, in_splits, layer):
+    """the [n, D] fp32 row (or row-gradient) exchange.  layer.wire_dtype == torch.bfloat16: the rows travel as bf16 (half
+    the bytes on every xGMI link: the row exchanges are the wire time of a sharded step) and are widened
+    again on arrival — a stated-tolerance mode like the bf16 tables (2^-9 relative per travelling value; logits within
+    3e-2), the fp32 wire stays the parity mode.  The bits are exchanged as bytes so that every backend takes them."""
+    if layer.world == 1 and not _force_a2a():
+        return rows
+    if getattr(layer, "wire_dtype", torch.float32) == torch.bfloat16:
+        packed = rows.to(torch.bfloat16).view(torch.uint8)  # [n, 2 D] bytes: every backend exchanges uint8
+        _WIRE_BYTES[0] += packed.numel()
+        return _a2a(packed, out_splits, in_splits, layer.group, layer.world).view(torch.bfloat16).to(torch.float32)
+    _WIRE_BYTES[0] += rows.numel() * 4
+    return _a2a(rows, out_splits, in_splits, layer.group, layer.world)
+
+
 class _Route:
     """One lookup exchange: the n = F*b row requests of the local batch are DEDUPLICATED and bucketed by owner.
 
@@ -175,7 +193,7 @@ class _ShardedRows(torch.autograd.Function):
         served = layer._local_gather(recv_rows, served_sorted)  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
-        rows = _a2a(served, route.send, route.recv, layer.group, layer.world)
+        rows = _a2a_rows(served, route.send, route.recv, layer)
         ctx.layer, ctx.route = layer, route
         ctx.scaled, layer._scaled = layer._scaled, None
         ctx.save_for_backward(recv_rows)
@@ -189,7 +207,7 @@ class _ShardedRows(torch.autograd.Function):
         # 1/G: the update must equal the 1-GPU update on the global batch (unless the producer already folded it in)
         prescaled = layer.world == 1 or (ctx.scaled is not None and ctx.scaled[0])
         g_rows = g_rows.contiguous() if prescaled else (g_rows * (1.0 / layer.world)).contiguous()
-        recv_g = _a2a(g_rows, route.recv, route.send, layer.group, layer.world)
+        recv_g = _a2a_rows(g_rows, route.recv, route.send, layer)
         layer._local_scatter_add(recv_rows, recv_g, presorted=ctx.presorted)
         return None, None, None
 
@@ -317,6 +335,7 @@ class ShardedEmbeddingLayer(nn.Module):
         self.emb_feature = emb_feature
         self.world, self.rank, self.group = world, rank, group
         self.check_indices = "sync"
+        self.wire_dtype = torch.float32  # torch.bfloat16: rows and row gradients travel as bf16 (_a2a_rows)
         base = [0]
         for r in rows[:-1]:
             base.append(base[-1] + r)
