@@ -80,13 +80,20 @@ def test_two_fused_adam_steps_vs_reference(name):
         if v.dtype.is_floating_point:
             tol = 2e-4 * max(1e-2, float(v.abs().max()))
             assert (sd[k].cpu() - v).abs().max() <= tol, f"{name}: {k} off by {(sd[k].cpu() - v).abs().max()}"
+    # train-mode cases: the +-lr noise steps of the zero-gradient pre-BatchNorm biases (and the running statistics that
+    # inherit them) are not comparable across devices — which way such a bias steps hangs on the last bit of a GEMM's
+    # rounding.  They are therefore FROZEN at the reference's own post-step values on this side before the inference
+    # output is compared: every other parameter — checked above at 2e-4 — then has to carry the
+    # output to within 2e-3 of the reference's (the gate was 4e-2 with the noisy biases left in).
+    if name.endswith("_train"):
+        noisy = {k: v for k, v in g["adam2"].items()
+                 if (k in g["grad"] and float(g["grad"][k].abs().max()) < 1e-6) or "running_" in k or "num_batches" in k}
+        assert noisy, "the train-mode cases are expected to have zero-gradient biases"
+        model.load_state_dict({**{k: v for k, v in sd.items()}, **{k: v.to(DEV) for k, v in noisy.items()}})
     model.eval()
     with torch.no_grad():
         r = model(_to_dev(g["batch"]), is_training=False)
-    # (mmoe_train: the +-lr noise steps of the pre-BatchNorm biases move the running means, hence eval outputs: which way
-    #  a zero-gradient bias steps depends on the last bit of the GEMM's rounding — observed spread across split
-    #  schemes / devices 1.5e-2 .. 2.4e-2 — so this bound only guards against gross errors)
-    atol = 4e-2 if name.endswith("_train") else 1e-4
+    atol = 2e-3 if name.endswith("_train") else 1e-4
     for k, v in g["adam2_out"].items():
         torch.testing.assert_close(r[k].cpu(), v, rtol=1e-3, atol=atol)
 
