@@ -107,7 +107,7 @@ int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, cons
 /* bf16-STORAGE inference (SURVEY D6's secondary mode; the fp32 tables stay the parity path and the training path): the same
  * launch over a bf16 copy of the arena (rows of D bf16 = 128 bytes at D = 64), fp32 accumulation everywhere, nothing stored
  * but h1 and the FM term.  The looked-up values differ from the fp32 tables' by bf16 rounding (2^-9 relative per element):
- * logits within 3e-2 (tests/test_hip_models.py), not within the 1e-4 parity gate. */
+ * logits within 6e-2 (measured 3.7e-2 at the Criteo shape: tests/test_hip_models.py), not within the 1e-4 parity gate. */
 int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
                                     const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
                                     int D, const float *W, int64_t ldw, const float *bias, float *h1, float *fm_out,

@@ -92,7 +92,7 @@ def _a2a_rows(rows, out_splits, in_splits, layer):
     """the [n, D] fp32 row (or row-gradient) exchange.  layer.wire_dtype == torch.bfloat16: the rows travel as bf16 (half
     the bytes on every xGMI link: the row exchanges are the wire time of a sharded step) and are widened
     again on arrival — a stated-tolerance mode like the bf16 tables (2^-9 relative per travelling value; logits within
-    3e-2), the fp32 wire stays the parity mode.  The bits are exchanged as bytes so that every backend takes them."""
+    6e-2), the fp32 wire stays the parity mode.  The bits are exchanged as bytes so that every backend takes them."""
     if layer.world == 1 and not _force_a2a():
         return rows
     if getattr(layer, "wire_dtype", torch.float32) == torch.bfloat16:
