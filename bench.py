@@ -119,6 +119,8 @@ KERNELS_OF = {
     "sort_pairs_i32": ("field_sort", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
     "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
+    "attention_core_fwd": ("attn_core_fwd_kernel",),
+    "attention_core_bwd": ("attn_core_bwd_kernel",),
 }
 
 
