@@ -11,6 +11,7 @@
 // a row of up to 256*CROSS_J floats lives in CROSS_J registers per thread.  Dot products are a wave
 // shuffle reduction + one LDS exchange between the 4 waves.
 #include "common.h"
+#include <cstdlib>
 
 #define CROSS_J 8  // d <= 2048
 #define CROSS_MAXL 6
@@ -28,6 +29,11 @@ __device__ __forceinline__ float block_allsum_256(float v, float *sh) {
 // next to them — the biases are staged once per workgroup, zero-padded to 256-column chunks; lane l owns columns
 // 256j + 4l .. +3 of chunk j (dwordx4 global accesses, conflict-free ds_read_b128).  The row stays in registers
 // through all L layers; each layer is one dot product (wave shuffles, no barrier) and one axpy.
+static int64_t cross_nb_max(int64_t dflt) {  // (RP_CROSS_NB: experiment knob for the persistent grid size)
+    static const int64_t v = getenv("RP_CROSS_NB") ? atoll(getenv("RP_CROSS_NB")) : 0;
+    return v > 0 ? v : dflt;
+}
+
 #define CROSS_NJ 8  // 256-column chunks per row: d <= 2048
 template <bool VEC, bool B_LDS>
 __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
@@ -278,7 +284,8 @@ extern "C" int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, 
     const bool vec = (ldx % 4 == 0) && (lddx % 4 == 0) && rp_aligned16(x0) && rp_aligned16(dx0) &&
                      (g_x == nullptr || ((ldg % 4 == 0) && rp_aligned16(g_x)));
     int64_t nb = rp_cdiv(B, 4);
-    if (nb > 2048) nb = 2048;  // persistent: each wave walks over B / (4 * 2048) rows, W staged once per workgroup
+    const int64_t nb_max = cross_nb_max(2048);
+    if (nb > nb_max) nb = nb_max;  // persistent: each wave walks over B / (4 * nb) rows, W staged once per workgroup
     if (vec)
         hipLaunchKernelGGL((crossnet_bwd_rows_kernel<true>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, x0,
                            ldx, d, L, W, wfc, s_in, g_x, ldg, g_logit, dx0, lddx, V, B);
@@ -304,7 +311,8 @@ extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const
     const size_t lds = (size_t)(b_lds ? 2 * L + 1 : L + 1) * dp * sizeof(float);
     const bool vec = (ldx % 4 == 0) && rp_aligned16(x0) && (xout == nullptr || ((ldo % 4 == 0) && rp_aligned16(xout)));
     int64_t nb = rp_cdiv(B, 4);
-    if (nb > 2048) nb = 2048;
+    const int64_t nb_max = cross_nb_max(2048);
+    if (nb > nb_max) nb = nb_max;
     hipStream_t st = (hipStream_t)stream;
 #define CF(VEC, BL)                                                                                                   \
     hipLaunchKernelGGL((crossnet_fwd_kernel<VEC, BL>), dim3((unsigned)nb), dim3(256), lds, st, x0, ldx, d, L, W, Bv, wfc, \
