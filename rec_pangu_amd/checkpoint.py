@@ -73,8 +73,11 @@ def shard_file(ckpt_dir: str, rank: int, world: int) -> str:
 
 
 def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, optimizer=None, group=None,
-                    merge: bool = True, filename: str = "model.pth") -> None:
-    """See the module docstring.  Collective over `group` when the model is sharded over more than one rank."""
+                    merge: bool = True, filename: str = "model.pth", keep_shards: bool = False) -> None:
+    """See the module docstring.  COLLECTIVE over `group` when the model is sharded over more than one rank: EVERY rank
+    must call it (two barriers inside) — a caller that saves "on rank 0 only", as single-process code does, deadlocks.
+    keep_shards=False: after a successful merge every rank removes its `shard_*` file (each holds a full shard of the
+    weights and moments; `model.pth` / `optimizer.pth` are what `load_checkpoint` reads)."""
     world, rank = _world(group)
     layers = _sharded_layers(model)
     if not layers:
@@ -114,6 +117,11 @@ def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, o
         merge_shards(ckpt_dir, world, enc_dict, filename)
     if world > 1:
         dist.barrier(group=group)
+    if merge and not keep_shards:
+        try:
+            os.remove(shard_file(ckpt_dir, rank, world))
+        except OSError:
+            pass
 
 
 def _merge_table(parts, f: int, rows, base, D: int, world: int, dtype):

@@ -99,7 +99,9 @@ class PinnedBatchLoader:
         other = [k for k in self._keys if cols[k].dtype not in (torch.int64, torch.float32)]
         if other:
             raise TypeError(f"columns {other}: only int64 ids and float32 values are fed")
-        self._host: List[torch.Tensor] = []   # per group: [n_batches, ncols, batch] pinned
+        self._host: List[torch.Tensor] = []   # per group: [n_batches, ncols, batch] pinned, allocated ONCE, refilled per epoch
+        lab = getattr(dataset, "_label_columns", None)
+        self._label_keys = set(lab().keys()) if callable(lab) else {k for k in self._keys if k == "label" or k.endswith("_label")}
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self.bytes_per_batch = sum(len(ks) * self.batch_size * (8 if dt == torch.int64 else 4)
                                    for dt, ks, _ in self._groups)
@@ -111,15 +113,23 @@ class PinnedBatchLoader:
         """Batch-major pinned layout for this epoch: host[g][i] = the [ncols, batch] block of batch i (the tail of the
         last, partial batch is padding that is never handed out)."""
         nb, bs = len(self), self.batch_size
-        self._host = []
-        for dt, ks, mat in self._groups:
-            src = mat if perm is None else mat[:, perm]
-            pad = nb * bs - min(src.shape[1], nb * bs)
-            src = src[:, :nb * bs]
-            if pad:
-                src = torch.cat([src, src.new_zeros((src.shape[0], pad))], dim=1)
-            blk = src.reshape(len(ks), nb, bs).permute(1, 0, 2).contiguous()
-            self._host.append(blk.pin_memory() if not blk.is_pinned() else blk)
+        first = not self._host
+        if not first:
+            # the pinned blocks are refilled IN PLACE: every host->device copy of the previous epoch that was still queued
+            # (the host runs ahead of the device) must have read them before they are overwritten
+            self._copy_stream.synchronize()
+        for g, (dt, ks, mat) in enumerate(self._groups):
+            if first:  # the pinned batch-major block of this group: one hipHostMalloc for the loader's lifetime
+                self._host.append(torch.zeros((nb, len(ks), bs), dtype=dt).pin_memory())
+            src = mat if perm is None else torch.index_select(mat, 1, perm)
+            full = min(src.shape[1], nb * bs) // bs  # whole batches; the tail batch (if any) is copied separately
+            if full:
+                self._host[g][:full].copy_(src[:, :full * bs].reshape(len(ks), full, bs).permute(1, 0, 2))
+            rest = min(src.shape[1], nb * bs) - full * bs
+            if rest:
+                self._host[g][full, :, :rest].copy_(src[:, full * bs:full * bs + rest])
+            if perm is None and not self.shuffle:
+                self._groups[g] = (dt, ks, None)  # never re-staged: the stacked copy is not needed any more
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         perm = _epoch_permutation(self.n, self.shuffle, self.generator)
@@ -156,7 +166,7 @@ class PinnedBatchLoader:
                 for j, k in enumerate(ks):
                     # feature columns are views of the recycled buffer (consumed within the step); label columns
                     # are kept by the training loop for the epoch's metrics, so they get their own (tiny) tensor
-                    batch[k] = buf[j, :rows].clone() if "label" in k else buf[j, :rows]
+                    batch[k] = buf[j, :rows].clone() if k in self._label_keys else buf[j, :rows]
             yield {k: batch[k] for k in self._keys}
             # asked for the next batch: everything the consumer enqueued for batch i - (hold - 1) is ahead of this event
             # on its stream

@@ -448,13 +448,23 @@ class EmbeddingLayer(nn.Module):
         side.wait_stream(main)  # the id tensors (and whatever produced them) are ordered on the caller's stream
         with torch.cuda.stream(side):
             idx = self._idx_list(X)
-            keys = hip.embed_keys(self.row_base, self.row_count, idx, self.err_flag)
+            # 'sync' mode raises at the step that finds a bad id: the keys of the NEXT batch must not set this step's flag
+            # (its own gather checks the same ids again when its turn comes) — they get a scratch flag
+            keys = hip.embed_keys(self.row_base, self.row_count, idx, self._ahead_flag())
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
             event = torch.cuda.Event()
             event.record(side)
         for t in src:
             t.record_stream(side)
         self._cache_sort(src, sig, (keys, sk, sp), event)
+
+    def _ahead_flag(self):
+        if self.check_indices != "sync":
+            return self.err_flag
+        f = self.__dict__.get("_scratch_flag")
+        if f is None or f.device != self._arena.device:
+            f = self.__dict__["_scratch_flag"] = torch.zeros((1,), dtype=torch.int32, device=self._arena.device)
+        return f
 
     def _sort_into(self, X, out, on_side_stream: bool) -> None:
         from ... import hip

@@ -295,8 +295,8 @@ def test_sharded_checkpoint_reference_layout_resume_and_reshard(tmp_path):
     mp.spawn(_ckpt_worker, args=(world, _free_port(), ckpt_dir, ret), nprocs=world, join=True)
     assert len(ret) == world and ret[0]["n_sharded"] == 2
     g = load_golden("model_xdeepfm.npz")
-    assert sorted(f for f in os.listdir(ckpt_dir) if f.endswith(".pth")) == [
-        "model.pth", "optimizer.pth", "shard_000_of_002.pth", "shard_001_of_002.pth"]
+    # (the per-rank shard files are removed after the merge: ADVICE r2)
+    assert sorted(f for f in os.listdir(ckpt_dir) if f.endswith(".pth")) == ["model.pth", "optimizer.pth"]
     saved = torch.load(os.path.join(ckpt_dir, "model.pth"), weights_only=False)
     assert sorted(saved.keys()) == ["enc_dict", "model"]
     plain = _build("xdeepfm")
