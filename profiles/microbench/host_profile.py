@@ -37,4 +37,4 @@ for i in range(200):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumulative").print_stats(45)
