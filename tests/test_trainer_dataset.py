@@ -331,3 +331,25 @@ def test_rank_trainer_fit_on_the_reference_sample_data(tmp_path):
     assert trainer.evaluate_model(model, test_loader, device=torch.device("cpu")) == meta["test_metric"]
     np.testing.assert_allclose(np.asarray(trainer.predict_dataloader(model, test_loader)), g["pred_dataloader"].numpy(),
                                rtol=1e-4, atol=1e-6)
+
+
+def test_one_ahead_pairs_for_the_graphed_loop():
+    """model_pipeline._one_ahead(pairs=True): (batch, next batch) pairs for a GraphedTrainStep — the same batches in the
+    same order, the last one paired with None, nothing announced to the model (the captured step sorts the next batch)."""
+    from rec_pangu_amd.model_pipeline import _one_ahead
+
+    class _Model:
+        def __init__(self):
+            self.announced = 0
+
+        def prefetch(self, data):
+            self.announced += 1
+
+    loader = [{"a": torch.tensor([i])} for i in range(5)]
+    m = _Model()
+    pairs = list(_one_ahead(loader, torch.device("cpu"), m, pairs=True))
+    assert [int(c["a"]) for c, _ in pairs] == [0, 1, 2, 3, 4]
+    assert [None if n is None else int(n["a"]) for _, n in pairs] == [1, 2, 3, 4, None]
+    assert all(pairs[i][1] is pairs[i + 1][0] for i in range(4)), "the announced batch IS the next current batch (identity)"
+    assert m.announced == 0
+    assert list(_one_ahead([], torch.device("cpu"), m, pairs=True)) == []
