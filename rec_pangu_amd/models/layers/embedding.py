@@ -557,8 +557,8 @@ class EmbeddingLayer(nn.Module):
             table = self.embedding_layer[base_name]
             if offsets is None:
                 e = table(ids if ids.dim() == 2 else ids.view(-1, 1))
-                s = torch.sum(e, dim=1)
-                return s if pooling == "sum" else s / ((e != 0).sum(dim=1).float() + 1e-16)
+                s = e.sum(dim=1)
+                return s if pooling == "sum" else s / (e.ne(0).sum(dim=1).to(e.dtype) + 1e-16)
             rows = table(ids.view(-1))  # ragged bags: segment sums over the flat id list
             lens = offsets[1:] - offsets[:-1]
             bag = torch.repeat_interleave(torch.arange(lens.numel()), lens)

@@ -16,9 +16,8 @@ class MaskedAveragePooling(nn.Module):
     def forward(self, embedding_matrix: torch.Tensor) -> torch.Tensor:
         if embedding_matrix.is_cuda and embedding_matrix.dim() == 3:
             return Fh.seq_pool(embedding_matrix, "average")
-        sum_pooling_matrix = torch.sum(embedding_matrix, dim=1)
-        non_padding_length = (embedding_matrix != 0).sum(dim=1)
-        return sum_pooling_matrix / (non_padding_length.float() + 1e-16)
+        nonzero = embedding_matrix.ne(0).sum(dim=1).to(embedding_matrix.dtype)  # per (sample, column), like the reference
+        return embedding_matrix.sum(dim=1) / (nonzero + 1e-16)
 
 
 class MaskedSumPooling(nn.Module):
@@ -27,4 +26,4 @@ class MaskedSumPooling(nn.Module):
     def forward(self, embedding_matrix: torch.Tensor) -> torch.Tensor:
         if embedding_matrix.is_cuda and embedding_matrix.dim() == 3:
             return Fh.seq_pool(embedding_matrix, "sum")
-        return torch.sum(embedding_matrix, dim=1)
+        return embedding_matrix.sum(dim=1)
