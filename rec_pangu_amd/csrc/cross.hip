@@ -34,6 +34,31 @@ static int64_t cross_nb_max(int64_t dflt) {  // (RP_CROSS_NB: experiment knob fo
     return v > 0 ? v : dflt;
 }
 
+// Stage `nrows` weight rows of d floats into LDS, zero padded to dp (a multiple of 256) columns per row.  A 256-column
+// chunk lies inside one row, so the row (and its source pointer) is wave-uniform; four chunks are requested per iteration
+// with UNCONDITIONAL, clamped loads (the element-by-element loop this replaces issued one guarded load at a time; measured:
+// no difference at Criteo shape, 0.224 / 0.265 ms forward / backward either way — the staging is not what bounds these
+// kernels).  row_ptr(l) returns the source of row l (NULL = a row of zeros).
+template <typename RowPtr>
+__device__ __forceinline__ void cross_stage_rows(float *__restrict__ wl, int nrows, int d, int dp, RowPtr row_ptr) {
+    const int cpr = dp / 256, nchunk = nrows * cpr;
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (c0 + u < nchunk) ? c0 + u : nchunk - 1;  // (uniform; the surplus chunks re-read the last one)
+            const int l = c / cpr;
+            const int e = (c - l * cpr) * 256 + (int)threadIdx.x;
+            const float *src = row_ptr(l);
+            const float t = (src != nullptr ? src : row_ptr(0))[e < d ? e : d - 1];
+            v[u] = (src != nullptr && e < d) ? t : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c0 + u < nchunk) wl[(c0 + u) * 256 + threadIdx.x] = v[u];
+    }
+}
+
 #define CROSS_NJ 8  // 256-column chunks per row: d <= 2048
 template <bool VEC, bool B_LDS>
 __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restrict__ x0, int64_t ldx, int d, int L,
@@ -45,16 +70,9 @@ __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restri
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [L][dp] W | [dp] wfc | (B_LDS: [L][dp] biases)
     const int dp = ((d + 255) / 256) * 256;
     const int nrows = B_LDS ? 2 * L + 1 : L + 1;
-    for (int idx = threadIdx.x; idx < nrows * dp; idx += 256) {
-        const int l = idx / dp, e = idx - l * dp;
-        float v = 0.f;
-        if (e < d) {
-            if (l < L) v = W[(int64_t)l * d + e];
-            else if (l == L) v = (wfc != nullptr) ? wfc[e] : 0.f;
-            else v = Bv[(int64_t)(l - L - 1) * d + e];
-        }
-        wl[idx] = v;
-    }
+    cross_stage_rows(wl, nrows, d, dp, [&](int l) -> const float * {
+        return l < L ? W + (int64_t)l * d : (l == L ? wfc : Bv + (int64_t)(l - L - 1) * d);
+    });
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nj = dp / 256;
@@ -175,12 +193,7 @@ __global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__r
                                                                 float *__restrict__ V, int64_t B) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [(L+1)][dp]
     const int dp = ((d + 255) / 256) * 256;
-    for (int idx = threadIdx.x; idx < (L + 1) * dp; idx += 256) {
-        const int l = idx / dp, e = idx - l * dp;
-        float v = 0.f;
-        if (e < d) v = (l < L) ? W[(int64_t)l * d + e] : (wfc != nullptr ? wfc[e] : 0.f);
-        wl[idx] = v;
-    }
+    cross_stage_rows(wl, L + 1, d, dp, [&](int l) -> const float * { return l < L ? W + (int64_t)l * d : wfc; });
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nj = dp / 256;
