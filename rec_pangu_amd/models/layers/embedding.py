@@ -319,9 +319,17 @@ class EmbeddingLayer(nn.Module):
         d = F * D + n_dense
         ldx = (d + pad_to - 1) // pad_to * pad_to
         w = linear.weight
-        return (os.environ.get("RP_GATHER_LINEAR", "1") != "0" and self._arena.is_cuda and D == 64 and linear.out_features == 64 and linear.in_features == d
-                and hip.get_matmul_precision() != "fp32"
-                and hip.embed_gather_linear_fits(D, F, n_dense, 64, ldx, Fh._rows16(w)))
+        # (the answer only depends on shapes, alignment and the matrix-core mode: remembered per weight tensor — the check
+        #  runs in every forward and used to stage the weight and cross the C ABI each time)
+        key = (id(w), w.data_ptr() % 16, tuple(w.shape), F, D, n_dense, pad_to, self._arena.is_cuda, hip.get_matmul_precision())
+        hit = self.__dict__.get("_glf_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        ok = (os.environ.get("RP_GATHER_LINEAR", "1") != "0" and self._arena.is_cuda and D == 64 and linear.out_features == 64 and linear.in_features == d
+              and hip.get_matmul_precision() != "fp32"
+              and hip.embed_gather_linear_fits(D, F, n_dense, 64, ldx, Fh._rows16(w)))
+        self.__dict__["_glf_cache"] = (key, ok)
+        return ok
 
     def bf16_lookup(self, enable: bool = True) -> None:
         """bf16-STORAGE inference (SURVEY D6's secondary mode): snapshot the tables into a bf16 copy of the arena (half the
@@ -365,7 +373,8 @@ class EmbeddingLayer(nn.Module):
         F, D = len(idx), self.embedding_dim
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
-        dense = [t.float().reshape(-1).contiguous() for t in dense]
+        dense = [t if (t.dtype is torch.float32 and t.dim() == 1 and t.is_contiguous()) else t.float().reshape(-1).contiguous()
+                 for t in dense]
         src = tuple(X[c] for c in self.emb_feature)
         self._presorted = None
         if self._lazy is not None and self._lazy.t > 0:
