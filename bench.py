@@ -116,7 +116,7 @@ KERNELS_OF = {
     "lazy_adam_rows_replay": ("lazy_replay_wave_kernel", "lazy_adam_rows_kernel"),
     "lazy_adam_rows_step": ("lazy_adam_rows_kernel",),
     "lazy_adam_flush": ("lazy_flush_wave_kernel", "lazy_adam_flush_kernel"),
-    "sort_pairs_i32": ("field_sort", "rocprim", "radix"),
+    "sort_pairs_i32": ("sort_hist", "sort_scan", "sort_scatter", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
     "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
     "attention_core_fwd": ("attn_core_fwd_kernel",),

@@ -115,8 +115,11 @@ int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_b
 
 /* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
  * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
- * interaction.py:38-44.  rp_sort_pairs_i32 sorts (key, position) pairs by key (stable, so
- * equal rows keep ascending sample order); workspace size from rp_sort_workspace_bytes. */
+ * interaction.py:38-44.  rp_sort_pairs_i32 sorts (key, position) pairs by the low end_bit bits of the key
+ * (stable, so equal rows keep ascending sample order; end_bit = 32 orders the keys as SIGNED ints);
+ * position = index into keys_in.  keys_in / keys_out / pos_out must not alias.  Kernel launches only (no
+ * memset, nothing carried between calls): capturable into a hipGraph at any n.  Workspace size from
+ * rp_sort_workspace_bytes.  RP_SORT=rocprim in the environment selects rocPRIM's radix sort instead. */
 int rp_sort_workspace_bytes(int64_t n, size_t *bytes);
 int rp_sort_pairs_i32(void *workspace, size_t workspace_bytes, const int32_t *keys_in, int32_t *keys_out,
                       int32_t *pos_out, int64_t n, int end_bit, rp_stream_t stream);

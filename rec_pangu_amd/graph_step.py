@@ -23,6 +23,7 @@ source): results are bit-identical to the eager loop (tests/test_hip_graph.py). 
 on ROCm) for the capture and for the allocator's graph-private pool; the first `eager_steps` calls run eagerly so that
 optimizer state, gradient buffers and caches exist before the capture.
 """
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -88,19 +89,21 @@ class GraphedTrainStep:
         # stream) alive into the capture, which runs on another stream — that cross-stream dependency breaks the capture
         return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
 
-    # rocPRIM switches to its onesweep radix sort above ~1 M pairs (global digit counters reset by memset nodes between
-    # the passes).  Replayed from a graph WITHOUT device-wide synchronisations in between, that path ends in memory access
-    # faults within a few hundred steps (B = 40960 x 26 fields = 1.06 M pairs: fault; B = 32768 = 0.85 M pairs: 600 steps
-    # clean; B = 65536 with torch.cuda.synchronize() every 50 steps: 1300 steps clean — scratch/probe_graph6.py).  Captured
-    # steps are the tool for SMALL, host-bound batches anyway (at B = 65536 a replay is slower than the eager launches).
-    MAX_PAIRS = 900_000
+    # Only with RP_SORT=rocprim: rocPRIM switches to its onesweep radix sort above ~1 M pairs (global digit counters reset
+    # by memset nodes between the passes).  Replayed from a graph WITHOUT device-wide synchronisations in between, that path
+    # ends in memory access faults within a few hundred steps (B = 40960 x 26 fields = 1.06 M pairs: fault; B = 32768 =
+    # 0.85 M pairs: 600 steps clean; B = 65536 with torch.cuda.synchronize() every 50 steps: 1300 steps clean).  The own
+    # radix sort of csrc/sort.hip (the default; kernels only, no memset nodes) replays cleanly at any size — B = 40960 and
+    # B = 65536, 1500 unsynchronised replays each, scratch/probe_graph6.py — which is what pinned the faults on that path.
+    # (Captured steps remain the tool for SMALL, host-bound batches: at B = 65536 a replay is slower than eager launches.)
+    MAX_PAIRS_ROCPRIM = 900_000
 
     def _alloc(self, batch):
         n_pairs = sum(batch[c].numel() for c in self.model.embedding_layer.emb_feature)
-        if n_pairs > self.MAX_PAIRS:
-            raise RuntimeError(f"GraphedTrainStep: {n_pairs} (sample, field) pairs per batch — above {self.MAX_PAIRS} the "
-                               "row sort takes rocPRIM's onesweep path, which does not survive unsynchronised graph "
-                               "replays on this runtime; run batches of this size eagerly (they are not host-bound)")
+        if os.environ.get("RP_SORT") == "rocprim" and n_pairs > self.MAX_PAIRS_ROCPRIM:
+            raise RuntimeError(f"GraphedTrainStep: {n_pairs} (sample, field) pairs per batch — above {self.MAX_PAIRS_ROCPRIM} "
+                               "rocPRIM's row sort takes its onesweep path, which does not survive unsynchronised graph "
+                               "replays on this runtime; unset RP_SORT=rocprim or run batches of this size eagerly")
         self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
         self._keys = list(batch.keys())
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured

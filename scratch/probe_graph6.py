@@ -21,7 +21,10 @@ gen = (lambda i: Bn.synth_batch(enc, B, 100 + i, dev, "uniform")) if fresh else 
 def eager(a, b):
     model.prefetch(b); out = model(a); out["loss"].backward(); opt.step(); model.zero_grad()
 nb = gen(0)
+t_start = None
 for i in range(steps):
+    if i == 100:
+        torch.cuda.synchronize(); t_start = time.perf_counter()
     cur, nb = nb, gen(i + 1)
     if inter and i % 400 in (395, 396, 397):
         eager(cur, nb)
@@ -32,5 +35,7 @@ for i in range(steps):
     if i % 200 == 199:
         print("enqueued", i + 1, "replays", gs.replays, flush=True)
 torch.cuda.synchronize()
+if t_start is not None:
+    print(f"ms/step over the last {steps - 100} steps: {(time.perf_counter() - t_start) / (steps - 100) * 1e3:.4f}")
 model.embedding_layer.raise_if_bad_index()
 print(f"OK B={B} steps={steps} fresh={fresh} inter={inter} sync={sync_every} replays={gs.replays} t={model.embedding_layer._lazy.t}")

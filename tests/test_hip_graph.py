@@ -147,6 +147,46 @@ def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch
         assert torch.equal(finals["eager"][k], finals["graph"][k]), k
 
 
+def test_graphed_step_above_a_million_pairs():
+    """1.2 M (sample, field) pairs per batch: the size at which rocPRIM's onesweep sort faulted under unsynchronised
+    replays (GraphedTrainStep.MAX_PAIRS_ROCPRIM).  The own radix sort has no memset nodes: 60 replays without a
+    synchronisation in between end in the same bits as the eager loop."""
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.optim import FusedAdam
+    from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+    from rec_pangu_amd.models.ranking import DeepFM
+    enc = _enc(2, [3000000, 70000])
+    batches = _batches(enc, 600000, 4, seed=4)
+    finals = {}
+    try:
+        for mode in ("eager", "graph"):
+            torch.manual_seed(0)
+            model = DeepFM(embedding_dim=8, hidden_units=[16], enc_dict=enc).to(DEV)
+            for m in model.modules():
+                if hasattr(m, "check_indices"):
+                    m.check_indices = "deferred"
+            opt = FusedAdam(model.parameters(), lr=2e-3, fuse_zero_grad=True, lazy_tables=True, replay="closed")
+            gstep = GraphedTrainStep(model, opt) if mode == "graph" else None
+            for i in range(64):
+                cur, nb = batches[i % 4], batches[(i + 1) % 4]
+                if gstep is not None:
+                    gstep(cur, nb)
+                else:
+                    model.prefetch(nb)
+                    model(cur)["loss"].backward()
+                    opt.step()
+                    model.zero_grad()
+            model.embedding_layer.raise_if_bad_index()
+            finals[mode] = {k: v.clone() for k, v in model.state_dict().items()}
+            if gstep is not None:
+                assert gstep.replays >= 60
+                del gstep
+    finally:
+        EmbeddingLayer.unpin_sorts()
+    for k in finals["eager"]:
+        assert torch.equal(finals["eager"][k], finals["graph"][k]), k
+
+
 def test_graphed_step_refuses_what_it_cannot_capture():
     from rec_pangu_amd.graph_step import GraphedTrainStep
     from rec_pangu_amd.models.ranking import DeepFM
@@ -159,14 +199,9 @@ def test_graphed_step_refuses_what_it_cannot_capture():
         GraphedTrainStep(model, opt)
     with pytest.raises(RuntimeError, match="FusedAdam"):
         GraphedTrainStep(model, torch.optim.Adam(model.parameters()))
-    # batches whose row sort would take rocPRIM's onesweep path (> 0.9 M pairs) are refused: see GraphedTrainStep.MAX_PAIRS
     for m in model.modules():
         if hasattr(m, "check_indices"):
             m.check_indices = "deferred"
-    gs = GraphedTrainStep(model, opt, eager_steps=0)
-    big = _batches(enc, 460000, 2, seed=1)
-    with pytest.raises(RuntimeError, match="onesweep"):
-        gs(big[0], big[1])
     # active dropout: the mask's (seed, offset) are launch arguments and would be frozen at capture
     from rec_pangu_amd import hip
     real = torch.cuda.is_current_stream_capturing

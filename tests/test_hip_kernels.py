@@ -23,6 +23,9 @@ def hip():
 
 
 DEV = "cuda"
+# the public Criteo-Kaggle cardinalities
+CRITEO = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10, 5652,
+          2173, 4, 7046547, 18, 15, 286181, 105, 142572]
 
 
 def _tables(rows, D, gen):
@@ -96,7 +99,13 @@ def test_embed_gather_flags_out_of_range(hip):
     assert int(err.item()) == 1
 
 
-@pytest.mark.parametrize("n,hi", [(1, 5), (1000, 7), (100001, 1 << 20), (1703936, 33762603)])
+# (n, hi): one pair / one wave / tile borders (4096-pair tiles, 1024-pair wave spans) / 1, 2, 3 and 4 digit passes of the
+# 9-bit radix (hi = 2^9, 2^9+1, 2^18+1, 2^27+1) / two keys only (every lane of a wave on one counter) / the DeepFM batch
+SORT_CASES = [(1, 5), (63, 3), (64, 2), (65, 600), (1000, 7), (4095, 512), (4096, 513), (4097, (1 << 18) + 1),
+              (5121, 2), (100001, 1 << 20), (262144 + 1023, (1 << 27) + 1), (1703936, 33762603)]
+
+
+@pytest.mark.parametrize("n,hi", SORT_CASES)
 def test_sort_pairs(hip, n, hi):
     g = torch.Generator().manual_seed(n)
     keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int32)
@@ -104,6 +113,54 @@ def test_sort_pairs(hip, n, hi):
     ref_k, ref_p = torch.sort(keys, stable=True)
     assert torch.equal(ko.cpu(), ref_k)
     assert torch.equal(po.cpu(), ref_p.to(torch.int32)), "sort must be stable (ascending position among equal rows)"
+
+
+def test_sort_pairs_field_ordered_keys_and_full_width(hip):
+    """the keys the gather backward sorts are 26 runs of one table's range each (field-major positions): most tiles hold a
+    handful of digits in the upper passes.  And all 32 bits = signed order (negative keys first)."""
+    g = torch.Generator().manual_seed(5)
+    rows = [r // 16 + 1 for r in CRITEO]
+    base = 0
+    parts = []
+    for r in rows:
+        parts.append(base + torch.randint(0, r, (8192,), generator=g))
+        base += r
+    keys = torch.cat(parts).to(torch.int32)
+    ko, po = hip.sort_pairs(keys.to(DEV), end_bit=(base - 1).bit_length())
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    assert torch.equal(ko.cpu(), ref_k) and torch.equal(po.cpu(), ref_p.to(torch.int32))
+    # end_bit below the keys' width: only the low bits order the pairs (rocPRIM's begin/end-bit meaning), stably
+    ko, po = hip.sort_pairs(keys.to(DEV), end_bit=11)
+    ref_p = torch.sort(keys & 2047, stable=True)[1]
+    assert torch.equal(po.cpu(), ref_p.to(torch.int32)) and torch.equal(ko.cpu(), keys[ref_p])
+    signed = torch.randint(-2 ** 31, 2 ** 31 - 1, (70001,), generator=g, dtype=torch.int64).to(torch.int32)
+    ko, po = hip.sort_pairs(signed.to(DEV), end_bit=32)
+    ref_k, ref_p = torch.sort(signed, stable=True)
+    assert torch.equal(ko.cpu(), ref_k) and torch.equal(po.cpu(), ref_p.to(torch.int32))
+    # persistent output buffers (the captured step's), twice: nothing is carried between calls
+    out = (torch.empty_like(ko), torch.empty_like(po))
+    for _ in range(2):
+        hip.sort_pairs(signed.to(DEV), end_bit=32, out=out)
+        assert torch.equal(out[0].cpu(), ref_k) and torch.equal(out[1].cpu(), ref_p.to(torch.int32))
+
+
+def test_sort_pairs_rocprim_path():
+    """RP_SORT=rocprim (read once per process) keeps rocPRIM's radix sort selectable: same results"""
+    import subprocess, sys, os
+    code = (
+        "import torch\n"
+        "from rec_pangu_amd import hip\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "for n, hi in [(1000, 7), (100001, 1 << 20), (1703936, 33762603)]:\n"
+        "    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int32)\n"
+        "    ko, po = hip.sort_pairs(keys.cuda(), end_bit=(hi - 1).bit_length())\n"
+        "    rk, rp = torch.sort(keys, stable=True)\n"
+        "    assert torch.equal(ko.cpu(), rk) and torch.equal(po.cpu(), rp.to(torch.int32))\n"
+        "print('ok')\n")
+    env = dict(os.environ, RP_SORT="rocprim")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("rows,D,B,with_fm,with_dx", [
