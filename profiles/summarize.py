@@ -30,7 +30,7 @@ LAST = 100
 def short(name):
     """kernel name without its parameter list, template arguments kept (they may contain parentheses: `float
     __vector(4)`), so that instantiations stay apart"""
-    n = name.replace("void ", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
     i = n.find(">(")
     n = n[:i + 1] if i >= 0 else n.split("(")[0]
     return n[:110]
