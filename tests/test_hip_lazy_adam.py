@@ -318,7 +318,7 @@ def test_closed_form_replay_model_level():
             preds.append(out["pred"].detach())
         if i + 1 in (256, 300, 500, 700, 1100):
             d_pred = float((preds[0] - preds[1]).abs().max())
-            d_dense = max(float((a - b).abs().max()) for (n, a), (_, b) in
+            d_dense = max(float((a.detach() - b.detach()).abs().max()) for (n, a), (_, b) in
                           zip(runs[0][0].named_parameters(), runs[1][0].named_parameters()) if "embedding" not in n)
             print(f"lockstep step {i + 1}: max |pred diff| {d_pred:.2e}, dense parameters {d_dense:.2e}")
             if i + 1 == 256:
