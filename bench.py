@@ -629,7 +629,10 @@ def main():
             # every sample's dH and sum row once per FIELD (F x 2 x B x 256 B), which is what the counters see: the
             # second figure says how fast it moves the bytes it does move
             r["note"] = ("frac = compulsory bytes (every dH / FM-sum row once) / time; the (field, row) pair order reads each "
-                         "of those rows once per field, which is the counter traffic: traffic_frac = traffic / time / peak")
+                         "of those rows once per field, which is the counter traffic: traffic_frac = traffic / time / peak.  "
+                         "The duration is event-bracketed while linear_wgrad runs BESIDE this kernel on a second stream "
+                         "(functional._wgrad_stream): alone (RP_WGRAD_OVERLAP=0, or rocprofv3's minimum) it takes "
+                         "0.29-0.32 ms = frac 0.12-0.14, traffic_frac 0.45-0.5")
             if r["traffic"]:
                 r["traffic_GBps"] = round(r["traffic"] / sec / 1e9, 1)
                 r["traffic_frac"] = round(r["traffic"] / sec / 1e9 / HBM_PEAK_GBS, 4)
