@@ -115,6 +115,7 @@ KERNELS_OF = {
     "linear_wgrad": ("linear_wgrad_bf16_kernel", "linear_wgrad_partial_kernel"),
     "lazy_adam_rows_replay": ("lazy_replay_wave_kernel", "lazy_adam_rows_kernel"),
     "lazy_adam_rows_step": ("lazy_adam_rows_kernel",),
+    "lazy_adam_catchup": ("lazy_adam_catchup_kernel",),
     "lazy_adam_flush": ("lazy_flush_wave_kernel", "lazy_adam_flush_kernel"),
     "sort_pairs_i32": ("sort_hist", "sort_scan", "sort_scatter", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
@@ -208,6 +209,10 @@ def main():
                     help="how the lazy optimizer catches a row up: 'closed' (library default) = closed-form replay of the "
                          "skipped zero-gradient steps (<= 1e-6 relative to the serial replay per replay, an HBM stream), "
                          "'exact' = serial replay, bit-identical to the dense HIP kernel (VALU-bound)")
+    ap.add_argument("--defer", action="store_true",
+                    help="lazy optimizer: run a row's real step at its next touch, in the one launch that also replays its "
+                         "skipped steps (FusedAdam(defer=True): same results after a flush, one optimizer launch per "
+                         "training step on the tables instead of two).  Opt-in; the default line does not use it")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the whole training step (fwd + bwd + optimizer + the next batch's sort) from a captured "
                          "hipGraph (rec_pangu_amd/graph_step.py; bit-identical to the eager step).  auto = on for single-GPU "
@@ -276,7 +281,8 @@ def main():
         assert args.mode == "forward" and not sharded and args.model == "deepfm", "--storage bf16 is the forward-only DeepFM line"
         model.embedding_layer.bf16_lookup()
     lazy = args.optimizer == "lazy" and args.mode == "train"
-    opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"), replay=args.replay)
+    opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"), replay=args.replay,
+                    defer=(True if args.defer else None))
     replay_mode = getattr(opt, "replay", None) if lazy else None
     n_params = sum(p.numel() for p in model.parameters())
     n_table_params = sum(p.numel() for m in model.modules() if hasattr(m, "table_parameters") for p in m.table_parameters())
@@ -343,9 +349,16 @@ def main():
         for store in getattr(opt, "_stores", {}).values():
             lz = store._lazy
             if lz is not None:
-                owed = (lz.t - lz.last.long()).clamp_(min=0) * (lz.last > 0)
+                last = lz.last.long()
+                last = torch.where(last < 0, -last - 1, last)  # (deferred mode: a pending stamp encodes "current through")
+                owed = (lz.t - last).clamp_(min=0) * (last > 0)
                 tot += int(owed.sum().item()) * store.embedding_dim
         return tot
+
+    def pending_real_steps():
+        """--defer: rows whose real step is still waiting in the gradient arena (one step each)"""
+        return sum(int((st._lazy.last < 0).sum().item()) for st in getattr(opt, "_stores", {}).values()
+                   if st._lazy is not None)
 
     # ---- (1) cold start: what a 20-step run measures right after initialisation (most rows have never been touched,
     #          have m = v = 0 and cost the lazy optimizer nothing) — kept as an extra key, NOT the headline
@@ -399,6 +412,7 @@ def main():
     prof = hip.timing_summary() if n_prof else None
     hip.enable_timing(False)
     backlog0 = lazy_backlog() if lazy else None
+    pending0 = pending_real_steps() if (lazy and getattr(opt, "defer", False)) else None
     # ---- (4) timed region: EXACTLY --steps steps; events only around the launches the roofline objects report
     if prof is not None:
         ours = {n: c * m for n, (c, m) in prof.items() if not n.startswith("lazy_adam_flush") and not side_stream(n)}
@@ -455,6 +469,7 @@ def main():
     # ---- (5) the lazy optimizer's deferred work: equal at both ends of the timed region in the long-run state (nothing
     #          was pushed out of the window); the flush that a checkpoint would trigger is timed separately
     backlog1 = lazy_backlog() if lazy else None
+    pending1 = pending_real_steps() if (lazy and getattr(opt, "defer", False)) else None
     flush_ms = None
     replay_elem_steps = None
     if lazy:
@@ -466,6 +481,7 @@ def main():
                 keys = hip.embed_keys(store.row_base, store.row_count, idx, store.err_flag)
                 u = torch.unique(keys).long()
                 l_ = store._lazy.last[u].long()
+                l_ = torch.where(l_ < 0, -l_ - 1, l_)
                 replay_elem_steps = int(((store._lazy.t - l_) * (l_ > 0)).sum().item()) * store.embedding_dim
         barrier()
         t1 = time.perf_counter()
@@ -538,6 +554,8 @@ def main():
             fm = has_fm and dd == D
             return local_B * 64 * 4 + (local_B * rb if fm else 0) + 8 * n_pairs + (2 if fm else 1) * n_unique * rb \
                 + F * 64 * rb, 2.0 * n_pairs * 64 * dd
+        if entry == "lazy_adam_catchup":      # deferred mode: p,m,v read+written, g read + cleared, per unique row
+            return 8 * n_unique * rb, 0
         if entry == "lazy_adam_rows_step":    # p,m,v read+written, g read + cleared, per unique touched row
             return 8 * n_unique * rb, 0
         if entry == "lazy_adam_rows_replay":  # p,m,v read+written per unique row that is behind (bound: all of them)
@@ -724,6 +742,7 @@ def main():
                                    + (", CIN [128,128]" if args.model == "xdeepfm" else ""),
                        "global_batch": B, "per_gpu_batch": local_B, "optimizer": opt_txt,
                        "matmul_precision": precision, "lazy_replay": replay_mode,
+                       "deferred_real_step": bool(getattr(opt, "defer", False)),
                        "sort_ahead": bool(ahead),
                        "hip_graph": (f"the timed steps are replays of a captured hipGraph (fwd + bwd + optimizer step + "
                                      f"zero_grad + the next batch's sort; rec_pangu_amd/graph_step.py, bit-identical to the "
@@ -750,6 +769,12 @@ def main():
                 "state": f"long-run: {pre_roll} un-timed pre-roll steps on distinct batches before the warm-up",
                 "owed_element_steps_before": backlog0, "owed_element_steps_after": backlog1,
                 "flush_ms_after_timed_region": round(flush_ms, 3),
+                **({"deferred_real_steps_waiting_before": pending0, "deferred_real_steps_waiting_after": pending1,
+                    "deferred_note": "--defer: rows whose real step waits for their next touch.  In the true steady state "
+                                     "every touched row carries one and the count is constant; while rows of the large "
+                                     "tables are still being touched for the FIRST time it grows, i.e. that many real "
+                                     "steps (of the steps x unique rows the window owes) run after the window"}
+                   if pending0 is not None else {}),
                 "note": "no flush inside the timed region: in the long-run state the deferred zero-gradient work is the "
                         "same at both ends of the window (the two figures above), so none of it is pushed out of the "
                         "measurement; flush_ms is what state_dict()/a checkpoint pays to bring every row to the last step"}

@@ -507,6 +507,27 @@ int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_
  *                          changes.  ns_d: device double2 table indexed by step: {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)}.
  *   rp_lazy_adam_cf_terms  number of leading terms that carry weight (b1^J < 1e-17) */
 int rp_lazy_adam_cf_terms(double beta1, int *terms);
+/* DEFERRED real step (opt-in execution mode of the same optimizer; no reference counterpart beyond trainer.py:75).
+ * A row's real step needs only its own gradient row, which stays in the (dense) gradient arena: it can wait, like the
+ * zero-gradient steps, until the row is next needed.  One launch per training step then does what the rows of the
+ * incoming batch are owed — 8 rows of traffic per unique row instead of 6 (replay) + 8 (step).
+ *   last[row] >= 0: as above.  last[row] < 0: (p,m,v) current through step l = -last-1 and g[row] = the gradient of
+ *   step l+1, not applied yet.
+ *   rp_lazy_adam_catchup  for every unique row of sorted_keys: a pending gradient whose step has been taken
+ *                         (l+1 <= t_done) is applied with the scalars of step l+1 and its row cleared, then the
+ *                         zero-gradient steps up to t_done (serial up to cf_from, closed form beyond if cf_table);
+ *                         mark != 0: the row is stamped pending for step t_done+1 (the backward of the forward this
+ *                         launch precedes writes its gradient; a row that receives none holds zeros, and the real
+ *                         step with g = 0 IS the zero-gradient step).  t_dev: device counter of completed steps.
+ *   rp_lazy_adam_flush_deferred  the same for every row of the arena through t_target (g may be NULL when no
+ *                         gradient arena exists yet); stamps last[row] = t_target.
+ * Per row the same operations on the same values in the same order as rp_lazy_adam_rows: identical bits after a flush. */
+int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
+                         int32_t *last, const float *step_scalars, int64_t t_done, int mark, double beta1, double beta2,
+                         double eps, const float *cf_table, int64_t cf_from, const int32_t *t_dev, rp_stream_t stream);
+int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float *g, float *m, float *v, int32_t *last,
+                                const float *step_scalars, int64_t t_target, double beta1, double beta2, double eps,
+                                const float *cf_table, int64_t cf_from, rp_stream_t stream);
 int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2, float *cf_table,
                           const int32_t *t_dev, rp_stream_t stream);
 

@@ -795,6 +795,185 @@ extern "C" int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float
     return RP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// DEFERRED execution of the real step (opt-in: LazyAdamRows(defer=True), rec_pangu_amd/optim.py).
+//
+// The lazy execution above touches the rows of a batch twice per training step: the replay before the forward (read
+// p, m, s; write p, m, s: 6 rows) and the real step after the backward (read p, m, s, g; write p, m, s, g = 0: 8 rows).
+// But a row's real step needs nothing but its own gradient row, which stays where the backward wrote it (the gradient
+// arena is dense: one row per table row).  So the step of a row can wait, like its zero-gradient steps do, until the
+// row is next needed — and then ONE launch per training step does everything its batch's rows are owed:
+//     the pending real step (step number l+1, its own scalars, the stored gradient row; the row is cleared),
+//     then the zero-gradient steps l+2 .. t_done (serial up to cf_from, closed form beyond),
+// 8 rows of traffic per unique row instead of 14.  Per row the SAME operations run on the SAME values in the SAME order
+// as in the immediate execution (and, with the serial replay, as in the dense kernel): bit-identical results after a
+// flush; only their time of execution moves.
+//   last[row] >= 0 : (p, m, s) are current through step last[row]; no gradient pending (0 = never updated)
+//   last[row] <  0 : current through step l = -last[row] - 1, and grad_arena[row] holds the gradient of step l + 1
+// A pending gradient is applicable once its step has been taken (l + 1 <= t_done); one whose step is still in progress
+// (a second forward before optimizer.step(): gradient accumulation, or an evaluation pass) is left alone.
+// mark: this launch precedes a forward whose backward will write the rows' gradients of step t_done + 1: they are
+// stamped pending for it (a row that then receives no gradient holds zeros: adam1 with g = 0 IS the zero-gradient step).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void lazy_owed(T &p, T &m, T &v, bool apply, int l, int t_done, const T g,
+                                          const float2 *__restrict__ sc, const LazyCfg &c,
+                                          const CfEntry *__restrict__ cf, int cf_from) {
+    int lc = l;
+    if (apply) {
+        const float2 s = sc[l + 1];
+        adam1<T>(p, g, m, v, c.one_m_b1, c.b2, c.sqrt_b2, c.one_m_b2, s.x, s.y);
+        lc = l + 1;
+    }
+    if (lc > 0 && lc < t_done) {
+        const int t_serial = (cf && cf_from < t_done) ? cf_from : t_done;  // (exact mode: everything)
+#pragma unroll 4
+        for (int j = lc + 1; j <= t_serial; ++j) {
+            const float2 s = sc[j];
+            adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
+        }
+        const int l2 = lc > t_serial ? lc : t_serial;
+        if (l2 < t_done) adam_zero_grad_closed<T>(p, m, v, cf[t_done - l2], c.eps);
+    }
+}
+
+template <int TPR, typename T>
+__global__ __launch_bounds__(256) void lazy_adam_catchup_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
+                                                                float *__restrict__ P, float *__restrict__ G,
+                                                                float *__restrict__ Mo, float *__restrict__ Vo,
+                                                                int32_t *__restrict__ last,
+                                                                const float2 *__restrict__ sc, int t_done, int mark,
+                                                                LazyCfg c, const CfEntry *__restrict__ cf, int cf_from,
+                                                                const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) t_done = *t_dev;  // completed steps (graph replays)
+    constexpr int GPB = 256 / TPR;
+    const int t = threadIdx.x % TPR;
+    const int64_t i = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR;
+    if (i >= n) return;
+    const int32_t row = sk[i];
+    if (i > 0 && sk[i - 1] == row) return;  // not a run head
+    const int raw = last[row];
+    const bool pend = raw < 0;
+    const int l = pend ? -raw - 1 : raw;
+    const bool apply = pend && l + 1 <= t_done && G != nullptr;
+    const bool behind = apply || (l > 0 && l < t_done);
+    if (behind) {
+        constexpr int VW = sizeof(T) / sizeof(float);
+        for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
+            const int64_t off = (int64_t)row * D + cidx;
+            T p = *reinterpret_cast<T *>(P + off);
+            T m = *reinterpret_cast<T *>(Mo + off);
+            T v = *reinterpret_cast<T *>(Vo + off);
+            T g = rp_splat(0.f, p);
+            if (apply) {
+                g = *reinterpret_cast<const T *>(G + off);
+                *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
+            }
+            lazy_owed<T>(p, m, v, apply, l, t_done, g, sc, c, cf, cf_from);
+            *reinterpret_cast<T *>(P + off) = p;
+            *reinterpret_cast<T *>(Mo + off) = m;
+            *reinterpret_cast<T *>(Vo + off) = v;
+        }
+    }
+    if (t == 0) {
+        int nl = raw;
+        if (!(pend && !apply)) {  // (a gradient whose step is still in progress stays pending as it is)
+            if (mark) nl = -(t_done + 1);
+            else if (behind) nl = t_done;
+        }
+        if (nl != raw) last[row] = nl;
+    }
+}
+
+// every row of the arena: what it is owed through step t_target (checkpoints, state_dict(), evaluation on raw tables)
+template <int TPR, typename T>
+__global__ __launch_bounds__(256) void lazy_adam_flush_deferred_kernel(int64_t R, int D, float *__restrict__ P,
+                                                                       float *__restrict__ G, float *__restrict__ Mo,
+                                                                       float *__restrict__ Vo, int32_t *__restrict__ last,
+                                                                       const float2 *__restrict__ sc, int t_target,
+                                                                       LazyCfg c, const CfEntry *__restrict__ cf,
+                                                                       int cf_from) {
+    constexpr int GPB = 256 / TPR;
+    constexpr int VW = sizeof(T) / sizeof(float);
+    const int t = threadIdx.x % TPR;
+    const int64_t stride = (int64_t)gridDim.x * GPB;
+    for (int64_t row = (int64_t)blockIdx.x * GPB + threadIdx.x / TPR; row < R; row += stride) {
+        const int raw = last[row];
+        const bool pend = raw < 0;
+        const int l = pend ? -raw - 1 : raw;
+        const bool apply = pend && l + 1 <= t_target && G != nullptr;
+        const bool behind = apply || (l > 0 && l < t_target);
+        if (!behind) continue;
+        for (int cidx = t * VW; cidx < D; cidx += TPR * VW) {
+            const int64_t off = row * D + cidx;
+            T p = *reinterpret_cast<T *>(P + off);
+            T m = *reinterpret_cast<T *>(Mo + off);
+            T v = *reinterpret_cast<T *>(Vo + off);
+            T g = rp_splat(0.f, p);
+            if (apply) {
+                g = *reinterpret_cast<const T *>(G + off);
+                *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
+            }
+            lazy_owed<T>(p, m, v, apply, l, t_target, g, sc, c, cf, cf_from);
+            *reinterpret_cast<T *>(P + off) = p;
+            *reinterpret_cast<T *>(Mo + off) = m;
+            *reinterpret_cast<T *>(Vo + off) = v;
+        }
+        if (t == 0) last[row] = t_target;
+    }
+}
+
+extern "C" int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
+                                    int32_t *last, const float *step_scalars, int64_t t_done, int mark, double beta1,
+                                    double beta2, double eps, const float *cf_table, int64_t cf_from,
+                                    const int32_t *t_dev, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_catchup: null pointer");
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
+               "lazy_adam_catchup: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
+    RP_REQUIRE(D >= 1, "lazy_adam_catchup: D must be positive");
+    RP_REQUIRE(t_dev != nullptr || (t_done >= 0 && t_done < INT32_MAX - 1), "lazy_adam_catchup: bad step");
+    if (n == 0) return RP_OK;
+    const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
+    LazyCfg c{(float)(1.0 - beta1), (float)beta2, (float)std::sqrt(beta2), (float)(1.0 - beta2), (float)eps};
+    const int tpr = lazy_tpr(D, vw);
+    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
+    hipStream_t s = (hipStream_t)stream;
+    const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
+    const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
+#define CALL(T, TY)                                                                                                      \
+    hipLaunchKernelGGL((lazy_adam_catchup_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
+                       sc, (int)t_done, mark, c, cf, (int)cf_from, t_dev)
+    LAZY_DISPATCH(tpr, vw, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("lazy_adam_catchup");
+    return RP_OK;
+}
+
+extern "C" int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float *g, float *m, float *v, int32_t *last,
+                                           const float *step_scalars, int64_t t_target, double beta1, double beta2,
+                                           double eps, const float *cf_table, int64_t cf_from, rp_stream_t stream) {
+    RP_REQUIRE(p && m && v && last && step_scalars, "lazy_adam_flush_deferred: null pointer");
+    RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
+               "lazy_adam_flush_deferred: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
+    RP_REQUIRE(D >= 1 && t_target < INT32_MAX - 1, "lazy_adam_flush_deferred: bad D / step");
+    if (rows == 0 || t_target <= 0) return RP_OK;
+    const int vw = (D % 4 == 0 && rp_aligned16(p) && rp_aligned16(m) && rp_aligned16(v) && (!g || rp_aligned16(g))) ? 4 : 1;
+    LazyCfg c{(float)(1.0 - beta1), (float)beta2, (float)std::sqrt(beta2), (float)(1.0 - beta2), (float)eps};
+    const int tpr = lazy_tpr(D, vw);
+    int64_t nb = rp_cdiv(rows, 256 / tpr);
+    if (nb > 65536) nb = 65536;
+    hipStream_t s = (hipStream_t)stream;
+    const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
+    const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
+#define CALL(T, TY)                                                                                                       \
+    hipLaunchKernelGGL((lazy_adam_flush_deferred_kernel<T, TY>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, g, m, v, \
+                       last, sc, (int)t_target, c, cf, (int)cf_from)
+    LAZY_DISPATCH(tpr, vw, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("lazy_adam_flush_deferred");
+    return RP_OK;
+}
+
 // *counter += delta on the stream (the device-resident step counters of the hipGraph path)
 __global__ void counter_add_kernel(int32_t *c, int32_t delta) { *c += delta; }
 

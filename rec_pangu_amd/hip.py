@@ -116,6 +116,10 @@ _SIGNATURES = {
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _f64, _f64,
                                     _vp, _i64, _vp, _vp]),
     "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64, _vp]),
+    "rp_lazy_adam_catchup": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
+                                       _vp, _i64, _vp, _vp]),
+    "rp_lazy_adam_flush_deferred": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64,
+                                              _vp]),
     "rp_embed_gather_pool_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_embed_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "rp_seq_pool_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
@@ -1261,6 +1265,26 @@ def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, be
                                         scalars.data_ptr(), t_target, beta1, beta2, eps, _ptr(cf_table), cf_from,
                                         _stream()),
                "rp_lazy_adam_flush")
+
+
+def lazy_adam_catchup(sorted_keys, D: int, p, g, m, v, last, scalars, t_done: int, mark: bool, beta1: float,
+                      beta2: float, eps: float, cf_table=None, cf_from: int = 0, t_dev=None):
+    """deferred execution (rp_lazy_adam_catchup): everything the unique rows of sorted_keys are owed through step t_done —
+    their pending real step, then the zero-gradient steps — and, with mark, the stamp 'gradient of step t_done+1 coming'"""
+    with _Timed("lazy_adam_catchup", f"D={D}"):
+        _check(lib().rp_lazy_adam_catchup(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
+                                          m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_done,
+                                          int(mark), beta1, beta2, eps, _ptr(cf_table), cf_from, _ptr(t_dev), _stream()),
+               "rp_lazy_adam_catchup")
+
+
+def lazy_adam_flush_deferred(rows: int, D: int, p, g, m, v, last, scalars, t_target: int, beta1: float, beta2: float,
+                             eps: float, cf_table=None, cf_from: int = 0):
+    with _Timed("lazy_adam_flush", f"D={D}"):
+        _check(lib().rp_lazy_adam_flush_deferred(rows, D, p.data_ptr(), _ptr(g), m.data_ptr(), v.data_ptr(),
+                                                 last.data_ptr(), scalars.data_ptr(), t_target, beta1, beta2, eps,
+                                                 _ptr(cf_table), cf_from, _stream()),
+               "rp_lazy_adam_flush_deferred")
 
 
 def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table, t_dev=None):

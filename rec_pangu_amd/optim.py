@@ -94,8 +94,12 @@ class LazyAdamRows:
     TABLE_CHUNK = 1024
     CF_FROM = 256
 
-    def __init__(self, store, betas, eps, owner=None, t0: int = 0, replay: str = "exact"):
+    def __init__(self, store, betas, eps, owner=None, t0: int = 0, replay: str = "exact", defer: bool = False):
         a = store.arena
+        # defer: the real step of a row runs at its next touch, together with its zero-gradient steps (one launch per
+        # training step instead of two; adam.hip "DEFERRED execution").  `last` then carries pending stamps (< 0).
+        self.defer = defer
+        self._marked_for = -1  # the step whose gradient rows the last catch-up launch stamped pending
         self.m, self.v = torch.zeros_like(a), torch.zeros_like(a)
         self.last = torch.zeros((a.shape[0],), dtype=torch.int32, device=a.device)
         self.betas, self.eps = betas, eps
@@ -170,6 +174,19 @@ class LazyAdamRows:
         return self.tabs.t_dev if self.device_clock else None
 
     def replay(self, store, sorted_keys):
+        if self.defer:
+            # everything the batch's rows are owed (pending real step + skipped steps); under autograd their gradient of
+            # the step in progress is announced (they are stamped pending for step t + 1)
+            mark = torch.is_grad_enabled()
+            if self.t > 0 or mark:
+                self._check_table(self.t)
+                cf, cf_from = self._cf_args(self.t) if (self.t > 0 or self.device_clock) else (None, 0)
+                hip.lazy_adam_catchup(sorted_keys, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v,
+                                      self.last, self.tabs.sc, self.t, mark, self.betas[0], self.betas[1], self.eps, cf,
+                                      cf_from, self._t_dev())
+                if mark:
+                    self._marked_for = self.t + 1
+            return
         if self.t > 0:
             self._check_table(self.t)
             cf, cf_from = self._cf_args(self.t)
@@ -181,8 +198,13 @@ class LazyAdamRows:
         t_new = self.t + 1
         self._ensure_table(t_new, lr)
         self._check_table(t_new)
-        sk = self._sorted_touched(store)
-        if sk is not None and sk.numel():
+        sk = None if (self.defer and zero_grad and self._marked_for == t_new) else self._sorted_touched(store)
+        if self.defer and zero_grad and self._marked_for == t_new:
+            # the rows were stamped by the catch-up launch in front of their forward: their gradient rows stay where the
+            # backward wrote them and are applied (with THIS step's scalars, sc[t_new]) at the rows' next touch
+            pass
+        elif sk is not None and sk.numel():
+            # (deferred mode: the step right after this state was created — its forward ran before any stamp existed)
             cf, cf_from = self._cf_args(self.t, build=False)  # the catch-up before the real step ends at t_new - 1
             hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
                                self.tabs.sc, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps, cf, cf_from,
@@ -200,14 +222,19 @@ class LazyAdamRows:
         was, self.device_clock = self.device_clock, False  # (never inside a captured step: host arguments)
         cf, cf_from = self._cf_args(self.t)
         self.device_clock = was
-        hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
-                            self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
+        if self.defer:
+            hip.lazy_adam_flush_deferred(store.arena.shape[0], store.embedding_dim, store.arena, store.grad_arena, self.m,
+                                         self.v, self.last, self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps,
+                                         cf, cf_from)
+        else:
+            hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
+                                self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
         self.flushed_t = self.t
 
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, fuse_zero_grad=False,
-                 lazy_tables=False, replay="exact"):
+                 lazy_tables=False, replay="exact", defer=False):
         if weight_decay != 0:
             raise ValueError("FusedAdam mirrors the reference's optimiser: weight_decay must be 0")
         if replay not in ("exact", "closed"):
@@ -216,6 +243,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.fuse_zero_grad = fuse_zero_grad
         self.lazy_tables = lazy_tables
         self.replay = replay
+        # defer (lazy tables only, needs the fused zero_grad: a separate zero_grad() would clear gradient rows that are
+        # still waiting): LazyAdamRows(defer=True)
+        self.defer = bool(defer and lazy_tables and fuse_zero_grad)
         self._device_clock = False  # graph_step.GraphedTrainStep: the kernels read the step number on the device
         self._dense_tabs: Dict[int, StepTables] = {}
         self._arena_state: Dict[int, dict] = {}
@@ -315,7 +345,8 @@ class FusedAdam(torch.optim.Optimizer):
                         lz = None
                     if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
                         lz = store._lazy = LazyAdamRows(store, (b1, b2), eps, owner=weakref.ref(self), t0=step - 1,
-                                                        replay=self.replay)
+                                                        replay=self.replay,
+                                                        defer=self.defer and type(store).__name__ == "EmbeddingLayer")
                         self._adopt_loaded_state(store, lz.m, lz.v, lz)
                         self._expose_state(store, lz.m, lz.v)
                     lz.step(store, lr, zero_grad=self.fuse_zero_grad)
@@ -449,16 +480,22 @@ class FusedAdam(torch.optim.Optimizer):
             off += r
 
 
-def make_adam(model, lr, lazy_tables=True, replay=None):
+def make_adam(model, lr, lazy_tables=True, replay=None, defer=None):
     """What RankTrainer.fit uses: fused HIP Adam for a HIP-resident model (lazy dense Adam on the embedding arenas by
     default), torch.optim.Adam on CPU (BASELINE config 0).  Hyper-parameters are the reference's (trainer.py:75).
     replay: how the lazy execution catches a row up — "closed" (default; closed-form replay, <= 1e-6 relative to the
     serial one per replay, see LazyAdamRows) or "exact" (serial replay, bit-identical to dense execution);
-    the environment variable RP_LAZY_REPLAY overrides the default."""
+    the environment variable RP_LAZY_REPLAY overrides the default.
+    defer: run a row's real step at its next touch, in the one launch that also replays its skipped steps (identical
+    results after a flush; table .grad rows then hold gradients that are still waiting, so anything that READS table
+    gradients between backward and step — gradient clipping — must not be combined with it).  Default off
+    (environment variable RP_ADAM_DEFER=1 turns it on)."""
     params = list(model.parameters())
     if params and params[0].is_cuda:
         if replay is None:
             replay = os.environ.get("RP_LAZY_REPLAY", "closed")
+        if defer is None:
+            defer = os.environ.get("RP_ADAM_DEFER", "0") == "1"
         return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, fuse_zero_grad=True,
-                         lazy_tables=lazy_tables, replay=replay)
+                         lazy_tables=lazy_tables, replay=replay, defer=defer)
     return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
