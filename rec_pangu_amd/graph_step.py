@@ -1,6 +1,6 @@
 """A whole training step — forward, backward, optimizer step, zero_grad — captured once into a hipGraph and replayed.
 
-Why: the eager step of the headline configuration is 13 kernel launches + 5 rocPRIM launches + memsets behind autograd,
+Why: the eager step of the headline configuration is 13 kernel launches + the 9 launches of the row sort behind autograd,
 ctypes and torch.empty: ~1.0 ms of host time per step against ~1.3 ms on the device — and at the per-GPU batch of a
 strong-scaling run (8192) the host IS the step time (1.10 ms eager against 0.32 ms replayed, scratch/probe_graph.py).
 Replaying a captured graph costs the host one launch (~0.1 ms) and the device no inter-kernel gaps of host origin.

@@ -127,7 +127,7 @@ class _Route:
             n = len(idx) * idx[0].numel()
             err = layer._err_flag(idx[0].device)
             comp = hip.shard_keys(layer._row_base, layer._row_count, idx, world, lbits, err)
-            sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # rocPRIM radix sort, (key, position) pairs
+            sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # stable radix sort (csrc/sort.hip), (key, position) pairs
             self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
             self.pos_sorted = sp
             self.n_requests = n
