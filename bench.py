@@ -489,6 +489,47 @@ def main():
         barrier()
         flush_ms = (time.perf_counter() - t1) * 1e3
 
+    # ---- (5b) the same step with the table optimizer's real step DEFERRED (FusedAdam(defer=True): opt-in this round,
+    #           DESIGN 5c; identical results, tests/test_hip_deferred_adam.py) — a secondary figure, never `value`.  The mode
+    #           has its own long-run state (every touched row carries its waiting step): a second pre-roll brings it about
+    deferred_line = None
+    if (args.mode == "train" and lazy and not sharded and world == 1 and gstep is None and pre_roll > 0
+            and args.model in ("deepfm", "dcn") and hasattr(opt, "set_defer") and not getattr(opt, "defer", False) and not args.no_small_batch):
+        try:
+            opt.set_defer(True)
+            nb = gen(n_seen + 100000)
+            for i in range(pre_roll):
+                cur, nb = nb, gen(n_seen + 100001 + i)
+                step(cur, nb if ahead else None)
+            del cur, nb
+            waiting0 = pending_real_steps()
+            barrier()
+            t_ = time.perf_counter()
+            h_ = 0.0
+            for i in range(args.steps):
+                th_ = time.perf_counter()
+                step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None)
+                h_ += time.perf_counter() - th_
+            barrier()
+            d_ms = (time.perf_counter() - t_) / args.steps * 1e3
+            deferred_line = {
+                "ms_per_step": round(d_ms, 4), "value": round(B / (d_ms * 1e-3), 1), "unit": "samples/s",
+                "host_enqueue_ms_per_step": round(h_ / args.steps * 1e3, 4), "pre_roll_steps_in_this_mode": pre_roll,
+                "real_steps_waiting_before": waiting0, "real_steps_waiting_after": pending_real_steps(),
+                "note": "FusedAdam.set_defer(True) on the same model and optimizer: a row's real step waits in the gradient "
+                        "arena until the row is next needed, one optimizer launch per step on the tables instead of two; "
+                        "in the long-run state of this mode the waiting count is constant over the window, i.e. as many real "
+                        "steps are applied as deferred — compare the two figures.  Opt-in library mode: the headline above "
+                        "is the default (immediate) execution"}
+        except Exception as e:  # a secondary figure must never take the headline down with it
+            deferred_line = {"error": repr(e)}
+        finally:
+            try:
+                opt.set_defer(False)  # applies what is waiting (a flush)
+            except Exception as e:
+                deferred_line = {"error": "restoring the immediate execution failed: " + repr(e)}
+        barrier()
+
     # ---- (6) the per-GPU batch of a STRONG-scaling run at G = 8 (b = B / 8): eager against the captured hipGraph.  At this
     #          size the eager step is host-bound (the host needs ~1 ms to enqueue what the device runs in ~0.4 ms)
     small = None
@@ -764,6 +805,8 @@ def main():
             res["roofline_gemm"] = gemm
         if small is not None:
             res["strong_scaling_batch"] = small
+        if deferred_line is not None:
+            res["deferred_real_step"] = deferred_line
         if lazy:
             res["lazy_adam"] = {
                 "state": f"long-run: {pre_roll} un-timed pre-roll steps on distinct batches before the warm-up",

@@ -267,6 +267,19 @@ class FusedAdam(torch.optim.Optimizer):
             if store._lazy is not None:
                 store._lazy.set_replay(replay)
 
+    def set_defer(self, on: bool):
+        """switch the table optimizer between the immediate and the deferred execution of the real step mid-run, between
+        two iterations (same results either way; LazyAdamRows).  Turning it off applies what is waiting: a flush."""
+        on = bool(on and self.lazy_tables and self.fuse_zero_grad)
+        if not on and self.defer:
+            self.flush()
+        self.defer = on
+        for store in self._stores.values():
+            lz = store._lazy
+            if lz is not None and type(store).__name__ == "EmbeddingLayer":
+                lz.defer = on
+                lz._marked_for = -1
+
     def flush(self):
         """Lazy mode: bring every embedding row to the current step (dense-equivalent state)."""
         for store in self._stores.values():
