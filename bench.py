@@ -300,7 +300,7 @@ def main():
 
     # auto: only where the eager step is HOST-bound (small per-GPU batches).  On this runtime a replayed graph costs the
     # device ~10 us per node more than the same launches issued eagerly (B = 65536: 1.6 ms replayed against 1.26 eager in
-    # the cold state, scratch/probe_graph5.py) — a win at b = 8192, a loss at the headline batch
+    # the cold state, profiles/microbench/probes/probe_graph5.py) — a win at b = 8192, a loss at the headline batch
     use_graph = args.mode == "train" and not sharded and not args.no_sort_ahead and (
         args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn") and local_B <= 16384))
     gstep = None

@@ -363,6 +363,18 @@ int rp_batchnorm_apply(const float *x, int64_t ldx, const float *mean, const flo
 int rp_batchnorm_apply_bwd(const float *dy, int64_t lddy, const float *rstd, const float *gamma, float *dx,
                            int64_t lddx, int64_t M, int N, rp_stream_t stream);
 
+/* ---- Dice activation (layers/activation.py:10-34: p = sigmoid(BatchNorm1d(x, affine=False, eps=1e-9, momentum=0.01)),
+ * y = p x + (1 - p) alpha x).  The normalisation is rp_batchnorm_train_fwd / rp_batchnorm_apply with gamma = beta = NULL;
+ * these are the gate around it on xhat = the normalised tensor (row-major, leading dimensions in floats):
+ *   rp_dice_gate_fwd  y = x (alpha + s (1 - alpha)), s = sigmoid(xhat)
+ *   rp_dice_gate_bwd  dx_direct = dy (alpha + s (1 - alpha)),  dxhat = dy x (1 - alpha) s (1 - s),  dal = dy x (1 - s)
+ *                     (three packed [M, N] outputs; dalpha = column sums of dal: rp_batchnorm_colsum; dxhat goes on
+ *                     through rp_batchnorm_train_bwd / rp_batchnorm_apply_bwd) */
+int rp_dice_gate_fwd(const float *x, int64_t ldx, const float *xhat, int64_t ldh, const float *alpha, float *y, int64_t ldy,
+                     int64_t M, int N, rp_stream_t stream);
+int rp_dice_gate_bwd(const float *x, int64_t ldx, const float *xhat, int64_t ldh, const float *alpha, const float *dy,
+                     int64_t lddy, float *dx_direct, float *dxhat, float *dal, int64_t M, int N, rp_stream_t stream);
+
 /* building blocks of a BatchNorm1d whose batch statistics span several ranks (SyncBatchNorm1d of rec_pangu_amd/sharded.py;
  * mmoe.py:54 on the global batch).  The all-reduce between the stages is the caller's.
  *   rp_batchnorm_colsum     out[n] = sum_m x[m,n]  (center NULL)  |  sum_m (x[m,n] - center[n])^2  (center given)
@@ -459,7 +471,7 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * NULL = use the host arguments), the kernel reads the step from it: rp_adam_step applies step *t_dev + 1 with the
  * scalars step_scalars[*t_dev + 1] (the float2 table of rp_adam_step_scalars rows indexed by step; lr / step arguments
  * ignored), rp_lazy_adam_rows replays to *t_dev (real_step: applies *t_dev + 1), rp_lazy_adam_cf_table builds the table
- * for t_end = *t_dev (its `t_end` argument then is the CAPACITY the launch grid covers).  rp_counter_add advances a
+ * for t_end = *t_dev (a fixed-size window of the youngest stamps: consecutive replays keep it complete).  rp_counter_add advances a
  * counter on the stream.  rec_pangu_amd/graph_step.py captures fwd + bwd + optimizer on top of these. */
 int rp_counter_add(int32_t *counter, int32_t delta, rp_stream_t stream);
 
@@ -497,14 +509,20 @@ int rp_lazy_adam_flush(int64_t rows, int D, float *p, float *m, float *v, int32_
  * every term is expanded around the w-weighted mean abar of the a_i:  q [N0 + y^2 N2 - y^3 N3 + y^4 N4],
  * q = 1/(s abar + eps), y = s q, N_n = sum_i w_i (a_i - abar)^n — uniformly convergent in s (|y (a_i - abar)| <=
  * |a_i/abar - 1|), relative truncation error of the summed update <= 9e-8 once l >= 256 at b2 = 0.999
- * (scratch/closed_form_replay.py).  Steps up to `cf_from` are still replayed serially; steps cf_from+1 .. t cost one
+ * (profiles/microbench/probes/closed_form_replay.py).  Steps up to `cf_from` are still replayed serially; steps cf_from+1 .. t cost one
  * reciprocal and ~10 fp32 operations per element whatever their number.  Here `eps` counts (it is the eps of the
  * expansion) and must be the one the step scalars were built with.
- *   rp_lazy_adam_cf_table  cf_table[k] (8 floats: abar, N0, N2, -N3, N4, b1^k, r^k, 0), 1 <= k <= t_end - cf_from,
- *                          describes the steps t_end-k+1 .. t_end and is valid for replays that END at t_end
- *                          (rp_lazy_adam_rows(real_step=0, t_target=t_end), (real_step=1, t_target=t_end+1),
- *                          rp_lazy_adam_flush(t_target=t_end)); rebuilt on the device, in double, whenever the end step
- *                          changes.  ns_d: device double2 table indexed by step: {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)}.
+ *   rp_lazy_adam_cf_table  cf_table: `capacity` entries of 8 floats (abar, N0, N2, -N3, N4, b1^k, r^k, 0) with TWO index
+ *                          meanings: the first five of entry l describe a replay that starts at stamp l (steps l+1 ..
+ *                          t_end), cf_from <= l < t_end; the two powers of entry k belong to a replay of k steps.  Valid
+ *                          for replays that END at t_end (rp_lazy_adam_rows(real_step=0, t_target=t_end), (real_step=1,
+ *                          t_target=t_end+1), rp_lazy_adam_flush(t_target=t_end)).  Built on the device, in double:
+ *                          built_to < 0 = a fresh buffer (the power columns and every stamp: O(t_end) once); otherwise
+ *                          built_to = the t_end of the previous call on this buffer and only the stamps that were not
+ *                          final then ( >= built_to - J, J = rp_lazy_adam_cf_terms) are rebuilt: O(1) per training step
+ *                          whatever the step count.  With t_dev (consecutive graph replays) the window is the J + 4
+ *                          youngest stamps below *t_dev.  ns_d: device double2 table indexed by step:
+ *                          {-lr_j/(1-b1^j), 1/sqrt(1-b2^j)} (rows of steps already taken never change).
  *   rp_lazy_adam_cf_terms  number of leading terms that carry weight (b1^J < 1e-17) */
 int rp_lazy_adam_cf_terms(double beta1, int *terms);
 /* DEFERRED real step (opt-in execution mode of the same optimizer; no reference counterpart beyond trainer.py:75).
@@ -529,7 +547,7 @@ int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float *g, float *
                                 const float *step_scalars, int64_t t_target, double beta1, double beta2, double eps,
                                 const float *cf_table, int64_t cf_from, rp_stream_t stream);
 int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2, float *cf_table,
-                          const int32_t *t_dev, rp_stream_t stream);
+                          int64_t capacity, int64_t built_to, const int32_t *t_dev, rp_stream_t stream);
 
 /* ---- request routing for row-sharded tables (rec_pangu_amd/sharded.py; no reference counterpart: the reference is
  * single-device).  Arena row r lives on rank r % world at local row r / world.

@@ -164,6 +164,22 @@ def mlp_relu(x: Tensor, sd: Dict[str, Tensor], prefix: str, linear_ids: Sequence
     return x
 
 
+def dice(x: Tensor, alpha: Tensor, running_mean: Tensor, running_var: Tensor, training: bool, eps: float = 1e-9,
+         momentum: float = 0.01):
+    """layers/activation.py:18-34: p = sigmoid(BatchNorm1d(x, affine=False, eps=1e-9, momentum=0.01)),
+    out = p x + (1 - p) alpha x.  Training: batch mean / biased variance normalise, the running statistics move by
+    `momentum` (unbiased variance), as nn.BatchNorm1d does.  -> (out, running_mean', running_var')"""
+    if training:
+        mean, var = x.mean(dim=0), x.var(dim=0, unbiased=False)
+        n = x.shape[0]
+        new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
+        new_rv = (1 - momentum) * running_var + momentum * var.detach() * (n / max(n - 1, 1))
+    else:
+        mean, var, new_rm, new_rv = running_mean, running_var, running_mean, running_var
+    p = torch.sigmoid((x - mean) / torch.sqrt(var + eps))
+    return p * x + (1 - p) * alpha * x, new_rm, new_rv
+
+
 def lr_layer(sd: Dict[str, Tensor], prefix: str, enc_dict, data) -> Tensor:
     """shallow.py:22-27: dim-1 embedding per field -> [B,F]; cat dense; Linear(F+ND, 1)."""
     t = _tables(sd, prefix + "emb_layer.embedding_layer.", enc_dict)

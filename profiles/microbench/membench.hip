@@ -1,5 +1,5 @@
 // Scratch micro-benchmark: which global->LDS tile access pattern streams a row-major [M, ld] fp32 matrix fastest?
-// build: hipcc --offload-arch=gfx950 -O3 scratch/membench.hip -o gpurun_out/membench ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O3 profiles/microbench/probes/membench.hip -o gpurun_out/membench ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,6 +1,6 @@
 // Scratch micro-benchmark: the sustained issue rate of v_mfma_f32_32x32x16_bf16 on this box ("re-verify
 // the datasheet peak on the box").  Every wave issues independent MFMAs on 4 accumulators from registers, no memory.
-// build: hipcc --offload-arch=gfx950 -O3 scratch/mfmabench.hip -o gpurun_out/mfmabench ; run on the GPU box.
+// build: hipcc --offload-arch=gfx950 -O3 profiles/microbench/probes/mfmabench.hip -o gpurun_out/mfmabench ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

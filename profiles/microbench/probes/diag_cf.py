@@ -10,7 +10,7 @@ for t in range(1, steps + 1):
     table[t] = torch.tensor(hip.adam_step_scalars(lr, b1, b2, t, eps))
     nsd[t, 0] = -lr / (1 - b1 ** t); nsd[t, 1] = 1 / (1 - b2 ** t) ** 0.5
 cf = torch.zeros(steps + 8, 8, device=DEV)
-hip.lazy_adam_cf_table(nsd.to(DEV), steps, CF, b1, b2, cf)
+hip.lazy_adam_cf_table(nsd.to(DEV), steps, CF, b1, b2, cf)  # (built_to=-1: a full build)
 torch.cuda.synchronize()
 cfh = cf.cpu().numpy()
 ns = nsd[:, 0].numpy(); d = nsd[:, 1].numpy()

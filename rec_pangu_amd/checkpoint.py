@@ -39,7 +39,12 @@ def _dense_layers(model: nn.Module):
     return OrderedDict((n, m) for n, m in model.named_modules() if isinstance(m, EmbeddingLayer))
 
 
+_SOLO = object()  # save_checkpoint(group=_SOLO): this process alone, whatever process groups exist
+
+
 def _world(group):
+    if group is _SOLO:
+        return 1, 0
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0
@@ -81,7 +86,22 @@ def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, o
     world, rank = _world(group)
     layers = _sharded_layers(model)
     if not layers:
-        world, rank = 1, 0  # a replicated (unsharded) model: one writer
+        # a replicated (unsharded) model: ONE writer.  In a multi-rank job every rank holds the same weights: only global
+        # rank 0 writes / merges / removes, the others wait for it (concurrent writers of the same
+        # shard_000_of_001 file raced with each other's merge and removal)
+        job_world, job_rank = world, rank
+        world, rank = 1, 0
+        if job_world > 1:
+            if job_rank == 0:
+                try:
+                    save_checkpoint(model, enc_dict, ckpt_dir, optimizer, _SOLO, merge, filename, keep_shards)
+                finally:
+                    dist.barrier(group=group)
+            else:
+                if optimizer is not None and hasattr(optimizer, "flush"):
+                    optimizer.flush()  # (every rank's state moves the same way as the writer's)
+                dist.barrier(group=group)
+            return
     os.makedirs(ckpt_dir, exist_ok=True, mode=0o777)
     if optimizer is not None and hasattr(optimizer, "flush"):
         optimizer.flush()  # lazy dense Adam: every row to the optimizer's last step

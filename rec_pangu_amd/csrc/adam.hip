@@ -212,14 +212,27 @@ struct LazyCfg {
 //     sum_i w_i / (s a_i + eps) = q * [N0 + y^2 N2 - y^3 N3 + y^4 N4 - ...],   N_n = sum_i w_i (a_i - abar)^n  (N1 = 0)
 // |y (a_i - abar)| <= |a_i/abar - 1| for EVERY s >= 0 (s -> 0 and s -> inf included): the series converges uniformly in
 // s, with ratio ~2 % when l >= 256 (b2 = 0.999).  Truncated after N4 the relative error of the summed update is
-// <= 9e-8 for l >= 256 and <= 7e-9 for l >= 512 (scratch/closed_form_replay.py, double precision study) — fp32 rounding
+// <= 9e-8 for l >= 256 and <= 7e-9 for l >= 512 (profiles/microbench/probes/closed_form_replay.py, double precision study) — fp32 rounding
 // level.  Steps up to CF_FROM (= 256) are therefore replayed serially, everything after in one evaluation:
 // one v_rcp_f32 and ~10 fp32 operations per element for ANY k.  The per-k coefficients {abar, N0, N2, -N3, N4, b1^k,
 // r^k} come from a device table that rp_lazy_adam_cf_table rebuilds (in double) for the current end step.
 // ------------------------------------------------------------------------------------------------
+// TABLE LAYOUT (one buffer, two index meanings — so that the per-step rebuild is O(1) in the step count):
+//   entry[l].{abar, n0, n2, n3m, n4}  describe a replay that STARTS at stamp l (steps l+1 .. t_end).  Only the first
+//       J ~ 372 terms carry weight (b1^J is below double rounding), so an entry is final once t_end >= l + J: per step only
+//       the J youngest stamps are rebuilt (rp_lazy_adam_cf_table), everything older stays as it was written;
+//   entry[k].{pm, ps} = {b1^k, r^k}   depend on the NUMBER of skipped steps only: written once per buffer.
 struct CfEntry {
     float abar, n0, n2, n3m, n4, pm, ps, pad;  // n3m = -N3;  pm = b1^k, ps = r^k
 };
+
+// the coefficients of the replay of steps l+1 .. l+k
+__device__ __forceinline__ CfEntry cf_lookup(const CfEntry *__restrict__ cf, int l, int k) {
+    CfEntry e = cf[l];
+    e.pm = cf[k].pm;
+    e.ps = cf[k].ps;
+    return e;
+}
 
 template <typename T>
 __device__ __forceinline__ void adam_zero_grad_closed(T &p, T &m, T &s, const CfEntry &e, float eps) {
@@ -233,9 +246,12 @@ __device__ __forceinline__ void adam_zero_grad_closed(T &p, T &m, T &s, const Cf
     s = s * e.ps;
 }
 
-// entry k (1 <= k <= t_end - t_from) describes the steps t_end-k+1 .. t_end;  nsd[j] = {ns_j, 1/sqrt(1 - b2^j)} (double).
+// entry l (t_from <= l < t_end) describes the steps l+1 .. t_end;  nsd[j] = {ns_j, 1/sqrt(1 - b2^j)} (double).
 // One WAVE per entry: lane i takes the terms i+1, i+65, ... (at most J ~ 350 carry weight), wave reductions in double in
 // a fixed order — the launch sits on the step's critical path (it needs this step's lr), a serial loop per entry cost 25 us.
+// The launch covers the stamps [l_lo, t_end): l_lo = t_from for a full build, = (last build's t_end) - J for the per-step
+// rebuild (stamps older than that were final already); with t_dev (graph replays: consecutive steps) the window is
+// [*t_dev - J - 4, *t_dev) whatever the launch arguments say.
 __device__ __forceinline__ double wave_sum_f64(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -243,13 +259,17 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
 }
 
 __global__ __launch_bounds__(256) void lazy_cf_table_kernel(const double2 *__restrict__ nsd, int t_end, int t_from,
-                                                            int J, double b1e, double r, CfEntry *__restrict__ out,
-                                                            const int32_t *__restrict__ t_dev) {
-    if (t_dev != nullptr) t_end = *t_dev;  // graph replays: the grid covers the table's capacity, waves beyond t_end leave
+                                                            int l_lo, int J, double b1e, double r,
+                                                            CfEntry *__restrict__ out, const int32_t *__restrict__ t_dev) {
+    if (t_dev != nullptr) {
+        t_end = *t_dev;
+        l_lo = t_end - J - 4;
+    }
+    if (l_lo < t_from) l_lo = t_from;
     const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6) + 1;
-    if (k > t_end - t_from) return;  // wave-uniform
-    const int l = t_end - k;
+    const int l = l_lo + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= t_end) return;  // wave-uniform
+    const int k = t_end - l;
     const int nterm = k < J ? k : J;  // b1^J is below double rounding: later terms carry no weight
     const double lb = log(b1e), lr_ = log(r);
     double w[8], a[8];  // J <= 512 terms: 8 per lane
@@ -281,18 +301,22 @@ __global__ __launch_bounds__(256) void lazy_cf_table_kernel(const double2 *__res
     n2 = wave_sum_f64(n2);
     n3 = wave_sum_f64(n3);
     n4 = wave_sum_f64(n4);
-    if (lane == 0) {
-        CfEntry e;
-        e.abar = (float)abar;
-        e.n0 = (float)sw;
-        e.n2 = (float)n2;
-        e.n3m = (float)(-n3);
-        e.n4 = (float)n4;
-        e.pm = (float)exp(lb * (double)k);
-        e.ps = (float)exp(lr_ * (double)k);
-        e.pad = 0.f;
-        out[k] = e;
+    if (lane == 0) {  // (pm / ps of this slot belong to k = l: lazy_cf_pow_kernel)
+        out[l].abar = (float)abar;
+        out[l].n0 = (float)sw;
+        out[l].n2 = (float)n2;
+        out[l].n3m = (float)(-n3);
+        out[l].n4 = (float)n4;
     }
+}
+
+// entry[k].{pm, ps} = {b1e^k, r^k} for every k the buffer holds (once per buffer)
+__global__ __launch_bounds__(256) void lazy_cf_pow_kernel(CfEntry *__restrict__ out, int capacity, double b1e, double r) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= capacity) return;
+    out[k].pm = (float)exp(log(b1e) * (double)k);
+    out[k].ps = (float)exp(log(r) * (double)k);
+    out[k].pad = 0.f;
 }
 
 // REAL: the launch applies a real step (a compile-time copy of `real_step`: the replay and the step are then two kernels
@@ -331,7 +355,7 @@ __global__ __launch_bounds__(256) void lazy_adam_rows_kernel(const int32_t *__re
                 adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
             }
             const int lc = l0 > t_serial ? l0 : t_serial;
-            if (lc < t_catch) adam_zero_grad_closed<T>(p, m, v, cf[t_catch - lc], c.eps);
+            if (lc < t_catch) adam_zero_grad_closed<T>(p, m, v, cf_lookup(cf, lc, t_catch - lc), c.eps);
         }
         if (real_step) {
             const T g = *reinterpret_cast<const T *>(G + off);
@@ -390,7 +414,7 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_kernel(int64_t R, int D, 
                         adam1_zero_grad<T>(p[u], m[u], v[u], c.one_m_b1, c.sqrt_b2, s.x, s.y);
                     }
                     const int lc = l0[u] > t_serial ? l0[u] : t_serial;
-                    if (lc < t_target) adam_zero_grad_closed<T>(p[u], m[u], v[u], cf[t_target - lc], c.eps);
+                    if (lc < t_target) adam_zero_grad_closed<T>(p[u], m[u], v[u], cf_lookup(cf, lc, t_target - lc), c.eps);
                     const int64_t off = rows[u] * D + cidx;
                     *reinterpret_cast<T *>(P + off) = p[u];
                     *reinterpret_cast<T *>(Mo + off) = m[u];
@@ -689,22 +713,34 @@ extern "C" int rp_lazy_adam_cf_terms(double beta1, int *terms) {
 }
 
 extern "C" int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2,
-                                     float *cf_table, const int32_t *t_dev, rp_stream_t stream) {
+                                     float *cf_table, int64_t capacity, int64_t built_to, const int32_t *t_dev,
+                                     rp_stream_t stream) {
     RP_REQUIRE(ns_d && cf_table, "lazy_adam_cf_table: null pointer");
-    RP_REQUIRE(cf_from >= 1 && t_end < INT32_MAX, "lazy_adam_cf_table: bad step range");
+    RP_REQUIRE(cf_from >= 1 && t_end < INT32_MAX && capacity >= 1 && capacity < INT32_MAX, "lazy_adam_cf_table: bad step range");
+    RP_REQUIRE(t_dev != nullptr || t_end < capacity, "lazy_adam_cf_table: step %lld outside the table (%lld entries)",
+               (long long)t_end, (long long)capacity);
     RP_REQUIRE((((uintptr_t)ns_d) & 15u) == 0 && (((uintptr_t)cf_table) & 31u) == 0,
                "lazy_adam_cf_table: tables must be 16 / 32-byte aligned");
-    if (t_end <= cf_from) return RP_OK;
     int J;
     if (rp_lazy_adam_cf_terms(beta1, &J) != RP_OK) return RP_ERR_ARG;
     RP_REQUIRE(J <= 512, "lazy_adam_cf_table: beta1 = %g needs %d terms, the closed form holds 512 (use the serial replay)",
                (double)beta1, J);
     double b1e, r;
     cf_decay_factors(beta1, beta2, &b1e, &r);
-    const unsigned grid = (unsigned)rp_cdiv(t_end - cf_from, 4);  // one wave per entry
-    hipLaunchKernelGGL(lazy_cf_table_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const double2 *>(ns_d), (int)t_end, (int)cf_from, J, b1e, r,
-                       reinterpret_cast<CfEntry *>(cf_table), t_dev);
+    hipStream_t s = (hipStream_t)stream;
+    CfEntry *out = reinterpret_cast<CfEntry *>(cf_table);
+    if (built_to < 0) {  // a fresh buffer: the power columns, then every stamp
+        hipLaunchKernelGGL(lazy_cf_pow_kernel, dim3((unsigned)rp_cdiv(capacity, 256)), dim3(256), 0, s, out, (int)capacity, b1e, r);
+        RP_LAUNCH_CHECK("lazy_adam_cf_table (powers)");
+    }
+    int64_t l_lo = built_to < 0 ? cf_from : built_to - J;
+    if (l_lo < cf_from) l_lo = cf_from;
+    // graph replays (t_dev): consecutive steps, the window of the J + 4 youngest stamps whatever the step number is
+    const int64_t span = t_dev != nullptr ? (int64_t)J + 4 : t_end - l_lo;
+    if (span <= 0) return RP_OK;
+    const unsigned grid = (unsigned)rp_cdiv(span, 4);  // one wave per entry
+    hipLaunchKernelGGL(lazy_cf_table_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const double2 *>(ns_d), (int)t_end,
+                       (int)cf_from, (int)l_lo, J, b1e, r, out, t_dev);
     RP_LAUNCH_CHECK("lazy_adam_cf_table");
     return RP_OK;
 }
@@ -833,7 +869,7 @@ __device__ __forceinline__ void lazy_owed(T &p, T &m, T &v, bool apply, int l, i
             adam1_zero_grad<T>(p, m, v, c.one_m_b1, c.sqrt_b2, s.x, s.y);
         }
         const int l2 = lc > t_serial ? lc : t_serial;
-        if (l2 < t_done) adam_zero_grad_closed<T>(p, m, v, cf[t_done - l2], c.eps);
+        if (l2 < t_done) adam_zero_grad_closed<T>(p, m, v, cf_lookup(cf, l2, t_done - l2), c.eps);
     }
 }
 

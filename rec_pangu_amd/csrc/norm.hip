@@ -448,3 +448,70 @@ extern "C" int rp_accumulate(float *dst, const float *src, int64_t n, rp_stream_
     RP_LAUNCH_CHECK("accumulate");
     return RP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ Dice gate
+// reference: layers/activation.py:10-34   p = sigmoid(BatchNorm1d(x, affine=False)),  y = p x + (1 - p) alpha x.
+// The normalisation is rp_batchnorm_* (training: batch statistics; eval: running statistics); these two launches are the
+// gate around it, on the normalised tensor xhat:
+//   fwd   y  = x (alpha + s (1 - alpha)),  s = sigmoid(xhat)
+//   bwd   dx_direct = dy (alpha + s (1 - alpha));  dxhat = dy x (1 - alpha) s (1 - s);  dal = dy x (1 - s)  (column-summed
+//         by the caller with rp_batchnorm_colsum: one deterministic reduction for every gradient of a [N] parameter)
+// Elementwise, HBM-bound: grid-stride over rows, one lane per column quad when N % 4 == 0 is not required (scalar lanes).
+__global__ __launch_bounds__(256) void dice_gate_fwd_kernel(const float *__restrict__ x, int64_t ldx,
+                                                            const float *__restrict__ xhat, int64_t ldh,
+                                                            const float *__restrict__ alpha, float *__restrict__ y,
+                                                            int64_t ldy, int64_t M, int N) {
+    const int64_t total = M * (int64_t)N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        const float xv = x[m * ldx + n], a = alpha[n];
+        const float s = 1.f / (1.f + __expf(-xhat[m * ldh + n]));
+        y[m * ldy + n] = xv * (a + s * (1.f - a));
+    }
+}
+
+__global__ __launch_bounds__(256) void dice_gate_bwd_kernel(const float *__restrict__ x, int64_t ldx,
+                                                            const float *__restrict__ xhat, int64_t ldh,
+                                                            const float *__restrict__ alpha,
+                                                            const float *__restrict__ dy, int64_t lddy,
+                                                            float *__restrict__ dx_direct, float *__restrict__ dxhat,
+                                                            float *__restrict__ dal, int64_t M, int N) {
+    const int64_t total = M * (int64_t)N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / N;
+        const int n = (int)(i - m * N);
+        const float xv = x[m * ldx + n], a = alpha[n], g = dy[m * lddy + n];
+        const float s = 1.f / (1.f + __expf(-xhat[m * ldh + n]));
+        dx_direct[i] = g * (a + s * (1.f - a));
+        dxhat[i] = g * xv * (1.f - a) * s * (1.f - s);
+        dal[i] = g * xv * (1.f - s);
+    }
+}
+
+extern "C" int rp_dice_gate_fwd(const float *x, int64_t ldx, const float *xhat, int64_t ldh, const float *alpha, float *y,
+                                int64_t ldy, int64_t M, int N, rp_stream_t stream) {
+    RP_REQUIRE(x && xhat && alpha && y, "dice_gate_fwd: null pointer");
+    RP_REQUIRE(M >= 0 && N >= 1 && ldx >= N && ldh >= N && ldy >= N, "dice_gate_fwd: bad shape");
+    if (M == 0) return RP_OK;
+    int64_t nb = rp_cdiv(M * (int64_t)N, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(dice_gate_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, xhat, ldh, alpha, y,
+                       ldy, M, N);
+    RP_LAUNCH_CHECK("dice_gate_fwd");
+    return RP_OK;
+}
+
+extern "C" int rp_dice_gate_bwd(const float *x, int64_t ldx, const float *xhat, int64_t ldh, const float *alpha,
+                                const float *dy, int64_t lddy, float *dx_direct, float *dxhat, float *dal, int64_t M, int N,
+                                rp_stream_t stream) {
+    RP_REQUIRE(x && xhat && alpha && dy && dx_direct && dxhat && dal, "dice_gate_bwd: null pointer");
+    RP_REQUIRE(M >= 0 && N >= 1 && ldx >= N && ldh >= N && lddy >= N, "dice_gate_bwd: bad shape");
+    if (M == 0) return RP_OK;
+    int64_t nb = rp_cdiv(M * (int64_t)N, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(dice_gate_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, xhat, ldh, alpha, dy,
+                       lddy, dx_direct, dxhat, dal, M, N);
+    RP_LAUNCH_CHECK("dice_gate_bwd");
+    return RP_OK;
+}

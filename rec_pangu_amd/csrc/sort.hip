@@ -13,7 +13,7 @@
 // program order, so the 16 rounds chain without a barrier.  Waves then take their offsets from the waves before them.
 // Positions are implicit in the first pass (no iota buffer).  26 key bits = 3 passes = 9 launches, ~35 MB of traffic
 // per pass at 1.7 M pairs: latency-bound, like rocPRIM's onesweep (four 8-bit passes).  Measured (MI355X,
-// scratch/probe_sort_host.py): 1.7 M pairs 151 us on the device / 28 us of host time per call (rocPRIM 148 / 49);
+// profiles/microbench/probes/probe_sort_host.py): 1.7 M pairs 151 us on the device / 28 us of host time per call (rocPRIM 148 / 49);
 // 213 k pairs (the per-GPU batch of a strong-scaling run) 77 us / 29 us (rocPRIM's merge sort 94 / 50); beside a step
 // on the side stream the event-bracketed duration is 0.13 ms against rocPRIM's 0.33.  What the own kernels buy besides:
 // NO memset nodes and no global counters carried between launches — a captured step replays at any batch size (with

@@ -562,7 +562,8 @@ class _BatchNormTrain(torch.autograd.Function):
     def backward(ctx, dy, _gm, _gv):
         x, mean, rstd, gamma = ctx.saved_tensors
         dx, dgamma, dbeta = hip.batchnorm_train_bwd(x, _unit_inner(dy), mean, rstd, gamma)
-        return dx, (dgamma if gamma is not None else None), dbeta, None
+        # (affine=False — Dice's BatchNorm — has neither: a gradient for a None input is an autograd error)
+        return dx, (dgamma if gamma is not None else None), (dbeta if ctx.needs_input_grad[2] else None), None
 
 
 class _BatchNormApply(torch.autograd.Function):
@@ -602,6 +603,31 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d):
         return y
     rstd = torch.rsqrt(bn.running_var + bn.eps)
     return _BatchNormApply.apply(x, bn.running_mean, rstd, bn.weight, bn.bias)
+
+
+# ----------------------------------------------------------------------------------------------
+# Dice   — layers/activation.py:10-34:  p = sigmoid(bn(x)),  y = p x + (1 - p) alpha x
+# ----------------------------------------------------------------------------------------------
+class _DiceGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, xhat, alpha):
+        x, xhat = _unit_inner(x), _unit_inner(xhat)
+        alpha = alpha.contiguous()
+        ctx.save_for_backward(x, xhat, alpha)
+        return hip.dice_gate_fwd(x, xhat, alpha)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xhat, alpha = ctx.saved_tensors
+        dxd, dxh, dal = hip.dice_gate_bwd(x, xhat, alpha, _unit_inner(dy))
+        dalpha = hip.batchnorm_colsum(dal) if ctx.needs_input_grad[2] else None  # deterministic two-stage column sums
+        return dxd, dxh, dalpha
+
+
+def dice(x, bn: torch.nn.BatchNorm1d, alpha):
+    """Dice on the HIP kernels for 2-D x [M, N]: batch_norm (rp_batchnorm_*, running statistics updated in training
+    mode exactly like nn.BatchNorm1d) + the gate (rp_dice_gate_*)."""
+    return _DiceGate.apply(x, batch_norm(x, bn), alpha)
 
 
 # ----------------------------------------------------------------------------------------------

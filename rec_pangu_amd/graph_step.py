@@ -2,7 +2,7 @@
 
 Why: the eager step of the headline configuration is 13 kernel launches + the 9 launches of the row sort behind autograd,
 ctypes and torch.empty: ~1.0 ms of host time per step against ~1.3 ms on the device — and at the per-GPU batch of a
-strong-scaling run (8192) the host IS the step time (1.10 ms eager against 0.32 ms replayed, scratch/probe_graph.py).
+strong-scaling run (8192) the host IS the step time (1.10 ms eager against 0.32 ms replayed, profiles/microbench/probes/probe_graph.py).
 Replaying a captured graph costs the host one launch (~0.1 ms) and the device no inter-kernel gaps of host origin.
 
 What makes a step capturable here:
@@ -15,7 +15,7 @@ What makes a step capturable here:
     is NOT overlapped with the step as the eager path does it (side stream): a fork inside one graph is replayed without
     overlap by this runtime, and a second graph on a second stream (measured 0.49 against 0.52 ms at b = 8192) died with
     memory access faults whenever the host ran more than a few steps ahead without a device-wide synchronisation
-    (scratch/probe_graph6.py) — one linear graph on one stream has run thousands of unsynchronised steps;
+    (profiles/microbench/probes/probe_graph6.py) — one linear graph on one stream has run thousands of unsynchronised steps;
   * no host synchronisation inside the step: check_indices = "deferred" (raise_if_bad_index() after the run).
 
 The captured launches are the eager path's own (same kernels, same order, same arguments except the step number's
@@ -94,7 +94,7 @@ class GraphedTrainStep:
     # ends in memory access faults within a few hundred steps (B = 40960 x 26 fields = 1.06 M pairs: fault; B = 32768 =
     # 0.85 M pairs: 600 steps clean; B = 65536 with torch.cuda.synchronize() every 50 steps: 1300 steps clean).  The own
     # radix sort of csrc/sort.hip (the default; kernels only, no memset nodes) replays cleanly at any size — B = 40960 and
-    # B = 65536, 1500 unsynchronised replays each, scratch/probe_graph6.py — which is what pinned the faults on that path.
+    # B = 65536, 1500 unsynchronised replays each, profiles/microbench/probes/probe_graph6.py — which is what pinned the faults on that path.
     # (Captured steps remain the tool for SMALL, host-bound batches: at B = 65536 a replay is slower than eager launches.)
     MAX_PAIRS_ROCPRIM = 900_000
 

@@ -95,6 +95,8 @@ _SIGNATURES = {
     "rp_batchnorm_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_sums": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_apply": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_dice_gate_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_dice_gate_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "rp_mlp_tail_fits": (C.c_int, [_i32, _i32, _i64]),
     "rp_mlp_tail_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "rp_mlp_tail_bwd_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -125,7 +127,7 @@ _SIGNATURES = {
     "rp_seq_pool_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "rp_seq_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "rp_lazy_adam_cf_terms": (C.c_int, [_f64, C.POINTER(C.c_int)]),
-    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f64, _f64, _vp, _vp, _vp]),
+    "rp_lazy_adam_cf_table": (C.c_int, [_vp, _i64, _i64, _f64, _f64, _vp, _i64, _i64, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -156,6 +158,33 @@ def available() -> bool:
 
 def launch_count() -> int:
     return int(lib().rp_launch_count())
+
+
+# ---- HIP-resident modules that take a torch (ATen) path: counted and warned about once, never silent ----------------
+_torch_paths: dict = {}
+
+
+def note_torch_path(what: str) -> None:
+    """A module whose tensors live on the HIP device is about to compose its result from torch device ops instead of the
+    library's kernels (a configuration no kernel covers: a masked / cross attention, a CIN over more than 32 fields, a
+    non-ReLU activation module inside an MLP ...).  Results are the same; the launch is not ours.  Counted per reason
+    (torch_path_count / torch_paths) and warned about once per reason; RP_STRICT_HIP=1 turns it into an error."""
+    n = _torch_paths.get(what, 0)
+    _torch_paths[what] = n + 1
+    if os.environ.get("RP_STRICT_HIP", "0") == "1":
+        raise RuntimeError(f"RP_STRICT_HIP=1: a HIP-resident module took a torch path: {what}")
+    if n == 0:
+        import warnings
+        warnings.warn(f"rec_pangu_amd: HIP-resident module on a torch (ATen) path, not on the library's kernels: {what} "
+                      "(reported once; hip.torch_paths() has the counts)", RuntimeWarning, stacklevel=3)
+
+
+def torch_path_count() -> int:
+    return sum(_torch_paths.values())
+
+
+def torch_paths() -> dict:
+    return dict(_torch_paths)
 
 
 def _check(rc: int, what: str):
@@ -981,6 +1010,30 @@ def batchnorm_apply(x, mean, rstd, gamma, beta):
     return y
 
 
+def dice_gate_fwd(x, xhat, alpha):
+    """y = x * (alpha + sigmoid(xhat) * (1 - alpha))  (rp_dice_gate_fwd)"""
+    _req(x, torch.float32, "x")
+    _req(xhat, torch.float32, "xhat")
+    _req(alpha, torch.float32, "alpha")
+    M, N = x.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _Timed("dice_gate_fwd", f"{M}x{N}", 12 * M * N):
+        _check(lib().rp_dice_gate_fwd(x.data_ptr(), _rowmajor(x, "x"), xhat.data_ptr(), _rowmajor(xhat, "xhat"),
+                                      alpha.data_ptr(), y.data_ptr(), N, M, N, _stream()), "rp_dice_gate_fwd")
+    return y
+
+
+def dice_gate_bwd(x, xhat, alpha, dy):
+    """-> (dx_direct, dxhat, dal) packed [M, N] each (rp_dice_gate_bwd); dalpha = column sums of dal"""
+    M, N = x.shape
+    dxd, dxh, dal = (torch.empty((M, N), dtype=torch.float32, device=x.device) for _ in range(3))
+    with _Timed("dice_gate_bwd", f"{M}x{N}", 24 * M * N):
+        _check(lib().rp_dice_gate_bwd(x.data_ptr(), _rowmajor(x, "x"), xhat.data_ptr(), _rowmajor(xhat, "xhat"),
+                                      alpha.data_ptr(), dy.data_ptr(), _rowmajor(dy, "dy"), dxd.data_ptr(), dxh.data_ptr(),
+                                      dal.data_ptr(), M, N, _stream()), "rp_dice_gate_bwd")
+    return dxd, dxh, dal
+
+
 def batchnorm_apply_bwd(dy, rstd, gamma):
     M, N = dy.shape
     dx = torch.empty((M, N), dtype=torch.float32, device=dy.device)
@@ -1287,14 +1340,15 @@ def lazy_adam_flush_deferred(rows: int, D: int, p, g, m, v, last, scalars, t_tar
                "rp_lazy_adam_flush_deferred")
 
 
-def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table, t_dev=None):
-    """(re)build the closed-form replay table for replays ending at step t_end (see rp_lazy_adam_cf_table):
-    ns_d [>= t_end + 1, 2] float64 device table by step, cf_table [>= t_end - cf_from + 1, 8] float32 (written in place)"""
-    assert ns_d.dtype == torch.float64 and ns_d.shape[0] > t_end and ns_d.is_contiguous()
-    assert cf_table.dtype == torch.float32 and cf_table.shape[0] >= t_end - cf_from + 1 and cf_table.is_contiguous()
+def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table, built_to: int = -1, t_dev=None):
+    """bring the closed-form replay table to replays ending at step t_end (see rp_lazy_adam_cf_table): ns_d [>= t_end + 1, 2]
+    float64 device table by step, cf_table [capacity > t_end, 8] float32 (written in place).  built_to: the t_end of the
+    previous call on this buffer (only the stamps that were not final then are rebuilt), -1 = a fresh buffer."""
+    assert ns_d.dtype == torch.float64 and ns_d.is_contiguous() and (t_dev is not None or ns_d.shape[0] > t_end)
+    assert cf_table.dtype == torch.float32 and cf_table.is_contiguous() and (t_dev is not None or cf_table.shape[0] > t_end)
     with _Timed("lazy_adam_cf_table"):
-        _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), _ptr(t_dev),
-                                           _stream()), "rp_lazy_adam_cf_table")
+        _check(lib().rp_lazy_adam_cf_table(ns_d.data_ptr(), t_end, cf_from, beta1, beta2, cf_table.data_ptr(), cf_table.shape[0],
+                                           built_to, _ptr(t_dev), _stream()), "rp_lazy_adam_cf_table")
 
 
 POOL_MODES = {"sum": 0, "average": 1}

@@ -81,6 +81,12 @@ class BaseModel(nn.Module):
         (Submodules registered after the first call are picked up when any parameter changes — or call
         `model.__dict__.pop("_zg", None)`.)"""
         if not set_to_none:
+            # the deferred table optimizer keeps gradient rows that still wait for their step in the gradient arena:
+            # zeroing them in place would drop those updates (ADVICE r3) — they are applied first (a flush)
+            for m in self.modules():
+                lz = getattr(m, "_lazy", None)
+                if lz is not None and getattr(lz, "defer", False):
+                    m.flush_lazy()
             return super().zero_grad(set_to_none=False)
         plan = self.__dict__.get("_zg")
         if plan is not None:

@@ -1,4 +1,4 @@
-from .activation import get_activation
+from .activation import Dice, get_activation
 from .embedding import EmbeddingLayer
 from .deep import MLP
 from .shallow import LR_Layer
@@ -7,6 +7,6 @@ from .interaction import (InnerProductLayer, FM_Layer, CrossInteractionLayer, Cr
 from .attention import ScaledDotProductAttention, MultiHeadAttention, MultiHeadSelfAttention
 from .sequence import MaskedAveragePooling, MaskedSumPooling
 
-__all__ = ["get_activation", "EmbeddingLayer", "MLP", "LR_Layer", "InnerProductLayer", "FM_Layer",
+__all__ = ["Dice", "get_activation", "EmbeddingLayer", "MLP", "LR_Layer", "InnerProductLayer", "FM_Layer",
            "CrossInteractionLayer", "CrossNet", "CompressedInteractionNet", "ScaledDotProductAttention",
            "MultiHeadAttention", "MultiHeadSelfAttention", "MaskedAveragePooling", "MaskedSumPooling"]

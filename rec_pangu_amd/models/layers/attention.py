@@ -121,6 +121,10 @@ class MultiHeadAttention(nn.Module):
     def forward(self, query, key, value, mask=None):
         if self._fused_ok(query, key, value, mask):
             return self._fused(query), None  # attention weights are not materialised by the fused layer
+        if query.is_cuda:
+            from ... import hip
+            hip.note_torch_path("MultiHeadAttention outside the fused layer's configurations (mask, distinct q/k/v, "
+                                "layer_norm, train-mode dropout, align_to='input' or a shape the kernels' LDS budget does not hold)")
         return self._compose(query, key, value, mask)
 
 

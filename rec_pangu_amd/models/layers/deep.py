@@ -12,7 +12,7 @@ from typing import List, Union
 import torch.nn as nn
 
 from ... import functional as Fh
-from .activation import get_activation
+from .activation import Dice, get_activation
 
 
 class MLP(nn.Module):
@@ -117,6 +117,10 @@ class MLP(nn.Module):
                     pending = None
                 i += 1
             else:
+                if not isinstance(m, (nn.Identity, Dice)):  # (Dice dispatches to its own kernels)
+                    from ... import hip
+                    hip.note_torch_path(f"{type(m).__name__} inside an MLP (the fused epilogues cover ReLU; BatchNorm1d, "
+                                        "Dropout and Dice have kernels of their own)")
                 x = m(x)
                 pending = None
                 i += 1

@@ -344,13 +344,21 @@ class EmbeddingLayer(nn.Module):
         self._ensure_packed()
         self.flush_lazy()
         self._arena_bf16 = self._arena.detach().to(torch.bfloat16)
-        self._bf16_stamp = (self._arena._version, None if self._lazy is None else self._lazy.t)
+        self._bf16_stamp = self._bf16_stamp_now()
+
+    def _bf16_stamp_now(self):
+        """what the snapshot is valid for: torch's version counter of the arena, the lazy optimizer's step AND the
+        library's weight epoch — the fused optimizers write the arena through raw pointers, which torch's counter does
+        not see (FusedAdam(lazy_tables=False), torch.optim.Adam on the table views: ADVICE r3)"""
+        from ... import hip
+        return (self._arena._version, None if self._lazy is None else self._lazy.t, hip.weight_epoch(),
+                tuple(p._version for p in self._tables()))
 
     def _bf16_arena_for_inference(self):
         a = self.__dict__.get("_arena_bf16")
         if a is None or torch.is_grad_enabled():
             return None
-        stamp = (self._arena._version, None if self._lazy is None else self._lazy.t)
+        stamp = self._bf16_stamp_now()
         if stamp != self._bf16_stamp or a.device != self._arena.device:
             raise RuntimeError("the bf16 snapshot of the embedding tables is stale (the model was trained or moved since "
                                "bf16_lookup()): call bf16_lookup() again, or bf16_lookup(False) to read the fp32 tables")
@@ -442,8 +450,11 @@ class EmbeddingLayer(nn.Module):
         sig = (self._rows_sig(), str(self._arena.device))
         pinned = next((c_out for c_src, c_sig, c_out in _SORT_PINNED
                        if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src))), None)
-        if pinned is not None:  # static input buffers of a graphed step: re-sort into the persistent tensors
-            self._sort_into(X, pinned, on_side_stream=True)
+        if pinned is not None:
+            # static input buffers of a graphed step: re-sort into the persistent tensors, ON THIS STREAM — their readers
+            # (a captured step's launches, eager forwards that match the pinned entry by identity) take no event from a
+            # side stream (the side-stream form had no join back)
+            self._sort_into(X, pinned, on_side_stream=False)
             return
         for c_src, c_ver, c_sig, _, _ in _SORT_CACHE:
             if c_sig == sig and len(c_src) == len(src) and all(a is b for a, b in zip(c_src, src)) \

@@ -158,6 +158,11 @@ class CompressedInteractionNet(nn.Module):
         B, H, D = feature_emb.shape
         if feature_emb.is_cuda and self.hip_supported(H, D):
             return self._forward_hip(feature_emb)
+        if feature_emb.is_cuda:
+            from ... import hip
+            hip.note_torch_path(f"CompressedInteractionNet with {H} fields, D={D}, layers {list(self.cin_layer_units)}, "
+                                f"{self.fc.weight.shape[0]} outputs (the kernels cover <= 32 fields, one output; wide middle "
+                                "layers need D in {32, 64})")
         X_0, X_i, pooled = feature_emb, feature_emb, []
         for i in range(len(self.cin_layer_units)):
             conv = self.cin_layer["layer_" + str(i + 1)]

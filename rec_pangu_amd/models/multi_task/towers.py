@@ -75,6 +75,8 @@ def run_towers(model: nn.Module, inputs, data, is_training: bool, p_eps: float =
                 elif model.training and mod.p >= 1:
                     x_t = mod(x_t)
             else:
+                from ... import hip
+                hip.note_torch_path(f"{type(mod).__name__} inside a task tower")
                 x_t = mod(x_t)
         if is_training:
             pred, l_i = Fh.sigmoid_bce([x_t], data[f'task{i + 1}_label'].float(), apply_sigmoid=True, p_eps=p_eps,

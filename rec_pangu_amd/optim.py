@@ -109,8 +109,10 @@ class LazyAdamRows:
         # tables with the step number
         self.tabs = StepTables(betas, eps, a.device, t0, self.TABLE_CHUNK)
         self._cf_from = max(self.CF_FROM, t0)  # no row carries a stamp in (0, t0)
-        # closed form: the per-k coefficient table valid for replays that end at step `_cf_for`
-        self._cf, self._cf_for, self._cf_gen = None, -1, -1
+        # closed form: the coefficient table (adam.hip "TABLE LAYOUT": indexed by a row's stamp, final once the stamp is
+        # ~372 steps old) is valid for replays that end at step `_cf_built`; -1 = a fresh buffer.  Bringing it to the next
+        # step rebuilds only the youngest stamps: O(1) per training step whatever the step count
+        self._cf, self._cf_built, self._cf_gen = None, -1, -1
         self.device_clock = False
         self.set_replay(replay)
 
@@ -125,7 +127,7 @@ class LazyAdamRows:
     def apply(self, fn):
         self.m, self.v, self.last = fn(self.m), fn(self.v), fn(self.last)
         self.tabs.apply(fn)
-        self._cf, self._cf_for = None, -1
+        self._cf, self._cf_built = None, -1
 
     def _ensure_table(self, t_new, lr):
         if self.device_clock:  # inside a captured step: graph_step prepared the tables before the launch
@@ -136,27 +138,34 @@ class LazyAdamRows:
     def _cf_buffer(self):
         if self._cf is None or self._cf_gen != self.tabs.generation or self._cf.shape[0] < self.tabs.capacity:
             self._cf = torch.zeros((self.tabs.capacity, 8), dtype=torch.float32, device=self.m.device)
-            self._cf_gen, self._cf_for = self.tabs.generation, -1
+            self._cf_gen, self._cf_built = self.tabs.generation, -1
         return self._cf
+
+    def cf_sync(self, t_end):
+        """host-clock build: the table is valid for replays that end at t_end (no launch when it already is)"""
+        cf = self._cf_buffer()
+        if self._cf_built != t_end and (t_end > self._cf_from or self._cf_built < 0):  # (a fresh buffer gets its power columns)
+            hip.lazy_adam_cf_table(self.tabs.ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], cf,
+                                   built_to=self._cf_built)
+            self._cf_built = t_end
+        return cf
 
     def _cf_args(self, t_end, build: bool = True):
         """closed-form arguments of a replay that ends at step t_end: (table, cf_from), or (None, 0) = serial replay"""
         if not self.closed:
             return None, 0
-        if self.device_clock:  # the table is rebuilt on the device for *t_dev by every replay launch of a step
+        if self.device_clock:
+            # inside a captured step: the launch reads the step on the device and rebuilds the window of stamps that are
+            # not final yet; everything older was built before the capture (FusedAdam.prepare_step -> cf_sync) and by the
+            # replays since (consecutive steps).  `_cf_built` is advanced by FusedAdam.advance_host().
             cf = self._cf_buffer()
             if build:
                 hip.lazy_adam_cf_table(self.tabs.ns_d, self.tabs.capacity - 1, self._cf_from, self.betas[0], self.betas[1],
-                                       cf, t_dev=self.tabs.t_dev)
-                self._cf_for = -1
+                                       cf, built_to=0, t_dev=self.tabs.t_dev)
             return cf, self._cf_from
         if t_end <= self._cf_from:
             return None, 0
-        cf = self._cf_buffer()
-        if self._cf_for != t_end:
-            hip.lazy_adam_cf_table(self.tabs.ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], cf)
-            self._cf_for = t_end
-        return cf, self._cf_from
+        return self.cf_sync(t_end), self._cf_from
 
     def _check_table(self, t_target):
         if self.tabs.filled_to < t_target:
@@ -173,11 +182,13 @@ class LazyAdamRows:
     def _t_dev(self):
         return self.tabs.t_dev if self.device_clock else None
 
-    def replay(self, store, sorted_keys):
+    def replay(self, store, sorted_keys, mark=None):
         if self.defer:
             # everything the batch's rows are owed (pending real step + skipped steps); under autograd their gradient of
-            # the step in progress is announced (they are stamped pending for step t + 1)
-            mark = torch.is_grad_enabled()
+            # the step in progress is announced (they are stamped pending for step t + 1).  mark: given by callers that
+            # run inside an autograd.Function.forward, where grad mode is off whatever the caller's was (sharded.py)
+            if mark is None:
+                mark = torch.is_grad_enabled()
             if self.t > 0 or mark:
                 self._check_table(self.t)
                 cf, cf_from = self._cf_args(self.t) if (self.t > 0 or self.device_clock) else (None, 0)
@@ -276,9 +287,16 @@ class FusedAdam(torch.optim.Optimizer):
         self.defer = on
         for store in self._stores.values():
             lz = store._lazy
-            if lz is not None and type(store).__name__ == "EmbeddingLayer":
+            if lz is not None:
                 lz.defer = on
                 lz._marked_for = -1
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch semantics.  In-place zeroing (set_to_none=False) would wipe the gradient rows that still wait for their
+        deferred step: they are applied first (a flush)."""
+        if not set_to_none and self.defer:
+            self.flush()
+        return super().zero_grad(set_to_none=set_to_none)
 
     def flush(self):
         """Lazy mode: bring every embedding row to the current step (dense-equivalent state)."""
@@ -358,8 +376,7 @@ class FusedAdam(torch.optim.Optimizer):
                         lz = None
                     if lz is None or lz.m.shape != store.arena.shape or lz.m.device != store.arena.device:
                         lz = store._lazy = LazyAdamRows(store, (b1, b2), eps, owner=weakref.ref(self), t0=step - 1,
-                                                        replay=self.replay,
-                                                        defer=self.defer and type(store).__name__ == "EmbeddingLayer")
+                                                        replay=self.replay, defer=self.defer)
                         self._adopt_loaded_state(store, lz.m, lz.v, lz)
                         self._expose_state(store, lz.m, lz.v)
                     lz.step(store, lr, zero_grad=self.fuse_zero_grad)
@@ -409,10 +426,22 @@ class FusedAdam(torch.optim.Optimizer):
             lz.device_clock = on
             lz.tabs.t_dev.fill_(lz.t)
 
+    def _lr_of(self, lz):
+        """the learning rate of the parameter group that owns the tables of this lazy state"""
+        for store in self._stores.values():
+            if store._lazy is lz:
+                tabs = store.table_parameters()
+                for group in self.param_groups:
+                    if tabs and any(p is tabs[0] for p in group["params"]):
+                        return group["lr"]
+        return self.param_groups[0]["lr"]
+
     def prepare_step(self):
         """tables of the NEXT step exist for the current lr (host work that cannot run inside a capture); returns a
-        signature that changes when a buffer a captured graph holds has moved"""
-        sig = []
+        signature that changes when a captured step would no longer do what the eager step does: a buffer it holds has
+        moved, or the launch sequence depends on a switch that was flipped since (closed / serial replay, deferred /
+        immediate real step, fused zero_grad) — GraphedTrainStep re-captures on any change of it"""
+        sig = [self.fuse_zero_grad, self.defer]
         for group in self.param_groups:
             tabs = self._dense_tabs.get(id(group))
             if tabs is None:
@@ -422,10 +451,15 @@ class FusedAdam(torch.optim.Optimizer):
             if tabs is not None:
                 tabs.ensure(group.get("_rp_step", 0) + 1, group["lr"])
                 sig.append(tabs.generation)
-            for lz in self._lazies():
-                lz.tabs.ensure(lz.t + 1, group["lr"], lz.TABLE_CHUNK)
+        for lz in self._lazies():  # (once per lazy state, with the lr of the group that owns its tables)
+            lz.tabs.ensure(lz.t + 1, self._lr_of(lz), lz.TABLE_CHUNK)
+            if lz.closed:
                 lz._cf_buffer()
-                sig.append((lz.tabs.generation, lz.closed))
+                # a captured step rebuilds the window of stamps that are not final yet (consecutive steps); anything the
+                # window cannot reach — a fresh buffer, eager steps in serial mode since the last build — is built here
+                if lz._cf_built < 0 or lz._cf_built < lz.t - 4:
+                    lz.cf_sync(lz.t)
+            sig.append((lz.tabs.generation, lz.closed, lz.defer, lz._cf_gen))
         return tuple(sig)
 
     def host_counters(self):
@@ -442,6 +476,8 @@ class FusedAdam(torch.optim.Optimizer):
         for g in self.param_groups:
             g["_rp_step"] = g.get("_rp_step", 0) + 1
         for lz in self._lazies():
+            if lz.closed:
+                lz._cf_built = lz.t  # the replay in front of the captured forward brought the table to this step
             lz.t += 1
 
     def _adopt_loaded_state(self, store, m, v, lz):
@@ -500,15 +536,16 @@ def make_adam(model, lr, lazy_tables=True, replay=None, defer=None):
     serial one per replay, see LazyAdamRows) or "exact" (serial replay, bit-identical to dense execution);
     the environment variable RP_LAZY_REPLAY overrides the default.
     defer: run a row's real step at its next touch, in the one launch that also replays its skipped steps (identical
-    results after a flush; table .grad rows then hold gradients that are still waiting, so anything that READS table
-    gradients between backward and step — gradient clipping — must not be combined with it).  Default off
-    (environment variable RP_ADAM_DEFER=1 turns it on)."""
+    results after a flush — tests/test_hip_deferred_adam.py; one optimizer launch per step on the tables instead of two).
+    Table .grad rows then hold gradients that are still waiting after step(), so anything that READS or rewrites table
+    gradients between backward and step (gradient clipping on the tables) must use defer=False.  Default ON since round 4
+    (the whole -m gpu suite runs in it; environment variable RP_ADAM_DEFER=0 turns it off)."""
     params = list(model.parameters())
     if params and params[0].is_cuda:
         if replay is None:
             replay = os.environ.get("RP_LAZY_REPLAY", "closed")
         if defer is None:
-            defer = os.environ.get("RP_ADAM_DEFER", "0") == "1"
+            defer = os.environ.get("RP_ADAM_DEFER", "1") != "0"
         return FusedAdam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, fuse_zero_grad=True,
                          lazy_tables=lazy_tables, replay=replay, defer=defer)
     return torch.optim.Adam(params, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)

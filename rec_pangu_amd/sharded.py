@@ -190,7 +190,8 @@ class _ShardedRows(torch.autograd.Function):
             route = _Route(keys, layer)
         if recv_rows is None:
             recv_rows = _a2a(route.local_rows, route.recv, route.send, layer.group, layer.world)
-        served = layer._local_gather(recv_rows, served_sorted)  # [n_recv, D]
+        # (grad mode is off inside a Function.forward: the deferred optimizer is told explicitly whether a backward follows)
+        served = layer._local_gather(recv_rows, served_sorted, mark=bool(ctx.needs_input_grad[2]))  # [n_recv, D]
         ctx.presorted = getattr(layer, "_served_sorted", None)
         layer._served_sorted = None
         rows = _a2a_rows(served, route.send, route.recv, layer)
@@ -527,7 +528,7 @@ class ShardedEmbeddingLayer(nn.Module):
         self._ahead = (src, ver, route, event, recv_rows, served_sorted)
 
     # ---- local primitives: HIP kernels on a HIP device, torch ops on CPU ---------------------------
-    def _local_gather(self, rows_idx, served_sorted=None):
+    def _local_gather(self, rows_idx, served_sorted=None, mark=None):
         if self.local_arena.is_cuda:
             from . import hip
             n = rows_idx.numel()
@@ -538,7 +539,7 @@ class ShardedEmbeddingLayer(nn.Module):
                 # exact lazy dense Adam: rows about to be served first replay the steps they skipped
                 sk, sp = served_sorted if served_sorted is not None else \
                     hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
-                self._lazy.replay(self, sk)
+                self._lazy.replay(self, sk, mark=mark)
                 self._served_sorted = (sk, sp)
             zero = torch.zeros((1,), dtype=torch.int64, device=rows_idx.device)
             cnt = torch.full((1,), self.local_arena.shape[0], dtype=torch.int64, device=rows_idx.device)

@@ -38,6 +38,11 @@ def small_enc_dict():
     return {k: ({"min": 0.0, "max": 1.0} if k.startswith("I") else {"vocab_size": VOCAB[k]}) for k in ENC_ORDER}
 
 
+# the ordered enc_dict of tests/golden/adam_long.npz (make_golden_r4.py feeds it to the reference's DeepFM)
+ADAM_LONG_ENC = {"I1": {"min": 0.0, "max": 1.0}, "I2": {"min": 0.0, "max": 1.0},
+                 "C1": {"vocab_size": 3000}, "C2": {"vocab_size": 700}, "C3": {"vocab_size": 40}, "C4": {"vocab_size": 5}}
+
+
 @pytest.fixture(scope="session")
 def enc_dict():
     return small_enc_dict()

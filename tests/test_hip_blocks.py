@@ -350,3 +350,57 @@ def test_mlp_with_batchnorm_eval_vs_reference_fixture():
     mlp = mlp.to(DEV).eval()
     y = mlp(g["mlp"]["in"].to(DEV))
     _close(y.detach().cpu(), g["mlp2"]["out"], rel=2e-5, what="mlp2 eval out")
+
+
+# ------------------------------------------------------------------------------------------------ Dice (activation.py:10-34)
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_dice_vs_reference_fixture(case):
+    """rp_batchnorm_* (affine=False) + rp_dice_gate_* against the reference's Dice: training mode (batch statistics,
+    running statistics after the step) and eval mode, forward and every gradient."""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.layers import Dice
+    g = load_golden("dice.npz")[case]
+    N = g["x"].shape[1]
+    d = Dice(N)
+    with torch.no_grad():
+        d.alpha.copy_(g["alpha"])
+    d = d.to(DEV)
+    n0, tp0 = hip.launch_count(), hip.torch_path_count()
+    for mode in ("train", "eval"):
+        d.train(mode == "train")
+        d.alpha.grad = None
+        x = g["x"].to(DEV).requires_grad_(True)
+        y = d(x)
+        (y * g["cot"].to(DEV)).sum().backward()
+        _close(y.detach().cpu(), g[f"{mode}/y"], rel=1e-5, what=f"dice {mode} y")
+        _close(x.grad.cpu(), g[f"{mode}/dx"], what=f"dice {mode} dx")
+        _close(d.alpha.grad.cpu(), g[f"{mode}/dalpha"], what=f"dice {mode} dalpha")
+        if mode == "train":
+            _close(d.bn.running_mean.cpu(), g["running_mean"], rel=1e-5, what="running_mean")
+            _close(d.bn.running_var.cpu(), g["running_var"], rel=1e-5, what="running_var")
+            assert int(d.bn.num_batches_tracked) == int(g["num_batches_tracked"])
+    assert hip.launch_count() - n0 >= 8 and hip.torch_path_count() == tp0
+
+
+def test_mlp_with_dice_activations_vs_reference_fixture():
+    """deep.py:11-84 with Dice instances as hidden activations (what the reference's DIN-style towers pass): the MLP walks
+    Linear -> Dice -> Linear -> Dice -> Linear on HIP kernels, no torch path."""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.models.layers import MLP, Dice
+    g = load_golden("dice.npz")["mlp"]
+    mlp = MLP(input_dim=10, output_dim=1, hidden_units=[16, 8], hidden_activations=[Dice(16), Dice(8)], dropout_rates=0)
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w/")}
+    assert list(mlp.state_dict().keys()) == list(w.keys())
+    mlp.load_state_dict(w)
+    mlp = mlp.to(DEV).train()
+    tp0 = hip.torch_path_count()
+    x = g["x"].to(DEV).requires_grad_(True)
+    y = mlp(x)
+    (y * g["cot"].to(DEV)).sum().backward()
+    assert hip.torch_path_count() == tp0
+    _close(y.detach().cpu(), g["y"], what="mlp+dice y")
+    _close(x.grad.cpu(), g["dx"], what="mlp+dice dx")
+    for k, p in mlp.named_parameters():
+        _close(p.grad.cpu(), g["g/" + k], what=f"mlp+dice grad {k}")
+    for k, v in mlp.state_dict().items():
+        _close(v.detach().cpu().float(), g["after/" + k].float(), rel=1e-5, what=f"mlp+dice after {k}")

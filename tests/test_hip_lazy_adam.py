@@ -172,10 +172,14 @@ def test_closed_form_replay_vs_serial_and_float64(D):
     p64, m64, v64 = p0.double(), torch.zeros(R, D, dtype=torch.float64), torch.zeros(R, D, dtype=torch.float64)
     hot = torch.arange(0, 20)
 
+    built = {"t": -1}  # the table is brought forward step by step (only the stamps that are not final yet are rebuilt)
+
     def cf_args(kind, t_end):
         if kind == "serial" or t_end <= CF_FROM:
             return None, 0
-        hip.lazy_adam_cf_table(dev_nsd, t_end, CF_FROM, b1, b2, cf)
+        if built["t"] != t_end:
+            hip.lazy_adam_cf_table(dev_nsd, t_end, CF_FROM, b1, b2, cf, built_to=built["t"])
+            built["t"] = t_end
         return cf, CF_FROM
 
     for t in range(1, steps + 1):
@@ -249,9 +253,9 @@ def test_closed_form_replay_model_level():
     hovers around zero (a ReLU unit that is almost never active) takes +-lr steps whose SIGN depends on the last bits of
     that gradient.  On this seed such an event separates the two runs between steps 701 and 751 (dense parameters: 1.8e-7
     -> 2.9e-4 apart within 50 steps, predictions 1e-2 apart at step 1100); from then on the two are different, equally
-    valid fp32 trajectories of the same optimizer (scratch/diag_cf2.py prints the trace).  The serial replay is no
+    valid fp32 trajectories of the same optimizer (profiles/microbench/probes/diag_cf2.py prints the trace).  The serial replay is no
     reference point in that comparison: against float64 Adam the closed form is the MORE accurate of the two
-    (test_closed_form_replay_vs_serial_and_float64; scratch/diag_cf.py: 1.5e-6 rms of the update against 2e-5).  The
+    (test_closed_form_replay_vs_serial_and_float64; profiles/microbench/probes/diag_cf.py: 1.5e-6 rms of the update against 2e-5).  The
     final divergence is printed, not asserted."""
     import copy
     from rec_pangu_amd.models.ranking import DeepFM

@@ -788,7 +788,7 @@ def test_xdeepfm_three_cin_layers_of_128_vs_oracle(matmul_mode):
     worst = 0.0
     # the embedding tables are views of ONE arena (and their gradients of one gradient arena): their common scale is the
     # arena's — a cubic CIN is heavy-tailed, the largest gradient row of one table can be 100x another table's, and the
-    # split-bf16 products are exact to 2^-24 of the LARGEST terms of a tile, not of each output (scratch/diag_cin.py: the CIN
+    # split-bf16 products are exact to 2^-24 of the LARGEST terms of a tile, not of each output (profiles/microbench/probes/diag_cin.py: the CIN
     # block alone is within 3e-7 of float64 at [128, 128, 128], like the fp32 oracle)
     emb_scale = max(float(sd64[k].grad.abs().max()) for k in sd64 if k.startswith("embedding_layer."))
     for k, p in model.named_parameters():
@@ -939,3 +939,52 @@ def test_sharded_fused_first_layer_single_rank():
             assert float((tabs[c] - ref).abs().max()) <= 2e-5 * max(1e-2, float(ref.abs().max())), c
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["deepfm", "xdeepfm", "dcn", "autoint", "mmoe"])
+def test_baseline_models_stay_on_the_library_kernels(name):
+    """the five BASELINE models, one training step each (forward, backward, optimizer) at a Criteo-shaped
+    batch: no module reports a torch path (hip.torch_path_count), and the ATen ops the step dispatches — recorded in the
+    forward AND on the autograd thread — contain none of the reference's compute ops (GEMMs, einsum, conv, embedding,
+    softmax, batch norm, dropout): those all run as library launches."""
+    import os
+    import sys
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.optim import make_adam
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    enc = bench.mmoe_enc_dict() if name == "mmoe" else bench.criteo_enc_dict(64)
+    torch.manual_seed(3)
+    model = bench.build_model(name, enc).to(DEV)
+    model.train()
+    opt = make_adam(model, 1e-3)
+    batches = [bench.synth_batch(enc, 2048, 5 + i, DEV) for i in range(3)]
+
+    def step(b):
+        out = model(b)
+        out["loss"].backward()
+        opt.step()
+        model.zero_grad()
+
+    step(batches[0])  # (first step: buffers and optimizer state come into being)
+    seen = set()
+
+    class Rec(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.add(str(func))
+            return func(*args, **(kwargs or {}))
+
+    tp0, n0 = hip.torch_path_count(), hip.launch_count()
+    with Rec():
+        step(batches[1])
+        step(batches[2])
+    torch.cuda.synchronize()
+    assert hip.torch_path_count() == tp0, hip.torch_paths()
+    assert hip.launch_count() - n0 >= 10
+    banned = ("aten.mm", "aten.addmm", "aten.bmm", "aten.baddbmm", "aten.matmul", "aten.einsum", "aten.linear", "aten.convolution",
+              "aten.embedding", "aten.index_select", "aten._softmax", "aten.native_batch_norm", "aten.cudnn_batch_norm",
+              "aten.miopen_batch_norm", "aten.native_dropout", "aten.sigmoid.", "aten.binary_cross_entropy", "aten.relu",
+              "aten.threshold_backward", "aten.index_add", "aten.scatter_add", "aten._foreach_addcdiv")
+    hit = sorted(op for op in seen if any(op.startswith(b) for b in banned))
+    assert not hit, f"{name}: the step dispatched ATen compute ops: {hit}"

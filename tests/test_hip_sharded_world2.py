@@ -217,7 +217,7 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model():
         torch.testing.assert_close(got, p, rtol=0, atol=2e-6, msg=lambda m: f"step {i}: {m}")
     # Weights after the 5 Adam steps (lr 1e-2).  Predictions agree to 1 ulp, but Adam divides by |g| + 1e-8: elements
     # whose gradient is of the size of eps turn reduction-order noise (two half batches vs one) into ~1e-5 differences.
-    # Measured with scratch/diag_world2.py: a ONE-process control that accumulates the gradients of the two half batches
+    # Measured with profiles/microbench/probes/diag_world2.py: a ONE-process control that accumulates the gradients of the two half batches
     # (no exchange at all) differs from the full-batch run by the same 1.0e-5 on the big tables / 1.4e-5 on dnn.net.0.weight
     # and from this two-rank run by 7e-8 on the dense weights.  So: a bound of 0.5 % of one Adam step on every element,
     # and all but 1e-4 of the elements within 1e-6.

@@ -199,3 +199,60 @@ def test_seq_pooling(case):
         for mode, (out, _, _) in modes.items():
             y = R.embedding_bags_pooled(table, seq[keep], offsets, "sum" if mode == "sum" else "average")
             torch.testing.assert_close(y, out, rtol=1e-6, atol=1e-7)
+
+
+# ---- round 4: Dice (activation.py:10-34) and the 600-step dense-Adam run of the reference ---------------------------
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_dice_oracle_and_cpu_module_vs_reference(case):
+    from rec_pangu_amd.models.layers import Dice
+    g = load_golden("dice.npz")[case]
+    N = g["x"].shape[1]
+    for mode in ("train", "eval"):
+        x = g["x"].clone().requires_grad_(True)
+        alpha = g["alpha"].clone().requires_grad_(True)
+        rm = torch.zeros(N) if mode == "train" else g["running_mean"]
+        rv = torch.ones(N) if mode == "train" else g["running_var"]
+        y, nrm, nrv = R.dice(x, alpha, rm, rv, training=(mode == "train"))
+        (y * g["cot"]).sum().backward()
+        torch.testing.assert_close(y.detach(), g[f"{mode}/y"], **TOL)
+        torch.testing.assert_close(x.grad, g[f"{mode}/dx"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(alpha.grad, g[f"{mode}/dalpha"], rtol=1e-4, atol=1e-5)
+        if mode == "train":
+            torch.testing.assert_close(nrm, g["running_mean"], **TOL)
+            torch.testing.assert_close(nrv, g["running_var"], **TOL)
+    # the drop-in module on CPU (BASELINE config 0): same keys, same numbers
+    d = Dice(N)
+    assert list(d.state_dict().keys()) == ["alpha", "bn.running_mean", "bn.running_var", "bn.num_batches_tracked"]
+    with torch.no_grad():
+        d.alpha.copy_(g["alpha"])
+    d.train()
+    x = g["x"].clone().requires_grad_(True)
+    y = d(x)
+    (y * g["cot"]).sum().backward()
+    torch.testing.assert_close(y.detach(), g["train/y"], **TOL)
+    torch.testing.assert_close(d.alpha.grad, g["train/dalpha"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(d.bn.running_var, g["running_var"], **TOL)
+
+
+def test_cpu_deepfm_reproduces_the_reference_600_step_adam_run():
+    """tests/golden/adam_long.npz: the reference's DeepFM under the reference's dense Adam (trainer.py:75) for 600 steps.
+    The CPU drop-in (BASELINE config 0: same modules, torch.optim.Adam from make_adam) must land on the same weights."""
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.optim import make_adam
+    from conftest import ADAM_LONG_ENC
+    g = load_golden("adam_long.npz")
+    torch.manual_seed(0)
+    model = DeepFM(embedding_dim=8, hidden_units=[16, 8], enc_dict=ADAM_LONG_ENC)
+    model.load_state_dict(g["init"])
+    opt = make_adam(model, 1e-3)
+    assert type(opt) is torch.optim.Adam
+    cols = list(g["batch"].keys())
+    for t in range(1, 601):
+        batch = {c: g["batch"][c][t - 1] for c in cols}
+        out = model(batch)
+        out["loss"].backward()
+        opt.step()
+        model.zero_grad()
+        if t in (300, 600):
+            for k, v in model.state_dict().items():
+                torch.testing.assert_close(v, g[f"step{t}"][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"step {t} {k}: {m}")
