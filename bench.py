@@ -100,13 +100,18 @@ def _pmc_rows():
     """profiles/r*_<config>_pmc.json of the latest round: one row per (kernel name, grid size) with the mean duration
     rocprofv3 measured and the HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (profiles/summarize.py)."""
     import glob
+    global PMC_FILE
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{PMC_TAG}_pmc.json")))
     if not files:
         return {}
     try:
+        PMC_FILE = os.path.relpath(files[-1], ROOT)
         return json.load(open(files[-1]))
     except Exception:
         return {}
+
+
+PMC_FILE = None  # the committed counter summary `roofline.traffic` was read from (recorded in the bench line)
 
 
 # C-ABI entry point -> prefixes of the kernels behind it (rocprofv3 reports kernels, bench.py times entry points)
@@ -152,7 +157,8 @@ def cpu_baseline(seconds_budget=18.0):
     (dense Adam then touches 2.1 M rows instead of 33.8 M), 1 warm-up + timed steps for ~18 s (at most 12)."""
     from oracle import ref_ops as R  # checker/baseline only
     from rec_pangu_amd.models.ranking import DeepFM
-    cores = min(os.cpu_count() or 1, 64)  # more threads than this only adds contention in ATen's scatter ops
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 64)  # more threads than this only adds contention in ATen's scatter ops
     torch.set_num_threads(cores)
     enc = criteo_enc_dict(scale=16)
     torch.manual_seed(0)
@@ -175,7 +181,7 @@ def cpu_baseline(seconds_budget=18.0):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(B / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": round(B / dt, 1), "unit": "samples/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"{n} train step(s) of B={B} (fwd+bwd+dense Adam), vocabulary/16 = "
                       f"{sum(v['vocab_size'] + 1 for v in enc.values() if 'vocab_size' in v)} rows, "
                       f"{dt:.2f} s/step, torch CPU fp32"}
@@ -209,14 +215,18 @@ def main():
                     help="how the lazy optimizer catches a row up: 'closed' (library default) = closed-form replay of the "
                          "skipped zero-gradient steps (<= 1e-6 relative to the serial replay per replay, an HBM stream), "
                          "'exact' = serial replay, bit-identical to the dense HIP kernel (VALU-bound)")
-    ap.add_argument("--defer", action="store_true",
+    ap.add_argument("--defer", default=None, choices=["on", "off"],
                     help="lazy optimizer: run a row's real step at its next touch, in the one launch that also replays its "
                          "skipped steps (FusedAdam(defer=True): same results after a flush, one optimizer launch per "
-                         "training step on the tables instead of two).  Opt-in; the default line does not use it")
+                         "training step on the tables instead of two).  Default: the library's (on since round 4: the whole "
+                         "GPU suite runs in it; RP_ADAM_DEFER=0 / --defer off = the immediate execution)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="replay the whole training step (fwd + bwd + optimizer + the next batch's sort) from a captured "
-                         "hipGraph (rec_pangu_amd/graph_step.py; bit-identical to the eager step).  auto = on for single-GPU "
-                         "training of the models without active dropout (deepfm, dcn)")
+                    help="replay the whole training step (fwd + bwd + optimizer + the next batch's sort) from ONE capture "
+                         "(rec_pangu_amd/graph_step.py; bit-identical to the eager step): as a launch plan (csrc/plan.hip) "
+                         "when the step holds library launches only (deepfm: any batch size), else as a hipGraph (dcn: "
+                         "small, host-bound batches only — a replayed hipGraph is slower than eager launches at B = 65536)")
+    ap.add_argument("--graph-backend", default=None, choices=["plan", "hipgraph"],
+                    help="force the replay form of the captured step (default: plan, falling back to hipgraph per model)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: SECONDARY inference line (--mode forward only) — the fused lookup + FM + first layer reads a "
                          "bf16 snapshot of the tables (half the gather traffic; logits within 6e-2 of the fp32 tables', outside "
@@ -282,7 +292,7 @@ def main():
         model.embedding_layer.bf16_lookup()
     lazy = args.optimizer == "lazy" and args.mode == "train"
     opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"), replay=args.replay,
-                    defer=(True if args.defer else None))
+                    defer=(None if args.defer is None else args.defer == "on"))
     replay_mode = getattr(opt, "replay", None) if lazy else None
     n_params = sum(p.numel() for p in model.parameters())
     n_table_params = sum(p.numel() for m in model.modules() if hasattr(m, "table_parameters") for p in m.table_parameters())
@@ -301,12 +311,17 @@ def main():
     # auto: only where the eager step is HOST-bound (small per-GPU batches).  On this runtime a replayed graph costs the
     # device ~10 us per node more than the same launches issued eagerly (B = 65536: 1.6 ms replayed against 1.26 eager in
     # the cold state, profiles/microbench/probes/probe_graph5.py) — a win at b = 8192, a loss at the headline batch
+    # Round 4: the LAUNCH PLAN (csrc/plan.hip) re-issues the captured step's launches itself — the device sees the eager
+    # stream of kernels, the host pays a few us per launch — so a DeepFM step (library launches only) is replayed at every
+    # batch size; a step that must fall back to a hipGraph (dcn: ATen launches inside) only where the host is the limit.
+    plan_ok = args.graph_backend != "hipgraph" and os.environ.get("RP_GRAPH_BACKEND", "plan") == "plan"
     use_graph = args.mode == "train" and not sharded and not args.no_sort_ahead and (
-        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn") and local_B <= 16384))
+        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn")
+                               and (local_B <= 16384 or (plan_ok and args.model == "deepfm"))))
     gstep = None
     if use_graph:
         from rec_pangu_amd.graph_step import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt)
+        gstep = GraphedTrainStep(model, opt, backend=args.graph_backend)
 
     def step(data, nxt=None, graphed=False):
         if args.mode == "forward":
@@ -382,6 +397,11 @@ def main():
         del cur, nb
         n_seen += pre_roll + 1
         barrier()
+        if gstep is not None and args.graph == "auto" and local_B > 16384 and gstep.backend_used == "hipgraph":
+            # the step could not be replayed as a plan (gstep.why_not_plan): at this batch size eager launches beat a hipGraph
+            print(f"bench: captured step fell back to a hipGraph ({gstep.why_not_plan}); timing the eager step", file=sys.stderr)
+            torch.cuda.synchronize()
+            gstep = None
 
     # ---- (3) warm-up; its last few steps double as the per-kernel profiling pass (a HIP-event pair around EVERY
     #          launch — that serialises the queue and costs ~45 % of the step, so it stays out of the timed region)
@@ -489,14 +509,16 @@ def main():
         barrier()
         flush_ms = (time.perf_counter() - t1) * 1e3
 
-    # ---- (5b) the same step with the table optimizer's real step DEFERRED (FusedAdam(defer=True): opt-in this round,
-    #           DESIGN 5c; identical results, tests/test_hip_deferred_adam.py) — a secondary figure, never `value`.  The mode
-    #           has its own long-run state (every touched row carries its waiting step): a second pre-roll brings it about
+    # ---- (5b) the same EAGER step with the table optimizer's real step executed the other way round (deferred is the
+    #           library default since round 4; FusedAdam.set_defer switches mid-run, identical results:
+    #           tests/test_hip_deferred_adam.py) — a secondary figure, never `value`.  Each mode has its own long-run state
+    #           (deferred: every touched row carries its waiting step): a second pre-roll brings it about
     deferred_line = None
-    if (args.mode == "train" and lazy and not sharded and world == 1 and gstep is None and pre_roll > 0
-            and args.model in ("deepfm", "dcn") and hasattr(opt, "set_defer") and not getattr(opt, "defer", False) and not args.no_small_batch):
+    if (args.mode == "train" and lazy and not sharded and world == 1 and pre_roll > 0 and args.model in ("deepfm", "dcn")
+            and hasattr(opt, "set_defer") and not args.no_small_batch):
+        was = bool(getattr(opt, "defer", False))
         try:
-            opt.set_defer(True)
+            opt.set_defer(not was)
             nb = gen(n_seen + 100000)
             for i in range(pre_roll):
                 cur, nb = nb, gen(n_seen + 100001 + i)
@@ -513,21 +535,22 @@ def main():
             barrier()
             d_ms = (time.perf_counter() - t_) / args.steps * 1e3
             deferred_line = {
+                "deferred": not was, "execution": "eager launches",
                 "ms_per_step": round(d_ms, 4), "value": round(B / (d_ms * 1e-3), 1), "unit": "samples/s",
                 "host_enqueue_ms_per_step": round(h_ / args.steps * 1e3, 4), "pre_roll_steps_in_this_mode": pre_roll,
                 "real_steps_waiting_before": waiting0, "real_steps_waiting_after": pending_real_steps(),
-                "note": "FusedAdam.set_defer(True) on the same model and optimizer: a row's real step waits in the gradient "
-                        "arena until the row is next needed, one optimizer launch per step on the tables instead of two; "
-                        "in the long-run state of this mode the waiting count is constant over the window, i.e. as many real "
-                        "steps are applied as deferred — compare the two figures.  Opt-in library mode: the headline above "
-                        "is the default (immediate) execution"}
+                "note": "FusedAdam.set_defer(%s) on the same model and optimizer, EAGER launches (no captured step): deferred = "
+                        "a row's real step waits in the gradient arena until the row is next needed, one optimizer launch per "
+                        "step on the tables instead of two; in the long-run state of that mode the waiting count is constant "
+                        "over the window, i.e. as many real steps are applied as deferred.  The headline runs deferred = %s"
+                        % (not was, was)}
         except Exception as e:  # a secondary figure must never take the headline down with it
             deferred_line = {"error": repr(e)}
         finally:
             try:
-                opt.set_defer(False)  # applies what is waiting (a flush)
+                opt.set_defer(was)  # (turning it off applies what is waiting: a flush)
             except Exception as e:
-                deferred_line = {"error": "restoring the immediate execution failed: " + repr(e)}
+                deferred_line = {"error": "restoring the headline's execution failed: " + repr(e)}
         barrier()
 
     # ---- (6) the per-GPU batch of a STRONG-scaling run at G = 8 (b = B / 8): eager against the captured hipGraph.  At this
@@ -556,10 +579,11 @@ def main():
         gs_small = GraphedTrainStep(model, opt)
         graph = run(lambda a, b: gs_small(a, b), 10, 40)
         assert gs_small.replays >= 40
-        small = {"per_gpu_batch": sb, "eager": eager, "hip_graph": graph,
+        small = {"per_gpu_batch": sb, "eager": eager, "hip_graph": graph, "captured_step_backend": gs_small.backend_used,
                  "samples_per_s_hip_graph": round(sb / (graph["ms_per_step"] * 1e-3), 1),
                  "note": "fwd + bwd + optimizer at the per-GPU batch of a strong-scaling run on 8 GPUs, same model and "
-                         "optimizer state: eager launches against replays of the captured step (bit-identical results)"}
+                         "optimizer state: eager launches against replays of the captured step (bit-identical results; "
+                         "key names kept from round 3: 'hip_graph' = the captured step, replayed as captured_step_backend)"}
         barrier()
         del gs_small
 
@@ -683,6 +707,11 @@ def main():
         r = {"kernel": key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy_peak": round(gbs / HBM_COPY_GBS, 4),
              "traffic": pmc_traffic(key, mean_ms) if world == 1 else None, "algorithmic_bytes_per_launch": int(nbytes)}
+        if r["traffic"]:
+            # (state the fraction on the bytes that actually moved as well, and where they were counted)
+            r["traffic_source"] = f"RECORDED rocprofv3 FETCH_SIZE + WRITE_SIZE of this workload ({PMC_FILE}), matched by kernel " \
+                                  f"name and duration; not measured in this run"
+            r["frac_on_counter_bytes"] = round(r["traffic"] / sec / 1e9 / HBM_PEAK_GBS, 4)
         if key.startswith("embed_grad_gemm"):
             # `frac` prices the kernel on COMPULSORY bytes (dH / sum rows read ONCE).  Its field-major pair order reads
             # every sample's dH and sum row once per FIELD (F x 2 x B x 256 B), which is what the counters see: the
@@ -785,9 +814,15 @@ def main():
                        "matmul_precision": precision, "lazy_replay": replay_mode,
                        "deferred_real_step": bool(getattr(opt, "defer", False)),
                        "sort_ahead": bool(ahead),
-                       "hip_graph": (f"the timed steps are replays of a captured hipGraph (fwd + bwd + optimizer step + "
-                                     f"zero_grad + the next batch's sort; rec_pangu_amd/graph_step.py, bit-identical to the "
-                                     f"eager step: tests/test_hip_graph.py)" if gstep is not None else None),
+                       "hip_graph": (None if gstep is None else
+                                     (f"the timed steps are replays of ONE captured step (fwd + bwd + optimizer step + zero_grad "
+                                      f"+ the next batch's sort; rec_pangu_amd/graph_step.py, bit-identical to the eager step: "
+                                      f"tests/test_hip_graph.py), replayed as "
+                                      + (f"a LAUNCH PLAN (csrc/plan.hip: {gstep.plans[0].nodes} recorded library launches re-issued "
+                                         f"with hipLaunchKernel, {gstep.plans[0].side} of them — the next batch's keys + sort — on the "
+                                         f"plan's side stream beside the step)" if gstep.backend_used == "plan" else
+                                         f"a hipGraph ({gstep.why_not_plan or 'backend hipgraph'})"))),
+                       "captured_step_backend": None if gstep is None else gstep.backend_used,
                        "unique_rows_per_batch": n_unique,
                        "parallelism": "single GPU" if not sharded else
                        f"tables row-sharded x{world}, all-to-all lookup ({args.wire} rows on the wire)"},
@@ -806,7 +841,7 @@ def main():
         if small is not None:
             res["strong_scaling_batch"] = small
         if deferred_line is not None:
-            res["deferred_real_step"] = deferred_line
+            res["other_real_step_mode"] = deferred_line
         if lazy:
             res["lazy_adam"] = {
                 "state": f"long-run: {pre_roll} un-timed pre-roll steps on distinct batches before the warm-up",

@@ -178,6 +178,8 @@ int rp_linear_wgrad_gather(const float *dy, int64_t lddy, const float *arena, co
                            void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* out[C,R] = in[R,C]^T (weights for the dgrad GEMM); rows C .. C_out-1 of out (C_out >= C) are written as zeros */
 int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, rp_stream_t stream);
+/* out[r, 0:C] = in[r, 0:C], r < R, with another row stride (staging copy of a weight with unaligned rows) */
+int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
 /* y = dy * (act_out > 0), elementwise over [M,N] */
 int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
                 int64_t M, int N, rp_stream_t stream);
@@ -570,6 +572,26 @@ int rp_route_build(void *workspace, size_t workspace_bytes, const int32_t *sorte
 int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int world, int lbits,
                  int64_t capacity, const int64_t *counts, int32_t *slot_sorted, int64_t *slot_of_pair,
                  int64_t *rows_padded, int32_t *err_flag, rp_stream_t stream);
+
+/* ---- LAUNCH PLANS: record a sequence of this library's kernel launches once, re-issue it with one call (csrc/plan.hip).
+ * No reference counterpart (the reference's step loop is Python: model_pipeline.py:47-61); this is the host-side
+ * mechanism behind rec_pangu_amd/graph_step.py's captured training step.  Between rp_plan_begin and rp_plan_end every
+ * kernel launch any entry point of this library issues — from any host thread — is appended to the plan with its packed
+ * arguments (and still issued: under a stream capture it becomes a graph node, otherwise it runs).  rp_plan_replay
+ * re-issues the recorded launches with the recorded arguments on `stream`; launches recorded under rp_plan_section(1)
+ * are independent of the others and go to a side stream owned by the plan, forked at the start of the replay and joined
+ * at its end.  The caller guarantees that every address baked into the plan stays valid and that step numbers are read
+ * on the device (t_dev arguments).  One plan may be recorded at a time, process-wide.
+ *   rp_plan_info          launches recorded, those of section 1, distinct streams they were issued on while recording
+ *   rp_graph_node_counts  kernel nodes / other nodes (memset, memcpy, ...) of a captured hipGraph_t: the check that a
+ *                         captured step holds no launch the plan has not seen */
+int rp_plan_begin(void **plan_out);
+int rp_plan_section(int section);
+int rp_plan_end(void *plan);
+int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
+int rp_plan_replay(void *plan, rp_stream_t stream);
+int rp_plan_destroy(void *plan);
+int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other);
 
 #ifdef __cplusplus
 }

@@ -5,9 +5,68 @@
 #include <stddef.h>
 #include "../../include/rec_pangu_hip.h"
 
+#include <string.h>
+#include <tuple>
+#include <utility>
+
 // thread-local error text + process-wide launch counter (defined in common.hip)
 int rp_fail(int code, const char *fmt, ...);
 void rp_count_launch();
+
+// ------------------------------------------------------------------------------------------------------------------
+// Every kernel launch of the library goes through rp_launch (the hipLaunchKernelGGL macro is redirected to it below):
+// the arguments are packed into one buffer the way the kernel takes them and handed to hipLaunchKernel; while a LAUNCH
+// PLAN is being recorded (plan.hip: rp_plan_begin .. rp_plan_end) the packed launch is also appended to the plan, which
+// rp_plan_replay later re-issues with the same arguments — the library's own, node-overhead-free form of a captured step
+// (rec_pangu_amd/graph_step.py).  gfx950 kernel arguments are at most 4 KB.
+// ------------------------------------------------------------------------------------------------------------------
+#define RP_MAX_KERNARG 4096
+bool rp_plan_recording();
+void rp_plan_record(const void *func, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, const char *blob,
+                    size_t blob_bytes, const size_t *offsets, int nargs);
+
+template <typename T>
+static inline size_t rp_pack_arg(char *buf, size_t &off, const T &v) {
+    off = (off + alignof(T) - 1) & ~(size_t)(alignof(T) - 1);
+    const size_t at = off;
+    memcpy(buf + at, &v, sizeof(T));
+    off += sizeof(T);
+    return at;
+}
+
+// argument I of the launch converted to the kernel's parameter type K, exactly as a <<< >>> launch would; a kernel
+// parameter the launch site leaves out takes K{} — every default argument of this library's kernels is 0 / nullptr
+// (embed_grad_reduce_kernel, linear_fwd_bf16_kernel, linear_wgrad_bf16_kernel), and a function pointer carries no defaults
+template <size_t I, typename K, typename Tup>
+static inline K rp_arg_or_zero(Tup &t) {
+    if constexpr (I < std::tuple_size<Tup>::value) return static_cast<K>(std::get<I>(t));
+    else return K{};
+}
+
+template <typename... KArgs, typename Tup, size_t... I>
+static inline void rp_launch_packed(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream,
+                                    Tup &args, std::index_sequence<I...>) {
+    constexpr int N = (int)sizeof...(KArgs);
+    static_assert((sizeof(KArgs) + ... + 0) + 16 * sizeof...(KArgs) <= RP_MAX_KERNARG, "kernel arguments exceed the packing buffer");
+    alignas(16) char buf[RP_MAX_KERNARG];
+    size_t off = 0;
+    size_t offs[N ? N : 1] = {rp_pack_arg<KArgs>(buf, off, rp_arg_or_zero<I, KArgs>(args))...};
+    void *ptrs[N ? N : 1];
+    for (int i = 0; i < N; ++i) ptrs[i] = buf + offs[i];
+    if (rp_plan_recording()) rp_plan_record(reinterpret_cast<const void *>(kernel), grid, block, shmem, stream, buf, off, offs, N);
+    (void)hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, shmem, stream);
+}
+
+template <typename... KArgs, typename... Args>
+static inline void rp_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream,
+                             Args &&...args) {
+    static_assert(sizeof...(Args) <= sizeof...(KArgs), "kernel launch: too many arguments");
+    auto tup = std::forward_as_tuple(std::forward<Args>(args)...);
+    rp_launch_packed(kernel, grid, block, shmem, stream, tup, std::make_index_sequence<sizeof...(KArgs)>());
+}
+
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) rp_launch(kernel, grid, block, shmem, stream, __VA_ARGS__)
 
 #define RP_REQUIRE(cond, ...)                                  \
     do {                                                       \

@@ -1448,6 +1448,27 @@ extern "C" int rp_transpose(const float *in, int64_t ldin, float *out, int64_t l
     return RP_OK;
 }
 
+// out[r, 0:C] = in[r, 0:C] with another row stride (the [N, ceil4(K)] staging copy of a weight whose rows are not 16-byte
+// aligned: functional._rows16) — a library launch, so that a recorded launch plan of a training step holds it
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float *__restrict__ in, int64_t ldin, float *__restrict__ out,
+                                                        int64_t ldout, int R, int C) {
+    const int64_t total = (int64_t)R * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / C;
+        const int c = (int)(e - r * C);
+        out[r * ldout + c] = in[r * ldin + c];
+    }
+}
+
+extern "C" int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream) {
+    RP_REQUIRE(in && out && R >= 1 && C >= 1 && ldin >= C && ldout >= C, "copy_rows: bad argument");
+    int64_t blocks = rp_cdiv((int64_t)R * C, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C);
+    RP_LAUNCH_CHECK("copy_rows");
+    return RP_OK;
+}
+
 extern "C" int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out,
                            int64_t ldo, int64_t M, int N, rp_stream_t stream) {
     RP_REQUIRE(dy && act_out && out && M >= 0 && N >= 1, "relu_bwd: bad argument");

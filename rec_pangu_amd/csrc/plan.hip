@@ -1,0 +1,207 @@
+// LAUNCH PLANS: the library's own replayable form of a sequence of its kernel launches (host code only).
+//
+// Why not a hipGraph alone: on this runtime a replayed graph costs the device ~10 us per kernel node more than the same
+// launches issued on a stream (B = 65536: 1.5 - 1.6 ms replayed against 1.26 ms eager, profiles/microbench/probes/
+// probe_graph5.py), so a captured step only paid off for small, host-bound batches — while the eager step needs ~1 ms
+// of Python / ctypes / autograd host time per step.  A plan keeps what the capture gives (one host call per step, frozen
+// arguments, device-resident step counters) and re-issues the launches with hipLaunchKernel: the device sees exactly the
+// eager stream of kernels, the host spends a few microseconds per launch.
+//
+// Recording: between rp_plan_begin and rp_plan_end every launch of the library (common.h: rp_launch) is appended with its
+// packed arguments — from whatever host thread issues it (the autograd engine runs backward nodes on its own thread).
+// rec_pangu_amd/graph_step.py records while a stream capture is active: the capture supplies the allocator's private
+// pool (the addresses baked into the plan stay reserved) and, through rp_graph_node_counts, the proof that the step holds
+// no launch the plan has not seen (an ATen kernel, a memset or memcpy node): such a step is replayed as a hipGraph instead.
+//
+// Sections: launches recorded while rp_plan_section(1) is in force are independent of the rest of the plan (the row sort
+// of the NEXT batch) and are re-issued on the plan's side stream, forked at the start of the replay and joined at its end —
+// the overlap the eager path gets from its side stream, which a fork inside a hipGraph does not give on this runtime.
+#include "common.h"
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct PlanNode {
+    const void *func;
+    dim3 grid, block;
+    unsigned shmem;
+    int section;
+    hipStream_t rec_stream;
+    size_t blob_at;                 // offset of the packed arguments in Plan::blob
+    std::vector<size_t> offs;       // argument offsets inside the packed buffer
+};
+
+struct Plan {
+    std::vector<PlanNode> nodes;
+    std::vector<char> blob;         // every node's packed arguments, 16-byte aligned each
+    std::vector<void *> ptrs;       // per node: pointers into blob (built by rp_plan_end)
+    std::vector<size_t> ptrs_at;
+    int section = 0;
+    int n_side = 0;
+    bool ended = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+
+std::atomic<Plan *> g_recording{nullptr};
+std::mutex g_mu;
+
+}  // namespace
+
+bool rp_plan_recording() { return g_recording.load(std::memory_order_acquire) != nullptr; }
+
+void rp_plan_record(const void *func, dim3 grid, dim3 block, unsigned shmem, hipStream_t stream, const char *blob,
+                    size_t blob_bytes, const size_t *offsets, int nargs) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load(std::memory_order_acquire);
+    if (p == nullptr) return;
+    PlanNode n;
+    n.func = func;
+    n.grid = grid;
+    n.block = block;
+    n.shmem = shmem;
+    n.section = p->section;
+    n.rec_stream = stream;
+    n.blob_at = (p->blob.size() + 15) & ~(size_t)15;
+    p->blob.resize(n.blob_at + (blob_bytes ? blob_bytes : 1));
+    memcpy(p->blob.data() + n.blob_at, blob, blob_bytes);
+    n.offs.assign(offsets, offsets + nargs);
+    if (n.section != 0) p->n_side++;
+    p->nodes.push_back(std::move(n));
+}
+
+extern "C" int rp_plan_begin(void **plan_out) {
+    RP_REQUIRE(plan_out, "plan_begin: null pointer");
+    std::lock_guard<std::mutex> lock(g_mu);
+    RP_REQUIRE(g_recording.load() == nullptr, "plan_begin: another plan is being recorded");
+    Plan *p = new Plan();
+    g_recording.store(p, std::memory_order_release);
+    *plan_out = p;
+    return RP_OK;
+}
+
+extern "C" int rp_plan_section(int section) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_section: no plan is being recorded");
+    RP_REQUIRE(section == 0 || section == 1, "plan_section: 0 (main) or 1 (side)");
+    p->section = section;
+    return RP_OK;
+}
+
+extern "C" int rp_plan_end(void *plan) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && g_recording.load() == p, "plan_end: this plan is not the one being recorded");
+    g_recording.store(nullptr, std::memory_order_release);
+    p->ptrs_at.clear();
+    p->ptrs.clear();
+    for (const PlanNode &n : p->nodes) {  // (blob no longer grows: the pointers are stable from here on)
+        p->ptrs_at.push_back(p->ptrs.size());
+        for (size_t o : n.offs) p->ptrs.push_back(p->blob.data() + n.blob_at + o);
+        if (n.offs.empty()) p->ptrs.push_back(nullptr);
+    }
+    p->ended = true;
+    return RP_OK;
+}
+
+// n_nodes: recorded launches; n_side: those of section 1; n_streams: distinct streams the launches were issued on while
+// recording (graph_step.py records on ONE capture stream and refuses anything else)
+extern "C" int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p && n_nodes && n_side && n_streams, "plan_info: null pointer");
+    *n_nodes = (int)p->nodes.size();
+    *n_side = p->n_side;
+    std::vector<hipStream_t> seen;
+    for (const PlanNode &n : p->nodes) {
+        bool found = false;
+        for (hipStream_t s : seen) found = found || s == n.rec_stream;
+        if (!found) seen.push_back(n.rec_stream);
+    }
+    *n_streams = (int)seen.size();
+    return RP_OK;
+}
+
+extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended, "plan_replay: the plan was not finished with rp_plan_end");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    const bool fork = p->n_side > 0;
+    if (fork) {
+        if (p->side == nullptr) {
+            e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
+        }
+        // the side section first: it depends on nothing this replay computes, only on what was enqueued before it
+        e = hipEventRecord(p->ev_fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: fork: %s", hipGetErrorString(e));
+        for (size_t i = 0; i < p->nodes.size(); ++i) {
+            const PlanNode &n = p->nodes[i];
+            if (n.section == 0) continue;
+            e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, p->side);
+            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", i, hipGetErrorString(e));
+        }
+        e = hipEventRecord(p->ev_join, p->side);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join record: %s", hipGetErrorString(e));
+    }
+    for (size_t i = 0; i < p->nodes.size(); ++i) {
+        const PlanNode &n = p->nodes[i];
+        if (n.section != 0) continue;
+        e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, s);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: launch %zu: %s", i, hipGetErrorString(e));
+        rp_count_launch();
+    }
+    if (fork) {
+        e = hipStreamWaitEvent(s, p->ev_join, 0);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join: %s", hipGetErrorString(e));
+    }
+    return RP_OK;
+}
+
+extern "C" int rp_plan_destroy(void *plan) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    if (p == nullptr) return RP_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (g_recording.load() == p) g_recording.store(nullptr, std::memory_order_release);
+    }
+    if (p->side != nullptr) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipEventDestroy(p->ev_fork);
+        (void)hipEventDestroy(p->ev_join);
+        (void)hipStreamDestroy(p->side);
+    }
+    delete p;
+    return RP_OK;
+}
+
+// kernel nodes / other nodes (memset, memcpy, host, ...) of a captured hipGraph (torch.cuda.CUDAGraph.raw_cuda_graph())
+extern "C" int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other) {
+    RP_REQUIRE(graph && n_kernel && n_other, "graph_node_counts: null pointer");
+    hipGraph_t g = reinterpret_cast<hipGraph_t>(graph);
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes(g, nullptr, &n);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "graph_node_counts: %s", hipGetErrorString(e));
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n > 0) {
+        e = hipGraphGetNodes(g, nodes.data(), &n);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "graph_node_counts: %s", hipGetErrorString(e));
+    }
+    int k = 0, o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        hipGraphNodeType t;
+        e = hipGraphNodeGetType(nodes[i], &t);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "graph_node_counts: %s", hipGetErrorString(e));
+        if (t == hipGraphNodeTypeKernel) ++k;
+        else if (t != hipGraphNodeTypeEmpty) ++o;
+    }
+    *n_kernel = k;
+    *n_other = o;
+    return RP_OK;
+}

@@ -38,9 +38,12 @@ def _rows16(w: torch.Tensor) -> torch.Tensor:
     if hit is not None and hit[0] == key:
         return hit[1]
     with torch.no_grad():  # (a cached tensor with a grad_fn would keep the weight's AccumulateGrad node alive)
-        buf = torch.empty((w.shape[0], (K + 3) // 4 * 4), dtype=w.dtype, device=w.device)
-        buf[:, :K].copy_(w)
-        out = buf[:, :K]
+        if w.dtype is torch.float32:
+            out = hip.copy_rows(w.detach(), (K + 3) // 4 * 4)  # a library launch: part of a recorded launch plan
+        else:
+            buf = torch.empty((w.shape[0], (K + 3) // 4 * 4), dtype=w.dtype, device=w.device)
+            buf[:, :K].copy_(w)
+            out = buf[:, :K]
     if not key[3]:  # (inside a stream capture the copy must stay a node of every graph that uses it)
         try:
             w._rp_rows16 = (key, out)

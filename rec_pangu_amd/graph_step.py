@@ -1,4 +1,8 @@
-"""A whole training step — forward, backward, optimizer step, zero_grad — captured once into a hipGraph and replayed.
+"""A whole training step — forward, backward, optimizer step, zero_grad — captured once and replayed: as a LAUNCH PLAN
+(the library's own recorder, csrc/plan.hip: the recorded launches are re-issued with hipLaunchKernel — the device sees the
+eager stream of kernels, the host spends a few microseconds per launch, and the next batch's row sort runs on a side stream
+beside the step) when the captured step holds nothing but library launches, else as a hipGraph (backend="hipgraph", or a
+step with ATen kernels / memsets in it: DCN's weight-space cumsum, a model with active dropout ...).
 
 Why: the eager step of the headline configuration is 13 kernel launches + the 9 launches of the row sort behind autograd,
 ctypes and torch.empty: ~1.0 ms of host time per step against ~1.3 ms on the device — and at the per-GPU batch of a
@@ -48,10 +52,14 @@ class GraphedTrainStep:
         try:
             if any(g is not None for g in self.graphs):
                 torch.cuda.synchronize()
+            for pl in self.plans:
+                if pl is not None:
+                    pl.destroy()
         except Exception:
             pass
 
-    def __init__(self, model, optimizer, post_backward: Optional[Callable[[], None]] = None, eager_steps: int = 2):
+    def __init__(self, model, optimizer, post_backward: Optional[Callable[[], None]] = None, eager_steps: int = 2,
+                 backend: Optional[str] = None):
         if not getattr(model, "on_hip", False):
             raise RuntimeError("GraphedTrainStep needs a HIP-resident model")
         if not hasattr(optimizer, "set_device_clock"):
@@ -63,6 +71,14 @@ class GraphedTrainStep:
         if not hasattr(model.embedding_layer, "pin_sort"):
             raise RuntimeError("GraphedTrainStep: row-sharded embedding layers (collectives inside the step) are not captured")
         self.model, self.opt, self.post_backward = model, optimizer, post_backward
+        # "plan": replay the captured step as a launch plan when it holds only library launches (checked against the
+        # captured hipGraph's nodes), else as the hipGraph; "hipgraph": always the hipGraph
+        self.backend = backend or os.environ.get("RP_GRAPH_BACKEND", "plan")
+        if self.backend not in ("plan", "hipgraph"):
+            raise ValueError("backend must be 'plan' or 'hipgraph'")
+        self.plans = [None, None]
+        self.backend_used = None     # "plan" | "hipgraph" once the first step has been captured
+        self.why_not_plan = None
         self.eager_left = eager_steps
         self.X = None            # the two static batches
         self.graphs = [None, None]
@@ -124,24 +140,53 @@ class GraphedTrainStep:
         self.opt.set_device_clock(True)
         self._dev = counters
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        want_plan = self.backend == "plan"
+        # (keep_graph: the hipGraph_t stays inspectable — rp_graph_node_counts — and is only instantiated if it is replayed)
+        g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
+        plan = hip.LaunchPlan() if want_plan else None
         try:
-            with torch.cuda.graph(g, pool=self._pool):
-                out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
-                out["loss"].backward()
-                if self.post_backward is not None:
-                    self.post_backward()
-                self.opt.step()
-                self.model.zero_grad()
-                # the next batch (already staged in X[1-P] when the graph is launched): keys + sort into its pinned tensors
-                self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
+            if plan is not None:
+                plan.begin()
+            try:
+                with torch.cuda.graph(g, pool=self._pool):
+                    out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
+                    out["loss"].backward()
+                    if self.post_backward is not None:
+                        self.post_backward()
+                    self.opt.step()
+                    self.model.zero_grad()
+                    # the next batch (already staged in X[1-P] when the step is launched): keys + sort into its pinned
+                    # tensors.  It depends on nothing the step computes and touches persistent buffers only: a plan
+                    # re-issues these launches on its side stream, beside the step (section 1)
+                    if plan is not None:
+                        plan.section(1)
+                    self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
+                    if plan is not None:
+                        plan.section(0)
+            finally:
+                if plan is not None:
+                    plan.end()
         finally:
             # the capture ran the python of one step without executing a kernel: put the host counters back
             self.opt.set_host_counters(counters)
             self.opt.set_device_clock(False)
         if self._pool is None:
             self._pool = g.pool()
-        self.graphs[P], self.outs[P] = g, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+        if plan is not None:
+            n_kernel, n_other = hip.graph_node_counts(g.raw_cuda_graph())
+            why = None
+            if n_other != 0:
+                why = f"the captured step holds {n_other} non-kernel node(s) (memset / memcpy)"
+            elif n_kernel != plan.nodes:
+                why = f"the captured step holds {n_kernel} kernel nodes, {plan.nodes} of them library launches"
+            elif plan.streams != 1:
+                why = f"the library launches were issued on {plan.streams} streams"
+            if why is not None:
+                plan.destroy()
+                plan, self.why_not_plan = None, why
+        self.graphs[P], self.plans[P] = g, plan
+        self.backend_used = "plan" if plan is not None else "hipgraph"
+        self.outs[P] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         del out
 
     def _pinned(self, Q):
@@ -151,11 +196,18 @@ class GraphedTrainStep:
                 return c_out
         raise RuntimeError("GraphedTrainStep: the static batch lost its pinned sort buffers")
 
+    def _drop_captures(self):
+        for pl in self.plans:
+            if pl is not None:
+                pl.destroy()
+        self.plans = [None, None]
+        self.graphs, self.outs, self._pool = [None, None], [None, None], None  # (the pool dies with its graphs)
+
     def reset(self):
         """drop the captured graphs (buffers they hold moved, the model or the batch shape changed)"""
         if torch.cuda.is_available():
             torch.cuda.synchronize()  # never destroy a graph executable that is still in flight
-        self.graphs, self.outs, self._pool = [None, None], [None, None], None
+        self._drop_captures()
         if self.X is not None:
             for x in self.X:
                 _emb.EmbeddingLayer.unpin_sorts(x)
@@ -189,7 +241,7 @@ class GraphedTrainStep:
                 # launches of the old graphs may still be in flight (the host runs steps ahead): destroying a graph
                 # executable under them frees the kernel arguments they read (observed: memory aperture violation)
                 torch.cuda.synchronize()
-                self.graphs, self.outs, self._pool = [None, None], [None, None], None  # (the pool dies with its graphs)
+                self._drop_captures()
             self._sig = sig
         if self.graphs[P] is None:
             self._capture(P)
@@ -202,7 +254,10 @@ class GraphedTrainStep:
             done = self._inflight.pop(0)
             done.synchronize()
             self._ev_pool.append(done)
-        self.graphs[P].replay()
+        if self.plans[P] is not None:
+            self.plans[P].replay()
+        else:
+            self.graphs[P].replay()
         ev = self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()
         ev.record()
         self._inflight.append(ev)

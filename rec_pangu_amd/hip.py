@@ -47,6 +47,14 @@ _SIGNATURES = {
     "rp_linear_wgrad_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "rp_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_plan_begin": (C.c_int, [C.POINTER(_vp)]),
+    "rp_plan_section": (C.c_int, [_i32]),
+    "rp_plan_end": (C.c_int, [_vp]),
+    "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "rp_plan_replay": (C.c_int, [_vp, _vp]),
+    "rp_plan_destroy": (C.c_int, [_vp]),
+    "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "rp_crossnet_bwd_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
@@ -395,13 +403,25 @@ def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torc
     return h1, fm
 
 
-def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None):
-    """out = (sorted keys, positions) to write into (persistent buffers of the hipGraph path), else fresh tensors"""
+def sort_workspace(n: int, device) -> torch.Tensor:
+    """a workspace rp_sort_pairs_i32 accepts for n pairs (callers that must not allocate per call keep one)"""
+    nbytes = _sz(0)
+    _check(lib().rp_sort_workspace_bytes(n, C.byref(nbytes)), "rp_sort_workspace_bytes")
+    return torch.empty((nbytes.value,), dtype=torch.uint8, device=device)
+
+
+def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None, workspace=None):
+    """out = (sorted keys, positions) to write into (persistent buffers of the captured-step path), else fresh tensors;
+    workspace: a persistent sort_workspace(n) (else one is allocated per call)"""
     _req(keys, torch.int32, "keys")
     n = keys.numel()
     nbytes = _sz(0)
     _check(lib().rp_sort_workspace_bytes(n, C.byref(nbytes)), "rp_sort_workspace_bytes")
-    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
+    if workspace is not None:
+        assert workspace.numel() >= nbytes.value and workspace.device == keys.device
+        ws = workspace
+    else:
+        ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
     ko, po = out if out is not None else (torch.empty_like(keys), torch.empty_like(keys))
     assert ko.shape == keys.shape and po.shape == keys.shape and ko.dtype == po.dtype == torch.int32
     with _Timed("sort_pairs_i32"):
@@ -543,6 +563,64 @@ def transpose(w, rows_out: Optional[int] = None):
         _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, _stream()),
                "rp_transpose")
     return out
+
+
+def copy_rows(w, ld_out: int):
+    """a copy of the 2-D tensor w with row stride ld_out >= w.shape[1] (rp_copy_rows); returns the [R, C] view of it"""
+    _req(w, torch.float32, "w")
+    R, Cc = w.shape
+    buf = torch.empty((R, ld_out), dtype=torch.float32, device=w.device)
+    with _Timed("copy_rows", f"{R}x{Cc}", 8 * R * Cc):
+        _check(lib().rp_copy_rows(w.data_ptr(), _rowmajor(w, "w"), buf.data_ptr(), ld_out, R, Cc, _stream()), "rp_copy_rows")
+    return buf[:, :Cc]
+
+
+# ---- launch plans (csrc/plan.hip; used by graph_step.GraphedTrainStep) -------------------------------------------------
+class LaunchPlan:
+    """A recorded sequence of the library's kernel launches (rp_plan_*).  `with plan.recording(): ...` records every
+    launch issued inside — from any thread — and `plan.replay()` re-issues them on the current stream."""
+
+    def __init__(self):
+        self._h = None
+        self.nodes = self.side = self.streams = 0
+
+    def begin(self):
+        h = _vp()
+        _check(lib().rp_plan_begin(C.byref(h)), "rp_plan_begin")
+        self._h = h
+
+    def end(self):
+        _check(lib().rp_plan_end(self._h), "rp_plan_end")
+        a, b, c = _i32(), _i32(), _i32()
+        _check(lib().rp_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "rp_plan_info")
+        self.nodes, self.side, self.streams = a.value, b.value, c.value
+
+    @staticmethod
+    def section(k: int):
+        _check(lib().rp_plan_section(k), "rp_plan_section")
+
+    def replay(self):
+        rc = lib().rp_plan_replay(self._h, _stream())
+        if rc != 0:
+            _check(rc, "rp_plan_replay")
+
+    def destroy(self):
+        if self._h is not None and _lib is not None:
+            _lib.rp_plan_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def graph_node_counts(raw_graph: int):
+    """(kernel nodes, other nodes) of a captured hipGraph (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph())"""
+    k, o = _i32(), _i32()
+    _check(lib().rp_graph_node_counts(_vp(raw_graph), C.byref(k), C.byref(o)), "rp_graph_node_counts")
+    return k.value, o.value
 
 
 def relu_bwd(dy, act_out):

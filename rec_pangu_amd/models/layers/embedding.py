@@ -34,6 +34,9 @@ _SIDE_STREAMS: dict = {}  # device -> the stream sorts started ahead run on
 # holds all their addresses.  Matched by identity only (a refill bumps the versions), never evicted, no events (the
 # order is the capture's: the side stream is joined before the capture ends).
 _SORT_PINNED: list = []
+# id(keys tensor of a pinned entry) -> its persistent sort workspace: a captured step's re-sort must not allocate (its
+# launches may be re-issued on a side stream, where memory of the capture's pool could alias the step's temporaries)
+_PINNED_WS: dict = {}
 
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
@@ -492,7 +495,7 @@ class EmbeddingLayer(nn.Module):
         dev = self._arena.device
         if not on_side_stream:
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
-            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp))
+            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp), workspace=_PINNED_WS.get(id(keys)))
             return
         side = _SIDE_STREAMS.get(dev)
         if side is None:
@@ -505,6 +508,7 @@ class EmbeddingLayer(nn.Module):
     def pin_sort(self, X) -> None:
         """graph_step: X holds STATIC id tensors (refilled in place from now on).  Sort their current content into
         persistent tensors on the current stream and pin the cache entry; later prefetch_sort(X) calls re-sort in place."""
+        from ... import hip
         src = tuple(X[c] for c in self.emb_feature)
         sig = (self._rows_sig(), str(self._arena.device))
         for c_src, c_sig, c_out in _SORT_PINNED:
@@ -513,6 +517,7 @@ class EmbeddingLayer(nn.Module):
                 return
         n = sum(t.numel() for t in src)
         out = tuple(torch.empty((n,), dtype=torch.int32, device=self._arena.device) for _ in range(3))
+        _PINNED_WS[id(out[0])] = hip.sort_workspace(n, self._arena.device)
         self._sort_into(X, out, on_side_stream=False)
         _SORT_PINNED.append((src, sig, out))
 
@@ -521,8 +526,12 @@ class EmbeddingLayer(nn.Module):
         """drop the pinned entries of the static batch X (all of them when X is None)"""
         if X is None:
             del _SORT_PINNED[:]
+            _PINNED_WS.clear()
         else:
             ids = {id(t) for t in X.values()}
+            for e in _SORT_PINNED:
+                if any(id(t) in ids for t in e[0]):
+                    _PINNED_WS.pop(id(e[2][0]), None)
             _SORT_PINNED[:] = [e for e in _SORT_PINNED if not any(id(t) in ids for t in e[0])]
 
     def _rows_sig(self):

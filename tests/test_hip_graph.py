@@ -1,6 +1,7 @@
-"""The captured training step (rec_pangu_amd/graph_step.py: forward + backward + FusedAdam step + zero_grad in one
-hipGraph, device-resident step counters, static double-buffered inputs, next batch's sort inside the graph) against the
-eager loop on the same batches: every prediction, loss, weight and optimizer moment bit-identical."""
+"""The captured training step (rec_pangu_amd/graph_step.py: forward + backward + FusedAdam step + zero_grad captured once,
+device-resident step counters, static double-buffered inputs, next batch's sort inside the capture) against the eager loop
+on the same batches: every prediction, loss, weight and optimizer moment bit-identical — replayed as a LAUNCH PLAN
+(csrc/plan.hip; the sort on the plan's side stream) and as a hipGraph."""
 import pytest
 import torch
 
@@ -15,6 +16,12 @@ def _gpu():
     require_gpu()
     from rec_pangu_amd import hip
     hip.lib()
+
+
+@pytest.fixture(params=["plan", "hipgraph"])
+def backend(request, monkeypatch):
+    monkeypatch.setenv("RP_GRAPH_BACKEND", request.param)
+    return request.param
 
 
 def _enc(n_dense, vocabs):
@@ -50,9 +57,10 @@ def _build(kind, enc):
     return model
 
 
-@pytest.mark.parametrize("kind,replay,steps", [("deepfm64", "closed", 330), ("deepfm64", "exact", 60), ("deepfm16", "closed", 300),
-                                               ("dcn", "closed", 60)])
-def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps):
+@pytest.mark.parametrize("kind,replay,steps,defer", [("deepfm64", "closed", 330, False), ("deepfm64", "exact", 60, False),
+                                                     ("deepfm16", "closed", 300, False), ("dcn", "closed", 60, False),
+                                                     ("deepfm64", "closed", 300, True)])
+def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, defer, backend):
     """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
     in-place extensions of the step tables; the learning rate changes twice on the way)"""
     from rec_pangu_amd import hip
@@ -65,7 +73,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps):
     try:
         for mode in ("eager", "graph"):
             model = _build(kind, enc)
-            opt = FusedAdam(model.parameters(), lr=1e-3, fuse_zero_grad=True, lazy_tables=True, replay=replay)
+            opt = FusedAdam(model.parameters(), lr=1e-3, fuse_zero_grad=True, lazy_tables=True, replay=replay, defer=defer)
             gstep = GraphedTrainStep(model, opt) if mode == "graph" else None
             preds, losses = [], []
             for i in range(steps):
@@ -86,6 +94,13 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps):
             if gstep is not None:
                 assert gstep.replays == steps - 2, "every step after the two eager ones must have been a graph replay"
                 assert gstep.graphs[0] is not None and gstep.graphs[1] is not None
+                if backend == "plan" and kind != "dcn":
+                    # DeepFM's step is library launches only: it must replay as a plan, the sort in the side section
+                    assert gstep.backend_used == "plan" and gstep.plans[0].side >= 4, (gstep.backend_used, gstep.why_not_plan)
+                elif backend == "plan":
+                    assert gstep.backend_used == "hipgraph" and gstep.why_not_plan, "DCN's step holds ATen launches"
+                else:
+                    assert gstep.backend_used == "hipgraph"
             lz = model.embedding_layer._lazy
             assert lz.t == steps
             if mode == "graph":
@@ -113,7 +128,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps):
     assert hip.launch_count() > 0
 
 
-def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch():
+def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch(backend):
     """a batch that was not announced by the previous call is staged and sorted on the spot; a call without a next batch
     (end of an epoch) runs eagerly; the run continues on the graphs afterwards — all bit-identical to the eager loop"""
     from rec_pangu_amd.graph_step import GraphedTrainStep
@@ -147,7 +162,7 @@ def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch
         assert torch.equal(finals["eager"][k], finals["graph"][k]), k
 
 
-def test_graphed_step_above_a_million_pairs():
+def test_graphed_step_above_a_million_pairs(backend):
     """1.2 M (sample, field) pairs per batch: the size at which rocPRIM's onesweep sort faulted under unsynchronised
     replays (GraphedTrainStep.MAX_PAIRS_ROCPRIM).  The own radix sort has no memset nodes: 60 replays without a
     synchronisation in between end in the same bits as the eager loop."""
