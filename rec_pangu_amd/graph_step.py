@@ -89,6 +89,7 @@ class GraphedTrainStep:
         self._sig = None
         self._pool = None
         self._dev = None         # host mirror of the device counters
+        self._one = None         # the seed gradient of captured backward passes (see _seed_grad)
         self.replays = 0
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
@@ -121,6 +122,7 @@ class GraphedTrainStep:
                                "rocPRIM's row sort takes its onesweep path, which does not survive unsynchronised graph "
                                "replays on this runtime; unset RP_SORT=rocprim or run batches of this size eagerly")
         self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
+        self._one = torch.ones((), dtype=torch.float32, device=next(iter(batch.values())).device)
         self._keys = list(batch.keys())
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
             self.model.embedding_layer.pin_sort(x)
@@ -150,7 +152,9 @@ class GraphedTrainStep:
             try:
                 with torch.cuda.graph(g, pool=self._pool):
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
-                    out["loss"].backward()
+                    # the seed gradient is a persistent 1.0: loss.backward() would create it with an ATen fill kernel — the
+                    # one launch of a DeepFM step that is not the library's (a launch plan must hold them all)
+                    out["loss"].backward(gradient=self._seed_grad(out["loss"]))
                     if self.post_backward is not None:
                         self.post_backward()
                     self.opt.step()
@@ -188,6 +192,14 @@ class GraphedTrainStep:
         self.backend_used = "plan" if plan is not None else "hipgraph"
         self.outs[P] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         del out
+
+    def _seed_grad(self, loss):
+        """the persistent 1.0 a captured backward starts from (created in _alloc, outside any capture); None — the default
+        seed, an ATen fill — when the loss is not the float32 scalar every model here returns"""
+        one = self._one
+        if one is not None and one.device == loss.device and one.dtype == loss.dtype and one.shape == loss.shape:
+            return one
+        return None
 
     def _pinned(self, Q):
         src = tuple(self.X[Q][c] for c in self.model.embedding_layer.emb_feature)

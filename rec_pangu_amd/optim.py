@@ -54,10 +54,23 @@ class StepTables:
     def covers(self, t_new, lr) -> bool:
         return t_new <= self.filled_to and (self.lr == lr or t_new < self.lr_from)
 
-    def ensure(self, t_new, lr, chunk: int = 1024):
-        """rows [.., t_new] exist and row t_new has been built with `lr`"""
+    def ensure(self, t_new, lr, chunk: int = 1024, allow_gap: bool = False):
+        """rows [.., t_new] exist and row t_new has been built with `lr`.  allow_gap: rows between the last one built and
+        t_new were never needed and never will be (the DENSE table: a dense step reads its own row only, and eager dense
+        steps read none — the table only moves when captured steps run); a lazy table is read for every skipped step
+        and must be gap-free."""
         if self.covers(t_new, lr):
             return
+        if allow_gap and self.filled_to < t_new - 1:
+            self.filled_to = t_new - 1
+            if t_new >= self.capacity:  # (the copy below keeps the old rows; the gap stays zero: never read)
+                cap = max(2 * self.capacity, t_new + 1 + 2 * chunk)
+                for name in ("sc", "ns_d"):
+                    old = getattr(self, name)
+                    new = torch.zeros((cap, 2), dtype=old.dtype, device=old.device)
+                    new[:old.shape[0]].copy_(old)
+                    setattr(self, name, new)
+                self.generation += 1
         assert self.filled_to >= t_new - 1, f"step table filled to {self.filled_to}, step {t_new} needs {t_new - 1}"
         hi = t_new + chunk
         if hi >= self.capacity:
@@ -449,7 +462,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if dev is not None:
                     tabs = self._dense_tabs[id(group)] = StepTables(group["betas"], group["eps"], dev, group.get("_rp_step", 0))
             if tabs is not None:
-                tabs.ensure(group.get("_rp_step", 0) + 1, group["lr"])
+                tabs.ensure(group.get("_rp_step", 0) + 1, group["lr"], allow_gap=True)
                 sig.append(tabs.generation)
         for lz in self._lazies():  # (once per lazy state, with the lr of the group that owns its tables)
             lz.tabs.ensure(lz.t + 1, self._lr_of(lz), lz.TABLE_CHUNK)
