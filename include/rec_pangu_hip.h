@@ -587,6 +587,7 @@ int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t 
  *                         captured step holds no launch the plan has not seen */
 int rp_plan_begin(void **plan_out);
 int rp_plan_section(int section);
+int rp_plan_fork_here(void); /* the side section is forked in front of the NEXT main launch (default: start of the replay) */
 int rp_plan_end(void *plan);
 int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
 int rp_plan_replay(void *plan, rp_stream_t stream);

@@ -40,6 +40,7 @@ struct Plan {
     std::vector<size_t> ptrs_at;
     int section = 0;
     int n_side = 0;
+    size_t fork_at = 0;             // the side section is forked in front of main-section node `fork_at` (node index)
     bool ended = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -91,6 +92,17 @@ extern "C" int rp_plan_section(int section) {
     return RP_OK;
 }
 
+// the side section of a replay is forked HERE (in front of the next main-section launch) instead of at the start of the
+// replay: the row sort of the next batch overlaps well with the backward's kernels and badly with the optimizer catch-up
+// and the gather in front of them (measured on the eager path's side stream as well)
+extern "C" int rp_plan_fork_here(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_fork_here: no plan is being recorded");
+    p->fork_at = p->nodes.size();
+    return RP_OK;
+}
+
 extern "C" int rp_plan_end(void *plan) {
     std::lock_guard<std::mutex> lock(g_mu);
     Plan *p = reinterpret_cast<Plan *>(plan);
@@ -130,27 +142,30 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const bool fork = p->n_side > 0;
-    if (fork) {
-        if (p->side == nullptr) {
-            e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
-            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
-        }
-        // the side section first: it depends on nothing this replay computes, only on what was enqueued before it
-        e = hipEventRecord(p->ev_fork, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
-        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: fork: %s", hipGetErrorString(e));
-        for (size_t i = 0; i < p->nodes.size(); ++i) {
-            const PlanNode &n = p->nodes[i];
-            if (n.section == 0) continue;
-            e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, p->side);
-            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", i, hipGetErrorString(e));
-        }
-        e = hipEventRecord(p->ev_join, p->side);
-        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join record: %s", hipGetErrorString(e));
+    if (fork && p->side == nullptr) {
+        e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
     }
-    for (size_t i = 0; i < p->nodes.size(); ++i) {
+    bool forked = false;
+    for (size_t i = 0; i <= p->nodes.size(); ++i) {
+        if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
+            // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
+            forked = true;
+            e = hipEventRecord(p->ev_fork, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
+            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: fork: %s", hipGetErrorString(e));
+            for (size_t j = 0; j < p->nodes.size(); ++j) {
+                const PlanNode &n = p->nodes[j];
+                if (n.section == 0) continue;
+                e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[j], n.shmem, p->side);
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", j, hipGetErrorString(e));
+            }
+            e = hipEventRecord(p->ev_join, p->side);
+            if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join record: %s", hipGetErrorString(e));
+        }
+        if (i == p->nodes.size()) break;
         const PlanNode &n = p->nodes[i];
         if (n.section != 0) continue;
         e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, s);

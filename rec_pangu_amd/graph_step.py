@@ -152,6 +152,10 @@ class GraphedTrainStep:
             try:
                 with torch.cuda.graph(g, pool=self._pool):
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
+                    if plan is not None:
+                        # the side section (the next batch's sort, recorded last) is forked here: beside the backward,
+                        # where the eager path starts it too — beside the catch-up and the gather it costs more than it hides
+                        plan.fork_here()
                     # the seed gradient is a persistent 1.0: loss.backward() would create it with an ATen fill kernel — the
                     # one launch of a DeepFM step that is not the library's (a launch plan must hold them all)
                     out["loss"].backward(gradient=self._seed_grad(out["loss"]))

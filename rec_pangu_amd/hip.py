@@ -50,6 +50,7 @@ _SIGNATURES = {
     "rp_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "rp_plan_begin": (C.c_int, [C.POINTER(_vp)]),
     "rp_plan_section": (C.c_int, [_i32]),
+    "rp_plan_fork_here": (C.c_int, []),
     "rp_plan_end": (C.c_int, [_vp]),
     "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_plan_replay": (C.c_int, [_vp, _vp]),
@@ -598,6 +599,10 @@ class LaunchPlan:
     @staticmethod
     def section(k: int):
         _check(lib().rp_plan_section(k), "rp_plan_section")
+
+    @staticmethod
+    def fork_here():
+        _check(lib().rp_plan_fork_here(), "rp_plan_fork_here")
 
     def replay(self):
         rc = lib().rp_plan_replay(self._h, _stream())

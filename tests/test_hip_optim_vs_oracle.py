@@ -153,16 +153,16 @@ def _run_reference_schedule(replay, defer, graph=False):
 @pytest.mark.parametrize("replay,defer", [("exact", False), ("closed", False), ("closed", True), ("exact", True)])
 def test_hip_training_matches_the_reference_600_step_adam_run(replay, defer):
     """Stated bound: after 300 and after 600 steps of the reference's own schedule every weight of the HIP model is within
-    1e-3 of the reference's (lr = 1e-3: ONE Adam step of one element; rms <= 1e-4), table rows nobody touched since step
-    300 included — they took 300+ zero-gradient steps in ONE replay (serial or closed form) here and one by one there;
-    predictions of the final weights within 2e-3.  The observed figures are printed (pytest -s)."""
+    2e-5 of the reference's (lr = 1e-3: 1/50 of ONE Adam step of one element; rms <= 5e-6), table rows nobody touched since
+    step 300 included — they took 300+ zero-gradient steps in ONE replay (serial or closed form) here and one by one there;
+    predictions of the final weights within 1e-5.  Observed on MI355X (round 4, all four modes): 3.2e-6 / 9.5e-7."""
     g, snaps, pred = _run_reference_schedule(replay, defer)
     worst = 0.0
     for t in (300, 600):
         for k, ref in g[f"step{t}"].items():
             d = (snaps[t][k].float() - ref.float()).abs()
             worst = max(worst, float(d.max()))
-            assert float(d.max()) <= 1e-3 and float(d.pow(2).mean().sqrt()) <= 1e-4, (replay, defer, t, k, float(d.max()))
+            assert float(d.max()) <= 2e-5 and float(d.pow(2).mean().sqrt()) <= 5e-6, (replay, defer, t, k, float(d.max()))
     dp = float((pred - g["probe_pred"]).abs().max())
     print(f"\nreplay={replay} defer={defer}: max |w - w_ref| over steps 300/600 = {worst:.2e}, max |pred - pred_ref| = {dp:.2e}")
-    assert dp <= 2e-3
+    assert dp <= 1e-5
