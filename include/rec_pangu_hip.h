@@ -593,6 +593,9 @@ int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
 int rp_plan_replay(void *plan, rp_stream_t stream);
 int rp_plan_destroy(void *plan);
 int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other);
+/* dst_ptrs[i][0 : bytes[i]] = src_ptrs[i][..] for i < n in ONE launch (per 96 buffers): a batch of ~40 columns into the static
+ * input buffers of a captured step.  Host arrays of device addresses; buffers must not overlap. */
+int rp_multi_copy(void *const *dst_ptrs, const void *const *src_ptrs, const uint64_t *bytes, int n, rp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -130,7 +130,11 @@ class GraphedTrainStep:
     def _copy(self, P, batch):
         dst = [self.X[P][k] for k in self._keys]
         src = [batch[k] for k in self._keys]
-        torch._foreach_copy_(dst, src)
+        # ONE launch for the ~40 columns of a batch: torch._foreach_copy_ issues a device-to-device copy per tensor here, and
+        # 40 small copies cost the stream ~0.25 ms per step in dispatch gaps (rocprofv3: 42 x __amd_rocclr_copyBuffer per
+        # step — what round 3 had read as "~10 us per graph node")
+        if not hip.multi_copy(dst, src):
+            torch._foreach_copy_(dst, src)
 
     def _stage_current(self, batch):
         self._copy(self.P, batch)

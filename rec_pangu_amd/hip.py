@@ -56,6 +56,7 @@ _SIGNATURES = {
     "rp_plan_replay": (C.c_int, [_vp, _vp]),
     "rp_plan_destroy": (C.c_int, [_vp]),
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "rp_multi_copy": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "rp_crossnet_bwd_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
@@ -619,6 +620,29 @@ class LaunchPlan:
             self.destroy()
         except Exception:
             pass
+
+
+_COPY_PLANS: dict = {}
+
+
+def multi_copy(dst: Sequence[torch.Tensor], src: Sequence[torch.Tensor]) -> bool:
+    """dst[i].copy_(src[i]) for every i in ONE launch (rp_multi_copy).  Only for same-shape, same-dtype, contiguous
+    tensors on the current device — returns False (nothing done) otherwise, the caller then copies tensor by tensor."""
+    n = len(dst)
+    for d, s_ in zip(dst, src):
+        if not (d.is_cuda and s_.is_cuda and d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape
+                and d.is_contiguous() and s_.is_contiguous()):
+            return False
+    key = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+    arrs = _COPY_PLANS.get(key)
+    if arrs is None:
+        if len(_COPY_PLANS) >= 256:
+            _COPY_PLANS.clear()
+        arrs = ((C.c_void_p * n)(*[t.data_ptr() for t in dst]), (C.c_void_p * n)(*[t.data_ptr() for t in src]),
+                (C.c_uint64 * n)(*[t.numel() * t.element_size() for t in dst]))
+        _COPY_PLANS[key] = arrs
+    _check(lib().rp_multi_copy(arrs[0], arrs[1], arrs[2], n, _stream()), "rp_multi_copy")
+    return True
 
 
 def graph_node_counts(raw_graph: int):
