@@ -579,8 +579,8 @@ int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t 
  * kernel launch any entry point of this library issues — from any host thread — is appended to the plan with its packed
  * arguments (and still issued: under a stream capture it becomes a graph node, otherwise it runs).  rp_plan_replay
  * re-issues the recorded launches with the recorded arguments on `stream`; launches recorded under rp_plan_section(1)
- * are independent of the others and go to a side stream owned by the plan, forked at the start of the replay and joined
- * at its end.  The caller guarantees that every address baked into the plan stays valid and that step numbers are read
+ * are independent of the others and go to a side stream owned by the plan, forked at rp_plan_fork_here (default: the start
+ * of the replay) and joined at its end.  The caller guarantees that every address baked into the plan stays valid and that step numbers are read
  * on the device (t_dev arguments).  One plan may be recorded at a time, process-wide.
  *   rp_plan_info          launches recorded, those of section 1, distinct streams they were issued on while recording
  *   rp_graph_node_counts  kernel nodes / other nodes (memset, memcpy, ...) of a captured hipGraph_t: the check that a
@@ -588,6 +588,12 @@ int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t 
 int rp_plan_begin(void **plan_out);
 int rp_plan_section(int section);
 int rp_plan_fork_here(void); /* the side section is forked in front of the NEXT main launch (default: start of the replay) */
+/* rp_plan_section(2): an INLINE fork — the launches recorded under it run on a second side stream beside the main launches
+ * recorded after them, from the point where they were recorded until rp_plan_join() (the first layer's weight gradient
+ * beside the fused gather backward: both depend only on the masked dH).  The caller keeps every buffer those launches use
+ * alive until the join: the capture's allocator assumes ONE stream and would hand a freed workspace to the next launch. */
+int rp_plan_join(void);
+int rp_plan_is_recording(void);
 int rp_plan_end(void *plan);
 int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
 int rp_plan_replay(void *plan, rp_stream_t stream);

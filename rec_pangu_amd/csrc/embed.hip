@@ -647,6 +647,15 @@ static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const 
 // one matrix pass per field with the other field's rows masked out (any other order of the fields inside a tile — the
 // owner borders of the row-sharded path — is handled too, by walking all fields for that tile).
 // ------------------------------------------------------------------------------------------------
+// FM_U (round 4): the FM part  g_fm[b] * S[b, :]  of a pair's row is put into the MFMA accumulators BEFORE the matrix
+// passes (acc = g * S gathered in the accumulator layout, 32 coalesced 128-byte half-wave loads per lane, in flight
+// together with the dH gathers) instead of being gathered per pair in the reduce phase, and the tile's sorted keys, sample
+// indices, fields and g_fm values are staged in LDS once, so that the reduce phase starts with ONE round trip to memory
+// (the table rows of the run ends) instead of three dependent ones (keys / positions -> g_fm, S rows -> table rows).
+// Measured before the change (profiles/microbench/probes/probe_grad_gemm.py, Criteo shape): 0.320 ms with the FM term,
+// 0.198 ms without it, 0.303 ms with perfectly sequential gathers — the launch is bound by its chain of dependent
+// round trips per tile, not by the bytes the random gathers move.
+template <bool FM_U>
 __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
     int64_t lddh, const float *__restrict__ wt, int64_t ldwt, const float *__restrict__ dx, int64_t ldx,
@@ -659,6 +668,10 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     __shared__ __attribute__((aligned(16))) float piece[GPB][2][W];
     __shared__ int32_t pkey[GPB][2];
     __shared__ int32_t pcont[GPB];
+    __shared__ int32_t tkey[130];  // sorted keys of the tile's rows, [0] = the key in front of the tile, [129] = the one behind
+    __shared__ int32_t tsmp[128];  // sample index b of each tile row (0 beyond n)
+    __shared__ int32_t tfld[128];  // field of each tile row
+    __shared__ float tgf[128];     // g_fm[b] of each tile row (0 beyond n / without the FM term)
     typedef __bf16(*BTile)[64][EG_LD];
     BTile Bt = reinterpret_cast<BTile>(smem);                 // [3][64 d][64 n (+pad)]: W1^T slice of one field, pieces
     float(*Ct)[EG_CT] = reinterpret_cast<float(*)[EG_CT]>(smem);  // [128][64 (+pad)]: the tile's dX rows (after the MFMAs)
@@ -671,10 +684,25 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
         const int64_t prow = wg0 + 32 * wv + i;  // this lane's row of the tile (A operand: lane = row, 8 k per lane)
         const bool rok = prow < n;
         const int32_t pp = rok ? sp[prow] : 0;
+        const int32_t kk = rok ? sk[prow] : -1;
+        if (threadIdx.x == 0) tkey[0] = wg0 > 0 ? sk[wg0 - 1] : -1;
+        if (threadIdx.x == 64) tkey[129] = wg0 + 128 < n ? sk[wg0 + 128] : -1;
         const int fr = pp / Bi, br = pp - fr * Bi;
         const int64_t plast = (wg0 + 127 < n ? wg0 + 127 : n - 1);
         const int f_lo = __builtin_amdgcn_readfirstlane(sp[wg0] / Bi), f_hi = __builtin_amdgcn_readfirstlane(sp[plast] / Bi);
-        // the gathered dH row of this lane: 4 k-steps x 8 floats, loaded up front (the longest latency of the kernel)
+        if (h == 0) {  // one lane per tile row: the tile tables (everything the first trip to memory brought)
+            tkey[1 + 32 * wv + i] = kk;
+            tsmp[32 * wv + i] = br;
+            tfld[32 * wv + i] = fr;
+        }
+        // Field-major positions: the tile's fields are f_lo..f_hi.  The row-sharded path sorts by (owner, local row):
+        // field-major only INSIDE an owner, so a tile that spans an owner border holds fields {f_a..F-1} u {0..f_b} (and a
+        // tiny batch any mix).  Such a tile (one per owner border) walks every field and skips the absent ones.
+        const bool wrap = __syncthreads_or(rok && (fr < f_lo || fr > f_hi)) != 0;  // (also: the tile tables are visible)
+        // ---- the second trip to memory, everything in flight together: g_fm of the row, its dH row (A operand), and the
+        //      FM sum values of the accumulator layout.  g_fm first: the LDS write below waits for THAT load only (in-order
+        //      counter), the rest stays in flight behind it
+        const float gme = (gfm != nullptr && rok) ? gfm[br] : 0.f;
         f32x4 araw[4][2];
         const float *asrc = dh + (int64_t)br * lddh + 8 * h;
 #pragma unroll
@@ -682,18 +710,26 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
             araw[ks][0] = *reinterpret_cast<const f32x4 *>(asrc + ks * 16);
             araw[ks][1] = *reinterpret_cast<const f32x4 *>(asrc + ks * 16 + 4);
         }
+        // acc[nt][r] is the element (row 32 wv + (r & 3) + 8 (r >> 2) + 4 h, column 32 nt + i) of the tile: it starts at
+        // g_fm[b] * S[b, column].  Rows beyond n have g = 0 and read sample 0 (no branch around a load: counted waits).
+        float uraw[2][16];
+        if (FM_U) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *src = sum_in + (int64_t)tsmp[32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h] * D + i;
+                uraw[0][r] = src[0];
+                uraw[1][r] = src[32];
+            }
+        }
+        if (h == 0) tgf[32 * wv + i] = gme;  // (read after the first staging barrier below)
         f32x16 acc[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         const int wd = threadIdx.x >> 2, wc = (threadIdx.x & 3) * 16;  // staging: row d of the slice, 16 floats from wc
-        // Field-major positions: the tile's fields are f_lo..f_hi.  The row-sharded path sorts by (owner, local row):
-        // field-major only INSIDE an owner, so a tile that spans an owner border holds fields {f_a..F-1} u {0..f_b} (and a
-        // tiny batch any mix).  Such a tile (one per owner border) walks every field and skips the absent ones.
-        const bool wrap = __syncthreads_or(rok && (fr < f_lo || fr > f_hi)) != 0;
         const int f_from = wrap ? 0 : f_lo, f_to = wrap ? (int)((n - 1) / Bi) : f_hi;
-        bool first_pass = true;
+        bool first_pass = true, need_init = FM_U;
         for (int f = f_from; f <= f_to; ++f) {
             if (wrap && !__syncthreads_or(rok && fr == f)) continue;
             if (!first_pass) __syncthreads();  // the previous field's fragment reads are done
@@ -716,6 +752,15 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
                 }
             }
             __syncthreads();
+            if (FM_U && need_init) {  // (tgf is visible since the barrier above)
+                need_init = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float gR = tgf[32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    acc[0][r] = gR * uraw[0][r];
+                    acc[1][r] = gR * uraw[1][r];
+                }
+            }
             // rows of another field (only in a tile that spans a field border) and rows beyond n contribute zero
             const float keep = (rok && fr == f) ? 1.f : 0.f;
 #pragma unroll
@@ -746,22 +791,15 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
             for (int r = 0; r < 16; ++r) Ct[32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h][nt * 32 + i] = acc[nt][r];
         __syncthreads();
     }
-    // keys / positions of this group's segment (loaded after the matrix phase: they would only occupy registers there)
+    // keys / samples / fields of this group's segment: from the tile tables in LDS (no trip to memory)
     const int64_t start = wg0 + (int64_t)grp * RP_SEG;
     const bool active = start < n;
     const int cnt = active ? (int)((n - start) < RP_SEG ? (n - start) : RP_SEG) : 0;
     int32_t k[RP_SEG];
-    int bb[RP_SEG], ff[RP_SEG];
 #pragma unroll
-    for (int j = 0; j < RP_SEG; ++j) {
-        const bool ok = j < cnt;
-        k[j] = ok ? sk[start + j] : -1;
-        const int32_t p = ok ? sp[start + j] : 0;
-        ff[j] = p / Bi;
-        bb[j] = p - ff[j] * Bi;
-    }
-    const int32_t kprev = (active && start > 0) ? sk[start - 1] : -1;
-    const int32_t knext = (active && start + cnt < n) ? sk[start + cnt] : -1;
+    for (int j = 0; j < RP_SEG; ++j) k[j] = (j < cnt) ? tkey[1 + grp * RP_SEG + j] : -1;
+    const int32_t kprev = active ? tkey[grp * RP_SEG] : -1;            // ([0] = the key in front of the tile, -1 at 0)
+    const int32_t knext = active ? tkey[1 + grp * RP_SEG + cnt] : -1;  // (rows beyond n hold -1, [129] = behind the tile)
     // ---- the deterministic segmented reduce of embed_grad_reduce_kernel over those rows (D = 64: one column pass) ----
     float *hp = gpiece + (int64_t)blockIdx.x * 2 * D, *tp = hp + D;
     const int c = t * VEC;
@@ -774,10 +812,11 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
         gf[j] = 0.f;
         if (j < cnt) {
             r[j] = V::load(&Ct[grp * RP_SEG + j][c]);
-            if (dx != nullptr) r[j] += V::load(dx + (int64_t)bb[j] * ldx + (int64_t)ff[j] * D + c);
+            if (dx != nullptr)
+                r[j] += V::load(dx + (int64_t)tsmp[grp * RP_SEG + j] * ldx + (int64_t)tfld[grp * RP_SEG + j] * D + c);
             if (gfm != nullptr) {
-                gf[j] = gfm[bb[j]];
-                if (sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)bb[j] * D + c);
+                gf[j] = tgf[grp * RP_SEG + j];
+                if (!FM_U && sum_in != nullptr) r[j] += gf[j] * V::load(sum_in + (int64_t)tsmp[grp * RP_SEG + j] * D + c);
                 if (j + 1 >= cnt || k[j + 1] != k[j]) w[j] = V::load(arena + (int64_t)k[j] * D + c);
             }
         }
@@ -1136,8 +1175,17 @@ extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sor
     float *piece0 = reinterpret_cast<float *>(wbase);
     int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(embed_grad_gemm_kernel, dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B, dh, lddh,
-                       wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
+    // RP_GRAD_GEMM_FMU=0: the FM sum rows are gathered per pair in the reduce phase (the round-3 form, kept for A/B runs)
+    static const bool fmu_on = []() {
+        const char *e = getenv("RP_GRAD_GEMM_FMU");
+        return !(e && e[0] == '0');
+    }();
+    if (gfm != nullptr && sum_in != nullptr && fmu_on)
+        hipLaunchKernelGGL((embed_grad_gemm_kernel<true>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B,
+                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
+    else
+        hipLaunchKernelGGL((embed_grad_gemm_kernel<false>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B,
+                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
     RP_LAUNCH_CHECK("embed_grad_gemm");
     return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }

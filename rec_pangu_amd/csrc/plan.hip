@@ -44,6 +44,9 @@ struct Plan {
     bool ended = false;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_inline = 0;               // launches of section 2 (forked where they were recorded, joined at rp_plan_join)
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
 };
 
 std::atomic<Plan *> g_recording{nullptr};
@@ -69,7 +72,8 @@ void rp_plan_record(const void *func, dim3 grid, dim3 block, unsigned shmem, hip
     p->blob.resize(n.blob_at + (blob_bytes ? blob_bytes : 1));
     memcpy(p->blob.data() + n.blob_at, blob, blob_bytes);
     n.offs.assign(offsets, offsets + nargs);
-    if (n.section != 0) p->n_side++;
+    if (n.section == 1) p->n_side++;
+    if (n.section == 2) p->n_inline++;
     p->nodes.push_back(std::move(n));
 }
 
@@ -87,10 +91,29 @@ extern "C" int rp_plan_section(int section) {
     std::lock_guard<std::mutex> lock(g_mu);
     Plan *p = g_recording.load();
     RP_REQUIRE(p != nullptr, "plan_section: no plan is being recorded");
-    RP_REQUIRE(section == 0 || section == 1, "plan_section: 0 (main) or 1 (side)");
+    RP_REQUIRE(section >= 0 && section <= 2, "plan_section: 0 (main), 1 (side, forked at the fork point) or 2 (inline fork)");
     p->section = section;
     return RP_OK;
 }
+
+// the launches recorded under section 2 since the last join run BESIDE the main launches recorded after them; the main
+// stream waits for them here (a marker node: func == nullptr)
+extern "C" int rp_plan_join(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_join: no plan is being recorded");
+    PlanNode n;
+    n.func = nullptr;
+    n.grid = n.block = dim3(0, 0, 0);
+    n.shmem = 0;
+    n.section = -2;
+    n.rec_stream = nullptr;
+    n.blob_at = p->blob.size();
+    p->nodes.push_back(std::move(n));
+    return RP_OK;
+}
+
+extern "C" int rp_plan_is_recording(void) { return rp_plan_recording() ? 1 : 0; }
 
 // the side section of a replay is forked HERE (in front of the next main-section launch) instead of at the start of the
 // replay: the row sort of the next batch overlaps well with the backward's kernels and badly with the optimizer catch-up
@@ -124,10 +147,13 @@ extern "C" int rp_plan_end(void *plan) {
 extern "C" int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p && n_nodes && n_side && n_streams, "plan_info: null pointer");
-    *n_nodes = (int)p->nodes.size();
+    int launches = 0;
+    for (const PlanNode &n : p->nodes) launches += n.func != nullptr ? 1 : 0;
+    *n_nodes = launches;
     *n_side = p->n_side;
     std::vector<hipStream_t> seen;
     for (const PlanNode &n : p->nodes) {
+        if (n.func == nullptr) continue;
         bool found = false;
         for (hipStream_t s : seen) found = found || s == n.rec_stream;
         if (!found) seen.push_back(n.rec_stream);
@@ -148,7 +174,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
     }
-    bool forked = false;
+    if (p->n_inline > 0 && p->side2 == nullptr) {
+        e = hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork2, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
+    }
+    bool forked = false, open2 = false;
     for (size_t i = 0; i <= p->nodes.size(); ++i) {
         if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
             // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
@@ -158,7 +190,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: fork: %s", hipGetErrorString(e));
             for (size_t j = 0; j < p->nodes.size(); ++j) {
                 const PlanNode &n = p->nodes[j];
-                if (n.section == 0) continue;
+                if (n.section != 1) continue;
                 e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[j], n.shmem, p->side);
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", j, hipGetErrorString(e));
             }
@@ -167,10 +199,34 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         }
         if (i == p->nodes.size()) break;
         const PlanNode &n = p->nodes[i];
-        if (n.section != 0) continue;
-        e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, s);
+        if (n.section == 1) continue;
+        if (n.func == nullptr) {  // join marker of the inline section
+            if (open2) {
+                e = hipEventRecord(p->ev_join2, p->side2);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
+                open2 = false;
+            }
+            continue;
+        }
+        hipStream_t target = s;
+        if (n.section == 2) {
+            if (!open2) {  // fork: what was enqueued on the main stream so far is what these launches depend on
+                e = hipEventRecord(p->ev_fork2, s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork: %s", hipGetErrorString(e));
+                open2 = true;
+            }
+            target = p->side2;
+        }
+        e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, target);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: launch %zu: %s", i, hipGetErrorString(e));
         rp_count_launch();
+    }
+    if (open2) {  // (a section that was never joined explicitly joins at the end)
+        e = hipEventRecord(p->ev_join2, p->side2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
     }
     if (fork) {
         e = hipStreamWaitEvent(s, p->ev_join, 0);
@@ -191,6 +247,12 @@ extern "C" int rp_plan_destroy(void *plan) {
         (void)hipEventDestroy(p->ev_fork);
         (void)hipEventDestroy(p->ev_join);
         (void)hipStreamDestroy(p->side);
+    }
+    if (p->side2 != nullptr) {
+        (void)hipStreamSynchronize(p->side2);
+        (void)hipEventDestroy(p->ev_fork2);
+        (void)hipEventDestroy(p->ev_join2);
+        (void)hipStreamDestroy(p->side2);
     }
     delete p;
     return RP_OK;

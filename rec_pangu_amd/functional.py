@@ -823,16 +823,28 @@ class _EmbedGatherLinear(torch.autograd.Function):
         need_w = ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5])
         need_t = keys is not None and ctx.need_tables
 
-        def wgrad():
+        def wgrad(keep=None):
             if ctx.x_mode == "dense":  # x holds the dense columns only: the embedding columns are gathered from the arena
                 return hip.linear_wgrad_gather(dpre, store.arena, keys, ctx.Kg, x, ctx.K, want_bias=ctx.has_bias)
-            return hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
+            return hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias, keep=keep)
 
         # The weight gradient (streams x: 0.15 ms at Criteo shape) and the fused gather backward (bound by its random row
         # gathers, ~1 TB/s of HBM: 0.30 ms) both depend only on dpre and are independent of each other: the weight gradient
         # runs on a second stream BESIDE the gather backward instead of in front of it.  Same kernels, same inputs: bit-identical.
         wstream = _wgrad_stream(dpre.device) if (need_w and need_t) else None
-        if wstream is not None:
+        # ... and while a LAUNCH PLAN is being recorded (a captured step: one stream), the weight gradient's launches are
+        # marked as an inline section: the replay issues them on the plan's second side stream, joined after the gather
+        # backward.  Their workspace stays referenced until the join (the capture's allocator would reuse it at once).
+        in_plan = (wstream is None and need_w and need_t and ctx.x_mode != "dense"
+                   and os.environ.get("RP_WGRAD_OVERLAP", "1") != "0" and hip.LaunchPlan.is_recording())
+        keep = []
+        if in_plan:
+            hip.LaunchPlan.section(2)
+            try:
+                dw, db = wgrad(keep)
+            finally:
+                hip.LaunchPlan.section(0)
+        elif wstream is not None:
             main = torch.cuda.current_stream(dpre.device)
             wstream.wait_stream(main)
             with torch.cuda.stream(wstream):
@@ -844,6 +856,9 @@ class _EmbedGatherLinear(torch.autograd.Function):
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
                                   fused=(dpre, wt))
+        if in_plan:
+            hip.LaunchPlan.join()
+            del keep
         if wstream is not None:
             main.wait_stream(wstream)  # whoever consumes dw / db (AccumulateGrad, the optimizer) is ordered behind them
             dw.record_stream(main)     # (allocated under the second stream, consumed and freed on the main one)

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "rp_plan_begin": (C.c_int, [C.POINTER(_vp)]),
     "rp_plan_section": (C.c_int, [_i32]),
     "rp_plan_fork_here": (C.c_int, []),
+    "rp_plan_join": (C.c_int, []),
+    "rp_plan_is_recording": (C.c_int, []),
     "rp_plan_end": (C.c_int, [_vp]),
     "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_plan_replay": (C.c_int, [_vp, _vp]),
@@ -510,8 +512,9 @@ def linear_fwd_rowadd(a, w, row_scale, row_add, add_cols: int, out) -> bool:
     return True
 
 
-def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want_bias: bool = True):
-    """dw[N,K] = dy[M,N]^T @ x[:, :K]; db[N] = colsum(dy)."""
+def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want_bias: bool = True, keep=None):
+    """dw[N,K] = dy[M,N]^T @ x[:, :K]; db[N] = colsum(dy).  keep: a list that receives the launch's workspace (a caller that
+    lets the launch run beside later ones keeps it alive until they are joined)."""
     _req(dy, torch.float32, "dy")
     _req(x, torch.float32, "x")
     M, N = dy.shape
@@ -523,6 +526,8 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     nbytes = _sz(0)
     _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
+    if keep is not None:
+        keep.append(ws)
     with _Timed("linear_wgrad", f"{M}x{N}x{K}", 4 * (M * N + M * K + N * K), 2 * M * N * K):
         _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
                                  M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
@@ -604,6 +609,14 @@ class LaunchPlan:
     @staticmethod
     def fork_here():
         _check(lib().rp_plan_fork_here(), "rp_plan_fork_here")
+
+    @staticmethod
+    def join():
+        _check(lib().rp_plan_join(), "rp_plan_join")
+
+    @staticmethod
+    def is_recording() -> bool:
+        return bool(lib().rp_plan_is_recording())
 
     def replay(self):
         rc = lib().rp_plan_replay(self._h, _stream())
