@@ -44,9 +44,14 @@ def step(i):
 for i in range(40):
     step(i)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(40, 40 + steps):
-    step(i)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps * 1e3
-print(f"{mode}: {dt:.4f} ms/step at B={B}" + ("" if g is None else f" (backend used: {g.backend_used}, {g.why_not_plan})"))
+done, parts = 40, []
+for seg in ([steps] if steps <= 200 else [60, 140, 300, 600, steps - 1100] if steps > 1100 else [steps]):
+    if seg <= 0:
+        continue
+    t0 = time.perf_counter()
+    for i in range(done, done + seg):
+        step(i)
+    torch.cuda.synchronize()
+    parts.append(f"steps {done}-{done + seg}: {(time.perf_counter() - t0) / seg * 1e3:.4f}")
+    done += seg
+print(f"{mode} at B={B}, ms/step: " + "; ".join(parts) + ("" if g is None else f" (backend used: {g.backend_used}, {g.why_not_plan})"))

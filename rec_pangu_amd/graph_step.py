@@ -91,6 +91,7 @@ class GraphedTrainStep:
         self._dev = None         # host mirror of the device counters
         self._one = None         # the seed gradient of captured backward passes (see _seed_grad)
         self.replays = 0
+        self.captures = 0
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
     def _eager(self, batch, nxt):
@@ -196,6 +197,7 @@ class GraphedTrainStep:
             if why is not None:
                 plan.destroy()
                 plan, self.why_not_plan = None, why
+        self.captures += 1
         self.graphs[P], self.plans[P] = g, plan
         self.backend_used = "plan" if plan is not None else "hipgraph"
         self.outs[P] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

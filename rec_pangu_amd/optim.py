@@ -34,8 +34,13 @@ class StepTables:
     current step on when lr changes; steps already taken keep the lr they were taken with.  The buffers only move when
     the capacity doubles (`generation` counts that: a captured graph holds their addresses)."""
 
+    # Buffers start with room for this many steps (1.5 MB): a captured step holds their addresses, so every capacity
+    # doubling costs a re-capture of both static input sets (a few ms) — with the round-3 start of ~2 k steps one of them
+    # fell into the bench's timed window (+0.3 ms/step over 20 steps).  Tests lower it to exercise the doubling.
+    MIN_CAPACITY = 65536
+
     def __init__(self, betas, eps, device, t0: int = 0, chunk: int = 1024):
-        cap = t0 + 2 + 2 * chunk
+        cap = max(t0 + 2 + 2 * chunk, self.MIN_CAPACITY)
         self.betas, self.eps = betas, eps
         self.sc = torch.zeros((cap, 2), dtype=torch.float32, device=device)
         self.ns_d = torch.zeros((cap, 2), dtype=torch.float64, device=device)

@@ -65,11 +65,12 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, de
     in-place extensions of the step tables; the learning rate changes twice on the way)"""
     from rec_pangu_amd import hip
     from rec_pangu_amd.graph_step import GraphedTrainStep
-    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows
+    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows, StepTables
     enc = _enc(5, [3000, 17, 900, 4, 20000, 250])
     batches = _batches(enc, 384, steps + 1, seed=4)
     results = {}
     chunk, LazyAdamRows.TABLE_CHUNK = LazyAdamRows.TABLE_CHUNK, 100
+    min_cap, StepTables.MIN_CAPACITY = StepTables.MIN_CAPACITY, 0  # (small tables: capacity doublings re-capture on the way)
     try:
         for mode in ("eager", "graph"):
             model = _build(kind, enc)
@@ -112,6 +113,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, de
                              [g["_rp_step"] for g in osd["param_groups"]])
     finally:
         LazyAdamRows.TABLE_CHUNK = chunk
+        StepTables.MIN_CAPACITY = min_cap
         from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
         EmbeddingLayer.unpin_sorts()
     e, g = results["eager"], results["graph"]

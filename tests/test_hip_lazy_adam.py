@@ -113,8 +113,9 @@ def test_model_lazy_equals_dense_and_reference(name):
 def test_scalar_table_growth_keeps_lazy_exact(monkeypatch):
     """The per-step scalar table grows in chunks (LazyAdamRows.TABLE_CHUNK = 1024 steps): with a chunk of 3 a 10-step
     run with a learning-rate change crosses several extensions and must still equal the dense optimizer bit for bit."""
-    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows
+    from rec_pangu_amd.optim import FusedAdam, LazyAdamRows, StepTables
     monkeypatch.setattr(LazyAdamRows, "TABLE_CHUNK", 3)
+    monkeypatch.setattr(StepTables, "MIN_CAPACITY", 0)  # (so that the buffers themselves double on the way)
     g = load_golden("model_deepfm.npz")
     batch = {k: v.to(DEV) for k, v in g["batch"].items()}
     other = {k: (v.flip(0) if v.dtype.is_floating_point else torch.zeros_like(v)) for k, v in batch.items()}
