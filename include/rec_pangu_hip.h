@@ -596,6 +596,9 @@ int rp_plan_join(void);
 int rp_plan_is_recording(void);
 int rp_plan_end(void *plan);
 int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
+/* the streams sections 1 / 2 are re-issued on (NULL: the plan creates one); before the first replay */
+int rp_plan_set_streams(void *plan, rp_stream_t side, rp_stream_t side2);
+int rp_plan_inline_count(void *plan, int *n_inline);
 int rp_plan_replay(void *plan, rp_stream_t stream);
 int rp_plan_destroy(void *plan);
 int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other);

@@ -23,7 +23,8 @@ for i in range(PRE):
     cur, nb = nb, gen(i + 1)
     g(cur, nb)
 torch.cuda.synchronize()
-print("after pre-roll: captures", g.captures, "replays", g.replays, "backend", g.backend_used)
+print("after pre-roll: captures", g.captures, "replays", g.replays, "backend", g.backend_used,
+      "| plan launches", g.plans[0].nodes, "side", g.plans[0].side, "inline", g.plans[0].inline)
 batches = [gen(5000 + i) for i in range(20)]
 for rep in range(3):
     torch.cuda.synchronize()

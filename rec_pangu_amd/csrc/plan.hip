@@ -47,6 +47,7 @@ struct Plan {
     int n_inline = 0;               // launches of section 2 (forked where they were recorded, joined at rp_plan_join)
     hipStream_t side2 = nullptr;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    bool own_side = false, own_side2 = false;  // streams created here (else: the caller's, rp_plan_set_streams)
 };
 
 std::atomic<Plan *> g_recording{nullptr};
@@ -162,20 +163,45 @@ extern "C" int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_stream
     return RP_OK;
 }
 
+// The streams the side section (1) and the inline section (2) are re-issued on.  HIP multiplexes streams onto a handful
+// of hardware queues (4 by default): a stream the plan created itself landed on the MAIN stream's hardware queue in a
+// process that already owned three others, and its launches ran in line with the main ones.  The caller therefore hands
+// in the streams its eager path overlaps on (they demonstrably sit on other queues); NULL = create one.
+extern "C" int rp_plan_set_streams(void *plan, rp_stream_t side, rp_stream_t side2) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ev_fork == nullptr && p->ev_fork2 == nullptr, "plan_set_streams: before the first replay");
+    p->side = (hipStream_t)side;
+    p->side2 = (hipStream_t)side2;
+    return RP_OK;
+}
+
+extern "C" int rp_plan_inline_count(void *plan, int *n_inline) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p && n_inline, "plan_inline_count: null pointer");
+    *n_inline = p->n_inline;
+    return RP_OK;
+}
+
 extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && p->ended, "plan_replay: the plan was not finished with rp_plan_end");
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const bool fork = p->n_side > 0;
-    if (fork && p->side == nullptr) {
-        e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+    if (fork && p->ev_fork == nullptr) {
+        if (p->side == nullptr) {
+            e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+            p->own_side = true;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
     }
-    if (p->n_inline > 0 && p->side2 == nullptr) {
-        e = hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking);
+    if (p->n_inline > 0 && p->ev_fork2 == nullptr) {
+        if (p->side2 == nullptr) {
+            e = hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking);
+            p->own_side2 = true;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork2, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
@@ -242,17 +268,17 @@ extern "C" int rp_plan_destroy(void *plan) {
         std::lock_guard<std::mutex> lock(g_mu);
         if (g_recording.load() == p) g_recording.store(nullptr, std::memory_order_release);
     }
-    if (p->side != nullptr) {
+    if (p->ev_fork != nullptr) {
         (void)hipStreamSynchronize(p->side);
         (void)hipEventDestroy(p->ev_fork);
         (void)hipEventDestroy(p->ev_join);
-        (void)hipStreamDestroy(p->side);
+        if (p->own_side) (void)hipStreamDestroy(p->side);
     }
-    if (p->side2 != nullptr) {
+    if (p->ev_fork2 != nullptr) {
         (void)hipStreamSynchronize(p->side2);
         (void)hipEventDestroy(p->ev_fork2);
         (void)hipEventDestroy(p->ev_join2);
-        (void)hipStreamDestroy(p->side2);
+        if (p->own_side2) (void)hipStreamDestroy(p->side2);
     }
     delete p;
     return RP_OK;

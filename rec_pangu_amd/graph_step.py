@@ -197,6 +197,18 @@ class GraphedTrainStep:
             if why is not None:
                 plan.destroy()
                 plan, self.why_not_plan = None, why
+            else:
+                # the sections run on the very streams the eager path overlaps on (sort-ahead / first-layer weight gradient):
+                # a stream of the plan's own may share the main stream's hardware queue (csrc/plan.hip)
+                from . import functional as _Fh
+                dev = next(iter(self.X[0].values())).device
+                side = _emb._SIDE_STREAMS.get(dev)
+                if side is None:
+                    side = _emb._SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                side2 = _Fh._WGRAD_STREAMS.get(dev)
+                if side2 is None:
+                    side2 = _Fh._WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                plan.set_streams(side, side2)
         self.captures += 1
         self.graphs[P], self.plans[P] = g, plan
         self.backend_used = "plan" if plan is not None else "hipgraph"

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "rp_plan_end": (C.c_int, [_vp]),
     "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_plan_replay": (C.c_int, [_vp, _vp]),
+    "rp_plan_set_streams": (C.c_int, [_vp, _vp, _vp]),
+    "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_multi_copy": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
@@ -589,7 +591,8 @@ class LaunchPlan:
 
     def __init__(self):
         self._h = None
-        self.nodes = self.side = self.streams = 0
+        self._streams = None
+        self.nodes = self.side = self.streams = self.inline = 0
 
     def begin(self):
         h = _vp()
@@ -601,6 +604,14 @@ class LaunchPlan:
         a, b, c = _i32(), _i32(), _i32()
         _check(lib().rp_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "rp_plan_info")
         self.nodes, self.side, self.streams = a.value, b.value, c.value
+        _check(lib().rp_plan_inline_count(self._h, C.byref(a)), "rp_plan_inline_count")
+        self.inline = a.value
+
+    def set_streams(self, side, side2):
+        """torch streams the side / inline sections are re-issued on (kept alive by the caller)"""
+        self._streams = (side, side2)
+        _check(lib().rp_plan_set_streams(self._h, _vp(side.cuda_stream) if side is not None else None,
+                                         _vp(side2.cuda_stream) if side2 is not None else None), "rp_plan_set_streams")
 
     @staticmethod
     def section(k: int):
