@@ -144,13 +144,27 @@ int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *sorted_pos, 
  *   dh  [B, 64]            gradient w.r.t. the layer's pre-activation (lddh floats per row)
  *   wt  [>= F*64, 64]      the layer's weight transposed (rp_transpose): row f*64+d = column f*64+d of W1 [64, K]
  *   dx  optional           sum of the gradients of x's other consumers, added per pair (NULL: none)
+ *   skip_fields            bit f set: the pairs of field f are left out (their tables' gradient rows come from
+ *                          rp_embed_grad_tiny); only with FIELD-MAJOR positions (position = field * B + sample), 0 otherwise
  * rp_embed_grad_gemm_fits: D == 64, a 64-wide layer, row strides multiples of 4 floats; otherwise RP_ERR_UNSUPPORTED
  * (compose rp_linear_fwd + rp_embed_grad_reduce).  Workspace: rp_embed_grad_reduce_workspace_bytes(n, D). */
 int rp_embed_grad_gemm_fits(int D, int hidden, int64_t lddh, int64_t ldwt);
 int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D, const float *dh,
                        int64_t lddh, const float *wt, int64_t ldwt, const float *dx, int64_t ldx, const float *gfm,
-                       const float *sum_in, const float *arena, float *grad_arena, int accumulate, void *workspace,
-                       size_t workspace_bytes, rp_stream_t stream);
+                       const float *sum_in, const float *arena, float *grad_arena, int accumulate, uint64_t skip_fields,
+                       void *workspace, size_t workspace_bytes, rp_stream_t stream);
+/* The same gradient for TINY tables (each <= 254 rows, <= 224 rows together, <= 16 tables), SAMPLE-major (csrc/embed_tiny.hip):
+ * G[r] = (sum_b dH[b]) . W1_f^T + sum_b g_fm[b] S[b] - (sum_b g_fm[b]) v_r over the samples b with id_f[b] = r; the 129-wide row
+ * sums are one-hot GEMMs on the matrix core (one-hot exact in bf16, the data split into three bf16 pieces, fp32 accumulation
+ * in a fixed order: deterministic), every sample's dH / S row is read once for all tiny tables.  Writes EVERY row of those
+ * tables (0 for rows nobody looked up; accumulate != 0 adds).  keys [F * B]: arena row of pair (field, sample) at
+ * field * B + sample (rp_embed_keys / the gather's keys_out).  Host arrays: tiny_field (field index), tiny_base (first arena
+ * row), tiny_rows.  rp_embed_grad_gemm(skip_fields = bits of those fields) then covers the other fields. */
+int rp_embed_grad_tiny_workspace_bytes(int64_t B, size_t *bytes);
+int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t *tiny_field, const int64_t *tiny_base,
+                       const int32_t *tiny_rows, int n_tiny, const float *dh, int64_t lddh, const float *wt, int64_t ldwt,
+                       const float *gfm, const float *sum_in, const float *arena, float *grad_arena, int accumulate,
+                       void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
 

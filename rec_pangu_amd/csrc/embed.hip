@@ -655,12 +655,22 @@ static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const 
 // Measured before the change (profiles/microbench/probes/probe_grad_gemm.py, Criteo shape): 0.320 ms with the FM term,
 // 0.198 ms without it, 0.303 ms with perfectly sequential gathers — the launch is bound by its chain of dependent
 // round trips per tile, not by the bytes the random gathers move.
+// Ranges of sorted positions the launch covers (round 4: the fields whose tables rp_embed_grad_tiny handles are left out;
+// positions are field-major, field f = [f B, (f + 1) B), so the kept fields are a few contiguous ranges).  Tiles are laid
+// out per range: tile j of range g covers [start[g] + 128 j, min(.. + 128, end[g])).
+#define EG_MAXG 34
+struct GradRanges {
+    int n;
+    int64_t start[EG_MAXG], end[EG_MAXG];
+    int tile0[EG_MAXG];  // first workgroup of the range
+};
+
 template <bool FM_U>
 __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
     int64_t lddh, const float *__restrict__ wt, int64_t ldwt, const float *__restrict__ dx, int64_t ldx,
     const float *__restrict__ gfm, const float *__restrict__ sum_in, const float *__restrict__ arena,
-    float *__restrict__ G, int accumulate, float *__restrict__ gpiece, int32_t *__restrict__ gkey) {
+    float *__restrict__ G, int accumulate, float *__restrict__ gpiece, int32_t *__restrict__ gkey, GradRanges rg) {
     typedef Vec<4> V;
     constexpr int D = 64, TPR = 16, VEC = 4, GPB = 16, W = 64;
     constexpr int SM_B = 3 * 64 * EG_LD * 2, SM_C = 128 * EG_CT * 4;
@@ -676,19 +686,25 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     BTile Bt = reinterpret_cast<BTile>(smem);                 // [3][64 d][64 n (+pad)]: W1^T slice of one field, pieces
     float(*Ct)[EG_CT] = reinterpret_cast<float(*)[EG_CT]>(smem);  // [128][64 (+pad)]: the tile's dX rows (after the MFMAs)
     const int t = threadIdx.x % TPR, grp = threadIdx.x / TPR;
-    const int64_t wg0 = (int64_t)blockIdx.x * GPB * RP_SEG;
+    // this workgroup's tile: [wg0, min(wg0 + 128, gend)) inside one range of kept positions (gend <= n)
+    int gi = 0;
+    for (int g2 = 1; g2 < rg.n; ++g2)
+        if ((int)blockIdx.x >= rg.tile0[g2]) gi = g2;
+    const int64_t wg0 = rg.start[gi] + (int64_t)((int)blockIdx.x - rg.tile0[gi]) * GPB * RP_SEG;
+    const int64_t gend = rg.end[gi];
     // ---- the tile's dX rows on the matrix core (kept register-lean: three workgroups per CU have to overlap the
     //      gather latencies of this phase with the matrix / reduce phases of the others) ----------------------------
     {
         const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
         const int64_t prow = wg0 + 32 * wv + i;  // this lane's row of the tile (A operand: lane = row, 8 k per lane)
-        const bool rok = prow < n;
+        const bool rok = prow < gend;
         const int32_t pp = rok ? sp[prow] : 0;
         const int32_t kk = rok ? sk[prow] : -1;
+        // (the neighbours across a range border belong to another table: their keys differ from every key of this tile)
         if (threadIdx.x == 0) tkey[0] = wg0 > 0 ? sk[wg0 - 1] : -1;
         if (threadIdx.x == 64) tkey[129] = wg0 + 128 < n ? sk[wg0 + 128] : -1;
         const int fr = pp / Bi, br = pp - fr * Bi;
-        const int64_t plast = (wg0 + 127 < n ? wg0 + 127 : n - 1);
+        const int64_t plast = (wg0 + 127 < gend ? wg0 + 127 : gend - 1);
         const int f_lo = __builtin_amdgcn_readfirstlane(sp[wg0] / Bi), f_hi = __builtin_amdgcn_readfirstlane(sp[plast] / Bi);
         if (h == 0) {  // one lane per tile row: the tile tables (everything the first trip to memory brought)
             tkey[1 + 32 * wv + i] = kk;
@@ -793,8 +809,8 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
     }
     // keys / samples / fields of this group's segment: from the tile tables in LDS (no trip to memory)
     const int64_t start = wg0 + (int64_t)grp * RP_SEG;
-    const bool active = start < n;
-    const int cnt = active ? (int)((n - start) < RP_SEG ? (n - start) : RP_SEG) : 0;
+    const bool active = start < gend;
+    const int cnt = active ? (int)((gend - start) < RP_SEG ? (gend - start) : RP_SEG) : 0;
     int32_t k[RP_SEG];
 #pragma unroll
     for (int j = 0; j < RP_SEG; ++j) k[j] = (j < cnt) ? tkey[1 + grp * RP_SEG + j] : -1;
@@ -865,7 +881,7 @@ __global__ __launch_bounds__(256, 3) void embed_grad_gemm_kernel(
                 break;
             }
         const int64_t wg_end = wg0 + GPB * RP_SEG;
-        const int last_active = (int)(((n < wg_end ? n : wg_end) - wg0 + RP_SEG - 1) / RP_SEG) - 1;
+        const int last_active = (int)(((gend < wg_end ? gend : wg_end) - wg0 + RP_SEG - 1) / RP_SEG) - 1;
         const bool tail_open = last_g >= 0 && last_g == last_active && pcont[last_g] != 0;
         int32_t cur = -1;
         bool cur_is_head = false;
@@ -1158,8 +1174,8 @@ extern "C" int rp_embed_grad_gemm_fits(int D, int hidden, int64_t lddh, int64_t 
 extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
                                   const float *dh, int64_t lddh, const float *wt, int64_t ldwt, const float *dx,
                                   int64_t ldx, const float *gfm, const float *sum_in, const float *arena,
-                                  float *grad_arena, int accumulate, void *workspace, size_t workspace_bytes,
-                                  rp_stream_t stream) {
+                                  float *grad_arena, int accumulate, uint64_t skip_fields, void *workspace,
+                                  size_t workspace_bytes, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && sorted_pos && dh && wt && grad_arena && workspace, "embed_grad_gemm: null pointer");
     RP_REQUIRE(gfm == nullptr || arena, "embed_grad_gemm: the FM term needs the arena");
     RP_REQUIRE(B >= 1 && B < INT32_MAX, "embed_grad_gemm: bad B");
@@ -1170,8 +1186,42 @@ extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sor
     size_t need = 0;
     rp_embed_grad_reduce_workspace_bytes(n, D, &need);
     RP_REQUIRE(workspace_bytes >= need, "embed_grad_gemm: workspace %zu < %zu bytes", workspace_bytes, need);
+    // the ranges of positions this launch covers: everything, or — skip_fields != 0, FIELD-MAJOR positions only (position =
+    // field * B + sample, n = F * B) — the fields whose bit is clear (the others' tables are rp_embed_grad_tiny's)
+    GradRanges rg;
+    rg.n = 0;
+    int64_t tiles = 0;
+    if (skip_fields == 0) {
+        rg.n = 1;
+        rg.start[0] = 0;
+        rg.end[0] = n;
+        rg.tile0[0] = 0;
+        tiles = grad_reduce_blocks(n, D, 4);
+    } else {
+        RP_REQUIRE(n % B == 0 && n / B <= 64, "embed_grad_gemm: skip_fields needs field-major positions (n = F * B, F <= 64)");
+        const int F = (int)(n / B);
+        for (int f = 0; f < F; ++f) {
+            if ((skip_fields >> f) & 1u) continue;
+            if (rg.n > 0 && rg.end[rg.n - 1] == (int64_t)f * B) {
+                rg.end[rg.n - 1] = (int64_t)(f + 1) * B;
+            } else {
+                RP_REQUIRE(rg.n < EG_MAXG, "embed_grad_gemm: too many field ranges");
+                rg.start[rg.n] = (int64_t)f * B;
+                rg.end[rg.n] = (int64_t)(f + 1) * B;
+                rg.n++;
+            }
+        }
+        if (rg.n == 0) return RP_OK;  // every field is handled elsewhere
+        for (int g = 0; g < rg.n; ++g) {
+            rg.tile0[g] = (int)tiles;
+            tiles += rp_cdiv(rg.end[g] - rg.start[g], 128);
+        }
+    }
+    for (int g = rg.n; g < EG_MAXG; ++g) rg.start[g] = rg.end[g] = 0, rg.tile0[g] = INT32_MAX;
     char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int64_t nb0 = grad_reduce_blocks(n, D, 4);
+    // (tiles <= n / 128 + ranges; the piece region of the workspace is sized for the scalar layout's n / 32 workgroups)
+    const int64_t nb0 = tiles;
+    RP_REQUIRE(nb0 <= grad_reduce_blocks(n, D, 1), "embed_grad_gemm: %lld tiles do not fit the workspace", (long long)nb0);
     float *piece0 = reinterpret_cast<float *>(wbase);
     int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
     hipStream_t s = (hipStream_t)stream;
@@ -1182,10 +1232,10 @@ extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sor
     }();
     if (gfm != nullptr && sum_in != nullptr && fmu_on)
         hipLaunchKernelGGL((embed_grad_gemm_kernel<true>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B,
-                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
+                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0, rg);
     else
         hipLaunchKernelGGL((embed_grad_gemm_kernel<false>), dim3((unsigned)nb0), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B,
-                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0);
+                           dh, lddh, wt, ldwt, dx, ldx, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0, rg);
     RP_LAUNCH_CHECK("embed_grad_gemm");
     return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }

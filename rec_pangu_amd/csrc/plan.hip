@@ -206,7 +206,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
     }
-    bool forked = false, open2 = false;
+    bool forked = false, open2 = false, main_since_fork2 = false;
     for (size_t i = 0; i <= p->nodes.size(); ++i) {
         if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
             // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
@@ -237,13 +237,19 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         }
         hipStream_t target = s;
         if (n.section == 2) {
-            if (!open2) {  // fork: what was enqueued on the main stream so far is what these launches depend on
+            // fork: what was enqueued on the main stream so far is what these launches depend on — also when main launches
+            // were recorded between two groups of inline launches (the tiny-table gradient reads the transposed weight that
+            // the main stream produces after the weight gradient was forked)
+            if (!open2 || main_since_fork2) {
                 e = hipEventRecord(p->ev_fork2, s);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork: %s", hipGetErrorString(e));
                 open2 = true;
+                main_since_fork2 = false;
             }
             target = p->side2;
+        } else if (open2) {
+            main_since_fork2 = true;
         }
         e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, target);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: launch %zu: %s", i, hipGetErrorString(e));

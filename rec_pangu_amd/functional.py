@@ -855,7 +855,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
             wt = hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
-                                  fused=(dpre, wt))
+                                  fused=(dpre, wt), plan_keep=keep if in_plan else None)
         if in_plan:
             hip.LaunchPlan.join()
             del keep

@@ -40,7 +40,10 @@ _SIGNATURES = {
     "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_gemm_fits": (C.c_int, [_i32, _i32, _i64, _i64]),
     "rp_embed_grad_gemm": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
-                                     _vp, _sz, _vp]),
+                                     C.c_uint64, _vp, _sz, _vp]),
+    "rp_embed_grad_tiny_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
+    "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz,
+                                     _vp]),
     "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
@@ -457,8 +460,37 @@ def embed_grad_gemm_fits(D: int, hidden: int, dh, wt) -> bool:
         and dh.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
 
 
-def embed_grad_gemm(sorted_keys, sorted_pos, B: int, D: int, dh, wt, dx, gfm, sum_in, arena, grad_arena, accumulate: bool):
-    """rp_embed_grad_gemm: the segmented reduce with the consuming Linear's dgrad formed inside (dh [B,64], wt = W1^T)."""
+def embed_grad_tiny(keys, B: int, tiny, dh, wt, gfm, sum_in, arena, grad_arena, accumulate: bool, keep=None):
+    """rp_embed_grad_tiny: the gradient rows of the tiny tables `tiny` = [(field, first arena row, rows), ...] from the
+    unsorted pair keys [F * B] (sample-major one-hot GEMMs).  keep: a list that receives the workspace (launches that run
+    beside later ones inside a recorded plan)."""
+    _req(keys, torch.int32, "keys")
+    _req(dh, torch.float32, "dh")
+    n = len(tiny)
+    ckey = tuple(tiny)
+    arrs = _TINY_ARRAYS.get(ckey)
+    if arrs is None:
+        arrs = _TINY_ARRAYS[ckey] = ((C.c_int32 * n)(*[t[0] for t in tiny]), (C.c_int64 * n)(*[t[1] for t in tiny]),
+                                     (C.c_int32 * n)(*[t[2] for t in tiny]))
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_tiny_workspace_bytes(B, C.byref(nbytes)), "rp_embed_grad_tiny_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+    if keep is not None:
+        keep.append(ws)
+    with _Timed("embed_grad_tiny", f"{n} tables", B * (64 * 8 + 4 + 4 * n)):
+        _check(lib().rp_embed_grad_tiny(keys.data_ptr(), B, arrs[0], arrs[1], arrs[2], n, dh.data_ptr(), _rowmajor(dh, "dh"),
+                                        wt.data_ptr(), _rowmajor(wt, "wt"), _ptr(gfm), _ptr(sum_in), _ptr(arena),
+                                        grad_arena.data_ptr(), int(accumulate), ws.data_ptr(), nbytes.value, _stream()),
+               "rp_embed_grad_tiny")
+
+
+_TINY_ARRAYS: dict = {}
+
+
+def embed_grad_gemm(sorted_keys, sorted_pos, B: int, D: int, dh, wt, dx, gfm, sum_in, arena, grad_arena, accumulate: bool,
+                    skip_fields: int = 0):
+    """rp_embed_grad_gemm: the segmented reduce with the consuming Linear's dgrad formed inside (dh [B,64], wt = W1^T).
+    skip_fields: bit f set = the pairs of field f are left out (field-major positions only; embed_grad_tiny's tables)."""
     _req(grad_arena, torch.float32, "grad_arena")
     _req(dh, torch.float32, "dh")
     _req(wt, torch.float32, "wt")
@@ -471,7 +503,7 @@ def embed_grad_gemm(sorted_keys, sorted_pos, B: int, D: int, dh, wt, dx, gfm, su
         _check(lib().rp_embed_grad_gemm(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B, D,
                                         dh.data_ptr(), _rowmajor(dh, "dh"), wt.data_ptr(), _rowmajor(wt, "wt"), _ptr(dx), ldx,
                                         _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(), int(accumulate),
-                                        ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_gemm")
+                                        skip_fields, ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_gemm")
 
 
 def zero_rows(keys, D: int, grad_arena):

@@ -251,7 +251,27 @@ class EmbeddingLayer(nn.Module):
         if self._lazy is not None:
             self._lazy.flush(self)
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None):
+    def _tiny_tables(self):
+        """[(field, first arena row, rows), ...] of the tables rp_embed_grad_tiny takes (D = 64; each <= 254 rows, the
+        smallest first while they fit 224 accumulator rows, at most 16), or None; RP_GRAD_TINY=0 turns the path off"""
+        hit = self.__dict__.get("_tiny_cache")
+        sig = self._rows_sig()
+        if hit is not None and hit[0] is sig:
+            return hit[1]
+        out = None
+        if self.embedding_dim == 64 and os.environ.get("RP_GRAD_TINY", "1") != "0" and len(sig) <= 64:
+            order = sorted(range(len(sig)), key=lambda f: sig[f])
+            pick, total = [], 0
+            for f in order:
+                if sig[f] <= 254 and total + sig[f] <= 224 and len(pick) < 16:
+                    pick.append(f)
+                    total += sig[f]
+            if total >= 1 and len(pick) >= 2:  # (a single tiny table is not worth two extra launches)
+                out = [(f, sum(sig[:f]), sig[f]) for f in sorted(pick)]
+        self.__dict__["_tiny_cache"] = (sig, out)
+        return out
+
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -281,8 +301,25 @@ class EmbeddingLayer(nn.Module):
             hip.embed_pool_bwd(sk, sp, D, pool[0], pool[1], pool[2], pool[3], self._grad_arena,
                                accumulate=not self._grad_clean)
         elif fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
+            skip = 0
+            tiny = self._tiny_tables() if (keys is not None and dx is None and keys.numel() == len(self.emb_feature) * B) else None
+            if tiny:
+                # the tables of a few rows (Criteo: 8 fields, 31 % of the pairs) take the sample-major one-hot path; the
+                # row-sorted kernel leaves their fields out.  Inside a recorded launch plan these launches join the first
+                # layer's weight gradient on the plan's second side stream (functional._EmbedGatherLinear.backward)
+                in_plan = plan_keep is not None
+                if in_plan:
+                    hip.LaunchPlan.section(2)
+                try:
+                    hip.embed_grad_tiny(keys, B, tiny, fused[0], fused[1], gfm, ssum, self._arena, self._grad_arena,
+                                        accumulate=not self._grad_clean, keep=plan_keep)
+                finally:
+                    if in_plan:
+                        hip.LaunchPlan.section(0)
+                for f, _, _ in tiny:
+                    skip |= 1 << f
             hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
-                                accumulate=not self._grad_clean)
+                                accumulate=not self._grad_clean, skip_fields=skip)
         else:
             hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
                                   accumulate=not self._grad_clean)

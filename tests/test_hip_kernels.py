@@ -794,3 +794,59 @@ def _wgrad_gather_case(hip, M, F, ND):
     dw_ref, db_ref = hip.linear_wgrad(dy, x, K)
     dw, db = hip.linear_wgrad_gather(dy, arena, keys, Kg, xd if ND else None, K)
     assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+
+
+@pytest.mark.parametrize("rows,B,with_fm,accumulate", [
+    ([3, 40, 500, 7, 100, 20000, 11], 3000, True, False),    # tiny tables 3, 7, 11, 40, 100 rows; B not a multiple of 64
+    ([25, 4, 1000, 28, 16, 106, 5], 8192, True, True),       # accumulate into a non-zero arena
+    ([10, 19, 3000, 4], 1100, False, False),                 # no FM term
+])
+def test_embed_grad_tiny_tables_vs_sorted_path_and_fp64(hip, rows, B, with_fm, accumulate):
+    """rp_embed_grad_tiny (sample-major one-hot GEMMs for the tables of a few rows) + rp_embed_grad_gemm(skip_fields) against
+    rp_embed_grad_gemm over every field and against an fp64 reference: the same gradient arena within fp32 rounding,
+    rows of the tiny tables nobody looked up exactly zero, bit-identical between two launches."""
+    D, H = 64, 64
+    g = torch.Generator().manual_seed(B + len(rows))
+    F = len(rows)
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    idx[0][:] = idx[0].clamp(max=rows[0] - 2) if rows[0] > 2 else idx[0]  # (the last row of table 0 is never looked up)
+    K = F * D + 5
+    ldx = (K + 63) // 64 * 64
+    W1 = torch.randn(H, K, generator=g) / K ** 0.5
+    dh = torch.randn(B, H, generator=g) * 1e-3
+    gfm = torch.randn(B, 1, generator=g) * 1e-3 if with_fm else None
+    ssum = torch.randn(B, D, generator=g) if with_fm else None
+    row_of = [base[f] + idx[f] for f in range(F)]
+    keys = torch.cat(row_of).to(torch.int32).to(DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=max(1, (arena.shape[0] - 1).bit_length()))
+    dev = lambda t_: None if t_ is None else t_.to(DEV)  # noqa: E731
+    wt = hip.transpose(dev(W1), rows_out=ldx)
+    NR = arena.shape[0]
+    init = 0.5 if accumulate else 0.0
+    tiny = [(f, int(base[f]), rows[f]) for f in range(F) if rows[f] <= 254]
+    assert sum(t[2] for t in tiny) <= 224 and len(tiny) >= 3
+    skip = sum(1 << t[0] for t in tiny)
+    Gs = []
+    for _ in range(2):
+        G = torch.full((NR, D), init, device=DEV)
+        hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G, accumulate)
+        hip.embed_grad_gemm(sk, sp, B, D, dev(dh), wt, None, dev(gfm), dev(ssum), dev(arena), G, accumulate, skip_fields=skip)
+        Gs.append(G)
+    assert torch.equal(Gs[0], Gs[1]), "two launches differ"
+    Gall = torch.full((NR, D), init, device=DEV)
+    hip.embed_grad_gemm(sk, sp, B, D, dev(dh), wt, None, dev(gfm), dev(ssum), dev(arena), Gall, accumulate)
+    dX = dh.double() @ W1.double()[:, :F * D]
+    ref = torch.full((NR, D), init, dtype=torch.float64)
+    for f in range(F):
+        contrib = dX[:, f * D:(f + 1) * D]
+        if with_fm:
+            contrib = contrib + gfm.double() * (ssum.double() - arena.double()[row_of[f].long()])
+        ref.index_add_(0, row_of[f].long(), contrib)
+    scale = float((ref - init).abs().max())
+    got = Gs[0].cpu().double()
+    assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1e-6), "against fp64"
+    assert float((Gs[0] - Gall).abs().max()) <= 2e-5 * max(scale, 1e-6), "against the row-sorted kernel over every field"
+    if rows[0] > 2:
+        never = int(base[0]) + rows[0] - 1
+        assert torch.equal(Gs[0][never].cpu(), torch.full((D,), init)), "a tiny-table row nobody looked up"
