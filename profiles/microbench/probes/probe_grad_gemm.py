@@ -75,3 +75,26 @@ def run18(name, n=20):
 
 
 run18("real positions, FM term, non-tiny fields only")
+
+# round 4: the tiny tables on the sample-major one-hot path, the row-sorted kernel over the other fields
+tiny_t = [(f, int(base[f]), rows[f]) for f in tiny]
+skip = sum(1 << f for f in tiny)
+
+
+def timeit(name, fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    print(f"{name:55s} {a.elapsed_time(b) / n:.4f} ms")
+
+
+timeit("rp_embed_grad_tiny alone (8 tables, 2 launches)", lambda: hip.embed_grad_tiny(keys, B, tiny_t, dh, wt, gfm, ssum, arena, G, False))
+timeit("rp_embed_grad_gemm(skip_fields) alone", lambda: hip.embed_grad_gemm(sk, sp, B, D, dh, wt, None, gfm, ssum, arena, G, False, skip_fields=skip))
+timeit("both, back to back", lambda: (hip.embed_grad_tiny(keys, B, tiny_t, dh, wt, gfm, ssum, arena, G, False),
+                                      hip.embed_grad_gemm(sk, sp, B, D, dh, wt, None, gfm, ssum, arena, G, False, skip_fields=skip)))

@@ -46,7 +46,7 @@ def test_fused_state_dict_is_loadable_by_torch_adam():
     assert float(back.state[back.param_groups[0]["params"][0]]["step"]) == 2.0
 
 
-def test_step_tables_extend_in_place_and_follow_lr_changes():
+def test_step_tables_extend_in_place_and_follow_lr_changes(monkeypatch):
     """optim.StepTables (the per-step scalar tables a captured hipGraph holds the addresses of): rows are built a chunk
     ahead with the current lr, rebuilt IN PLACE from the current step on when lr changes (steps already taken keep theirs),
     and the buffers only move — `generation` counts it — when the capacity doubles.  Host-side logic: runs on CPU tensors
@@ -55,6 +55,7 @@ def test_step_tables_extend_in_place_and_follow_lr_changes():
     from rec_pangu_amd import hip
     from rec_pangu_amd.optim import StepTables
     hip.lib()
+    monkeypatch.setattr(StepTables, "MIN_CAPACITY", 0)  # (the production default leaves room for 64 k steps)
     b1, b2, eps = 0.9, 0.999, 1e-8
     tabs = StepTables((b1, b2), eps, torch.device("cpu"), t0=0, chunk=16)
     cap0, ptr0, gen0 = tabs.capacity, tabs.sc.data_ptr(), tabs.generation
