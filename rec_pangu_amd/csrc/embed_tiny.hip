@@ -81,20 +81,37 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
     const int fl0 = rfld[32 * wv + i], lc0 = rloc[32 * wv + i];
     const int fl1 = mok1 ? rfld[32 * (wv + 4) + i] : 0, lc1 = mok1 ? rloc[32 * (wv + 4) + i] : ET_NOROW;
     const int s = t >> 2, q = t & 3;  // staging: sample s of the chunk, columns 16 q .. 16 q + 15 of dH and of S
+    // the chunk's rows travel global -> registers one chunk AHEAD: the loads of chunk c + 1 are issued before the matrix
+    // phase of chunk c (one workgroup per CU: nothing else would hide their latency)
+    f32x4 vd[4], vs[4];
+    float g = 0.f, okf = 0.f;
+    int rloc0 = ET_NOSMP, rloc1 = ET_NOSMP;  // this thread's (up to two) entries of the chunk's local-row table
+    auto fetch = [&](int64_t c0) {
+        const int64_t b = c0 + s;
+        const bool ok = b < s_end;
+        const int64_t bc = ok ? b : s_end - 1;
+        okf = ok ? 1.f : 0.f;
+        g = (gfm != nullptr) ? gfm[bc] * okf : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vd[e] = *reinterpret_cast<const f32x4 *>(dh + bc * lddh + 16 * q + 4 * e);
+        if (sum_in != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vs[e] = *reinterpret_cast<const f32x4 *>(sum_in + bc * 64 + 16 * q + 4 * e);
+        }
+        rloc0 = rloc1 = ET_NOSMP;
+        {
+            const int idx = t, j = idx >> 6, ss = idx & 63;
+            if (idx < tt.n * ET_CHUNK && c0 + ss < s_end) rloc0 = keys[(int64_t)tt.field[j] * B + c0 + ss] - tt.base[j];
+        }
+        {
+            const int idx = t + 256, j = idx >> 6, ss = idx & 63;
+            if (idx < tt.n * ET_CHUNK && c0 + ss < s_end) rloc1 = keys[(int64_t)tt.field[j] * B + c0 + ss] - tt.base[j];
+        }
+        // (tables 9 .. 16: two more entries per thread)
+    };
+    fetch(s_begin);
     for (int64_t c0 = s_begin; c0 < s_end; c0 += ET_CHUNK) {
         {
-            const int64_t b = c0 + s;
-            const bool ok = b < s_end;
-            const int64_t bc = ok ? b : s_end - 1;
-            const float okf = ok ? 1.f : 0.f;
-            const float g = (gfm != nullptr) ? gfm[bc] * okf : 0.f;
-            f32x4 vd[4], vs[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vd[e] = *reinterpret_cast<const f32x4 *>(dh + bc * lddh + 16 * q + 4 * e);
-            if (sum_in != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vs[e] = *reinterpret_cast<const f32x4 *>(sum_in + bc * 64 + 16 * q + 4 * e);
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int col = 16 * q + e;
@@ -103,14 +120,16 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
                 tiny_split3(uval, &Zt[0][64 + col][s], &Zt[1][64 + col][s], &Zt[2][64 + col][s]);
             }
             if (q == 0) tiny_split3(g, &Zt[0][128][s], &Zt[1][128][s], &Zt[2][128][s]);
-            for (int idx = t; idx < tt.n * ET_CHUNK; idx += 256) {
+            if (t < tt.n * ET_CHUNK) rid[t >> 6][t & 63] = (uint8_t)rloc0;
+            if (t + 256 < tt.n * ET_CHUNK) rid[(t + 256) >> 6][t & 63] = (uint8_t)rloc1;
+            for (int idx = t + 512; idx < tt.n * ET_CHUNK; idx += 256) {  // more than 8 tables: straight from memory
                 const int j = idx >> 6, ss = idx & 63;
-                const int64_t bb = c0 + ss;
                 int loc = ET_NOSMP;
-                if (bb < s_end) loc = keys[(int64_t)tt.field[j] * B + bb] - tt.base[j];
+                if (c0 + ss < s_end) loc = keys[(int64_t)tt.field[j] * B + c0 + ss] - tt.base[j];
                 rid[j][ss] = (uint8_t)loc;
             }
         }
+        if (c0 + ET_CHUNK < s_end) fetch(c0 + ET_CHUNK);  // in flight across the matrix phase below
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -152,32 +171,39 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
     }
 }
 
-// one workgroup per accumulator row: S = the fixed-order sum of the blocks' partial rows, then
-// G[row, d] (+)= sum_h S[h] W1[h, f 64 + d] + S[64 + d] - S[128] v[row, d]
-__global__ __launch_bounds__(192) void embed_grad_tiny_finish_kernel(const float *__restrict__ partial, int nblk, TinyTables tt,
-                                                                     const float *__restrict__ wt, int64_t ldwt,
-                                                                     const float *__restrict__ arena, float *__restrict__ G,
-                                                                     int accumulate, int has_fm) {
+// one workgroup per accumulator row: S = the fixed-order sum of the blocks' partial rows (four independent chains per
+// column, combined in a fixed order), then  G[row, d] (+)= sum_h S[h] W1[h, f 64 + d] + S[64 + d] - S[128] v[row, d]
+#define ET_FIN_PARTS 4
+__global__ __launch_bounds__(ET_COLS * ET_FIN_PARTS) void embed_grad_tiny_finish_kernel(
+    const float *__restrict__ partial, int nblk, TinyTables tt, const float *__restrict__ wt, int64_t ldwt,
+    const float *__restrict__ arena, float *__restrict__ G, int accumulate, int has_fm) {
+    __shared__ float Sp[ET_FIN_PARTS][ET_COLS];
     __shared__ float S[ET_COLS];
-    const int m = blockIdx.x, c = threadIdx.x;
+    const int m = blockIdx.x, c = threadIdx.x % ET_COLS, part = threadIdx.x / ET_COLS;
     int slot = 0;
     for (int j = 0; j < tt.n; ++j)
         if (m >= tt.acc0[j] && m < tt.acc0[j] + tt.rows[j]) slot = j;
     const int64_t arow = (int64_t)tt.base[slot] + (m - tt.acc0[slot]);
-    if (c < ET_COLS) {
+    {
+        const int per = (nblk + ET_FIN_PARTS - 1) / ET_FIN_PARTS;
+        const int b0 = part * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
         float s = 0.f;
-        for (int b = 0; b < nblk; ++b) s += partial[((int64_t)b * ET_ROWS + m) * ET_COLS + c];
-        S[c] = s;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += partial[((int64_t)b * ET_ROWS + m) * ET_COLS + c];
+        Sp[part][c] = s;
     }
     __syncthreads();
-    if (c < 64) {
-        const float *w = wt + ((int64_t)tt.field[slot] * 64 + c) * ldwt;  // row f 64 + d of W1^T = column of W1
+    if (threadIdx.x < ET_COLS) S[c] = (Sp[0][c] + Sp[1][c]) + (Sp[2][c] + Sp[3][c]);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int d = threadIdx.x;
+        const float *w = wt + ((int64_t)tt.field[slot] * 64 + d) * ldwt;  // row f 64 + d of W1^T = column of W1
         float a = 0.f;
 #pragma unroll 8
         for (int hh = 0; hh < 64; ++hh) a = __builtin_fmaf(S[hh], w[hh], a);
-        a += S[64 + c];
-        if (has_fm) a -= S[128] * arena[arow * 64 + c];
-        float *dst = G + arow * 64 + c;
+        a += S[64 + d];
+        if (has_fm) a -= S[128] * arena[arow * 64 + d];
+        float *dst = G + arow * 64 + d;
         *dst = accumulate ? *dst + a : a;
     }
 }
@@ -231,7 +257,7 @@ extern "C" int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t 
     hipLaunchKernelGGL(embed_grad_tiny_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, keys, B, tt, dh, lddh, sum_in, gfm, per,
                        partial);
     RP_LAUNCH_CHECK("embed_grad_tiny (partial sums)");
-    hipLaunchKernelGGL(embed_grad_tiny_finish_kernel, dim3((unsigned)total), dim3(192), 0, s, partial, (int)nblk, tt, wt, ldwt, arena,
+    hipLaunchKernelGGL(embed_grad_tiny_finish_kernel, dim3((unsigned)total), dim3(ET_COLS * ET_FIN_PARTS), 0, s, partial, (int)nblk, tt, wt, ldwt, arena,
                        grad_arena, accumulate, gfm != nullptr ? 1 : 0);
     RP_LAUNCH_CHECK("embed_grad_tiny (finish)");
     return RP_OK;
