@@ -133,27 +133,29 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            // A operands: lane (i, h) holds onehot[accumulator row 32 mt + i][samples 16 ks + 8 h .. + 7] (bf16 1.0 = 0x3F80)
+            bf16x8 a[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !mok1) continue;  // wave-uniform
                 const int fl = u == 0 ? fl0 : fl1, lc = u == 0 ? lc0 : lc1;
-                // A operand: lane (i, h) holds onehot[accumulator row 32 mt + i][samples 16 ks + 8 h .. + 7]
                 const uint64_t r8 = *reinterpret_cast<const uint64_t *>(&rid[fl][16 * ks + 8 * h]);
                 u32x4 aw;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t e0 = (uint32_t)((r8 >> (16 * j)) & 0xFF), e1 = (uint32_t)((r8 >> (16 * j + 8)) & 0xFF);
-                    aw[j] = (e0 == (uint32_t)lc ? 0x00003F80u : 0u) | (e1 == (uint32_t)lc ? 0x3F800000u : 0u);  // bf16 1.0
+                    aw[j] = (e0 == (uint32_t)lc ? 0x00003F80u : 0u) | (e1 == (uint32_t)lc ? 0x3F800000u : 0u);
                 }
-                const bf16x8 a = __builtin_bit_cast(bf16x8, aw);
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt)
-#pragma unroll
-                    for (int p = 2; p >= 0; --p) {  // smallest pieces first
-                        const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(&Zt[p][32 * nt + i][16 * ks + 8 * h]);
-                        acc[u][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[u][nt], 0, 0, 0);
-                    }
+                a[u] = __builtin_bit_cast(bf16x8, aw);
             }
+            // every B fragment (a piece of 16 samples x 32 columns of z) is read from LDS once and used for both row tiles
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+                for (int p = 2; p >= 0; --p) {  // smallest pieces first
+                    const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(&Zt[p][32 * nt + i][16 * ks + 8 * h]);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq, acc[0][nt], 0, 0, 0);
+                    if (mok1) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq, acc[1][nt], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
