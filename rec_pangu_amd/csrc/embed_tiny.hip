@@ -45,7 +45,7 @@ __device__ __forceinline__ void tiny_split3(float v, __bf16 *p0, __bf16 *p1, __b
     *reinterpret_cast<uint16_t *>(p2) = (uint16_t)(u >> 16);
 }
 
-__global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
+__global__ __launch_bounds__(256, 2) void embed_grad_tiny_partial_kernel(
     const int32_t *__restrict__ keys, int64_t B, TinyTables tt, const float *__restrict__ dh, int64_t lddh,
     const float *__restrict__ sum_in, const float *__restrict__ gfm, int64_t per_blk, float *__restrict__ partial) {
     __shared__ __attribute__((aligned(16))) __bf16 Zt[3][ET_COLS][ET_LD];      // [piece][column of z][sample of the chunk]
@@ -66,20 +66,19 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
         const int p = e / ((ET_COLS - 129) * ET_LD), rest = e - p * ((ET_COLS - 129) * ET_LD);
         Zt[p][129 + rest / ET_LD][rest % ET_LD] = (__bf16)0.f;
     }
-    f32x16 acc[2][5];
+    f32x16 acc[5];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     const int64_t s_begin = (int64_t)blockIdx.x * per_blk;
     const int64_t s_end = s_begin + per_blk < B ? s_begin + per_blk : B;
     __syncthreads();
-    // wave wv owns the accumulator row tiles wv and wv + 4 (7 tiles: the last wave has one)
-    const bool mok1 = wv + 4 < ET_ROWS / 32;
-    const int fl0 = rfld[32 * wv + i], lc0 = rloc[32 * wv + i];
-    const int fl1 = mok1 ? rfld[32 * (wv + 4) + i] : 0, lc1 = mok1 ? rloc[32 * (wv + 4) + i] : ET_NOROW;
+    // the 7 accumulator row tiles are split over TWO workgroups per block of samples (blockIdx.y: tiles 0..3 / 4..6, one per
+    // wave): both stage the same rows of z (the second read is an L2 hit), each does half the matrix work
+    const int mt = 4 * (int)blockIdx.y + wv;
+    const bool mok = mt < ET_ROWS / 32;
+    const int fl0 = mok ? rfld[32 * mt + i] : 0, lc0 = mok ? rloc[32 * mt + i] : ET_NOROW;
     const int s = t >> 2, q = t & 3;  // staging: sample s of the chunk, columns 16 q .. 16 q + 15 of dH and of S
     // the chunk's rows travel global -> registers one chunk AHEAD: the loads of chunk c + 1 are issued before the matrix
     // phase of chunk c (one workgroup per CU: nothing else would hide their latency)
@@ -133,43 +132,35 @@ __global__ __launch_bounds__(256, 1) void embed_grad_tiny_partial_kernel(
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            // A operands: lane (i, h) holds onehot[accumulator row 32 mt + i][samples 16 ks + 8 h .. + 7] (bf16 1.0 = 0x3F80)
-            bf16x8 a[2];
+            // A operand: lane (i, h) holds onehot[accumulator row 32 mt + i][samples 16 ks + 8 h .. + 7] (bf16 1.0 = 0x3F80)
+            const uint64_t r8 = *reinterpret_cast<const uint64_t *>(&rid[fl0][16 * ks + 8 * h]);
+            u32x4 aw;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int fl = u == 0 ? fl0 : fl1, lc = u == 0 ? lc0 : lc1;
-                const uint64_t r8 = *reinterpret_cast<const uint64_t *>(&rid[fl][16 * ks + 8 * h]);
-                u32x4 aw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t e0 = (uint32_t)((r8 >> (16 * j)) & 0xFF), e1 = (uint32_t)((r8 >> (16 * j + 8)) & 0xFF);
-                    aw[j] = (e0 == (uint32_t)lc ? 0x00003F80u : 0u) | (e1 == (uint32_t)lc ? 0x3F800000u : 0u);
-                }
-                a[u] = __builtin_bit_cast(bf16x8, aw);
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e0 = (uint32_t)((r8 >> (16 * j)) & 0xFF), e1 = (uint32_t)((r8 >> (16 * j + 8)) & 0xFF);
+                aw[j] = (e0 == (uint32_t)lc0 ? 0x00003F80u : 0u) | (e1 == (uint32_t)lc0 ? 0x3F800000u : 0u);
             }
-            // every B fragment (a piece of 16 samples x 32 columns of z) is read from LDS once and used for both row tiles
+            const bf16x8 a = __builtin_bit_cast(bf16x8, aw);
+            if (mok) {  // wave-uniform
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt)
+                for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
-                for (int p = 2; p >= 0; --p) {  // smallest pieces first
-                    const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(&Zt[p][32 * nt + i][16 * ks + 8 * h]);
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq, acc[0][nt], 0, 0, 0);
-                    if (mok1) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq, acc[1][nt], 0, 0, 0);
-                }
+                    for (int p = 2; p >= 0; --p) {  // smallest pieces first
+                        const bf16x8 bq = *reinterpret_cast<const bf16x8 *>(&Zt[p][32 * nt + i][16 * ks + 8 * h]);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[nt], 0, 0, 0);
+                    }
+            }
         }
         __syncthreads();
     }
-    // acc[u][nt][r] = element (row 32 mt + (r & 3) + 8 (r >> 2) + 4 h, column 32 nt + i)
+    // acc[nt][r] = element (row 32 mt + (r & 3) + 8 (r >> 2) + 4 h, column 32 nt + i)
     float *P = partial + (int64_t)blockIdx.x * ET_ROWS * ET_COLS;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !mok1) continue;
-        const int mt = u == 0 ? wv : wv + 4;
+    if (mok) {
 #pragma unroll
         for (int nt = 0; nt < 5; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                P[(int64_t)(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * ET_COLS + 32 * nt + i] = acc[u][nt][r];
+                P[(int64_t)(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h) * ET_COLS + 32 * nt + i] = acc[nt][r];
     }
 }
 
@@ -256,7 +247,7 @@ extern "C" int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t 
     RP_REQUIRE(workspace_bytes >= need, "embed_grad_tiny: workspace %zu < %zu bytes", workspace_bytes, need);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(embed_grad_tiny_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, s, keys, B, tt, dh, lddh, sum_in, gfm, per,
+    hipLaunchKernelGGL(embed_grad_tiny_partial_kernel, dim3((unsigned)nblk, 2), dim3(256), 0, s, keys, B, tt, dh, lddh, sum_in, gfm, per,
                        partial);
     RP_LAUNCH_CHECK("embed_grad_tiny (partial sums)");
     hipLaunchKernelGGL(embed_grad_tiny_finish_kernel, dim3((unsigned)total), dim3(ET_COLS * ET_FIN_PARTS), 0, s, partial, (int)nblk, tt, wt, ldwt, arena,
