@@ -156,8 +156,8 @@ int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, in
 /* The same gradient for TINY tables (each <= 254 rows, <= 224 rows together, <= 16 tables), SAMPLE-major (csrc/embed_tiny.hip):
  * G[r] = (sum_b dH[b]) . W1_f^T + sum_b g_fm[b] S[b] - (sum_b g_fm[b]) v_r over the samples b with id_f[b] = r; the 129-wide row
  * sums are one-hot GEMMs on the matrix core (one-hot exact in bf16, the data split into three bf16 pieces, fp32 accumulation
- * in a fixed order: deterministic), every sample's dH / S row is read once for all tiny tables.  Writes EVERY row of those
- * tables (0 for rows nobody looked up; accumulate != 0 adds).  keys [F * B]: arena row of pair (field, sample) at
+ * in a fixed order: deterministic), every sample's dH / S row is read once for all tiny tables.  Writes the rows somebody
+ * looked up in this batch (accumulate != 0 adds), like rp_embed_grad_gemm: other rows are not touched.  keys [F * B]: arena row of pair (field, sample) at
  * field * B + sample (rp_embed_keys / the gather's keys_out).  Host arrays: tiny_field (field index), tiny_base (first arena
  * row), tiny_rows.  rp_embed_grad_gemm(skip_fields = bits of those fields) then covers the other fields. */
 int rp_embed_grad_tiny_workspace_bytes(int64_t B, size_t *bytes);

@@ -12,14 +12,14 @@
 // instead of once per pair (the row-sorted kernel spends 128 x 64 x 64 x 6 MFMA products and two gathers per 128 pairs).
 //   rp_embed_grad_tiny      partial sums per block of samples ([blocks, 224, 160] fp32 workspace), then one small launch:
 //                           fixed-order sum over the blocks, the [129] -> [64] map with W1_f^T in fp32 FMAs, the FM term,
-//                           the store into the gradient arena (every row of the tiny tables: a row nobody looked up gets 0).
+//                           the store into the gradient arena (rows somebody looked up in this batch: column 129 counts).
 // rp_embed_grad_gemm then leaves those fields out (skip_mask).  Up to 16 tables of <= 254 rows, 224 rows together.
 #include "common.h"
 #include "bfsplit.h"
 
 #define ET_MAXF 16
 #define ET_ROWS 224   // accumulator rows: 7 m-tiles of 32
-#define ET_COLS 160   // 64 (dH sums) + 64 (g S sums) + 1 (g sums) + zero padding: 5 n-tiles of 32
+#define ET_COLS 160   // 64 (dH sums) + 64 (g S sums) + 1 (g sums) + 1 (lookups of the row) + zero padding: 5 n-tiles of 32
 #define ET_LD 72      // bf16 per LDS row: 64 samples + 8 pad (144 B = 9 x 16 B: conflict-free ds_read_b128)
 #define ET_CHUNK 64
 #define ET_NOROW 254  // rloc of an accumulator row no table owns
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(256, 2) void embed_grad_tiny_partial_kernel(
         rfld[m] = (uint8_t)slot;
         rloc[m] = (uint8_t)loc;
     }
-    for (int e = t; e < 3 * (ET_COLS - 129) * ET_LD; e += 256) {  // the padding columns stay zero for the whole launch
-        const int p = e / ((ET_COLS - 129) * ET_LD), rest = e - p * ((ET_COLS - 129) * ET_LD);
-        Zt[p][129 + rest / ET_LD][rest % ET_LD] = (__bf16)0.f;
+    for (int e = t; e < 3 * (ET_COLS - 130) * ET_LD; e += 256) {  // the padding columns stay zero for the whole launch
+        const int p = e / ((ET_COLS - 130) * ET_LD), rest = e - p * ((ET_COLS - 130) * ET_LD);
+        Zt[p][130 + rest / ET_LD][rest % ET_LD] = (__bf16)0.f;
     }
     f32x16 acc[5];
 #pragma unroll
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void embed_grad_tiny_partial_kernel(
                 tiny_split3(uval, &Zt[0][64 + col][s], &Zt[1][64 + col][s], &Zt[2][64 + col][s]);
             }
             if (q == 0) tiny_split3(g, &Zt[0][128][s], &Zt[1][128][s], &Zt[2][128][s]);
+            if (q == 1) tiny_split3(okf, &Zt[0][129][s], &Zt[1][129][s], &Zt[2][129][s]);  // column 129 counts the lookups
             if (t < tt.n * ET_CHUNK) rid[t >> 6][t & 63] = (uint8_t)rloc0;
             if (t + 256 < tt.n * ET_CHUNK) rid[(t + 256) >> 6][t & 63] = (uint8_t)rloc1;
             for (int idx = t + 512; idx < tt.n * ET_CHUNK; idx += 256) {  // more than 8 tables: straight from memory
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(ET_COLS * ET_FIN_PARTS) void embed_grad_tiny_finish
         a += S[64 + d];
         if (has_fm) a -= S[128] * arena[arow * 64 + d];
         float *dst = G + arow * 64 + d;
-        *dst = accumulate ? *dst + a : a;
+        // a row nobody looked up in THIS batch is left alone, like the row-sorted path leaves it: under the deferred
+        // optimizer it may still hold the waiting gradient of an earlier step
+        if (S[129] > 0.f) *dst = accumulate ? *dst + a : a;
     }
 }
 
