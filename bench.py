@@ -124,6 +124,7 @@ KERNELS_OF = {
     "lazy_adam_flush": ("lazy_flush_wave_kernel", "lazy_adam_flush_kernel"),
     "sort_pairs_i32": ("sort_hist", "sort_scan", "sort_scatter", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
+    "embed_grad_tiny": ("embed_grad_tiny_partial_kernel", "embed_grad_tiny_finish_kernel"),
     "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
     "attention_core_fwd": ("attn_core_fwd_kernel",),
     "attention_core_bwd": ("attn_core_bwd_kernel",),
@@ -593,6 +594,10 @@ def main():
     D = model.embedding_dim
     n_unique = int(sum(torch.unique(batches[0][f"C{i + 1}"]).numel() for i in range(F)))
     n_pairs = F * local_B
+    # the tables whose gradient rows come from the sample-major one-hot launch (rp_embed_grad_tiny): their pairs and rows
+    # are not the row-sorted kernel's
+    tiny_tabs = (emb._tiny_tables() if hasattr(emb, "_tiny_tables") and not sharded else None) or []
+    n_unique_tiny = int(sum(torch.unique(batches[0][f"C{f + 1}"]).numel() for f, _, _ in tiny_tabs))
     d_in = F * D + ND
     has_fm = args.model == "deepfm"
 
@@ -617,8 +622,13 @@ def main():
             # of their rows are re-reads a cache should absorb), sorted (key, position) pairs read, table row read (FM) +
             # gradient row written per unique row, W1^T once; the dX rows themselves never touch memory
             fm = has_fm and dd == D
-            return local_B * 64 * 4 + (local_B * rb if fm else 0) + 8 * n_pairs + (2 if fm else 1) * n_unique * rb \
-                + F * 64 * rb, 2.0 * n_pairs * 64 * dd
+            np_, nu_ = n_pairs - len(tiny_tabs) * local_B, n_unique - n_unique_tiny
+            return local_B * 64 * 4 + (local_B * rb if fm else 0) + 8 * np_ + (2 if fm else 1) * nu_ * rb \
+                + (F - len(tiny_tabs)) * 64 * rb, 2.0 * np_ * 64 * dd
+        if entry == "embed_grad_tiny":    # dH and the FM sum row of every sample once, g_fm, one key per (sample, tiny table);
+            # (the [blocks, 224, 160] partial sums are written and read once more: 37 MB at B = 65536, not counted)
+            return local_B * (2 * 64 * 4 + 4 + 4 * len(tiny_tabs)) + (2 * n_unique_tiny + len(tiny_tabs) * 64) * rb, \
+                2.0 * 224 * 160 * local_B
         if entry == "lazy_adam_catchup":      # deferred mode: p,m,v read+written, g read + cleared, per unique row
             return 8 * n_unique * rb, 0
         if entry == "lazy_adam_rows_step":    # p,m,v read+written, g read + cleared, per unique touched row

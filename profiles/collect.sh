@@ -15,7 +15,7 @@ W=5; K=20
 FLAGS="--no-cpu-baseline --no-small-batch --pre-roll $PRE --warmup $W --steps $K $*"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT gpurun_out/profiles
-OURS='adam_kernel|embed_|linear_|wgrad_|transpose_kernel|relu_bwd|sigmoid_bce|loss_finish|zero_rows|iota_i32|cin_|crossnet|attn_|mmoe_|lazy_|counter_add|accumulate|pool_|fm_|bn_|batchnorm|field_sort|sort_hist|sort_scan|sort_scatter|mlp_tail|dropout|route_|shard_|DeviceRadixSort|radix|onesweep'
+OURS='adam_kernel|embed_|linear_|wgrad_|transpose_kernel|relu_bwd|sigmoid_bce|loss_finish|zero_rows|iota_i32|cin_|crossnet|attn_|mmoe_|lazy_|counter_add|accumulate|pool_|fm_|bn_|batchnorm|field_sort|sort_hist|sort_scan|sort_scatter|mlp_tail|dropout|route_|shard_|DeviceRadixSort|radix|onesweep|multi_copy|copy_rows|dice_'
 # steps before the timed region: (cold: W + min(K,64)) + PRE + W when PRE > 0, else W
 if [ "$PRE" -gt 0 ]; then S0=$((W + K + PRE + W - 3)); else S0=$((W - 3)); fi  # (cold: min(K,64) = K at K=20)
 S1=$((S0 + K + 3))

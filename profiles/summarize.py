@@ -23,7 +23,7 @@ import sys
 OURS = ("adam_kernel", "embed_", "linear_", "wgrad_", "transpose_kernel", "relu_bwd", "sigmoid_bce", "loss_finish",
         "zero_rows", "iota_i32", "cin_", "crossnet", "attn_", "mmoe_", "radix_sort", "lazy_", "a2a_", "fm_", "bn_",
         "trampoline_kernel", "onesweep", "field_sort", "sort_hist", "sort_scan", "sort_scatter", "mlp_tail", "dropout", "route_", "shard_", "batchnorm", "counter_add",
-        "accumulate", "pool_")
+        "accumulate", "pool_", "multi_copy", "copy_rows", "dice_")
 LAST = 100
 
 
