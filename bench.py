@@ -229,9 +229,10 @@ def main():
     ap.add_argument("--graph-backend", default=None, choices=["plan", "hipgraph"],
                     help="force the replay form of the captured step (default: plan, falling back to hipgraph per model)")
     ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16: SECONDARY inference line (--mode forward only) — the fused lookup + FM + first layer reads a "
-                         "bf16 snapshot of the tables (half the gather traffic; logits within 6e-2 of the fp32 tables', outside "
-                         "the 1e-4 parity gate; never the headline)")
+                    help="bf16: SECONDARY lines, never the headline — the fused lookup + FM + first layer reads a bf16 copy of "
+                         "the tables (half the gather traffic; logits within 6e-2 of the fp32 tables', outside the 1e-4 parity "
+                         "gate).  --mode forward: a snapshot (inference); --mode train: the copy is kept current by the deferred "
+                         "optimizer kernels, the activation is stored as bf16, master tables / moments / accumulation stay fp32")
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
                     help="row-sharded runs: bf16 = the looked-up rows and their gradients travel as bf16 (half the xGMI bytes; "
                          "stated tolerance, tests/test_sharded_gloo.py::test_bf16_wire_mode_two_ranks); fp32 = parity mode")
@@ -289,8 +290,13 @@ def main():
             m.wire_dtype = torch.bfloat16
     model.train()
     if args.storage == "bf16":
-        assert args.mode == "forward" and not sharded and args.model == "deepfm", "--storage bf16 is the forward-only DeepFM line"
-        model.embedding_layer.bf16_lookup()
+        assert not sharded and args.model == "deepfm" and hidden == (64, 64, 64), "--storage bf16 is a DeepFM [64,64,64] line"
+        if args.mode == "forward":
+            model.embedding_layer.bf16_lookup()
+        else:
+            # SECONDARY training line (never `value` of the default run): bf16 lookup copy of the tables + bf16 activation,
+            # fp32 master tables, moments and accumulation (EmbeddingLayer.bf16_training; tolerance: tests/test_hip_models.py)
+            model.embedding_layer.bf16_training(True)
     lazy = args.optimizer == "lazy" and args.mode == "train"
     opt = make_adam(model, 1e-3, lazy_tables=(args.optimizer == "lazy"), replay=args.replay,
                     defer=(None if args.defer is None else args.defer == "on"))
@@ -812,7 +818,10 @@ def main():
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32" if args.storage == "fp32" else "bf16 tables (secondary inference line; fp32 accumulation)",
+            "dtype": "f32" if args.storage == "fp32" else
+                     ("bf16 tables (secondary inference line; fp32 accumulation)" if args.mode == "forward" else
+                      "bf16 lookup copy of the tables + bf16 activation (SECONDARY training line with a stated tolerance; fp32 "
+                      "master tables, moments and accumulation)"),
             "config": {"workload": f"{type(model).__name__} ({args.model}), {F} sparse fields (Criteo-Kaggle "
                                    f"cardinalities/{args.vocab_scale}, {n_table_rows} arena rows) x D={D} + {ND} dense, "
                                    f"batch {local_B} per GPU (global {B}), "

@@ -107,11 +107,17 @@ int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, cons
 /* bf16-STORAGE inference (SURVEY D6's secondary mode; the fp32 tables stay the parity path and the training path): the same
  * launch over a bf16 copy of the arena (rows of D bf16 = 128 bytes at D = 64), fp32 accumulation everywhere, nothing stored
  * but h1 and the FM term.  The looked-up values differ from the fp32 tables' by bf16 rounding (2^-9 relative per element):
- * logits within 6e-2 (measured 3.7e-2 at the Criteo shape: tests/test_hip_models.py), not within the 1e-4 parity gate. */
+ * logits within 6e-2 (measured 3.7e-2 at the Criteo shape: tests/test_hip_models.py), not within the 1e-4 parity gate.
+ * bf16-STORAGE TRAINING (round 4, secondary mode with a stated tolerance: SURVEY D6): the same launch also stores what the
+ * backward needs — x_bf16 [B, ldx] as BF16 (the gathered values are bf16 already: exact; the dense columns are rounded to
+ * bf16 for the weight gradient only, the forward uses them in fp32), sum_out [B, 64] fp32, keys_out — all NULL for
+ * inference.  The bf16 arena then is the lookup copy the deferred optimizer kernels keep current (rp_lazy_adam_catchup's
+ * shadow_bf16); rp_linear_wgrad_xbf16 is the weight gradient over the bf16 activation. */
 int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
                                     const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
                                     int D, const float *W, int64_t ldw, const float *bias, float *h1, float *fm_out,
-                                    int32_t *err_flag, rp_stream_t stream);
+                                    void *x_bf16, int64_t ldx, float *sum_out, int32_t *keys_out, int32_t *err_flag,
+                                    rp_stream_t stream);
 
 /* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
  * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
@@ -181,6 +187,11 @@ int rp_linear_wgrad_workspace_bytes(int64_t M, int N, int K, size_t *bytes);
 int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dw, int64_t lddw,
                     float *db, int64_t M, int N, int K, int accumulate, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
+/* the same with the activation stored as bf16 (x_bf16 [M, ldx] bf16, ldx even, 4-byte aligned; the bf16-storage training
+ * mode): half the bytes of the dominant operand; bf16 matrix-core modes and N <= 128 only (RP_ERR_UNSUPPORTED otherwise) */
+int rp_linear_wgrad_xbf16(const float *dy, int64_t lddy, const void *x_bf16, int64_t ldx, float *dw, int64_t lddw,
+                          float *db, int64_t M, int N, int K, int accumulate, void *workspace, size_t workspace_bytes,
+                          rp_stream_t stream);
 /* The weight gradient of a layer whose input is the embedding lookup, WITHOUT the stored activation: the first Kg = F*64
  * columns of X are gathered — X[m, f*64 + j] = arena[keys[f*M + m]*64 + j], keys = the arena rows the forward saved
  * (rp_embed_gather_linear_fwd keys_out / rp_embed_keys) — the remaining K - Kg <= 64 columns (dense features) come from
@@ -555,13 +566,18 @@ int rp_lazy_adam_cf_terms(double beta1, int *terms);
  *                         step with g = 0 IS the zero-gradient step).  t_dev: device counter of completed steps.
  *   rp_lazy_adam_flush_deferred  the same for every row of the arena through t_target (g may be NULL when no
  *                         gradient arena exists yet); stamps last[row] = t_target.
- * Per row the same operations on the same values in the same order as rp_lazy_adam_rows: identical bits after a flush. */
+ * Per row the same operations on the same values in the same order as rp_lazy_adam_rows: identical bits after a flush.
+ * shadow_bf16 (both; NULL = none): the bf16 LOOKUP COPY of the tables ([rows, D] bf16, 16-byte aligned) of the bf16-storage
+ * training mode — every parameter row the launch writes is also written there, rounded to nearest even; rp_rows_to_bf16
+ * refreshes the run heads of a sorted key list after an update that went another way. */
 int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                          int32_t *last, const float *step_scalars, int64_t t_done, int mark, double beta1, double beta2,
-                         double eps, const float *cf_table, int64_t cf_from, const int32_t *t_dev, rp_stream_t stream);
+                         double eps, const float *cf_table, int64_t cf_from, const int32_t *t_dev, void *shadow_bf16,
+                         rp_stream_t stream);
 int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float *g, float *m, float *v, int32_t *last,
                                 const float *step_scalars, int64_t t_target, double beta1, double beta2, double eps,
-                                const float *cf_table, int64_t cf_from, rp_stream_t stream);
+                                const float *cf_table, int64_t cf_from, void *shadow_bf16, rp_stream_t stream);
+int rp_rows_to_bf16(const int32_t *sorted_keys, int64_t n, int D, const float *p, void *shadow_bf16, rp_stream_t stream);
 int rp_lazy_adam_cf_table(const double *ns_d, int64_t t_end, int64_t cf_from, double beta1, double beta2, float *cf_table,
                           int64_t capacity, int64_t built_to, const int32_t *t_dev, rp_stream_t stream);
 

@@ -200,6 +200,22 @@ struct LazyCfg {
     float one_m_b1, b2, sqrt_b2, one_m_b2, eps;
 };
 
+// bf16 LOOKUP COPY of the tables (round 4, the bf16-storage training mode): wherever the deferred kernels write a parameter
+// row they also write its round-to-nearest-even bf16 image to `shadow` (same [rows, D] layout, 2 bytes per element) — the
+// copy the forward gathers from (half the row bytes); the fp32 master and the moments stay what the optimizer works on.
+__device__ __forceinline__ uint32_t rp_bf16_rn(float v) {
+    uint32_t u = __float_as_uint(v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void rp_store_bf16(uint16_t *dst, float v) { *dst = (uint16_t)rp_bf16_rn(v); }
+__device__ __forceinline__ void rp_store_bf16(uint16_t *dst, f32x4 v) {
+    uint2 w;
+    w.x = rp_bf16_rn(v[0]) | (rp_bf16_rn(v[1]) << 16);
+    w.y = rp_bf16_rn(v[2]) | (rp_bf16_rn(v[3]) << 16);
+    *reinterpret_cast<uint2 *>(dst) = w;
+}
+
 // ------------------------------------------------------------------------------------------------
 // CLOSED-FORM replay of k zero-gradient steps (tolerance mode; the serial replay above stays the bit-exact one).
 //
@@ -880,7 +896,8 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_kernel(const int32_t *_
                                                                 int32_t *__restrict__ last,
                                                                 const float2 *__restrict__ sc, int t_done, int mark,
                                                                 LazyCfg c, const CfEntry *__restrict__ cf, int cf_from,
-                                                                const int32_t *__restrict__ t_dev) {
+                                                                const int32_t *__restrict__ t_dev,
+                                                                uint16_t *__restrict__ shadow) {
     if (t_dev != nullptr) t_done = *t_dev;  // completed steps (graph replays)
     constexpr int GPB = 256 / TPR;
     const int t = threadIdx.x % TPR;
@@ -907,6 +924,7 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_kernel(const int32_t *_
             }
             lazy_owed<T>(p, m, v, apply, l, t_done, g, sc, c, cf, cf_from);
             *reinterpret_cast<T *>(P + off) = p;
+            if (shadow != nullptr) rp_store_bf16(shadow + off, p);
             *reinterpret_cast<T *>(Mo + off) = m;
             *reinterpret_cast<T *>(Vo + off) = v;
         }
@@ -928,7 +946,7 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_deferred_kernel(int64_t R
                                                                        float *__restrict__ Vo, int32_t *__restrict__ last,
                                                                        const float2 *__restrict__ sc, int t_target,
                                                                        LazyCfg c, const CfEntry *__restrict__ cf,
-                                                                       int cf_from) {
+                                                                       int cf_from, uint16_t *__restrict__ shadow) {
     constexpr int GPB = 256 / TPR;
     constexpr int VW = sizeof(T) / sizeof(float);
     const int t = threadIdx.x % TPR;
@@ -952,6 +970,7 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_deferred_kernel(int64_t R
             }
             lazy_owed<T>(p, m, v, apply, l, t_target, g, sc, c, cf, cf_from);
             *reinterpret_cast<T *>(P + off) = p;
+            if (shadow != nullptr) rp_store_bf16(shadow + off, p);
             *reinterpret_cast<T *>(Mo + off) = m;
             *reinterpret_cast<T *>(Vo + off) = v;
         }
@@ -962,8 +981,9 @@ __global__ __launch_bounds__(256) void lazy_adam_flush_deferred_kernel(int64_t R
 extern "C" int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                                     int32_t *last, const float *step_scalars, int64_t t_done, int mark, double beta1,
                                     double beta2, double eps, const float *cf_table, int64_t cf_from,
-                                    const int32_t *t_dev, rp_stream_t stream) {
+                                    const int32_t *t_dev, void *shadow_bf16, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && p && m && v && last && step_scalars, "lazy_adam_catchup: null pointer");
+    RP_REQUIRE(shadow_bf16 == nullptr || (reinterpret_cast<uintptr_t>(shadow_bf16) & 15u) == 0, "lazy_adam_catchup: unaligned bf16 copy");
     RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
                "lazy_adam_catchup: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     RP_REQUIRE(D >= 1, "lazy_adam_catchup: D must be positive");
@@ -978,7 +998,7 @@ extern "C" int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D
     const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
 #define CALL(T, TY)                                                                                                      \
     hipLaunchKernelGGL((lazy_adam_catchup_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
-                       sc, (int)t_done, mark, c, cf, (int)cf_from, t_dev)
+                       sc, (int)t_done, mark, c, cf, (int)cf_from, t_dev, reinterpret_cast<uint16_t *>(shadow_bf16))
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_catchup");
@@ -987,8 +1007,11 @@ extern "C" int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D
 
 extern "C" int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float *g, float *m, float *v, int32_t *last,
                                            const float *step_scalars, int64_t t_target, double beta1, double beta2,
-                                           double eps, const float *cf_table, int64_t cf_from, rp_stream_t stream) {
+                                           double eps, const float *cf_table, int64_t cf_from, void *shadow_bf16,
+                                           rp_stream_t stream) {
     RP_REQUIRE(p && m && v && last && step_scalars, "lazy_adam_flush_deferred: null pointer");
+    RP_REQUIRE(shadow_bf16 == nullptr || (reinterpret_cast<uintptr_t>(shadow_bf16) & 15u) == 0,
+               "lazy_adam_flush_deferred: unaligned bf16 copy");
     RP_REQUIRE(!cf_table || (cf_from >= 1 && eps > 0.0 && (((uintptr_t)cf_table) & 31u) == 0),
                "lazy_adam_flush_deferred: the closed-form replay needs cf_from >= 1, eps > 0 and a 32-byte aligned table");
     RP_REQUIRE(D >= 1 && t_target < INT32_MAX - 1, "lazy_adam_flush_deferred: bad D / step");
@@ -1003,10 +1026,31 @@ extern "C" int rp_lazy_adam_flush_deferred(int64_t rows, int D, float *p, float 
     const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
 #define CALL(T, TY)                                                                                                       \
     hipLaunchKernelGGL((lazy_adam_flush_deferred_kernel<T, TY>), dim3((unsigned)nb), dim3(256), 0, s, rows, D, p, g, m, v, \
-                       last, sc, (int)t_target, c, cf, (int)cf_from)
+                       last, sc, (int)t_target, c, cf, (int)cf_from, reinterpret_cast<uint16_t *>(shadow_bf16))
     LAZY_DISPATCH(tpr, vw, CALL);
 #undef CALL
     RP_LAUNCH_CHECK("lazy_adam_flush_deferred");
+    return RP_OK;
+}
+
+// shadow[row, :] = bf16(p[row, :]) for the run heads of a sorted key list (the bf16 lookup copy after an update that did
+// not go through the deferred kernels: the first step after the optimizer state came into being)
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
+                                                           const float *__restrict__ P, uint16_t *__restrict__ shadow) {
+    const int64_t i = (int64_t)blockIdx.x * 16 + threadIdx.x / 16;
+    if (i >= n) return;
+    const int32_t row = sk[i];
+    if (i > 0 && sk[i - 1] == row) return;
+    for (int c = threadIdx.x % 16; c < D; c += 16) rp_store_bf16(shadow + (int64_t)row * D + c, P[(int64_t)row * D + c]);
+}
+
+extern "C" int rp_rows_to_bf16(const int32_t *sorted_keys, int64_t n, int D, const float *p, void *shadow_bf16,
+                               rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && p && shadow_bf16 && D >= 1, "rows_to_bf16: bad argument");
+    if (n == 0) return RP_OK;
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)rp_cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, sorted_keys, n, D, p,
+                       reinterpret_cast<uint16_t *>(shadow_bf16));
+    RP_LAUNCH_CHECK("rows_to_bf16");
     return RP_OK;
 }
 

@@ -397,8 +397,16 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             const int r = row_of(u);
             *reinterpret_cast<f32x4 *>(&Xs[r][col_of(u)]) = cur[u];
             const int64_t br = blk * 128 + r;
-            if (STORE_X && (FULL || (x != nullptr && br < B)))
-                *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + col_of(u)) = cur[u];
+            if (STORE_X && (FULL || (x != nullptr && br < B))) {
+                if (BF16_ROWS) {  // the activation is stored as bf16 (the values ARE bf16: exact): 8 bytes per lane
+                    uint2 w2;
+                    w2.x = (__float_as_uint(cur[u][0]) >> 16) | (__float_as_uint(cur[u][1]) & 0xFFFF0000u);
+                    w2.y = (__float_as_uint(cur[u][2]) >> 16) | (__float_as_uint(cur[u][3]) & 0xFFFF0000u);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(x) + br * ldx + (int64_t)f * D + col_of(u)) = w2;
+                } else {
+                    *reinterpret_cast<f32x4 *>(x + br * ldx + (int64_t)f * D + col_of(u)) = cur[u];
+                }
+            }
             S[u] += cur[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[u] = __builtin_fmaf(cur[u][e], cur[u][e], q[u]);
@@ -467,7 +475,17 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             dv[e] = k < ND ? dense.p[k][bc] : 0.f;
         }
         __syncthreads();
-        if (x != nullptr && bok) {
+        if (x != nullptr && bok && BF16_ROWS) {  // bf16 activation: the dense columns rounded to nearest even
+            uint16_t *xt = reinterpret_cast<uint16_t *>(x) + b * ldx + (int64_t)F * D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (8 * h + e < ND) {
+                    uint32_t ub = __float_as_uint(dv[e]);
+                    ub += 0x7FFFu + ((ub >> 16) & 1u);
+                    xt[8 * h + e] = (uint16_t)(ub >> 16);
+                }
+            for (int64_t j = (int64_t)F * D + ND + h; j < ldx; j += 2) reinterpret_cast<uint16_t *>(x)[b * ldx + j] = 0;
+        } else if (x != nullptr && bok) {
             float *xt = x + b * ldx + (int64_t)F * D;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -492,7 +510,9 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
         }
     } else {
-        if (x != nullptr && bok)
+        if (x != nullptr && bok && BF16_ROWS)
+            for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) reinterpret_cast<uint16_t *>(x)[b * ldx + j] = 0;
+        else if (x != nullptr && bok)
             for (int64_t j = (int64_t)F * D + h; j < ldx; j += 2) x[b * ldx + j] = 0.f;
         if (xd != nullptr && bok)
             for (int j = h; j < 64; j += 2) xd[b * 64 + j] = 0.f;
@@ -524,6 +544,10 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
             fmv += __shfl_xor(fmv, 2, 64);
             fmv += __shfl_xor(fmv, 4, 64);
             if ((FULL || br < B) && fm_out != nullptr && s8 == 0) fm_out[br] = 0.5f * fmv;
+            if ((FULL || br < B) && sum_out != nullptr) {  // (training: the FM backward needs the field sums)
+                *reinterpret_cast<f32x4 *>(sum_out + br * D + 8 * s8) = S[2 * u];
+                *reinterpret_cast<f32x4 *>(sum_out + br * D + 8 * s8 + 4) = S[2 * u + 1];
+            }
         }
         return;
     }
@@ -565,15 +589,19 @@ extern "C" int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row
                                       h1, fm_out, sum_out, keys_out, err_flag, xd, stream);
 }
 
-// the same launch over a bf16 copy of the arena (rows of D bf16): inference with bf16-STORED tables, fp32 accumulation.
-// Nothing is stored but h1 and the FM term (x, xd, sum_out, keys_out are for the training path, which keeps fp32 tables).
+// the same launch over a bf16 copy of the arena (rows of D bf16): bf16-STORED tables, fp32 accumulation.  Inference stores
+// nothing but h1 and the FM term; the bf16-storage training mode also stores the activation (as bf16), the field sums and
+// the keys.
 extern "C" int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
                                                const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
                                                int64_t B, int D, const float *W, int64_t ldw, const float *bias, float *h1,
-                                               float *fm_out, int32_t *err_flag, rp_stream_t stream) {
+                                               float *fm_out, void *x_bf16, int64_t ldx, float *sum_out, int32_t *keys_out,
+                                               int32_t *err_flag, rp_stream_t stream) {
+    RP_REQUIRE(x_bf16 == nullptr || (ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x_bf16) & 7u) == 0),
+               "embed_gather_linear_fwd_bf16: the bf16 activation needs ldx %% 4 == 0 and 8-byte alignment");
     return embed_gather_linear_launch(reinterpret_cast<const float *>(arena_bf16), true, row_base, row_count, idx_ptrs, F,
-                                      dense_ptrs, ND, B, D, nullptr, 0, W, ldw, bias, h1, fm_out, nullptr, nullptr, err_flag,
-                                      nullptr, stream);
+                                      dense_ptrs, ND, B, D, reinterpret_cast<float *>(x_bf16), ldx, W, ldw, bias, h1, fm_out,
+                                      sum_out, keys_out, err_flag, nullptr, stream);
 }
 
 static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const int64_t *row_base, const int64_t *row_count,
@@ -606,7 +634,11 @@ static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const 
     const int64_t nblk = rp_cdiv(B, 128);
     hipStream_t s = (hipStream_t)stream;
     if (bf16_rows) {
-        if (nfull > 0)
+        if (nfull > 0 && x != nullptr)  // training: the activation is stored (as bf16)
+            hipLaunchKernelGGL((embed_gather_linear_kernel<true, true, true>), dim3((unsigned)nfull), dim3(256), 0, s, arena,
+                               row_base, row_count, ip, F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out,
+                               keys_out, err_flag, xd);
+        else if (nfull > 0)
             hipLaunchKernelGGL((embed_gather_linear_kernel<true, false, true>), dim3((unsigned)nfull), dim3(256), 0, s, arena,
                                row_base, row_count, ip, F, dp, ND, B, (int64_t)0, x, ldx, W, ldw, bias, h1, fm_out, sum_out,
                                keys_out, err_flag, xd);

@@ -825,7 +825,10 @@ static void run_smallk(const float *a, int64_t lda, const float *w, int64_t ldw,
 // columns is two fields: lanes c < 32 read the row of field k0/64, the others the next one (two 256-byte segments per
 // wave-instruction, as coalesced as the activation read they replace).  Keys are fetched one stage ahead of the rows
 // they address.
-template <int NPROD, int NA, int PF, bool VEC_X, bool GATHER = false>
+// X_BF16 (round 4, the bf16-storage training mode): X is stored as bf16 [M, ldx] (ldx in elements): a lane reads its two
+// columns as one dword and widens them — exact — so everything downstream is unchanged; half the bytes of the operand that
+// dominates this launch's traffic.
+template <int NPROD, int NA, int PF, bool VEC_X, bool GATHER = false, bool X_BF16 = false>
 __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                 const float *__restrict__ X, int64_t ldx,
                                                                 float *__restrict__ P, float *__restrict__ Pb,
@@ -886,6 +889,10 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
                     if (kx < K) v.x = px[0];
                     if (kx + 1 < K) v.y = px[1];
                 }
+            } else if (ok && X_BF16) {
+                const uint16_t *px = reinterpret_cast<const uint16_t *>(X) + m * ldx + kx;
+                if (kx < K) v.x = __uint_as_float((uint32_t)px[0] << 16);
+                if (kx + 1 < K) v.y = __uint_as_float((uint32_t)px[1] << 16);
             } else if (ok) {
                 const float *px = X + m * ldx + kx;
                 if (VEC_X && kx + 1 < K) {
@@ -901,6 +908,7 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
     // interior tile: unguarded loads -> straight-line main loop -> counted vmcnt waits (see linear_fwd_bf16_kernel)
     const float *yb = dY + (mbeg + 8 * o) * lddy + n0 + c;
     const float *xb = X + (mbeg + 8 * o) * ldx + kx;
+    const uint16_t *xb16 = reinterpret_cast<const uint16_t *>(X) + (mbeg + 8 * o) * ldx + kx;  // (X_BF16)
     const int32_t *kb = GATHER ? kcol + mbeg + 8 * o : nullptr;
     int32_t kreg[8];  // GATHER: the keys of the rows the NEXT load_tile_full fetches
     auto load_keys = [&](int64_t moff) {
@@ -912,8 +920,14 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
         for (int r = 0; r < 8; ++r) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) dy_[u][r] = yb[(moff + r) * lddy + 64 * u];
-            if (GATHER) dx_[r] = *reinterpret_cast<const f32x2 *>(arena + (int64_t)kreg[r] * 64 + cin);
-            else dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
+            if (GATHER) {
+                dx_[r] = *reinterpret_cast<const f32x2 *>(arena + (int64_t)kreg[r] * 64 + cin);
+            } else if (X_BF16) {
+                const uint32_t w2 = *reinterpret_cast<const uint32_t *>(xb16 + (moff + r) * ldx);
+                dx_[r] = f32x2{__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xFFFF0000u)};
+            } else {
+                dx_[r] = *reinterpret_cast<const f32x2 *>(xb + (moff + r) * ldx);
+            }
         }
     };
 
@@ -1392,6 +1406,41 @@ extern "C" int rp_linear_wgrad(const float *dy, int64_t lddy, const float *x, in
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, S, N, K, dw,
                        lddw, db, accumulate);
     RP_LAUNCH_CHECK("linear_wgrad reduce");
+    return RP_OK;
+}
+
+extern "C" int rp_linear_wgrad_xbf16(const float *dy, int64_t lddy, const void *x_bf16, int64_t ldx, float *dw, int64_t lddw,
+                                     float *db, int64_t M, int N, int K, int accumulate, void *workspace,
+                                     size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(dy && x_bf16 && dw && workspace, "linear_wgrad_xbf16: null pointer");
+    RP_REQUIRE(M >= 1 && N >= 1 && K >= 1, "linear_wgrad_xbf16: bad M/N/K");
+    RP_REQUIRE(lddy >= N && ldx >= K && lddw >= K, "linear_wgrad_xbf16: leading dimension too small");
+    const int mode = linear_mode(M, N, K);
+    if (mode == RP_MATMUL_FP32 || wgrad_wide(N) || ldx % 2 != 0 || (reinterpret_cast<uintptr_t>(x_bf16) & 3u) != 0)
+        return rp_fail(RP_ERR_UNSUPPORTED, "linear_wgrad_xbf16: bf16 matrix-core modes, N <= 128, ldx even, 4-byte aligned x only");
+    size_t need = 0;
+    rp_linear_wgrad_workspace_bytes(M, N, K, &need);
+    RP_REQUIRE(workspace_bytes >= need, "linear_wgrad_xbf16: workspace %zu < %zu bytes", workspace_bytes, need);
+    int S;
+    int64_t rows;
+    wgrad_plan(M, N, K, &S, &rows);
+    float *P = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    float *Pb = P + (size_t)S * N * K;
+    dim3 gridb((unsigned)rp_cdiv(K, TN_BK), (unsigned)rp_cdiv(N, TN_BN), (unsigned)S);
+    hipStream_t s = (hipStream_t)stream;
+    const float *xf = reinterpret_cast<const float *>(x_bf16);
+#define CALLX(NPROD)                                                                                                       \
+    hipLaunchKernelGGL((linear_wgrad_bf16_kernel<NPROD, 1, 1, true, false, true>), gridb, dim3(256), 0, s, dy, lddy, xf, ldx, P, \
+                       Pb, M, N, K, rows, (const float *)nullptr, (const int32_t *)nullptr, (int64_t)0, 0, 0, 0, S)
+    if (mode == RP_MATMUL_BF16X6) CALLX(6);
+    else if (mode == RP_MATMUL_BF16X3) CALLX(3);
+    else CALLX(1);
+#undef CALLX
+    RP_LAUNCH_CHECK("linear_wgrad_xbf16 partial");
+    const int64_t total = (int64_t)N * K + N;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rp_cdiv(total, 16)), dim3(256), 0, s, P, Pb, S, N, K, dw, lddw, db,
+                       accumulate);
+    RP_LAUNCH_CHECK("linear_wgrad_xbf16 reduce");
     return RP_OK;
 }
 

@@ -779,13 +779,27 @@ class _EmbedGatherLinear(torch.autograd.Function):
     ReluLink shared with the consumer of h1 (the fused MLP tail hands back a gradient that is already masked)."""
 
     @staticmethod
-    def forward(ctx, store, idx, dense, ldx: int, weight, bias, out_link, *tables):
+    def forward(ctx, store, idx, dense, ldx: int, weight, bias, out_link, shadow, *tables):
         pre = store._presorted
         store._presorted = None
-        need_grad = any(ctx.needs_input_grad[7:])
+        need_grad = any(ctx.needs_input_grad[8:])
         need_w = ctx.needs_input_grad[4] or (bias is not None and ctx.needs_input_grad[5])
         w16 = _rows16(weight)
         B, K, Kg = idx[0].shape[0], weight.shape[1], len(idx) * store.embedding_dim
+        if shadow is not None:
+            # bf16-storage training (EmbeddingLayer.bf16_training): rows from the bf16 lookup copy, the activation stored as
+            # bf16 for the weight gradient (rp_linear_wgrad_xbf16); everything else as below
+            want_keys = pre is None
+            x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd_bf16(shadow, store.row_base, store.row_count, idx, dense, w16, bias,
+                                                                     store.err_flag, train_ldx=ldx, want_keys=want_keys)
+            ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, B, K, out_link, bias is not None
+            ctx.ldx, ctx.x_mode, ctx.Kg, ctx.need_tables = ldx, "bf16", Kg, need_grad
+            ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
+            if pre is not None:
+                keys = pre[0]
+            ctx.save_for_backward(keys, ssum, x, h1, weight)
+            store._fm_link = None
+            return h1, fm
         # x exists only for the weight gradient; inference stores none.  RP_WGRAD_GATHER=1: the weight gradient gathers the
         # embedding rows itself (rp_linear_wgrad_gather: the arena does not change between this forward and its backward) and
         # only the dense columns are stored.  Measured at Criteo shape: forward 0.195 -> 0.139 ms, weight gradient 0.148 ->
@@ -822,8 +836,13 @@ class _EmbedGatherLinear(torch.autograd.Function):
         dw = db = None
         need_w = ctx.needs_input_grad[4] or (ctx.has_bias and ctx.needs_input_grad[5])
         need_t = keys is not None and ctx.need_tables
+        if need_w and ctx.x_mode == "none":
+            raise RuntimeError("the fused lookup + first layer stored no activation (the forward ran without gradients for the "
+                               "layer's weight)")
 
         def wgrad(keep=None):
+            if ctx.x_mode == "bf16":   # the activation was stored as bf16 (bf16-storage training)
+                return hip.linear_wgrad_xbf16(dpre, x, ctx.K, want_bias=ctx.has_bias, keep=keep)
             if ctx.x_mode == "dense":  # x holds the dense columns only: the embedding columns are gathered from the arena
                 return hip.linear_wgrad_gather(dpre, store.arena, keys, ctx.Kg, x, ctx.K, want_bias=ctx.has_bias)
             return hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias, keep=keep)
@@ -864,12 +883,12 @@ class _EmbedGatherLinear(torch.autograd.Function):
             dw.record_stream(main)     # (allocated under the second stream, consumed and freed on the main one)
             if db is not None:
                 db.record_stream(main)
-        return (None, None, None, None, dw, db, None) + (None,) * len(store.emb_feature)
+        return (None, None, None, None, dw, db, None, None) + (None,) * len(store.emb_feature)
 
 
-def embed_gather_linear(store, idx, dense, ldx: int, weight, bias, out_link):
+def embed_gather_linear(store, idx, dense, ldx: int, weight, bias, out_link, shadow=None):
     tables = [store.embedding_layer[c].weight for c in store.emb_feature]
-    return _EmbedGatherLinear.apply(store, idx, dense, ldx, weight, bias, out_link, *tables)
+    return _EmbedGatherLinear.apply(store, idx, dense, ldx, weight, bias, out_link, shadow, *tables)
 
 
 def embed_gather(store, idx, dense, ldx: int, want_fm: bool, meta=None):

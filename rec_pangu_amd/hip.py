@@ -30,7 +30,7 @@ _SIGNATURES = {
     "rp_embed_gather_linear_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp, _vp]),
     "rp_embed_gather_linear_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp,
-                                                  _vp]),
+                                                  _i64, _vp, _vp, _vp, _vp]),
     "rp_linear_wgrad_gather_fits": (C.c_int, [_i64, _i32, _i32, _i32]),
     "rp_linear_wgrad_gather": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz,
                                          _vp]),
@@ -136,9 +136,11 @@ _SIGNATURES = {
                                     _vp, _i64, _vp, _vp]),
     "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64, _vp]),
     "rp_lazy_adam_catchup": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f64, _f64, _f64,
-                                       _vp, _i64, _vp, _vp]),
+                                       _vp, _i64, _vp, _vp, _vp]),
     "rp_lazy_adam_flush_deferred": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64,
-                                              _vp]),
+                                              _vp, _vp]),
+    "rp_rows_to_bf16": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "rp_linear_wgrad_xbf16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_embed_gather_pool_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_embed_pool_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "rp_seq_pool_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
@@ -392,8 +394,9 @@ def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor],
 
 
 def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], W, bias,
-                                 err_flag: torch.Tensor):
-    """bf16-storage inference: the fused lookup + FM + first Linear over a bf16 copy of the arena -> (h1 [B, 64], fm [B, 1])"""
+                                 err_flag: torch.Tensor, train_ldx: int = 0, want_keys: bool = False):
+    """bf16-storage: the fused lookup + FM + first Linear over a bf16 copy of the arena -> (h1 [B, 64], fm [B, 1]);
+    train_ldx > 0 (the bf16-storage TRAINING mode): -> (x_bf16 [B, train_ldx] bfloat16, h1, fm, ssum [B, 64], keys or None)"""
     _req(arena_bf16, torch.bfloat16, "arena_bf16")
     _req(W, torch.float32, "W")
     F, ND = len(idx), len(dense)
@@ -402,13 +405,26 @@ def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torc
     h1 = torch.empty((B, 64), dtype=torch.float32, device=dev)
     fm = torch.empty((B, 1), dtype=torch.float32, device=dev)
     K = F * D + ND
+    if train_ldx:
+        x16 = torch.empty((B, train_ldx), dtype=torch.bfloat16, device=dev)
+        ssum = torch.empty((B, D), dtype=torch.float32, device=dev)
+        keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
+        # algorithmic bytes: bf16 rows + ids read, the bf16 activation written, h1 + the field sums
+        with _Timed("embed_gather_linear_fwd_bf16", f"D={D}", B * (F * (D * 2 + 8) + (F * D + ND) * 2 + 64 * 4 + D * 4), 2 * B * K * 64):
+            _check(lib().rp_embed_gather_linear_fwd_bf16(arena_bf16.data_ptr(), row_base.data_ptr(), row_count.data_ptr(),
+                                                         _ptr_array(idx), F, _ptr_array(dense), ND, B, D, W.data_ptr(),
+                                                         _rowmajor(W, "W"), _ptr(bias), h1.data_ptr(), fm.data_ptr(),
+                                                         x16.data_ptr(), train_ldx, ssum.data_ptr(), _ptr(keys),
+                                                         err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd_bf16")
+        return x16, h1, fm, ssum, keys
     # algorithmic bytes: SURVEY 8d's bf16 figure — bf16 rows + int64 ids read, the [B, F*D] bf16 output "written" (it is
     # consumed in registers here) = F * (2 D + 8) + 2 F D per sample (6 864 B at Criteo shape) — plus h1
     with _Timed("embed_gather_linear_fwd_bf16", f"D={D}", B * (F * (D * 2 + 8) + F * D * 2 + 64 * 4), 2 * B * K * 64):
         _check(lib().rp_embed_gather_linear_fwd_bf16(arena_bf16.data_ptr(), row_base.data_ptr(), row_count.data_ptr(),
                                                      _ptr_array(idx), F, _ptr_array(dense), ND, B, D, W.data_ptr(),
                                                      _rowmajor(W, "W"), _ptr(bias), h1.data_ptr(), fm.data_ptr(),
-                                                     err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd_bf16")
+                                                     None, 0, None, None, err_flag.data_ptr(), _stream()),
+               "rp_embed_gather_linear_fwd_bf16")
     return h1, fm
 
 
@@ -565,6 +581,25 @@ def linear_wgrad(dy, x, K: int, dw=None, db=None, accumulate: bool = False, want
     with _Timed("linear_wgrad", f"{M}x{N}x{K}", 4 * (M * N + M * K + N * K), 2 * M * N * K):
         _check(lib().rp_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dw.data_ptr(), _rowmajor(dw, "dw"), _ptr(db),
                                  M, N, K, int(accumulate), ws.data_ptr(), nbytes.value, _stream()), "rp_linear_wgrad")
+    return dw, db
+
+
+def linear_wgrad_xbf16(dy, x16, K: int, want_bias: bool = True, keep=None):
+    """rp_linear_wgrad_xbf16: dw[N, K] = dy^T @ x16[:, :K] with the activation stored as bfloat16 (bf16-storage training)"""
+    _req(dy, torch.float32, "dy")
+    _req(x16, torch.bfloat16, "x16")
+    M, N = dy.shape
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = _sz(0)
+    _check(lib().rp_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "rp_linear_wgrad_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dy.device)
+    if keep is not None:
+        keep.append(ws)
+    with _Timed("linear_wgrad_xbf16", f"{M}x{N}x{K}", 4 * (M * N + N * K) + 2 * M * K, 2 * M * N * K):
+        _check(lib().rp_linear_wgrad_xbf16(dy.data_ptr(), _rowmajor(dy, "dy"), x16.data_ptr(), _rowmajor(x16, "x16"),
+                                           dw.data_ptr(), K, _ptr(db), M, N, K, 0, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_linear_wgrad_xbf16")
     return dw, db
 
 
@@ -1484,23 +1519,32 @@ def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, be
 
 
 def lazy_adam_catchup(sorted_keys, D: int, p, g, m, v, last, scalars, t_done: int, mark: bool, beta1: float,
-                      beta2: float, eps: float, cf_table=None, cf_from: int = 0, t_dev=None):
+                      beta2: float, eps: float, cf_table=None, cf_from: int = 0, t_dev=None, shadow=None):
     """deferred execution (rp_lazy_adam_catchup): everything the unique rows of sorted_keys are owed through step t_done —
-    their pending real step, then the zero-gradient steps — and, with mark, the stamp 'gradient of step t_done+1 coming'"""
+    their pending real step, then the zero-gradient steps — and, with mark, the stamp 'gradient of step t_done+1 coming'.
+    shadow: the bf16 lookup copy of the tables (bf16-storage training), written wherever a parameter row is"""
     with _Timed("lazy_adam_catchup", f"D={D}"):
         _check(lib().rp_lazy_adam_catchup(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),
                                           m.data_ptr(), v.data_ptr(), last.data_ptr(), scalars.data_ptr(), t_done,
-                                          int(mark), beta1, beta2, eps, _ptr(cf_table), cf_from, _ptr(t_dev), _stream()),
-               "rp_lazy_adam_catchup")
+                                          int(mark), beta1, beta2, eps, _ptr(cf_table), cf_from, _ptr(t_dev), _ptr(shadow),
+                                          _stream()), "rp_lazy_adam_catchup")
 
 
 def lazy_adam_flush_deferred(rows: int, D: int, p, g, m, v, last, scalars, t_target: int, beta1: float, beta2: float,
-                             eps: float, cf_table=None, cf_from: int = 0):
+                             eps: float, cf_table=None, cf_from: int = 0, shadow=None):
     with _Timed("lazy_adam_flush", f"D={D}"):
         _check(lib().rp_lazy_adam_flush_deferred(rows, D, p.data_ptr(), _ptr(g), m.data_ptr(), v.data_ptr(),
                                                  last.data_ptr(), scalars.data_ptr(), t_target, beta1, beta2, eps,
-                                                 _ptr(cf_table), cf_from, _stream()),
+                                                 _ptr(cf_table), cf_from, _ptr(shadow), _stream()),
                "rp_lazy_adam_flush_deferred")
+
+
+def rows_to_bf16(sorted_keys, D: int, p, shadow):
+    """shadow[row] = bf16(p[row]) for the unique rows of sorted_keys (rp_rows_to_bf16)"""
+    _req(shadow, torch.bfloat16, "shadow")
+    with _Timed("rows_to_bf16"):
+        _check(lib().rp_rows_to_bf16(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), shadow.data_ptr(), _stream()),
+               "rp_rows_to_bf16")
 
 
 def lazy_adam_cf_table(ns_d, t_end: int, cf_from: int, beta1: float, beta2: float, cf_table, built_to: int = -1, t_dev=None):

@@ -150,6 +150,8 @@ class EmbeddingLayer(nn.Module):
             self._grad_arena = fn(self._grad_arena)
             self._attach_grads()
         self._touched = None if self._touched is None else fn(self._touched)
+        if self.__dict__.get("_shadow") is not None:
+            self._shadow_stamp = None  # (rebuilt from the moved tables at the next training forward)
         return self
 
     def _ensure_packed(self):
@@ -386,6 +388,41 @@ class EmbeddingLayer(nn.Module):
         self._arena_bf16 = self._arena.detach().to(torch.bfloat16)
         self._bf16_stamp = self._bf16_stamp_now()
 
+    def bf16_training(self, enable: bool = True) -> None:
+        """bf16-STORAGE TRAINING (SURVEY D6's perf mode with a stated tolerance; never the parity path): the fused lookup +
+        first layer gathers from a bf16 LOOKUP COPY of the tables (half the row bytes) and stores its activation as bf16
+        (half the bytes the weight gradient reads); the fp32 tables stay the master the optimizer works on, moments and
+        every accumulation stay fp32.  The deferred table optimizer keeps the copy current: whenever rp_lazy_adam_catchup /
+        _flush_deferred write a parameter row they write its round-to-nearest-even bf16 image too (needs
+        make_adam(defer=True), the default; other optimizers on the tables raise).  Anything that changes the tables through
+        torch (load_state_dict, set_weights, .to()) is noticed and the copy rebuilt.  Tolerance: the looked-up values are
+        bf16-rounded (2^-9 relative): logits within 6e-2 of the fp32 tables' (tests/test_hip_models.py)."""
+        if not enable:
+            self._shadow = None
+            return
+        self._ensure_packed()
+        if not self._arena.is_cuda or self.embedding_dim != 64:
+            raise RuntimeError("bf16_training: a HIP-resident layer with embedding_dim 64 (the fused lookup + first layer)")
+        self._shadow_rebuild()
+
+    def _shadow_rebuild(self):
+        self.flush_lazy()
+        self._shadow = self._arena.detach().to(torch.bfloat16)
+        self._shadow_stamp = self._shadow_stamp_now()
+
+    def _shadow_stamp_now(self):
+        # (torch-side writes bump these counters; the fused optimizer writes through raw pointers and keeps the copy itself)
+        return (self._arena.data_ptr(), self._arena._version, tuple(p._version for p in self._tables()))
+
+    def _shadow_for_training(self):
+        sh = self.__dict__.get("_shadow")
+        if sh is None:
+            return None
+        if sh.device != self._arena.device or sh.shape != self._arena.shape or self._shadow_stamp != self._shadow_stamp_now():
+            self._shadow_rebuild()
+            sh = self._shadow
+        return sh
+
     def _bf16_stamp_now(self):
         """what the snapshot is valid for: torch's version counter of the arena, the lazy optimizer's step AND the
         library's weight epoch — the fused optimizers write the arena through raw pointers, which torch's counter does
@@ -425,13 +462,14 @@ class EmbeddingLayer(nn.Module):
                  for t in dense]
         src = tuple(X[c] for c in self.emb_feature)
         self._presorted = None
+        shadow = self._shadow_for_training()  # (before the replay below: a rebuild flushes)
         if self._lazy is not None and self._lazy.t > 0:
             keys, sk, sp = self._sorted_keys(idx, self.row_base, self.row_count, src)
             self._lazy.replay(self, sk)
             self._presorted = (keys, sk, sp)
         elif torch.is_grad_enabled():
             self._presorted = self._sorted_keys(idx, self.row_base, self.row_count, src, lookup_only=True)
-        out = Fh.embed_gather_linear(self, idx, dense, ldx, linear.weight, linear.bias, out_link)
+        out = Fh.embed_gather_linear(self, idx, dense, ldx, linear.weight, linear.bias, out_link, shadow=shadow)
         self._start_sort_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()

@@ -200,6 +200,12 @@ class LazyAdamRows:
     def _t_dev(self):
         return self.tabs.t_dev if self.device_clock else None
 
+    @staticmethod
+    def _shadow_of(store):
+        """the bf16 lookup copy of the store's tables (EmbeddingLayer.bf16_training), or None"""
+        sh = getattr(store, "_shadow", None)
+        return sh if (sh is not None and sh.shape == store.arena.shape and sh.device == store.arena.device) else None
+
     def replay(self, store, sorted_keys, mark=None):
         if self.defer:
             # everything the batch's rows are owed (pending real step + skipped steps); under autograd their gradient of
@@ -212,10 +218,13 @@ class LazyAdamRows:
                 cf, cf_from = self._cf_args(self.t) if (self.t > 0 or self.device_clock) else (None, 0)
                 hip.lazy_adam_catchup(sorted_keys, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v,
                                       self.last, self.tabs.sc, self.t, mark, self.betas[0], self.betas[1], self.eps, cf,
-                                      cf_from, self._t_dev())
+                                      cf_from, self._t_dev(), shadow=self._shadow_of(store))
                 if mark:
                     self._marked_for = self.t + 1
             return
+        if self._shadow_of(store) is not None:
+            raise RuntimeError("bf16-storage training (EmbeddingLayer.bf16_training) needs the deferred table optimizer: "
+                               "make_adam(defer=True), the default")
         if self.t > 0:
             self._check_table(self.t)
             cf, cf_from = self._cf_args(self.t)
@@ -238,6 +247,8 @@ class LazyAdamRows:
             hip.lazy_adam_rows(sk, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v, self.last,
                                self.tabs.sc, t_new, True, zero_grad, self.betas[0], self.betas[1], self.eps, cf, cf_from,
                                self._t_dev())
+            if self._shadow_of(store) is not None:  # (an update that did not go through the deferred kernels)
+                hip.rows_to_bf16(sk, store.embedding_dim, store.arena, store._shadow)
         if self.device_clock:
             hip.counter_add(self.tabs.t_dev, 1)
         self.t = t_new
@@ -254,7 +265,7 @@ class LazyAdamRows:
         if self.defer:
             hip.lazy_adam_flush_deferred(store.arena.shape[0], store.embedding_dim, store.arena, store.grad_arena, self.m,
                                          self.v, self.last, self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps,
-                                         cf, cf_from)
+                                         cf, cf_from, shadow=self._shadow_of(store))
         else:
             hip.lazy_adam_flush(store.arena.shape[0], store.embedding_dim, store.arena, self.m, self.v, self.last,
                                 self.tabs.sc, self.t, self.betas[0], self.betas[1], self.eps, cf, cf_from)
@@ -399,6 +410,9 @@ class FusedAdam(torch.optim.Optimizer):
                         self._expose_state(store, lz.m, lz.v)
                     lz.step(store, lr, zero_grad=self.fuse_zero_grad)
                     continue
+                if getattr(store, "_shadow", None) is not None:
+                    raise RuntimeError("bf16-storage training (EmbeddingLayer.bf16_training) needs FusedAdam(lazy_tables=True, "
+                                       "defer=True): the dense table step does not maintain the bf16 lookup copy")
                 st = self._arena_state.get(sid)
                 if st is None or st["m"].shape != store.arena.shape or st["m"].device != store.arena.device:
                     st = {"m": torch.zeros_like(store.arena), "v": torch.zeros_like(store.arena)}

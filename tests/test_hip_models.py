@@ -999,3 +999,88 @@ def test_baseline_models_stay_on_the_library_kernels(name):
               "aten.threshold_backward", "aten.index_add", "aten.scatter_add")
     hit = sorted(op for op in seen if any(op.startswith(b) for b in banned))
     assert not hit, f"{name}: the step dispatched ATen compute ops: {hit}"
+
+
+def test_bf16_storage_training_mode():
+    """EmbeddingLayer.bf16_training (row n2: north_star's bf16 configuration as a perf mode with a STATED tolerance, SURVEY
+    D6): the fused lookup reads a bf16 lookup copy of the tables and stores a bf16 activation; master tables, moments and
+    accumulation stay fp32.  Checked at a Criteo-shaped batch of 4096 against the SAME model on its fp32 tables:
+      * the copy is exactly bf16(master) before and after training steps (the deferred optimizer kernels keep it current),
+        including rows updated by the first (immediate) step and after a flush;
+      * one forward + backward: logits within 6e-2, the dense gradients within 3e-2 of their scale, the table gradients
+        within 3e-2 of theirs (the activation of the weight gradient is bf16-rounded);
+      * 30 training steps from the same start: the losses of the two runs stay within 2e-3 of each other;
+      * a torch-side change of the tables (load_state_dict) is noticed and the copy rebuilt; a non-deferred optimizer raises."""
+    import copy
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.optim import make_adam
+    enc = bench.criteo_enc_dict(64)
+    torch.manual_seed(5)
+    ref_model = bench.build_model("deepfm", enc).to(DEV)
+    model = copy.deepcopy(ref_model)
+    for m in list(ref_model.modules()) + list(model.modules()):
+        if hasattr(m, "check_indices"):
+            m.check_indices = "deferred"
+    emb = model.embedding_layer
+    emb.bf16_training(True)
+    assert emb._shadow.dtype is torch.bfloat16 and torch.equal(emb._shadow, emb.arena.to(torch.bfloat16))
+    batches = [bench.synth_batch(enc, 4096, 40 + i, DEV) for i in range(31)]
+    # ---- one forward + backward against the fp32 tables
+    n0 = hip.launch_count()
+    hip.enable_timing(True)
+    o_ref, o = ref_model(batches[0]), model(batches[0])
+    o_ref["loss"].backward()
+    o["loss"].backward()
+    torch.cuda.synchronize()
+    rows = hip.timing_summary()
+    hip.enable_timing(False)
+    assert any(k.startswith("embed_gather_linear_fwd_bf16") for k in rows) and any(k.startswith("linear_wgrad_xbf16") for k in rows)
+    assert hip.launch_count() > n0
+    z = lambda p: torch.log(p.clamp(1e-7, 1 - 1e-7)) - torch.log1p(-p.clamp(1e-7, 1 - 1e-7))  # noqa: E731
+    dz = float((z(o["pred"]) - z(o_ref["pred"])).abs().max())
+    assert 0.0 < dz <= 6e-2, dz
+    worst = 0.0
+    for (k, p), (_, q) in zip(ref_model.dnn.named_parameters(), model.dnn.named_parameters()):
+        e = float((p.grad - q.grad).abs().max()) / max(1e-8, float(p.grad.abs().max()))
+        worst = max(worst, e)
+        assert e <= 3e-2, (k, e)
+    ga, gb = ref_model.embedding_layer.grad_arena, emb.grad_arena
+    eg = float((ga - gb).abs().max()) / float(ga.abs().max())
+    assert eg <= 3e-2, eg
+    print(f"\nbf16-storage training vs fp32 tables: max |logit diff| {dz:.2e}, dense grads {worst:.2e}, table grads {eg:.2e} of scale")
+    # ---- training: the copy follows the master, the loss follows the fp32 run
+    opt_ref, opt = make_adam(ref_model, 1e-3), make_adam(model, 1e-3)
+    assert opt.defer
+    opt_ref.step(), opt.step()
+    ref_model.zero_grad(), model.zero_grad()
+    losses = []
+    for i in range(1, 31):
+        o_ref, o = ref_model(batches[i]), model(batches[i])
+        o_ref["loss"].backward()
+        o["loss"].backward()
+        opt_ref.step(), opt.step()
+        ref_model.zero_grad(), model.zero_grad()
+        losses.append((float(o_ref["loss"]), float(o["loss"])))
+    assert max(abs(a - b) for a, b in losses) <= 2e-3, losses[-3:]
+    opt.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(emb._shadow, emb.arena.to(torch.bfloat16)), "the bf16 copy must be bf16(master) after a flush"
+    # rows of the last batch were caught up BEFORE its forward and have not moved since (their step waits): in the copy too
+    # ---- a torch-side change of the tables is noticed
+    sd = {k: (v + 0.25 if "embedding_layer" in k else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model(batches[0])
+    assert torch.equal(emb._shadow, emb.arena.to(torch.bfloat16))
+    # ---- a table optimizer that does not maintain the copy raises
+    model2 = copy.deepcopy(ref_model)
+    model2.embedding_layer.bf16_training(True)
+    opt2 = make_adam(model2, 1e-3, defer=False)
+    model2(batches[0])["loss"].backward()
+    opt2.step()
+    model2.zero_grad()
+    with pytest.raises(RuntimeError, match="deferred"):
+        model2(batches[1])
