@@ -889,10 +889,15 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
                     if (kx < K) v.x = px[0];
                     if (kx + 1 < K) v.y = px[1];
                 }
-            } else if (ok && X_BF16) {
-                const uint16_t *px = reinterpret_cast<const uint16_t *>(X) + m * ldx + kx;
-                if (kx < K) v.x = __uint_as_float((uint32_t)px[0] << 16);
-                if (kx + 1 < K) v.y = __uint_as_float((uint32_t)px[1] << 16);
+            } else if (X_BF16) {
+                // branch-free (a load behind a branch turns every wait of the loop into vmcnt(0): the guarded k-tile of a
+                // bf16 activation ran 16 serialized 2-byte loads per stage): row and column clamped into the buffer, the
+                // dword always loaded, what lies outside masked afterwards (ldx is even and >= K)
+                const int64_t mc = ok ? m : mbeg;
+                const int kc = kx + 1 < (int)ldx ? kx : (int)ldx - 2;
+                const uint32_t w2 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(X) + mc * ldx + kc);
+                v.x = (ok && kx < K) ? __uint_as_float(w2 << 16) : 0.f;
+                v.y = (ok && kx + 1 < K) ? __uint_as_float(w2 & 0xFFFF0000u) : 0.f;
             } else if (ok) {
                 const float *px = X + m * ldx + kx;
                 if (VEC_X && kx + 1 < K) {
