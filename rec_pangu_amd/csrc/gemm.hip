@@ -898,14 +898,19 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
                 const uint32_t w2 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint16_t *>(X) + mc * ldx + kc);
                 v.x = (ok && kx < K) ? __uint_as_float(w2 << 16) : 0.f;
                 v.y = (ok && kx + 1 < K) ? __uint_as_float(w2 & 0xFFFF0000u) : 0.f;
+            } else if (VEC_X) {
+                // branch-free as above (VEC_X: ldx even, 8-byte aligned rows; ldx >= K): the pair is always loaded from a
+                // clamped (row, column) inside the buffer and masked afterwards — the k-tile that holds column K - 1 (one of
+                // 14 at K = 1677) otherwise waits for each of its row loads on its own
+                const int64_t mc = ok ? m : mbeg;
+                const int kc = kx + 1 < (int)ldx ? kx : (int)ldx - 2;
+                const f32x2 w2 = *reinterpret_cast<const f32x2 *>(X + mc * ldx + kc);
+                v.x = (ok && kx < K) ? w2.x : 0.f;
+                v.y = (ok && kx + 1 < K) ? w2.y : 0.f;
             } else if (ok) {
                 const float *px = X + m * ldx + kx;
-                if (VEC_X && kx + 1 < K) {
-                    v = *reinterpret_cast<const f32x2 *>(px);
-                } else {
-                    if (kx < K) v.x = px[0];
-                    if (kx + 1 < K) v.y = px[1];
-                }
+                if (kx < K) v.x = px[0];
+                if (kx + 1 < K) v.y = px[1];
             }
             dx_[r] = v;
         }
