@@ -288,6 +288,8 @@ def main():
             m.check_indices = "deferred"  # no per-step host sync; checked once after the run
         if hasattr(m, "wire_dtype") and args.wire == "bf16":
             m.wire_dtype = torch.bfloat16
+        if hasattr(m, "capacity_slack"):
+            m.capacity_slack = 1.0 / 16  # (synthetic ids are stationary: the per-owner counts move by a fraction of a per cent)
     model.train()
     if args.storage == "bf16":
         assert not sharded and args.model == "deepfm" and hidden == (64, 64, 64), "--storage bf16 is a DeepFM [64,64,64] line"
@@ -322,13 +324,16 @@ def main():
     # stream of kernels, the host pays a few us per launch — so a DeepFM step (library launches only) is replayed at every
     # batch size; a step that must fall back to a hipGraph (dcn: ATen launches inside) only where the host is the limit.
     plan_ok = args.graph_backend != "hipgraph" and os.environ.get("RP_GRAPH_BACKEND", "plan") == "plan"
-    use_graph = args.mode == "train" and not sharded and not args.no_sort_ahead and (
-        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn")
+    use_graph = args.mode == "train" and not args.no_sort_ahead and (
+        args.graph == "on" or (args.graph == "auto" and not sharded and args.model in ("deepfm", "dcn")
                                and (local_B <= 16384 or (plan_ok and args.model == "deepfm"))))
     gstep = None
     if use_graph:
         from rec_pangu_amd.graph_step import GraphedTrainStep
-        gstep = GraphedTrainStep(model, opt, backend=args.graph_backend)
+        # (row-sharded: --graph on captures the step WITH its collectives — RCCL all-to-alls and the dense all-reduce as
+        #  graph nodes; opt-in until a multi-GPU box has run it)
+        gstep = GraphedTrainStep(model, opt, backend=args.graph_backend,
+                                 post_backward=(lambda: allreduce_dense_grads(model)) if sharded else None)
 
     def step(data, nxt=None, graphed=False):
         if args.mode == "forward":

@@ -68,8 +68,14 @@ class GraphedTrainStep:
             if getattr(m, "check_indices", "deferred") != "deferred":
                 raise RuntimeError("GraphedTrainStep: set check_indices = 'deferred' on the embedding layers (a captured "
                                    "step cannot synchronise with the host; call raise_if_bad_index() after the run)")
-        if not hasattr(model.embedding_layer, "pin_sort"):
-            raise RuntimeError("GraphedTrainStep: row-sharded embedding layers (collectives inside the step) are not captured")
+        # Row-sharded tables (sharded.ShardedEmbeddingLayer, round 4): the step is captured WITH its collectives — in the
+        # fixed-capacity exchange every split size is a constant, so RCCL's all-to-alls and the dense all-reduce
+        # (post_backward = lambda: allreduce_dense_grads(model)) become graph nodes.  Such a step always replays as a
+        # hipGraph (the collectives are not the library's launches); the route of a batch is built inside its own step
+        # (no look-ahead: one graph, one stream).  Every rank must capture and replay in lockstep.
+        self._sharded = not hasattr(model.embedding_layer, "pin_sort")
+        if self._sharded and not hasattr(model.embedding_layer, "local_arena"):
+            raise RuntimeError("GraphedTrainStep: unknown embedding layer type")
         self.model, self.opt, self.post_backward = model, optimizer, post_backward
         # "plan": replay the captured step as a launch plan when it holds only library launches (checked against the
         # captured hipGraph's nodes), else as the hipGraph; "hipgraph": always the hipGraph
@@ -125,6 +131,8 @@ class GraphedTrainStep:
         self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
         self._one = torch.ones((), dtype=torch.float32, device=next(iter(batch.values())).device)
         self._keys = list(batch.keys())
+        if self._sharded:
+            return
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
             self.model.embedding_layer.pin_sort(x)
 
@@ -139,7 +147,8 @@ class GraphedTrainStep:
 
     def _stage_current(self, batch):
         self._copy(self.P, batch)
-        self.model.embedding_layer.pin_sort(self.X[self.P])
+        if not self._sharded:
+            self.model.embedding_layer.pin_sort(self.X[self.P])
         self._staged = batch
 
     def _capture(self, P):
@@ -147,7 +156,7 @@ class GraphedTrainStep:
         self.opt.set_device_clock(True)
         self._dev = counters
         torch.cuda.synchronize()
-        want_plan = self.backend == "plan"
+        want_plan = self.backend == "plan" and not self._sharded
         # (keep_graph: the hipGraph_t stays inspectable — rp_graph_node_counts — and is only instantiated if it is replayed)
         g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
         plan = hip.LaunchPlan() if want_plan else None
@@ -173,7 +182,8 @@ class GraphedTrainStep:
                     # re-issues these launches on its side stream, beside the step (section 1)
                     if plan is not None:
                         plan.section(1)
-                    self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
+                    if not self._sharded:
+                        self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
                     if plan is not None:
                         plan.section(0)
             finally:
@@ -223,6 +233,13 @@ class GraphedTrainStep:
             return one
         return None
 
+    def _sharded_capturable(self, batch) -> bool:
+        """the fixed-capacity exchange is active for this batch size (measured by an earlier eager step): no split size
+        comes back to the host inside the step"""
+        emb = self.model.embedding_layer
+        n = len(emb.emb_feature) * batch[emb.emb_feature[0]].numel()
+        return emb.check_indices == "deferred" and emb._capacity is not None and n <= emb._capacity_n
+
     def _pinned(self, Q):
         src = tuple(self.X[Q][c] for c in self.model.embedding_layer.emb_feature)
         for c_src, _, c_out in _emb._SORT_PINNED:
@@ -242,7 +259,7 @@ class GraphedTrainStep:
         if torch.cuda.is_available():
             torch.cuda.synchronize()  # never destroy a graph executable that is still in flight
         self._drop_captures()
-        if self.X is not None:
+        if self.X is not None and not self._sharded:
             for x in self.X:
                 _emb.EmbeddingLayer.unpin_sorts(x)
         self.X, self._staged = None, None
@@ -260,6 +277,9 @@ class GraphedTrainStep:
             return self._eager(batch, next_batch)
         if self.X is None:
             self._alloc(batch)
+        if self._sharded and not self._sharded_capturable(batch):
+            self._staged = None
+            return self._eager(batch, next_batch)
         if not (self._fits(batch) and self._fits(next_batch)):
             # another shape than the captured one (the smaller last batch of an epoch, or the batch before it, whose
             # captured step would sort it): this step runs eagerly

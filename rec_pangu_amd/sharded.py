@@ -156,7 +156,8 @@ class _Route:
                 m = torch.tensor([max(self.send + self.recv), n], dtype=torch.int64, device=sk.device)
                 all_reduce(m, op=dist.ReduceOp.MAX, group=layer.group)
                 m = m.tolist()
-                layer._capacity = max(layer._capacity or 0, (m[0] * 5 // 4 + 1024 + 255) // 256 * 256)
+                slack = float(getattr(layer, "capacity_slack", 0.25))
+                layer._capacity = max(layer._capacity or 0, (int(m[0] * (1.0 + slack)) + 1024 + 255) // 256 * 256)
                 layer._capacity_n = max(layer._capacity_n, m[1])
             return
         comp = ((keys % world) << lbits) | torch.div(keys, world, rounding_mode="floor")
@@ -350,6 +351,11 @@ class ShardedEmbeddingLayer(nn.Module):
         self._lazy = None
         self._served_sorted = None  # (sorted local rows, positions) of the requests being served, reused in backward
         self._err = None
+        # fixed-capacity exchange: per-owner slots = (1 + capacity_slack) x the largest per-owner count any rank saw on the
+        # measuring batch (+ 1024, rounded to 256).  0.25 is the safe default for drifting id distributions; every slot
+        # above the real counts is padding on the wire (a stationary stream holds its counts to a fraction of a per cent:
+        # bench.py runs with 1/16)
+        self.capacity_slack = 0.25
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
         self._capacity_n = 0   # requests of the (largest) batch the capacity was measured on
         self._prepared = None  # (route, requested rows, their sort) of the batch about to be looked up, as far as prepared ahead

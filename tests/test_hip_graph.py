@@ -228,3 +228,63 @@ def test_graphed_step_refuses_what_it_cannot_capture():
             hip._dropout_seed_offset(torch.device(DEV))
     finally:
         torch.cuda.is_current_stream_capturing = real
+
+
+@pytest.mark.parametrize("force_a2a", [False, True])
+def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, monkeypatch):
+    """The captured step WITH its collectives (round 4): a DeepFM whose tables are row-sharded under a 1-rank RCCL group —
+    route, exchange (the identity, or RCCL self-copies with RP_FORCE_A2A=1: all_to_all_single as a graph node), owner-side
+    gather / reduce, dense all-reduce, deferred lazy Adam with device-resident counters — replayed as a hipGraph, against
+    the eager loop on the same batches: every prediction and the final weights bit-identical."""
+    import copy
+    import socket
+    import torch.distributed as dist
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.models.ranking import DeepFM
+    from rec_pangu_amd.optim import make_adam
+    from rec_pangu_amd.sharded import ShardedEmbeddingLayer, allreduce_dense_grads, shard_model_tables
+    if force_a2a:
+        monkeypatch.setenv("RP_FORCE_A2A", "1")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0)
+    try:
+        enc = _enc(3, [3000, 17, 900, 20000, 6])
+        batches = _batches(enc, 512, 41, seed=8)
+        torch.manual_seed(0)
+        base = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc).to(DEV)
+        results = {}
+        for mode in ("eager", "graph"):
+            model = shard_model_tables(copy.deepcopy(base), 1, 0)
+            assert isinstance(model.embedding_layer, ShardedEmbeddingLayer)
+            for m in model.modules():
+                if hasattr(m, "check_indices"):
+                    m.check_indices = "deferred"
+            opt = make_adam(model, 1e-3)
+            gstep = GraphedTrainStep(model, opt, post_backward=lambda: allreduce_dense_grads(model)) if mode == "graph" else None
+            preds = []
+            for i in range(40):
+                if gstep is not None:
+                    out = gstep(batches[i], batches[i + 1])
+                else:
+                    model.prefetch(batches[i + 1])
+                    out = model(batches[i])
+                    out["loss"].backward()
+                    allreduce_dense_grads(model)
+                    opt.step()
+                    model.zero_grad()
+                preds.append(out["pred"].detach().clone())
+            model.embedding_layer.raise_if_bad_index()
+            if gstep is not None:
+                assert gstep.replays >= 36 and gstep.backend_used == "hipgraph", (gstep.replays, gstep.backend_used)
+            results[mode] = (preds, {k: v.clone() for k, v in model.state_dict().items()})
+            del gstep
+        for a, b in zip(results["eager"][0], results["graph"][0]):
+            assert torch.equal(a, b), "predictions differ"
+        for k in results["eager"][1]:
+            assert torch.equal(results["eager"][1][k], results["graph"][1][k]), k
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
