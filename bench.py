@@ -885,11 +885,18 @@ def main():
     # the JSON line is the LAST thing on stdout: RCCL's init banner sits in the C stdio buffer until exit otherwise
     import ctypes
     ctypes.CDLL(None).fflush(None)
-    if sharded:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(res), flush=True)
+    if sharded:
+        torch.distributed.barrier()
+        if gstep is not None:
+            # a captured step that holds RCCL nodes keeps the communicator busy: destroying the process group under live
+            # graph executables never returns on this runtime (measured: stuck in destroy_process_group).  Release the
+            # captures first.
+            gstep.reset()
+            gstep = None
+            torch.cuda.synchronize()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -164,7 +164,11 @@ class GraphedTrainStep:
             if plan is not None:
                 plan.begin()
             try:
-                with torch.cuda.graph(g, pool=self._pool):
+                # (sharded: the process group's watchdog thread polls the events of earlier, eager collectives while this
+                # thread captures — legal only in thread-local capture mode; in the default global mode its hipEventQuery
+                # aborts the process with hipErrorStreamCaptureUnsupported)
+                mode = "thread_local" if self._sharded else "global"
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode=mode):
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
                     if plan is not None:
                         # the side section (the next batch's sort, recorded last) is forked here: beside the backward,
