@@ -205,6 +205,20 @@ int rp_linear_wgrad_gather(const float *dy, int64_t lddy, const float *arena, co
 int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, rp_stream_t stream);
 /* out[r, 0:C] = in[r, 0:C], r < R, with another row stride (staging copy of a weight with unaligned rows) */
 int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
+/* ---- nn.Linear forward on PRE-SPLIT bf16 operands (csrc/gemm_pieces.hip; round 4) ---------------------------------
+ * Same contract as rp_linear_fwd (deep.py:62-72: out = act(a . w^T + bias)), but both operands arrive as bf16 PIECES in
+ * the "interleaved" layout: a row is a sequence of 128-byte k-tiles,
+ *   np = 2 (the bf16x3 products hi.lo + lo.hi + hi.hi):  [32 x bf16 hi | 32 x bf16 lo]  per 32 values of K
+ *   np = 1 (plain bf16, a stated-tolerance mode):        [64 x bf16]                    per 64 values of K
+ * K zero-padded to whole tiles: a row holds rp_pieces_ld(K, np) bf16 elements (lda / ldw >= that, multiples of 8).  The
+ * k-tiles go HBM -> LDS by LDS-DMA and the inner loop is fragment reads and MFMAs only.  np = 2 is bit-identical to
+ * rp_linear_fwd under RP_MATMUL_BF16X3.  rp_pieces_pack makes the layout from an fp32 matrix [M, K] (hi = RN(x),
+ * lo = RN(x - hi)); ldo in bf16 elements, a multiple of 64.  act: RP_ACT_NONE / RELU / MASK (aux as in rp_linear_fwd). */
+int64_t rp_pieces_ld(int K, int np);
+int rp_pieces_pack(const float *in, int64_t ld, int64_t M, int K, int np, void *out, int64_t ldo, rp_stream_t stream);
+int rp_linear_fwd_pieces(const void *a, int64_t lda, const void *w, int64_t ldw, const float *bias, float *out,
+                         int64_t ldo, int64_t M, int N, int K, int np, int act, const float *aux, int64_t ldaux,
+                         rp_stream_t stream);
 /* y = dy * (act_out > 0), elementwise over [M,N] */
 int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
                 int64_t M, int N, rp_stream_t stream);

@@ -51,6 +51,9 @@ _SIGNATURES = {
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rp_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_pieces_ld": (C.c_int64, [_i32, _i32]),
+    "rp_pieces_pack": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
+    "rp_linear_fwd_pieces": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_plan_begin": (C.c_int, [C.POINTER(_vp)]),
     "rp_plan_section": (C.c_int, [_i32]),
     "rp_plan_fork_here": (C.c_int, []),
@@ -638,6 +641,42 @@ def transpose(w, rows_out: Optional[int] = None):
     with _Timed("transpose", f"{R}x{Cc}", 4 * (R * Cc + rows * R)):
         _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, _stream()),
                "rp_transpose")
+    return out
+
+
+def pieces_ld(K: int, np_: int) -> int:
+    """bf16 elements per row of the interleaved-pieces layout (include/rec_pangu_hip.h: rp_pieces_ld)"""
+    return int(lib().rp_pieces_ld(int(K), int(np_)))
+
+
+def pieces_pack(x, np_: int = 2, K: Optional[int] = None, out=None):
+    """fp32 [M, >=K] -> bf16 pieces [M, rp_pieces_ld(K, np)] in the interleaved layout (rp_pieces_pack)"""
+    _req(x, torch.float32, "x")
+    M = x.shape[0]
+    K = x.shape[1] if K is None else K
+    ldo = pieces_ld(K, np_)
+    if out is None:
+        out = torch.empty((M, ldo), dtype=torch.bfloat16, device=x.device)
+    with _Timed("pieces_pack", f"{M}x{K}x{np_}", 4 * M * K + 2 * M * ldo):
+        _check(lib().rp_pieces_pack(x.data_ptr(), _rowmajor(x, "x"), M, K, np_, out.data_ptr(), _rowmajor(out, "out"), _stream()),
+               "rp_pieces_pack")
+    return out
+
+
+def linear_fwd_pieces(a_pc, w_pc, bias, K: int, np_: int = 2, act: int = ACT_NONE, aux=None, out=None):
+    """out[M,N] = act(a . w^T + bias) on pre-split operands (pieces_pack layout); np = 2 is bit-identical to linear_fwd under
+    RP_MATMUL_BF16X3, np = 1 is the plain-bf16 product"""
+    _req(a_pc, torch.bfloat16, "a_pc")
+    _req(w_pc, torch.bfloat16, "w_pc")
+    M, N = a_pc.shape[0], w_pc.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a_pc.device)
+    ldaux = _rowmajor(aux, "aux") if aux is not None else 0
+    with _Timed("linear_fwd_pieces", f"{M}x{N}x{K}x{np_}", 2 * (M + N) * pieces_ld(K, np_) + 4 * M * N * (2 if aux is not None else 1),
+                2 * M * N * K):
+        _check(lib().rp_linear_fwd_pieces(a_pc.data_ptr(), _rowmajor(a_pc, "a_pc"), w_pc.data_ptr(), _rowmajor(w_pc, "w_pc"),
+                                          _ptr(bias), out.data_ptr(), _rowmajor(out, "out"), M, N, K, np_, act, _ptr(aux), ldaux,
+                                          _stream()), "rp_linear_fwd_pieces")
     return out
 
 

@@ -541,6 +541,53 @@ def test_embed_grad_reduce_is_deterministic_and_ordered(hip):
     assert torch.equal(G2, G3)
 
 
+@pytest.mark.parametrize("M,N,K", [(65536, 1024, 1677), (1000, 300, 100), (4096 + 77, 256 + 32, 64), (513, 1677, 1024), (256, 256, 32)])
+@pytest.mark.parametrize("np_,mode", [(2, "bf16x3"), (1, "bf16")])
+def test_linear_fwd_pieces_bit_identical_to_the_in_kernel_split(hip, M, N, K, np_, mode):
+    """rp_linear_fwd_pieces (csrc/gemm_pieces.hip: operands pre-split into bf16 pieces by rp_pieces_pack, k-tiles staged by
+    LDS-DMA into an XOR-swizzled image) against rp_linear_fwd on the fp32 operands in the same product mode: the pieces are
+    the same values and every accumulator sees the same MFMA sequence, so the outputs are EQUAL — ragged M / N (clamped
+    rows, guarded stores), K tails that are zero padding in the piece layout, the mask epilogue, and the layout itself
+    (hi | lo per 32 values, against a torch split)."""
+    hip.set_matmul_precision(mode)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(M + N + K + np_)
+        ldx = (K + 3) // 4 * 4
+        a = torch.zeros(M, ldx, device=DEV)
+        a[:, :K] = torch.randn(M, K, generator=g, device=DEV)
+        w = torch.zeros(N, ldx, device=DEV)
+        w[:, :K] = torch.randn(N, K, generator=g, device=DEV) / K ** 0.5
+        b = torch.randn(N, generator=g, device=DEV)
+        ap, wp = hip.pieces_pack(a, np_, K=K), hip.pieces_pack(w, np_, K=K)
+        assert ap.shape[1] == hip.pieces_ld(K, np_) and ap.shape[1] % 64 == 0
+        # the layout, against torch: hi = RN(x), lo = RN(x - hi)
+        hi = a[:, :K].to(torch.bfloat16)
+        tiles = ap.view(M, -1, 64)
+        if np_ == 2:
+            lo = (a[:, :K] - hi.float()).to(torch.bfloat16)
+            kp = tiles.shape[1] * 32
+            want = torch.zeros(M, kp, 2, dtype=torch.bfloat16, device=DEV)
+            want[:, :K, 0], want[:, :K, 1] = hi, lo
+            want = want.view(M, kp // 32, 32, 2).permute(0, 1, 3, 2).reshape(M, -1, 64)
+        else:
+            want = torch.zeros(M, tiles.shape[1] * 64, dtype=torch.bfloat16, device=DEV)
+            want[:, :K] = hi
+            want = want.view(M, -1, 64)
+        assert torch.equal(tiles, want)
+        ref = hip.linear_fwd(a, w[:, :K], b, hip.ACT_RELU, K=K)
+        n0 = hip.launch_count()
+        out = hip.linear_fwd_pieces(ap, wp, b, K, np_, act=hip.ACT_RELU)
+        assert hip.launch_count() == n0 + 1
+        assert torch.equal(out, ref)
+        aux = torch.randn(M, N, generator=g, device=DEV)
+        ref2 = hip.linear_fwd(a, w[:, :K], None, hip.ACT_MASK, aux=aux, K=K)
+        out2 = torch.full((M, N), float("nan"), device=DEV)
+        hip.linear_fwd_pieces(ap, wp, None, K, np_, act=hip.ACT_MASK, aux=aux, out=out2)
+        assert torch.equal(out2, ref2)
+    finally:
+        hip.set_matmul_precision("auto")
+
+
 @pytest.mark.parametrize("M,N,K,lda_pad", [(65536, 1024, 1677, 1728), (65536, 384, 205, 208), (65536, 256, 192, 192),
                                            (131072, 512, 649, 704)])
 @pytest.mark.parametrize("mode", ["bf16x3", "auto", "bf16"])
