@@ -640,8 +640,9 @@ def main():
             # (the [blocks, 224, 160] partial sums are written and read once more: 37 MB at B = 65536, not counted)
             return local_B * (2 * 64 * 4 + 4 + 4 * len(tiny_tabs)) + (2 * n_unique_tiny + len(tiny_tabs) * 64) * rb, \
                 2.0 * 224 * 160 * local_B
-        if entry == "lazy_adam_catchup":      # deferred mode: p,m,v read+written, g read + cleared, per unique row
-            return 8 * n_unique * rb, 0
+        if entry == "lazy_adam_catchup":      # deferred mode: p,m,v read+written, g read (+ cleared: not in a plain training
+            # step since round 4 — the backward overwrites the row, mark = 2; RP_ADAM_NOCLEAR=0 restores the clear), per unique row
+            return (7 if os.environ.get("RP_ADAM_NOCLEAR", "1") != "0" and not args.sharded else 8) * n_unique * rb, 0
         if entry == "lazy_adam_rows_step":    # p,m,v read+written, g read + cleared, per unique touched row
             return 8 * n_unique * rb, 0
         if entry == "lazy_adam_rows_replay":  # p,m,v read+written per unique row that is behind (bound: all of them)

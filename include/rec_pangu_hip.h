@@ -577,7 +577,10 @@ int rp_lazy_adam_cf_terms(double beta1, int *terms);
  *                         zero-gradient steps up to t_done (serial up to cf_from, closed form beyond if cf_table);
  *                         mark != 0: the row is stamped pending for step t_done+1 (the backward of the forward this
  *                         launch precedes writes its gradient; a row that receives none holds zeros, and the real
- *                         step with g = 0 IS the zero-gradient step).  t_dev: device counter of completed steps.
+ *                         step with g = 0 IS the zero-gradient step).  mark == 2: the same stamp, and the applied
+ *                         rows are NOT cleared — the caller guarantees that the coming backward overwrites the gradient
+ *                         row of every stamped row (and clears them itself, rp_zero_rows, if that backward never comes).
+ *                         t_dev: device counter of completed steps.
  *   rp_lazy_adam_flush_deferred  the same for every row of the arena through t_target (g may be NULL when no
  *                         gradient arena exists yet); stamps last[row] = t_target.
  * Per row the same operations on the same values in the same order as rp_lazy_adam_rows: identical bits after a flush.

@@ -920,7 +920,10 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_kernel(const int32_t *_
             T g = rp_splat(0.f, p);
             if (apply) {
                 g = *reinterpret_cast<const T *>(G + off);
-                *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
+                // mark == 2: the caller promises that the backward this launch precedes OVERWRITES the gradient row of
+                // every row it stamps (one non-accumulating gradient launch over the same keys): the clear is dead
+                // traffic then, 1 of the 8 row transfers of this launch
+                if (mark != 2) *reinterpret_cast<T *>(G + off) = rp_splat(0.f, p);
             }
             lazy_owed<T>(p, m, v, apply, l, t_done, g, sc, c, cf, cf_from);
             *reinterpret_cast<T *>(P + off) = p;

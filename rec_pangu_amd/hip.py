@@ -1557,10 +1557,11 @@ def lazy_adam_flush(rows: int, D: int, p, m, v, last, scalars, t_target: int, be
                "rp_lazy_adam_flush")
 
 
-def lazy_adam_catchup(sorted_keys, D: int, p, g, m, v, last, scalars, t_done: int, mark: bool, beta1: float,
+def lazy_adam_catchup(sorted_keys, D: int, p, g, m, v, last, scalars, t_done: int, mark, beta1: float,
                       beta2: float, eps: float, cf_table=None, cf_from: int = 0, t_dev=None, shadow=None):
     """deferred execution (rp_lazy_adam_catchup): everything the unique rows of sorted_keys are owed through step t_done —
     their pending real step, then the zero-gradient steps — and, with mark, the stamp 'gradient of step t_done+1 coming'.
+    mark = 2: stamp, and leave the applied gradient rows uncleared (the caller's backward overwrites them).
     shadow: the bf16 lookup copy of the tables (bf16-storage training), written wherever a parameter row is"""
     with _Timed("lazy_adam_catchup", f"D={D}"):
         _check(lib().rp_lazy_adam_catchup(sorted_keys.data_ptr(), sorted_keys.numel(), D, p.data_ptr(), _ptr(g),

@@ -80,6 +80,7 @@ class EmbeddingLayer(nn.Module):
         self._grad_arena: Optional[torch.Tensor] = None
         self._touched: Optional[torch.Tensor] = None  # sorted keys written by the last backward
         self._grad_clean = True  # gradient arena known to be all zero
+        self._noclear_ok = True  # every gradient launch of this layer writes ALL rows of its key list (LazyAdamRows.replay)
         self._dev_meta = None
         self._lazy = None        # optim.LazyAdamRows when the optimiser runs the exact lazy dense Adam
         self._presorted = None   # (keys, sorted keys, sorted positions) of the batch being looked up
@@ -299,6 +300,10 @@ class EmbeddingLayer(nn.Module):
             sk, sp = presorted
         else:
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        if self._lazy is not None and self._lazy._noclear is not None:
+            # the catch-up launch in front of this step's forward left its applied gradient rows uncleared, counting on
+            # THIS launch to overwrite them (LazyAdamRows.replay): kept if it writes that key list without accumulating
+            self._lazy.resolve_noclear(self, sk if self._grad_clean else None)
         if pool is not None:  # (g [B, D], 1 / count or None, bag of every id or None, ids per dense bag, field, ids)
             hip.embed_pool_bwd(sk, sp, D, pool[0], pool[1], pool[2], pool[3], self._grad_arena,
                                accumulate=not self._grad_clean)

@@ -95,6 +95,10 @@ class StepTables:
         self.lr, self.lr_from, self.filled_to = lr, t_new, hi
 
 
+# RP_ADAM_NOCLEAR=0: the catch-up launch always clears the gradient rows it applies (the round-3 behaviour)
+NOCLEAR = os.environ.get("RP_ADAM_NOCLEAR", "1") != "0"
+
+
 class LazyAdamRows:
     """Per-EmbeddingLayer state of the lazy dense Adam: moment arenas, per-row `last` step stamps and the device tables
     of per-step scalars (StepTables).
@@ -118,6 +122,10 @@ class LazyAdamRows:
         # training step instead of two; adam.hip "DEFERRED execution").  `last` then carries pending stamps (< 0).
         self.defer = defer
         self._marked_for = -1  # the step whose gradient rows the last catch-up launch stamped pending
+        # (step, sorted keys) of a stamping launch that left the applied gradient rows UNCLEARED because the backward it
+        # precedes overwrites them (rp_lazy_adam_catchup mark = 2): resolved by that backward (EmbeddingLayer.
+        # accumulate_grad), or — when a second lookup or the optimizer step arrives first — by clearing those rows
+        self._noclear = None
         self.m, self.v = torch.zeros_like(a), torch.zeros_like(a)
         self.last = torch.zeros((a.shape[0],), dtype=torch.int32, device=a.device)
         self.betas, self.eps = betas, eps
@@ -216,11 +224,24 @@ class LazyAdamRows:
             if self.t > 0 or mark:
                 self._check_table(self.t)
                 cf, cf_from = self._cf_args(self.t) if (self.t > 0 or self.device_clock) else (None, 0)
+                mode = int(bool(mark))
+                if mark:
+                    # The clear of an applied gradient row is dead traffic (1 of the launch's 8 row transfers) when the
+                    # backward that follows overwrites the row anyway: the store's gradient arena is "clean" (its next
+                    # gradient launch does not accumulate) and this is the step's only stamping launch so far.  A second
+                    # lookup before any backward breaks the promise: the first one's rows are cleared now.
+                    clean = bool(getattr(store, "_noclear_ok", False)) and store.grad_arena is not None \
+                        and bool(getattr(store, "_grad_clean", False)) and NOCLEAR
+                    self.resolve_noclear(store)
+                    if clean and self._marked_for != self.t + 1:
+                        mode = 2
                 hip.lazy_adam_catchup(sorted_keys, store.embedding_dim, store.arena, store.grad_arena, self.m, self.v,
-                                      self.last, self.tabs.sc, self.t, mark, self.betas[0], self.betas[1], self.eps, cf,
+                                      self.last, self.tabs.sc, self.t, mode, self.betas[0], self.betas[1], self.eps, cf,
                                       cf_from, self._t_dev(), shadow=self._shadow_of(store))
                 if mark:
                     self._marked_for = self.t + 1
+                    if mode == 2:
+                        self._noclear = (self.t + 1, sorted_keys)
             return
         if self._shadow_of(store) is not None:
             raise RuntimeError("bf16-storage training (EmbeddingLayer.bf16_training) needs the deferred table optimizer: "
@@ -232,10 +253,24 @@ class LazyAdamRows:
                                self.tabs.sc, self.t, False, False, self.betas[0], self.betas[1], self.eps, cf, cf_from,
                                self._t_dev())
 
+    def resolve_noclear(self, store, written_keys=None):
+        """a stamping launch left its applied gradient rows uncleared (mark = 2): `written_keys` is the sorted key list a
+        non-accumulating gradient launch is about to overwrite — if it is that launch's own list the promise is kept;
+        in every other case (another lookup, the optimizer step, another key list) the rows are cleared here"""
+        pend, self._noclear = self._noclear, None
+        if pend is None:
+            return
+        keys = pend[1]
+        if written_keys is not None and (written_keys is keys or (written_keys.data_ptr() == keys.data_ptr()
+                                                                    and written_keys.numel() == keys.numel())):
+            return
+        hip.zero_rows(keys, store.embedding_dim, store.grad_arena)
+
     def step(self, store, lr, zero_grad: bool = True):
         t_new = self.t + 1
         self._ensure_table(t_new, lr)
         self._check_table(t_new)
+        self.resolve_noclear(store)  # (no backward consumed the promise: the stamped rows must read as zero gradients)
         sk = None if (self.defer and zero_grad and self._marked_for == t_new) else self._sorted_touched(store)
         if self.defer and zero_grad and self._marked_for == t_new:
             # the rows were stamped by the catch-up launch in front of their forward: their gradient rows stay where the
@@ -317,6 +352,7 @@ class FusedAdam(torch.optim.Optimizer):
         for store in self._stores.values():
             lz = store._lazy
             if lz is not None:
+                lz.resolve_noclear(store)
                 lz.defer = on
                 lz._marked_for = -1
 

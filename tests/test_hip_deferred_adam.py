@@ -185,3 +185,61 @@ def test_deferred_step_in_a_captured_graph():
         EmbeddingLayer.unpin_sorts()
     for k in finals["eager"]:
         assert torch.equal(finals["eager"][k], finals["graph"][k]), k
+
+
+def test_uncleared_catchup_rows_when_the_promised_backward_does_not_come():
+    """Round 4: the catch-up launch in front of a training forward leaves the gradient rows it applies UNCLEARED when the
+    backward that follows overwrites them anyway (rp_lazy_adam_catchup mark = 2, LazyAdamRows.replay) — 1 of its 8 row
+    transfers.  The promise can be broken; then the rows are cleared by whoever notices first and the results stay
+    bit-identical to the immediate execution:
+      i % 5 == 1  a training forward whose backward never runs, followed by the optimizer step (a zero-gradient step of
+                  every row; the stamped rows must read as zeros)
+      i % 5 == 2  two training forwards before any backward, then ONE backward of the summed loss (the second lookup
+                  arrives while the first one's rows are still uncleared; autograd runs the second lookup's backward first)
+      i % 5 == 3  a training forward, an evaluation forward, then the backward
+      otherwise   the plain step (the promise is kept: no clearing launch at all — asserted on the launch counter)"""
+    from rec_pangu_amd import hip
+    from rec_pangu_amd.optim import make_adam
+    enc = _enc(2, [50, 7, 3000, 20000])
+    batches = _batches(enc, 256, 16, seed=5)
+    runs = []
+    for defer in (False, True):
+        model = _model("deepfm64", enc)
+        opt = make_adam(model, 2e-3, replay="exact", defer=defer)
+        preds, plain_launches = [], []
+        for i in range(60):
+            b, b2 = batches[(i * 7) % 16], batches[(i * 7 + 3) % 16]
+            n0 = hip.launch_count()
+            if i % 5 == 1:
+                out = model(b)
+            elif i % 5 == 2:
+                out, out2 = model(b), model(b2)
+                (out["loss"] + out2["loss"]).backward()
+                preds.append(out2["pred"].detach().clone())
+            elif i % 5 == 3:
+                out = model(b)
+                model.eval()
+                with torch.no_grad():
+                    preds.append(model(b2, is_training=False)["pred"].clone())
+                model.train()
+                out["loss"].backward()
+            else:
+                out = model(b)
+                out["loss"].backward()
+            opt.step()
+            model.zero_grad()
+            if i % 5 in (0, 4) and i >= 10:
+                plain_launches.append(hip.launch_count() - n0)
+            preds.append(out["pred"].detach().clone())
+        if defer:
+            lz = model.embedding_layer._lazy
+            assert lz._noclear is None
+            assert len(set(plain_launches)) == 1, plain_launches  # (no clearing launch sneaks into a plain step)
+        runs.append((preds, _state(model, opt)))
+        if defer:
+            assert int((model.embedding_layer.grad_arena != 0).sum()) == 0, "after a flush no gradient row holds anything"
+    (pa, sa), (pb, sb) = runs
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a, b), f"prediction {i} differs"
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
