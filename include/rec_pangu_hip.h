@@ -449,6 +449,12 @@ int rp_mlp_tail_bwd_workspace_bytes(int64_t M, int n_hidden, size_t *bytes);
 int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw, const float *const *acts,
                     int64_t ldact0, const float *w_out, float *dhin, int64_t lddh, float *grads, int64_t M, void *workspace,
                     size_t workspace_bytes, rp_stream_t stream);
+/* the same in two separately issued parts: parts = 1 the per-workgroup launch (dhin + partial sums into the workspace),
+ * 2 = the second stage (workspace -> grads), 3 = both (= rp_mlp_tail_bwd).  The second stage reads only the workspace, so
+ * a captured step issues it beside the launches that follow the first one. */
+int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                          const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh, float *grads,
+                          int64_t M, void *workspace, size_t workspace_bytes, int parts, rp_stream_t stream);
 
 /* ---- Dropout (layers/deep.py:66-68 inside the MLP chain; the multi-task towers, mmoe.py:55) -------------------------
  * y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10(counter = (element group, offset), key = seed): a

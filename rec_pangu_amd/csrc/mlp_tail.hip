@@ -370,9 +370,14 @@ extern "C" int rp_mlp_tail_bwd_workspace_bytes(int64_t M, int n_hidden, size_t *
 // dz [M] (gradient of the logit) -> dhin [M, 64] (gradient w.r.t. the tail's input, already masked by hin > 0: hin is a
 // ReLU output), and `grads` = [dW_0 (64*64) | .. | dW_{L-1} | db_0 (64) | .. | db_{L-1} | dw_out (64) | db_out (1)] packed.
 // acts[0] = hin (row stride ldact0), acts[l] = output of hidden layer l (row stride 64).
-extern "C" int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
-                               const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
-                               float *grads, int64_t M, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+// parts: 1 = the per-workgroup launch (dhin + partial sums into the workspace), 2 = the second stage (partials -> grads),
+// 3 = both.  The second stage depends on nothing but the workspace: a captured step issues it beside the kernels that
+// follow the first one (rec_pangu_amd/hip.py: mlp_tail_bwd inside a launch plan).
+extern "C" int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                                     const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
+                                     float *grads, int64_t M, void *workspace, size_t workspace_bytes, int parts,
+                                     rp_stream_t stream) {
+    RP_REQUIRE(parts >= 1 && parts <= 3, "mlp_tail_bwd_parts: parts must be 1, 2 or 3");
     RP_REQUIRE(dz && W_hidden && ldw && acts && w_out && dhin && grads && workspace, "mlp_tail_bwd: null pointer");
     if (!rp_mlp_tail_fits(n_hidden, 64, ldact0) || lddh < 64)
         return rp_fail(RP_ERR_UNSUPPORTED, "mlp_tail_bwd: 1..3 hidden layers of width 64");
@@ -400,11 +405,22 @@ extern "C" int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const
     const int nwg = (int)rp_cdiv(M, 128);
     const int64_t per = (int64_t)n_hidden * 64 * 64 + (int64_t)n_hidden * 64 + 64 + 1;
     hipStream_t s = (hipStream_t)stream;
-    if (n_hidden == 1) hipLaunchKernelGGL((mlp_tail_bwd_kernel<1>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
-    else if (n_hidden == 2) hipLaunchKernelGGL((mlp_tail_bwd_kernel<2>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
-    else hipLaunchKernelGGL((mlp_tail_bwd_kernel<3>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
-    RP_LAUNCH_CHECK("mlp_tail_bwd");
-    hipLaunchKernelGGL(mlp_tail_reduce_kernel, dim3((unsigned)rp_cdiv(per, 16)), dim3(256), 0, s, P, nwg, per, grads);
-    RP_LAUNCH_CHECK("mlp_tail_bwd (partials)");
+    if (parts & 1) {
+        if (n_hidden == 1) hipLaunchKernelGGL((mlp_tail_bwd_kernel<1>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
+        else if (n_hidden == 2) hipLaunchKernelGGL((mlp_tail_bwd_kernel<2>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
+        else hipLaunchKernelGGL((mlp_tail_bwd_kernel<3>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
+        RP_LAUNCH_CHECK("mlp_tail_bwd");
+    }
+    if (parts & 2) {
+        hipLaunchKernelGGL(mlp_tail_reduce_kernel, dim3((unsigned)rp_cdiv(per, 16)), dim3(256), 0, s, P, nwg, per, grads);
+        RP_LAUNCH_CHECK("mlp_tail_bwd (partials)");
+    }
     return RP_OK;
+}
+
+extern "C" int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                               const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
+                               float *grads, int64_t M, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    return rp_mlp_tail_bwd_parts(dz, n_hidden, W_hidden, ldw, acts, ldact0, w_out, dhin, lddh, grads, M, workspace,
+                                 workspace_bytes, 3, stream);
 }

@@ -206,7 +206,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
     }
-    bool forked = false, open2 = false, main_since_fork2 = false;
+    bool forked = false, open2 = false, main_since_fork2 = false, side_joined = false;
     for (size_t i = 0; i <= p->nodes.size(); ++i) {
         if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
             // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
@@ -228,6 +228,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (n.section == 1) continue;
         if (n.func == nullptr) {  // join marker of the inline section
             if (open2) {
+                // the side section (issued at its fork point, long done by now) is joined through the same wait: every
+                // event operation on the main stream is a packet its next launch queues behind
+                if (forked && !side_joined) {
+                    e = hipStreamWaitEvent(p->side2, p->ev_join, 0);
+                    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join of the side section: %s", hipGetErrorString(e));
+                    side_joined = true;
+                }
                 e = hipEventRecord(p->ev_join2, p->side2);
                 if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
@@ -260,7 +267,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
     }
-    if (fork) {
+    if (fork && !side_joined) {
         e = hipStreamWaitEvent(s, p->ev_join, 0);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join: %s", hipGetErrorString(e));
     }

@@ -861,6 +861,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
             hip.LaunchPlan.section(2)
             try:
                 dw, db = wgrad(keep)
+                hip.LaunchPlan.run_deferred()  # (e.g. the MLP tail's second stage: behind the weight gradient, not in front)
             finally:
                 hip.LaunchPlan.section(0)
         elif wstream is not None:

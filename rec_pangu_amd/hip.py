@@ -121,6 +121,7 @@ _SIGNATURES = {
     "rp_mlp_tail_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "rp_mlp_tail_bwd_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_mlp_tail_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _vp]),
+    "rp_mlp_tail_bwd_parts": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _i32, _vp]),
     "rp_dropout_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp]),
     "rp_dropout_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
@@ -706,6 +707,9 @@ class LaunchPlan:
         self._h = h
 
     def end(self):
+        if LaunchPlan._deferred and LaunchPlan.is_recording():
+            LaunchPlan.join()  # (nobody joined the inline section after the last deferred launch was queued)
+        LaunchPlan._deferred, LaunchPlan._kept = [], []
         _check(lib().rp_plan_end(self._h), "rp_plan_end")
         a, b, c = _i32(), _i32(), _i32()
         _check(lib().rp_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "rp_plan_info")
@@ -727,9 +731,35 @@ class LaunchPlan:
     def fork_here():
         _check(lib().rp_plan_fork_here(), "rp_plan_fork_here")
 
-    @staticmethod
-    def join():
+    # launches a recording step wants on the inline section (2) but has no hurry with: issued behind the next launches
+    # recorded there (run_deferred), at the latest in front of the section's join; `keep` = the tensors they touch (the
+    # capture's allocator would hand their memory to the launches recorded in between)
+    _deferred: list = []
+    _kept: list = []
+
+    @classmethod
+    def defer_side(cls, fn, keep=()):
+        cls._deferred.append(fn)
+        cls._kept.append(keep)
+
+    @classmethod
+    def run_deferred(cls):
+        """issue the deferred launches now, on the inline section (the caller may already be inside it)"""
+        if not cls._deferred:
+            return
+        todo, cls._deferred = cls._deferred, []
+        _check(lib().rp_plan_section(2), "rp_plan_section")
+        try:
+            for fn in todo:
+                fn()
+        finally:
+            _check(lib().rp_plan_section(0), "rp_plan_section")
+
+    @classmethod
+    def join(cls):
+        cls.run_deferred()
         _check(lib().rp_plan_join(), "rp_plan_join")
+        cls._kept = []
 
     @staticmethod
     def is_recording() -> bool:
@@ -1475,10 +1505,22 @@ def mlp_tail_bwd(dz, Ws, acts, w_out):
     nbytes = _sz(0)
     _check(lib().rp_mlp_tail_bwd_workspace_bytes(M, L, C.byref(nbytes)), "rp_mlp_tail_bwd_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    def launch(parts):
+        _check(lib().rp_mlp_tail_bwd_parts(dz.data_ptr(), L, _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]),
+                                           _ptr_array(acts), _rowmajor(acts[0], "hin"), w_out.data_ptr(), dhin.data_ptr(), 64,
+                                           grads.data_ptr(), M, ws.data_ptr(), nbytes.value, parts, _stream()),
+               "rp_mlp_tail_bwd")
+
     with _Timed("mlp_tail_bwd", f"{M}x64x{L}", 4 * M * (64 * (L + 2) + 1), 2 * M * (2 * 64 * 64 * L + 128)):
-        _check(lib().rp_mlp_tail_bwd(dz.data_ptr(), L, _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]),
-                                     _ptr_array(acts), _rowmajor(acts[0], "hin"), w_out.data_ptr(), dhin.data_ptr(), 64,
-                                     grads.data_ptr(), M, ws.data_ptr(), nbytes.value, _stream()), "rp_mlp_tail_bwd")
+        if LaunchPlan.is_recording() and os.environ.get("RP_TAIL_REDUCE_SIDE", "1") != "0":
+            # a captured step: the second stage (workspace -> grads, ~20 us of latency) reads nothing the following
+            # launches write and nobody needs `grads` before the optimizer: it joins the plan's inline section (the second
+            # side stream) behind the next launches recorded there, instead of standing between this launch and the first
+            # layer's backward.  The workspace stays referenced until that section is joined.
+            launch(1)
+            LaunchPlan.defer_side(lambda: launch(2), (ws, grads))
+        else:
+            launch(3)
     dWs = [grads[l * 4096:(l + 1) * 4096].view(64, 64) for l in range(L)]
     dbs = [grads[L * 4096 + l * 64:L * 4096 + (l + 1) * 64] for l in range(L)]
     return dhin, dWs, dbs, grads[L * 4160:L * 4160 + 64].view(1, 64), grads[L * 4160 + 64:L * 4160 + 65]
