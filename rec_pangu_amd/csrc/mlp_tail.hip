@@ -199,13 +199,18 @@ struct TailBwdArgs {
 };
 
 // partial workspace layout per workgroup g:  P[g][L][64*64] (dW), then Pb[g][L][64] (db), then Pw[g][64] (dw_out), Pz[g] (db_out)
+// (round 4: the W_l^T operand of the dgrad lives in REGISTERS — 24 fragments per lane, read from global memory with the
+//  transposition in the addressing (8 coalesced 128-byte row segments per fragment), split in place — instead of in 27 KB
+//  of LDS written with 48 two-byte stores per thread and layer: the two activation tiles are then all the LDS a workgroup
+//  holds (70 KB), TWO workgroups fit a CU and all 512 of a 65536-row launch are resident at once.  With one workgroup per
+//  CU — one wave per SIMD — nothing hid the kernel's chains of LDS round trips: 67 us for ~6 us of matrix work.)
 template <int L>
-__global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(const float *__restrict__ dz, TailBwdArgs a,
-                                                           const float *__restrict__ wout, float *__restrict__ dhin,
-                                                           int64_t lddh, float *__restrict__ P, int64_t M, int nwg) {
-    __shared__ __attribute__((aligned(16))) __bf16 Wt[3][64][MT_LD];     // W_l^T pieces: [in][out]
+__global__ __launch_bounds__(256, 2) void mlp_tail_bwd_kernel(const float *__restrict__ dz, TailBwdArgs a,
+                                                              const float *__restrict__ wout, float *__restrict__ dhin,
+                                                              int64_t lddh, float *__restrict__ P, int64_t M, int nwg) {
     __shared__ __attribute__((aligned(16))) float T0[4][32][MT_CT];      // dpre_l  (rows of the four waves back to back)
     __shared__ __attribute__((aligned(16))) float T1[4][32][MT_CT];      // a_{l-1}
+    __shared__ float dzs[128];                                           // dz of the workgroup's rows (0 beyond M)
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 128;
     const int64_t row = row0 + 32 * wv + i;
@@ -217,6 +222,7 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(const float *__restri
     float *Pg = P + (int64_t)blockIdx.x * ((int64_t)L * 64 * 64 + (int64_t)L * 64 + 64 + 1);
     // ---- head: dpre_L = dz * wout, masked by a_L > 0; dw_out, db_out partials
     const float dzr = rok ? dz[row] : 0.f;
+    if (h == 0) dzs[32 * wv + i] = dzr;
     f32x8 dp[4];  // dpre of the current layer, A layout (lane = row, k = 16 ks + 8 h ..)
     {
         const float *src = a.act[L] + rowc * 64 + 8 * h;
@@ -238,10 +244,7 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(const float *__restri
         Pg[(int64_t)L * 64 * 64 + (int64_t)L * 64 + threadIdx.x] = s;
     } else if (threadIdx.x == 64) {
         float s = 0.f;
-        for (int r = 0; r < 128; ++r) {
-            const int64_t m = row0 + r;
-            s += m < M ? dz[m] : 0.f;
-        }
+        for (int r = 0; r < 128; ++r) s += dzs[r];  // (the same order as a serial walk over dz)
         Pg[(int64_t)L * 64 * 64 + (int64_t)L * 64 + 64] = s;
     }
 #pragma unroll
@@ -261,7 +264,21 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(const float *__restri
                 *reinterpret_cast<f32x4 *>(&T1[wv][i][ks * 16 + 8 * h + 4]) = rok ? v1 : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        mt_stage_wt(a.W[ly - 1], a.ldw[ly - 1], Wt);
+        // W_ly^T fragments: lane (i, h) of fragment (nt, ks) holds W[out = 16 ks + 8 h + e][in = 32 nt + i], e = 0..7
+        bf16x8 wf[2][4][3];
+        {
+            const float *Wl = a.W[ly - 1];
+            const int64_t ldw = a.ldw[ly - 1];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    f32x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = Wl[(int64_t)(ks * 16 + 8 * h + e) * ldw + nt * 32 + i];
+                    bf_split8<3>(v, wf[nt][ks]);
+                }
+        }
         __syncthreads();
         // ---- weight gradient tile of this wave: dW[out = mt*32 + .., in = ntw*32 + ..] = sum over 128 rows
         //      A = dpre^T (lane = out column, 8 consecutive rows per k-step), B = a^T (lane = in column)
@@ -304,12 +321,9 @@ __global__ __launch_bounds__(256) void mlp_tail_bwd_kernel(const float *__restri
             bf_split8<3>(dp[ks], af);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                bf16x8 b[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(&Wt[q][nt * 32 + i][ks * 16 + 8 * h]);
 #pragma unroll
                 for (int pr = 0; pr < 6; ++pr)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BfProd<6>::pa(pr)], b[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BfProd<6>::pa(pr)], wf[nt][ks][BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
             }
         }
         __syncthreads();  // every wave has finished reading T0 (wgrad): it now takes the masked gradient
