@@ -203,6 +203,11 @@ int rp_linear_wgrad_gather(const float *dy, int64_t lddy, const float *arena, co
                            void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* out[C,R] = in[R,C]^T (weights for the dgrad GEMM); rows C .. C_out-1 of out (C_out >= C) are written as zeros */
 int rp_transpose(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, rp_stream_t stream);
+/* rp_transpose and rp_copy_rows of the same matrix in ONE launch: out = in^T as rp_transpose, copy[r, 0:C] = in[r, 0:C] with
+ * row stride ldcopy (the first layer's weight: its transposed copy for the gather backward and its aligned copy for the
+ * gather forward are both made in front of the forward) */
+int rp_transpose_copy(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out, float *copy,
+                      int64_t ldcopy, rp_stream_t stream);
 /* out[r, 0:C] = in[r, 0:C], r < R, with another row stride (staging copy of a weight with unaligned rows) */
 int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
 /* ---- nn.Linear forward on PRE-SPLIT bf16 operands (csrc/gemm_pieces.hip; round 4) ---------------------------------
@@ -521,6 +526,8 @@ int rp_adam_step(float *const *p_ptrs, float *const *g_ptrs, float *const *m_ptr
  * for t_end = *t_dev (a fixed-size window of the youngest stamps: consecutive replays keep it complete).  rp_counter_add advances a
  * counter on the stream.  rec_pangu_amd/graph_step.py captures fwd + bwd + optimizer on top of these. */
 int rp_counter_add(int32_t *counter, int32_t delta, rp_stream_t stream);
+/* the same for 1..8 distinct counters in one launch (counters: host array of device pointers) */
+int rp_counters_add(int32_t *const *counters, int n, int32_t delta, rp_stream_t stream);
 
 /* ---- exact LAZY dense Adam for arena rows -----------------------------------------------------
  * Same semantics as rp_adam_step over the whole arena (trainer.py:75: DENSE Adam, every row every step), but a

@@ -1060,6 +1060,27 @@ extern "C" int rp_rows_to_bf16(const int32_t *sorted_keys, int64_t n, int D, con
 // *counter += delta on the stream (the device-resident step counters of the hipGraph path)
 __global__ void counter_add_kernel(int32_t *c, int32_t delta) { *c += delta; }
 
+// the same for up to eight counters in one launch (a captured step advances the table clock and the dense clock together)
+struct CounterList {
+    int32_t *c[8];
+};
+__global__ void counters_add_kernel(CounterList l, int n, int32_t delta) {
+    if ((int)threadIdx.x < n) *l.c[threadIdx.x] += delta;
+}
+
+extern "C" int rp_counters_add(int32_t *const *counters, int n, int32_t delta, rp_stream_t stream) {
+    RP_REQUIRE(counters && n >= 1 && n <= 8, "counters_add: 1..8 counters");
+    CounterList l;
+    for (int i = 0; i < 8; ++i) l.c[i] = i < n ? counters[i] : nullptr;
+    for (int i = 0; i < n; ++i) {
+        RP_REQUIRE(l.c[i] != nullptr, "counters_add: null pointer");
+        for (int j = 0; j < i; ++j) RP_REQUIRE(l.c[i] != l.c[j], "counters_add: the same counter twice");
+    }
+    hipLaunchKernelGGL(counters_add_kernel, dim3(1), dim3(8), 0, (hipStream_t)stream, l, n, delta);
+    RP_LAUNCH_CHECK("counters_add");
+    return RP_OK;
+}
+
 extern "C" int rp_counter_add(int32_t *counter, int32_t delta, rp_stream_t stream) {
     RP_REQUIRE(counter, "counter_add: null pointer");
     hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);

@@ -1112,15 +1112,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 // out rows C .. C_out-1 (if any) are written as zeros
+// copy (optional): the same elements are also written UNtransposed with another row stride, copy[r * ldcopy + c] — the
+// 16-byte-aligned staging copy of a weight whose rows are not (rp_copy_rows), made by the launch that reads the weight anyway
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int64_t ldin,
-                                                        float *__restrict__ out, int64_t ldout, int R, int C, int C_out) {
+                                                        float *__restrict__ out, int64_t ldout, int R, int C, int C_out,
+                                                        float *__restrict__ copy = nullptr, int64_t ldcopy = 0) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
         const int r = r0 + ty + j, c = c0 + tx;
-        tile[ty + j][tx] = (r < R && c < C) ? in[(int64_t)r * ldin + c] : 0.f;
+        const bool ok = r < R && c < C;
+        const float v = ok ? in[(int64_t)r * ldin + c] : 0.f;
+        tile[ty + j][tx] = v;
+        if (copy != nullptr && ok) copy[(int64_t)r * ldcopy + c] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -1517,6 +1523,16 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float *__restrict_
         const int c = (int)(e - r * C);
         out[r * ldout + c] = in[r * ldin + c];
     }
+}
+
+extern "C" int rp_transpose_copy(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, int C_out,
+                                 float *copy, int64_t ldcopy, rp_stream_t stream) {
+    RP_REQUIRE(in && out && copy && R >= 1 && C >= 1 && C_out >= C && ldin >= C && ldout >= R && ldcopy >= C,
+               "transpose_copy: bad argument");
+    const dim3 grid((unsigned)rp_cdiv(C_out, 32), (unsigned)rp_cdiv(R, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C, C_out, copy, ldcopy);
+    RP_LAUNCH_CHECK("transpose_copy");
+    return RP_OK;
 }
 
 extern "C" int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream) {

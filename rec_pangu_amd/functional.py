@@ -784,8 +784,17 @@ class _EmbedGatherLinear(torch.autograd.Function):
         store._presorted = None
         need_grad = any(ctx.needs_input_grad[8:])
         need_w = ctx.needs_input_grad[4] or (bias is not None and ctx.needs_input_grad[5])
-        w16 = _rows16(weight)
         B, K, Kg = idx[0].shape[0], weight.shape[1], len(idx) * store.embedding_dim
+        wt = None
+        if (need_grad and weight.is_cuda and weight.dtype is torch.float32 and K % 4 != 0 and K > 64
+                and os.environ.get("RP_STAGE_ONCE", "1") != "0"):
+            # the backward will want W^T (rp_embed_grad_gemm) and this forward wants the aligned copy of W: one launch makes
+            # both from one read of W, in front of the forward, and the transpose leaves the backward's critical path
+            with torch.no_grad():
+                wt, w16 = hip.transpose_copy(weight.detach(), rows_out=ldx, ld_copy=(K + 3) // 4 * 4)
+        else:
+            w16 = _rows16(weight)
+        ctx.wt = wt
         if shadow is not None:
             # bf16-storage training (EmbeddingLayer.bf16_training): rows from the bf16 lookup copy, the activation stored as
             # bf16 for the weight gradient (rp_linear_wgrad_xbf16); everything else as below
@@ -872,7 +881,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
         elif need_w:
             dw, db = wgrad()
         if need_t:
-            wt = hip.transpose(weight, rows_out=ctx.ldx)
+            wt = ctx.wt if ctx.wt is not None else hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
                                   fused=(dpre, wt), plan_keep=keep if in_plan else None)

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rp_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_transpose_copy": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_pieces_ld": (C.c_int64, [_i32, _i32]),
     "rp_pieces_pack": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "rp_linear_fwd_pieces": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
@@ -129,6 +130,7 @@ _SIGNATURES = {
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
     "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp, _vp, _vp]),
     "rp_counter_add": (C.c_int, [_vp, _i32, _vp]),
+    "rp_counters_add": (C.c_int, [_vp, _i32, _i32, _vp]),
     "rp_accumulate": (C.c_int, [_vp, _vp, _i64, _vp]),
     "rp_embed_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "rp_shard_keys": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
@@ -643,6 +645,20 @@ def transpose(w, rows_out: Optional[int] = None):
         _check(lib().rp_transpose(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, _stream()),
                "rp_transpose")
     return out
+
+
+def transpose_copy(w, rows_out: int, ld_copy: int):
+    """(transpose(w, rows_out), copy_rows(w, ld_copy)) from one launch (rp_transpose_copy)"""
+    _req(w, torch.float32, "w")
+    R, Cc = w.shape
+    R4 = (R + 3) // 4 * 4
+    rows = max(Cc, rows_out or 0)
+    out = torch.empty((rows, R4), dtype=torch.float32, device=w.device)[:, :R]
+    buf = torch.empty((R, ld_copy), dtype=torch.float32, device=w.device)
+    with _Timed("transpose_copy", f"{R}x{Cc}", 4 * (2 * R * Cc + rows * R)):
+        _check(lib().rp_transpose_copy(w.data_ptr(), _rowmajor(w, "w"), out.data_ptr(), R4, R, Cc, rows, buf.data_ptr(), ld_copy,
+                                       _stream()), "rp_transpose_copy")
+    return out, buf[:, :Cc]
 
 
 def pieces_ld(K: int, np_: int) -> int:
@@ -1356,6 +1372,13 @@ def bump_weight_epoch() -> None:
     """a captured step was replayed: its optimizer kernels ran without any python"""
     global _weight_epoch
     _weight_epoch += 1
+
+
+def counters_add(counters, delta: int = 1):
+    """*c += delta for every device counter in `counters` (1..8 int32[1] tensors) in ONE launch (rp_counters_add)"""
+    if len(counters) == 1:
+        return counter_add(counters[0], delta)
+    _check(lib().rp_counters_add(_ptr_array(counters), len(counters), delta, _stream()), "rp_counters_add")
 
 
 def counter_add(counter, delta: int = 1):

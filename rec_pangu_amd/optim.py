@@ -285,7 +285,11 @@ class LazyAdamRows:
             if self._shadow_of(store) is not None:  # (an update that did not go through the deferred kernels)
                 hip.rows_to_bf16(sk, store.embedding_dim, store.arena, store._shadow)
         if self.device_clock:
-            hip.counter_add(self.tabs.t_dev, 1)
+            owner = self.owner() if self.owner is not None else None
+            if owner is not None and owner._in_step:
+                owner._clock_ticks.append(self.tabs.t_dev)  # (one launch for every clock of the step: FusedAdam.step)
+            else:
+                hip.counter_add(self.tabs.t_dev, 1)
         self.t = t_new
         if zero_grad:  # FusedAdam(fuse_zero_grad=True): the gradient rows were cleared inside the step
             store.grads_were_zeroed()
@@ -326,6 +330,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._arena_state: Dict[int, dict] = {}
         self._stores = {}
         self._plans: Dict[int, list] = {}
+        self._in_step = False      # inside step(): the device clocks of the step are advanced by ONE launch at its end
+        self._clock_ticks: list = []
 
     @staticmethod
     def _store_of(p):
@@ -396,6 +402,17 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._in_step, self._clock_ticks = True, []
+        try:
+            self._step_groups()
+        finally:
+            self._in_step = False
+            ticks, self._clock_ticks = self._clock_ticks, []
+            for i in range(0, len(ticks), 8):  # (every lazy state and every parameter group has a clock of its own)
+                hip.counters_add(ticks[i:i + 8], 1)
+        return loss
+
+    def _step_groups(self):
         for group in self.param_groups:
             lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
             group["_rp_step"] = step = group.get("_rp_step", 0) + 1
@@ -467,10 +484,9 @@ class FusedAdam(torch.optim.Optimizer):
                     assert tabs.covers(step, lr), "graphed step: the dense step table was not prepared for this step / lr"
                     hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad, scalars=tabs.sc,
                                   t_dev=tabs.t_dev)
-                    hip.counter_add(tabs.t_dev, 1)
+                    self._clock_ticks.append(tabs.t_dev)
                 else:
                     hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
-        return loss
 
     # ---- device-resident step counters (graph_step.GraphedTrainStep) --------------------------------------------------
     def _lazies(self):
