@@ -177,6 +177,8 @@ class GraphedTrainStep:
                     # the seed gradient is a persistent 1.0: loss.backward() would create it with an ATen fill kernel — the
                     # one launch of a DeepFM step that is not the library's (a launch plan must hold them all)
                     out["loss"].backward(gradient=self._seed_grad(out["loss"]))
+                    if plan is not None:
+                        hip.LaunchPlan.settle()
                     if self.post_backward is not None:
                         self.post_backward()
                     self.opt.step()

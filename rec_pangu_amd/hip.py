@@ -772,6 +772,13 @@ class LaunchPlan:
             _check(lib().rp_plan_section(0), "rp_plan_section")
 
     @classmethod
+    def settle(cls):
+        """after the backward of a recording step: launches still waiting for the inline section are issued and joined NOW
+        (their results are the optimizer's inputs; a step without the fused first-layer node never joined them)"""
+        if cls._deferred and cls.is_recording():
+            cls.join()
+
+    @classmethod
     def join(cls):
         cls.run_deferred()
         _check(lib().rp_plan_join(), "rp_plan_join")

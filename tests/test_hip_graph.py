@@ -46,6 +46,8 @@ def _build(kind, enc):
     torch.manual_seed(0)
     if kind == "deepfm64":   # D = 64, [64, 64, 64]: the fused gather + Linear forward and the fused gather backward
         model = DeepFM(embedding_dim=64, hidden_units=[64, 64, 64], enc_dict=enc)
+    elif kind == "deepfm32tail":  # the fused MLP tail behind a GENERIC first layer: nobody joins the tail's deferred second
+        model = DeepFM(embedding_dim=32, hidden_units=[64, 64, 64], enc_dict=enc)  # stage but the step itself
     elif kind == "deepfm16":
         model = DeepFM(embedding_dim=16, hidden_units=[32, 16], enc_dict=enc)
     else:
@@ -59,6 +61,7 @@ def _build(kind, enc):
 
 @pytest.mark.parametrize("kind,replay,steps,defer", [("deepfm64", "closed", 330, False), ("deepfm64", "exact", 60, False),
                                                      ("deepfm16", "closed", 300, False), ("dcn", "closed", 60, False),
+                                                     ("deepfm32tail", "closed", 40, True),
                                                      ("deepfm64", "closed", 300, True)])
 def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, defer, backend):
     """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
