@@ -443,8 +443,11 @@ __global__ __launch_bounds__(256, 2) void embed_gather_linear_kernel(
 #pragma unroll
                 for (int qq = 0; qq < 3; ++qq) bq[qq] = *reinterpret_cast<const bf16x8 *>(&Wt[qq][nt * 32 + i][ks * 16 + 8 * h]);
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr)
+                for (int pr = 0; pr < 6; ++pr) {
+                    // bf16 rows ARE their first piece: the other two are zero and so are the three products they enter
+                    if (BF16_ROWS && BfProd<6>::pa(pr) != 0) continue;
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], acc[nt], 0, 0, 0);
+                }
             }
         }
 #pragma unroll

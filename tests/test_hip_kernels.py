@@ -287,6 +287,41 @@ def test_transpose_and_relu_bwd(hip):
     assert torch.equal(hip.relu_bwd(dy.to(DEV), y.to(DEV)).cpu(), dy * (y > 0))
 
 
+def test_transpose_copy_counters_and_tail_parts(hip):
+    """the small launches the captured step merges or splits (round 4): rp_transpose_copy = rp_transpose + rp_copy_rows of
+    one matrix; rp_counters_add = several rp_counter_add; rp_mlp_tail_bwd_parts(1) then (2) = rp_mlp_tail_bwd"""
+    g = torch.Generator().manual_seed(5)
+    for R, Cc, rows_out in ((64, 1677, 1728), (37, 5, 0), (64, 64, 64)):
+        w = torch.randn(R, Cc, generator=g).to(DEV)
+        ld = (Cc + 3) // 4 * 4
+        wt, w16 = hip.transpose_copy(w, rows_out, ld)
+        ref_t = hip.transpose(w, rows_out=rows_out)
+        assert wt.shape == ref_t.shape and torch.equal(wt, ref_t)
+        assert torch.equal(w16, w) and w16.stride(0) == ld
+    cs = [torch.full((1,), v, dtype=torch.int32, device=DEV) for v in (3, 10, -2)]
+    hip.counters_add(cs, 2)
+    hip.counters_add(cs[:1], 1)
+    assert [int(c.item()) for c in cs] == [6, 12, 0]
+    M, L = 1000, 2
+    Ws = [torch.randn(64, 64, generator=g).to(DEV) / 8 for _ in range(L)]
+    acts = [torch.randn(M, 64, generator=g).relu().to(DEV) for _ in range(L + 1)]
+    dz, w_out = torch.randn(M, generator=g).to(DEV), torch.randn(1, 64, generator=g).to(DEV)
+    a = hip.mlp_tail_bwd(dz, Ws, acts, w_out)   # (outside a launch plan: one call, both parts)
+    import ctypes as C
+    dhin = torch.empty(M, 64, device=DEV)
+    grads = torch.empty(L * 4096 + L * 64 + 65, device=DEV)
+    nbytes = C.c_size_t(0)
+    assert hip.lib().rp_mlp_tail_bwd_workspace_bytes(M, L, C.byref(nbytes)) == 0
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=DEV)
+    for parts in (1, 2):
+        rc = hip.lib().rp_mlp_tail_bwd_parts(dz.data_ptr(), L, hip._ptr_array(Ws), hip._i64_array([64] * L), hip._ptr_array(acts), 64,
+                                             w_out.data_ptr(), dhin.data_ptr(), 64, grads.data_ptr(), M, ws.data_ptr(), nbytes.value,
+                                             parts, hip._stream())
+        assert rc == 0
+    assert torch.equal(dhin, a[0])
+    assert torch.equal(grads[:4096].view(64, 64), a[1][0]) and torch.equal(grads[L * 4160:L * 4160 + 64].view(1, 64), a[3])
+
+
 @pytest.mark.parametrize("B,n_add,apply_sigmoid,p_eps,weight", [
     (24, 2, True, 0.0, 1.0), (65536, 3, True, 0.0, 1.0), (1000, 1, False, 1e-6, 0.5), (300001, 1, True, 0.0, 1.0)])
 def test_sigmoid_bce(hip, B, n_add, apply_sigmoid, p_eps, weight):
