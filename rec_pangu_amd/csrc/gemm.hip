@@ -996,6 +996,8 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void linear_wgrad_bf16_kernel
             }
 #pragma unroll
             for (int pr = 0; pr < NPROD; ++pr) {
+                // (a bf16 activation IS its first piece: the products its two zero pieces enter are skipped)
+                if (X_BF16 && BfProd<NPROD>::pb(pr) != 0) continue;
 #pragma unroll
                 for (int u = 0; u < NA; ++u) {
                     acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][BfProd<NPROD>::pa(pr)], b0[BfProd<NPROD>::pb(pr)],
