@@ -467,6 +467,12 @@ int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_h
  * dx = dy * keep / (1 - p).  One call consumes ONE offset value (the host advances its generator by one per call). */
 int rp_dropout_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
                    uint64_t seed, uint64_t offset, rp_stream_t stream);
+/* the same with offset = *offset_dev + offset_delta read on the device: what a captured step records (frozen launch
+ * arguments): offset_dev holds the generator offset of the step's start and is advanced at the step's end with
+ * rp_counter_add_u64, so a replay draws the masks the eager loop would draw at that point of the generator's stream */
+int rp_dropout_fwd_dev(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
+                       uint64_t seed, uint64_t offset_delta, const uint64_t *offset_dev, rp_stream_t stream);
+int rp_counter_add_u64(uint64_t *counter, uint64_t delta, rp_stream_t stream);
 int rp_dropout_bwd(const float *dy, int64_t lddy, const uint8_t *mask, float *dx, int64_t lddx, int64_t M, int N, float p,
                    rp_stream_t stream);
 

@@ -35,7 +35,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 template <bool VEC>
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
                                                           int64_t ldy, uint8_t *__restrict__ mask, int64_t M, int N,
-                                                          uint32_t thresh, float scale, uint64_t seed, uint64_t offset) {
+                                                          uint32_t thresh, float scale, uint64_t seed, uint64_t offset,
+                                                          const uint64_t *__restrict__ offset_dev = nullptr) {
+    if (offset_dev != nullptr) offset += *offset_dev;  // a captured step: the generator offset at the step's start, on the device
     const int64_t total = M * (int64_t)N;
     const int64_t ngroups = (total + 3) / 4;
     for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < ngroups;
@@ -111,8 +113,8 @@ static unsigned drop_grid(int64_t M, int N) {
     return (unsigned)b;
 }
 
-extern "C" int rp_dropout_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
-                              uint64_t seed, uint64_t offset, rp_stream_t stream) {
+static int dropout_fwd_impl(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
+                            uint64_t seed, uint64_t offset, const uint64_t *offset_dev, rp_stream_t stream) {
     RP_REQUIRE(x && y && mask && M >= 0 && N >= 1 && ldx >= N && ldy >= N, "dropout_fwd: bad argument");
     RP_REQUIRE(p >= 0.f && p < 1.f, "dropout_fwd: p = %f outside [0, 1)", (double)p);
     if (M == 0) return RP_OK;
@@ -126,11 +128,34 @@ extern "C" int rp_dropout_fwd(const float *x, int64_t ldx, float *y, int64_t ldy
     hipStream_t s = (hipStream_t)stream;
     if (vec)
         hipLaunchKernelGGL((dropout_fwd_kernel<true>), dim3(drop_grid(M, N)), dim3(256), 0, s, x, ldx, y, ldy, mask, M, N,
-                           thresh, scale, seed, offset);
+                           thresh, scale, seed, offset, offset_dev);
     else
         hipLaunchKernelGGL((dropout_fwd_kernel<false>), dim3(drop_grid(M, N)), dim3(256), 0, s, x, ldx, y, ldy, mask, M, N,
-                           thresh, scale, seed, offset);
+                           thresh, scale, seed, offset, offset_dev);
     RP_LAUNCH_CHECK("dropout_fwd");
+    return RP_OK;
+}
+
+extern "C" int rp_dropout_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
+                              uint64_t seed, uint64_t offset, rp_stream_t stream) {
+    return dropout_fwd_impl(x, ldx, y, ldy, mask, M, N, p, seed, offset, nullptr, stream);
+}
+
+// offset = *offset_dev + offset_delta, read on the device: the form a CAPTURED step records (its launch arguments are
+// frozen; the generator offset of the step's start lives in device memory and is advanced by rp_counter_add_u64 at the
+// step's end, so every replay draws the masks the eager loop would draw at that point of the generator's stream)
+extern "C" int rp_dropout_fwd_dev(const float *x, int64_t ldx, float *y, int64_t ldy, uint8_t *mask, int64_t M, int N, float p,
+                                  uint64_t seed, uint64_t offset_delta, const uint64_t *offset_dev, rp_stream_t stream) {
+    RP_REQUIRE(offset_dev != nullptr, "dropout_fwd_dev: null offset counter");
+    return dropout_fwd_impl(x, ldx, y, ldy, mask, M, N, p, seed, offset_delta, offset_dev, stream);
+}
+
+__global__ void counter_add_u64_kernel(uint64_t *c, uint64_t delta) { *c += delta; }
+
+extern "C" int rp_counter_add_u64(uint64_t *counter, uint64_t delta, rp_stream_t stream) {
+    RP_REQUIRE(counter, "counter_add_u64: null pointer");
+    hipLaunchKernelGGL(counter_add_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    RP_LAUNCH_CHECK("counter_add_u64");
     return RP_OK;
 }
 

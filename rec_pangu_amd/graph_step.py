@@ -96,6 +96,14 @@ class GraphedTrainStep:
         self._pool = None
         self._dev = None         # host mirror of the device counters
         self._one = None         # the seed gradient of captured backward passes (see _seed_grad)
+        # active dropout inside the step (the reference's default for xDeepFM / AutoInt / MMOE): the generator offset of a
+        # step's start lives on the device (`_drop_clock`, advanced by the step's last launch), every dropout launch adds
+        # its place in the step; the host generator is advanced after each replay, so eager and captured steps draw from
+        # ONE stream of offsets (hip._dropout_seed_offset, csrc/dropout.hip: rp_dropout_fwd_dev)
+        self._drop_clock = None
+        self._drop_clock_host = None   # the value the device clock holds (will hold once the queued replays have run)
+        self._drop_calls = [0, 0]      # dropout launches in the captured step of each static batch
+        self._drop_seed = None
         self.replays = 0
         self.captures = 0
 
@@ -130,6 +138,7 @@ class GraphedTrainStep:
                                "replays on this runtime; unset RP_SORT=rocprim or run batches of this size eagerly")
         self.X = [{k: torch.zeros_like(v) for k, v in batch.items()} for _ in range(2)]
         self._one = torch.ones((), dtype=torch.float32, device=next(iter(batch.values())).device)
+        self._drop_clock = torch.zeros((1,), dtype=torch.int64, device=self._one.device)
         self._keys = list(batch.keys())
         if self._sharded:
             return
@@ -160,6 +169,8 @@ class GraphedTrainStep:
         # (keep_graph: the hipGraph_t stays inspectable — rp_graph_node_counts — and is only instantiated if it is replayed)
         g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
         plan = hip.LaunchPlan() if want_plan else None
+        gen = hip.device_generator(self._drop_clock.device)
+        drop = hip.DROPOUT_CAPTURE[0] = {"seed": gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, "clock": self._drop_clock, "calls": 0}
         try:
             if plan is not None:
                 plan.begin()
@@ -186,6 +197,8 @@ class GraphedTrainStep:
                     # the next batch (already staged in X[1-P] when the step is launched): keys + sort into its pinned
                     # tensors.  It depends on nothing the step computes and touches persistent buffers only: a plan
                     # re-issues these launches on its side stream, beside the step (section 1)
+                    if drop["calls"] > 0:  # the step's last launch on the main stream: the dropout clock of the next step
+                        hip.counter_add_u64(self._drop_clock, 4 * drop["calls"])
                     if plan is not None:
                         plan.section(1)
                     if not self._sharded:
@@ -193,6 +206,7 @@ class GraphedTrainStep:
                     if plan is not None:
                         plan.section(0)
             finally:
+                hip.DROPOUT_CAPTURE[0] = None
                 if plan is not None:
                     plan.end()
         finally:
@@ -226,6 +240,7 @@ class GraphedTrainStep:
                     side2 = _Fh._WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
                 plan.set_streams(side, side2)
         self.captures += 1
+        self._drop_calls[P], self._drop_seed = drop["calls"], drop["seed"]
         self.graphs[P], self.plans[P] = g, plan
         self.backend_used = "plan" if plan is not None else "hipgraph"
         self.outs[P] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
@@ -296,6 +311,8 @@ class GraphedTrainStep:
         P = self.P
         self._copy(1 - P, next_batch)
         sig = self.opt.prepare_step()
+        gen = hip.device_generator(self._drop_clock.device)
+        sig = sig + (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF,)  # (the dropout seed is a frozen launch argument: re-seeding re-captures)
         if sig != self._sig:               # a table a graph points into has moved (capacity doubled, replay mode changed)
             if self._sig is not None:
                 # launches of the old graphs may still be in flight (the host runs steps ahead): destroying a graph
@@ -314,6 +331,13 @@ class GraphedTrainStep:
             done = self._inflight.pop(0)
             done.synchronize()
             self._ev_pool.append(done)
+        calls = self._drop_calls[P]
+        if calls > 0:
+            off = gen.get_offset()
+            if self._drop_clock_host != off:  # the first replay, or eager dropout calls since the last one
+                self._drop_clock.fill_(off)
+            gen.set_offset(off + 4 * calls)   # what `calls` eager dropout launches would have consumed
+            self._drop_clock_host = off + 4 * calls
         if self.plans[P] is not None:
             self.plans[P].replay()
         else:

@@ -124,6 +124,8 @@ _SIGNATURES = {
     "rp_mlp_tail_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _vp]),
     "rp_mlp_tail_bwd_parts": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _i32, _vp]),
     "rp_dropout_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp]),
+    "rp_dropout_fwd_dev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "rp_counter_add_u64": (C.c_int, [_vp, C.c_uint64, _vp]),
     "rp_dropout_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
@@ -1557,6 +1559,8 @@ def mlp_tail_bwd(dz, Ws, acts, w_out):
 
 
 _drop_calls = 0
+# the dropout state of the GraphedTrainStep whose capture is running: {"seed", "clock": int64[1] device tensor, "calls"}
+DROPOUT_CAPTURE = [None]
 
 
 def _dropout_seed_offset(device):
@@ -1566,30 +1570,52 @@ def _dropout_seed_offset(device):
     not expose generator offsets."""
     global _drop_calls
     if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("dropout inside a captured step: its (seed, offset) are launch arguments and would be frozen at "
-                           "capture (every replay would draw the same mask) — run models with active dropout eagerly")
+        st = DROPOUT_CAPTURE[0]
+        if st is None:
+            raise RuntimeError("dropout inside a stream capture that is not a GraphedTrainStep's: its (seed, offset) are launch "
+                               "arguments and would be frozen (every replay would draw the same mask)")
+        # a captured step: the offset is read on the device (st['clock'] = the generator offset of the step's start) plus
+        # this call's place in the step; the step's last launch advances the clock (graph_step.GraphedTrainStep)
+        delta = 4 * st["calls"]
+        st["calls"] += 1
+        return st["seed"], delta, st["clock"]
     try:
         gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
         seed, off = gen.initial_seed(), gen.get_offset()
         gen.set_offset(off + 4)
-        return seed & 0xFFFFFFFFFFFFFFFF, off
+        return seed & 0xFFFFFFFFFFFFFFFF, off, None
     except (AttributeError, RuntimeError):
         _drop_calls += 1
-        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 4 * _drop_calls
+        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, 4 * _drop_calls, None
 
 
 def dropout_fwd(x, p: float, seed: Optional[int] = None, offset: Optional[int] = None):
     """-> (y, mask uint8 [M, N]); seed / offset default to torch's device generator state (advanced)."""
     _req(x, torch.float32, "x")
     M, N = x.shape
+    clock = None
     if seed is None:
-        seed, offset = _dropout_seed_offset(x.device)
+        seed, offset, clock = _dropout_seed_offset(x.device)
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
     mask = torch.empty((M, N), dtype=torch.uint8, device=x.device)
     with _Timed("dropout_fwd", f"{M}x{N}", 9 * M * N):
-        _check(lib().rp_dropout_fwd(x.data_ptr(), _rowmajor(x, "x"), y.data_ptr(), N, mask.data_ptr(), M, N, p, seed, offset,
-                                    _stream()), "rp_dropout_fwd")
+        if clock is not None:
+            _check(lib().rp_dropout_fwd_dev(x.data_ptr(), _rowmajor(x, "x"), y.data_ptr(), N, mask.data_ptr(), M, N, p, seed,
+                                            offset, clock.data_ptr(), _stream()), "rp_dropout_fwd_dev")
+        else:
+            _check(lib().rp_dropout_fwd(x.data_ptr(), _rowmajor(x, "x"), y.data_ptr(), N, mask.data_ptr(), M, N, p, seed, offset,
+                                        _stream()), "rp_dropout_fwd")
     return y, mask
+
+
+def counter_add_u64(counter, delta: int):
+    """*counter += delta (uint64 / int64 device scalar) on the current stream (rp_counter_add_u64)"""
+    _check(lib().rp_counter_add_u64(counter.data_ptr(), int(delta), _stream()), "rp_counter_add_u64")
+
+
+def device_generator(device):
+    """torch's default generator of a HIP device"""
+    return torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
 
 
 def dropout_bwd(dy, mask, p: float):
