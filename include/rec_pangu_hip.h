@@ -165,12 +165,34 @@ int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sorted_pos, in
  * in a fixed order: deterministic), every sample's dH / S row is read once for all tiny tables.  Writes the rows somebody
  * looked up in this batch (accumulate != 0 adds), like rp_embed_grad_gemm: other rows are not touched.  keys [F * B]: arena row of pair (field, sample) at
  * field * B + sample (rp_embed_keys / the gather's keys_out).  Host arrays: tiny_field (field index), tiny_base (first arena
- * row), tiny_rows.  rp_embed_grad_gemm(skip_fields = bits of those fields) then covers the other fields. */
+ * row), tiny_rows.  rp_embed_grad_gemm(skip_fields = bits of those fields) then covers the other fields.  dw != NULL
+ * (round 5): also  dw[:, f*64:(f+1)*64] = sum over the table's rows of  (sum_b dH[b])^T (x) v_r  — the tiny tables' columns
+ * of the first layer's weight gradient (see rp_embed_grad_seg). */
 int rp_embed_grad_tiny_workspace_bytes(int64_t B, size_t *bytes);
 int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t *tiny_field, const int64_t *tiny_base,
                        const int32_t *tiny_rows, int n_tiny, const float *dh, int64_t lddh, const float *wt, int64_t ldwt,
                        const float *gfm, const float *sum_in, const float *arena, float *grad_arena, int accumulate,
-                       void *workspace, size_t workspace_bytes, rp_stream_t stream);
+                       float *dw, int64_t lddw, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+/* The first layer's WHOLE backward on the embedding columns, segment-sum first (csrc/embed.hip, round 5; replaces
+ * rp_embed_grad_gemm + the rp_linear_wgrad over a stored activation on the single-device path).  Reference ops:
+ * aten::embedding_dense_backward of rec_pangu/models/layers/embedding.py:61-63, the `** 2` backward of
+ * layers/interaction.py:38-44, the first Linear's dgrad and the embedding columns of its weight gradient
+ * (layers/deep.py:62-72 on the input built at ranking/deepfm.py:57-59).  Per run of equal keys in the row-sorted pair list
+ * (pairs p = (f, b) of one table row r):  Hs = sum dh[b, :],  u = sum gfm[b] sum_in[b, :],  s = sum gfm[b];
+ *     grad_arena[r, :] (+)= Hs . w[:, f*64:(f+1)*64] + u - s arena[r, :]
+ *     dw[:, f*64:(f+1)*64]  = sum over the field's runs of  Hs^T (x) arena[r, :]      (dw != NULL; written, not added)
+ * w = the layer's weight [64, ldw] (row-major, NOT transposed), dh [B, 64] the gradient of its pre-activation.  FIELD-MAJOR
+ * positions only: sorted_pos[i] = field * B + sample, n = F * B, F <= 64.  skip_fields: bit f set = field f is left out
+ * (its table is rp_embed_grad_tiny's, which fills the same dw columns when given dw).  field_rows: host array [F] of table
+ * sizes (scheduling only: long chunks first) or NULL.  gfm and sum_in both NULL = no FM term.  Deterministic (one writer
+ * per row, fixed summation orders).  Workspace: rp_embed_grad_seg_workspace_bytes(n, B, D).
+ * rp_embed_grad_seg_fits: D == 64, a 64-wide layer, lddh % 4 == 0; otherwise RP_ERR_UNSUPPORTED. */
+int rp_embed_grad_seg_fits(int D, int hidden, int64_t lddh);
+int rp_embed_grad_seg_workspace_bytes(int64_t n, int64_t B, int D, size_t *bytes);
+int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D, const float *dh,
+                      int64_t lddh, const float *w, int64_t ldw, const float *gfm, const float *sum_in, const float *arena,
+                      float *grad_arena, int accumulate, uint64_t skip_fields, const int64_t *field_rows, float *dw,
+                      int64_t lddw, void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
 
@@ -554,7 +576,9 @@ int rp_counters_add(int32_t *const *counters, int n, int32_t delta, rp_stream_t 
 int rp_embed_keys(const int64_t *row_base, const int64_t *row_count, const int64_t *const *idx_ptrs, int F, int64_t B,
                   int32_t *keys_out, int32_t *err_flag, rp_stream_t stream);
 int rp_adam_step_scalars(double lr, double beta1, double beta2, double eps, int64_t step, float *sa,
-                         float *sb); /* {A_t, B_t} = {1/sqrt(1-b2^t), eps} / (-lr/(1-b1^t)), computed in double: the update
+                         float *sb);
+/* the same for n consecutive steps step0 .. step0 + n - 1: out[2 i], out[2 i + 1] = {A, B} of step step0 + i (HOST array) */
+int rp_adam_step_scalars_range(double lr, double beta1, double beta2, double eps, int64_t step0, int64_t n, float *out); /* {A_t, B_t} = {1/sqrt(1-b2^t), eps} / (-lr/(1-b1^t)), computed in double: the update
                                       * is p += m * rcp(s * A_t + B_t) (s = sqrt(v)); lr = 0 gives (0, -inf) */
 int rp_lazy_adam_rows(const int32_t *sorted_keys, int64_t n, int D, float *p, float *g, float *m, float *v,
                       int32_t *last, const float *step_scalars, int64_t t_target, int real_step, int zero_grad,
@@ -666,6 +690,14 @@ int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);
 int rp_plan_set_streams(void *plan, rp_stream_t side, rp_stream_t side2);
 int rp_plan_inline_count(void *plan, int *n_inline);
 int rp_plan_replay(void *plan, rp_stream_t stream);
+/* Live timing of ONE launch inside replayed steps (bench.py's roofline: a replay runs no host code between its launches, so
+ * nothing outside the library can bracket one of them).  rp_plan_set_probe(plan, k): the k-th recorded launch (0 ..
+ * n_nodes - 1 of rp_plan_info, recorded order) of the following replays is bracketed by a HIP timing-event pair on the stream it
+ * is issued on; -1 = off.  rp_plan_probe_ms: elapsed milliseconds of the last replay's pair (waits for it).
+ * rp_plan_launch_name: the launch's (mangled) kernel name and section (0 main stream, 1 side, 2 inline side). */
+int rp_plan_set_probe(void *plan, int launch);
+int rp_plan_probe_ms(void *plan, float *ms);
+int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_len, int *section);
 int rp_plan_destroy(void *plan);
 int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other);
 /* dst_ptrs[i][0 : bytes[i]] = src_ptrs[i][..] for i < n in ONE launch (per 96 buffers): a batch of ~40 columns into the static

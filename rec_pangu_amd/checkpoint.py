@@ -78,29 +78,35 @@ def shard_file(ckpt_dir: str, rank: int, world: int) -> str:
 
 
 def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, optimizer=None, group=None,
-                    merge: bool = True, filename: str = "model.pth", keep_shards: bool = False) -> None:
-    """See the module docstring.  COLLECTIVE over `group` when the model is sharded over more than one rank: EVERY rank
-    must call it (two barriers inside) — a caller that saves "on rank 0 only", as single-process code does, deadlocks.
+                    merge: bool = True, filename: str = "model.pth", keep_shards: bool = False,
+                    collective: Optional[bool] = None) -> None:
+    """See the module docstring.
+
+    * Model with row-SHARDED tables over more than one rank: always COLLECTIVE over `group` — EVERY rank must call it (two
+      barriers inside); a caller that saves "on rank 0 only" would deadlock, and `collective=False` raises.
+    * REPLICATED (unsharded) model in a multi-rank job: every rank holds the same weights and there is ONE writer, rank 0
+      of `group`.  `collective=None` / `False` (the default): NO barrier — rank 0's call writes, any other rank's call only
+      flushes its own optimizer state and returns, so both `if rank == 0: save_checkpoint(...)` and "every rank calls it"
+      work and neither can hang.  `collective=True`: every rank calls it and all of them return only after the
+      file is complete (one barrier).
     keep_shards=False: after a successful merge every rank removes its `shard_*` file (each holds a full shard of the
     weights and moments; `model.pth` / `optimizer.pth` are what `load_checkpoint` reads)."""
     world, rank = _world(group)
     layers = _sharded_layers(model)
+    if layers and world > 1 and collective is False:
+        raise ValueError("save_checkpoint: a model with row-sharded tables is saved collectively (every rank holds a shard)")
     if not layers:
-        # a replicated (unsharded) model: ONE writer.  In a multi-rank job every rank holds the same weights: only global
-        # rank 0 writes / merges / removes, the others wait for it (ADVICE r3: concurrent writers of the same
-        # shard_000_of_001 file raced with each other's merge and removal)
         job_world, job_rank = world, rank
         world, rank = 1, 0
         if job_world > 1:
-            if job_rank == 0:
-                try:
+            try:
+                if job_rank == 0:
                     save_checkpoint(model, enc_dict, ckpt_dir, optimizer, _SOLO, merge, filename, keep_shards)
-                finally:
-                    dist.barrier(group=group)
-            else:
-                if optimizer is not None and hasattr(optimizer, "flush"):
+                elif optimizer is not None and hasattr(optimizer, "flush"):
                     optimizer.flush()  # (every rank's state moves the same way as the writer's)
-                dist.barrier(group=group)
+            finally:
+                if collective:
+                    dist.barrier(group=group)
             return
     os.makedirs(ckpt_dir, exist_ok=True, mode=0o777)
     if optimizer is not None and hasattr(optimizer, "flush"):

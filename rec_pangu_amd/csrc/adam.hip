@@ -711,6 +711,16 @@ extern "C" int rp_adam_step_scalars(double lr, double beta1, double beta2, doubl
     return RP_OK;
 }
 
+// n consecutive steps step0 .. step0 + n - 1 in one call: out[2 i] = A, out[2 i + 1] = B of step step0 + i (host array).  The
+// python side fills its per-step device table 1024 steps ahead: one C call instead of 1025 (that loop cost the host ~1 ms
+// every 1024th training step — the 2 ms step in profiles/r04_trace_periods.txt)
+extern "C" int rp_adam_step_scalars_range(double lr, double beta1, double beta2, double eps, int64_t step0, int64_t n,
+                                          float *out) {
+    RP_REQUIRE(out && step0 >= 1 && n >= 0, "adam_step_scalars_range: bad argument");
+    for (int64_t i = 0; i < n; ++i) adam_scalars(lr, beta1, beta2, eps, step0 + i, out + 2 * i, out + 2 * i + 1);
+    return RP_OK;
+}
+
 // the effective decay factors of one zero-gradient step as the kernels execute it in fp32: m <- m - m * fl(1 - b1),
 // s <- s * fl(sqrt(b2)); the closed form uses their exact (double) values so that it tracks the serial replay
 static void cf_decay_factors(double beta1, double beta2, double *b1e, double *r) {

@@ -1275,6 +1275,466 @@ extern "C" int rp_embed_grad_gemm(const int32_t *sorted_keys, const int32_t *sor
     return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// rp_embed_grad_seg (round 5): the first layer's whole backward on the embedding columns, SEGMENT-SUM FIRST.
+// (reference: aten::embedding_dense_backward of layers/embedding.py:61-63, the `** 2` backward of interaction.py:38-44,
+//  the first Linear's dgrad AND the embedding columns of its weight gradient, deep.py:62-72 on the input of deepfm.py:57-59)
+//
+// rp_embed_grad_gemm forms one dX row per (sample, field) PAIR on the matrix core and reduces them per table row, while
+// the layer's weight gradient is a separate GEMM over a stored activation x [B, F*64] (written by the forward for that one
+// reader: 0.88 GB of round trip at Criteo shape).  Both are linear in per-run sums: for the pairs p = (f, b) of one table
+// row r (a RUN of the row-sorted pair list)
+//     Hs = sum_b dH[b, :]      u = sum_b g_fm[b] S[b, :]      s = sum_b g_fm[b]
+//     G[r]                 = Hs . W1_f^T + u - s v_r                      (the table row's gradient)
+//     dW1[:, f*64:(f+1)*64] += Hs^T (x) v_r                               (the run's share of the weight gradient)
+// so a tile of 128 sorted positions is first segment-summed in registers (16 lanes x float4 own 8 positions: dH rows,
+// S rows and the run's table row v_r all in flight together — ONE dependent trip to memory after the keys), the sums of
+// every run PIECE (a run cut at the 8-position borders: everything downstream is linear, pieces are merged exactly as in
+// rp_embed_grad_gemm) are parked in LDS next to the pieces' table rows, and two matrix-core passes follow: the dgrad over
+// the piece rows (A = Hs rows, B = W1's field slice held as bf16 pieces in registers for the whole chunk) and the weight
+// gradient (A = V^T, B = Hs: K = the tile's 128 rows, operands read transposed from LDS), split-bf16 x6 (fp32-faithful).
+// A workgroup walks a CHUNK of consecutive tiles of ONE field with the 64 x 64 weight-gradient block in its accumulators
+// and writes one partial per chunk; a small launch sums the partials in a fixed order.  The forward stores no x, the
+// separate weight-gradient GEMM is gone (the 13 dense columns: a small rp_linear_wgrad over xd), v_r is read once per
+// piece for both uses.  Deterministic: one writer per gradient row, fixed summation orders, no atomics.
+// Field-major positions only (position = field * B + sample, n = F * B): the single-device path.
+// ------------------------------------------------------------------------------------------------
+#define SG_HT 68  // floats per row of the Hs / C tile (272 B: conflict-free ds_read_b128 A fragments, as EG_CT)
+struct SegFields {
+    int n;                    // kept fields
+    unsigned char sched[64];  // chunk block -> field: the kept fields, largest table first (long chunks start first)
+    unsigned char rank[64];   // field -> its ordinal among the kept fields in ascending order (tile ids = position order)
+};
+// SEG = sorted positions per 16-lane group: a tile is 16 * SEG positions.  SEG = 8: 128-row tiles, two workgroups per CU
+// (LDS 77 KB, up to 256 registers); SEG = 4: 64-row tiles, three workgroups per CU (42 KB, 168 registers).
+template <bool HAS_FM, int SEG>
+__global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel(
+    const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
+    int64_t lddh, const float *__restrict__ w, int64_t ldw, const float *__restrict__ gfm,
+    const float *__restrict__ sum_in, const float *__restrict__ arena, float *__restrict__ G, int accumulate,
+    float *__restrict__ gpiece, int32_t *__restrict__ gkey, float *__restrict__ dwpart, SegFields sf, int tpf, int T,
+    int cpf) {
+    typedef Vec<4> V;
+    constexpr int D = 64, GPB = 16, TILE = GPB * SEG, MB = TILE / 64;  // MB: 32-row blocks of the dgrad per wave
+    __shared__ __attribute__((aligned(16))) float HsT[TILE][SG_HT];  // the pieces' dH sums; after the matrix passes: the C tile
+    __shared__ __attribute__((aligned(16))) float VT[TILE][D];       // the pieces' table rows (zero rows elsewhere)
+    __shared__ __attribute__((aligned(16))) float piece[GPB][2][D];
+    __shared__ int32_t pkey[GPB][2];
+    __shared__ int32_t pcont[GPB];
+    __shared__ int32_t tkey[TILE + 2];  // sorted keys of the tile's rows (-1 beyond its end), [0] / [TILE + 1]: the neighbours
+    __shared__ int32_t tsmp[TILE];      // sample of every tile row (0 beyond the end)
+    const int tid = threadIdx.x, t = tid & 15, grp = tid >> 4, c = 4 * t;
+    const int wv = tid >> 6, l = tid & 63, i = l & 31, h = l >> 5;
+    const int chunk = (int)blockIdx.x;
+    const int o = chunk / cpf;
+    const int f = sf.sched[o];
+    const int j0 = (chunk - o * cpf) * T;
+    const int jn = (j0 + T < tpf) ? j0 + T : tpf;
+    const int64_t fbase = (int64_t)f * Bi, fend = fbase + Bi;
+    const int64_t tile_id0 = (int64_t)sf.rank[f] * tpf;
+    const bool want_dw = dwpart != nullptr;
+    // ---- the chunk's constants: this wave's B fragments of the dgrad (W1[hidden, f*64 + 32 nb + i], bf16 pieces) ----
+    const int nb = wv & 1, mh = wv >> 1;  // dgrad: rows (TILE / 2) mh .. of the tile x columns 32 nb .. + 31
+    bf16x8 wp[4][3];
+    {
+        const float *wsrc = w + (int64_t)f * D + 32 * nb + i;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = wsrc[(int64_t)(16 * ks + 8 * h + e) * ldw];
+            bf_split8<3>(v, wp[ks]);
+        }
+    }
+    // weight gradient: this wave's block  dW1^T[d = 32 (wv >> 1) + .., hidden = 32 (wv & 1) + ..]  of the field
+    f32x16 dwacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
+    // keys / samples of a tile travel through LDS, one tile ahead: thread x < TILE loads the key of row x, thread TILE + x
+    // the position (SEG = 4: the upper half of the workgroup idles here); threads 0 / 1 also load the two neighbours
+    auto tile_keys = [&](int64_t wg0, int64_t gend, int32_t &a0, int32_t &a1) {
+        a0 = 0;
+        a1 = -1;
+        const int x = tid < TILE ? tid : tid - TILE;
+        const bool in = x < TILE && tid < 2 * TILE && wg0 + x < gend;
+        const uint32_t q = in ? (uint32_t)(wg0 + x) : 0u;
+        const int32_t raw = tid < TILE ? sk[q] : sp[q];
+        a0 = in ? (tid < TILE ? raw : raw - (int32_t)fbase) : (tid < TILE ? -1 : 0);
+        const bool nb_ok = (tid == 0) ? (wg0 > 0) : (wg0 + TILE < n);
+        const int32_t rawn = sk[(tid < 2 && nb_ok) ? (uint32_t)(tid == 0 ? wg0 - 1 : wg0 + TILE) : 0u];
+        a1 = (tid < 2 && nb_ok) ? rawn : -1;
+    };
+    auto tile_keys_store = [&](int32_t a0, int32_t a1) {
+        if (tid < TILE) tkey[1 + tid] = a0;
+        else if (tid < 2 * TILE) {
+            int b = a0;
+            b = b < 0 ? 0 : (b >= Bi ? Bi - 1 : b);  // (a position outside the field's range would be a caller error)
+            tsmp[tid - TILE] = b;
+        }
+        if (tid == 0) tkey[0] = a1;
+        if (tid == 1) tkey[TILE + 1] = a1;
+    };
+    {
+        const int64_t wg0 = fbase + (int64_t)TILE * j0;
+        int32_t a0, a1;
+        tile_keys(wg0, (wg0 + TILE < fend) ? wg0 + TILE : fend, a0, a1);
+        tile_keys_store(a0, a1);
+    }
+    __syncthreads();
+    for (int j = j0; j < jn; ++j) {
+        const int64_t wg0 = fbase + (int64_t)TILE * j;
+        const int64_t gend = (wg0 + TILE < fend) ? wg0 + TILE : fend;
+        const int64_t start = wg0 + SEG * grp;
+        const int cnt = (gend - start) <= 0 ? 0 : ((gend - start) < SEG ? (int)(gend - start) : SEG);
+        int32_t k[SEG + 1];
+        int bs[SEG];
+#pragma unroll
+        for (int jj = 0; jj < SEG; ++jj) {
+            k[jj] = tkey[1 + SEG * grp + jj];
+            bs[jj] = tsmp[SEG * grp + jj];
+        }
+        k[SEG] = -1;
+        const int32_t kprev = cnt > 0 ? tkey[SEG * grp] : -1;
+        const int32_t knext = cnt > 0 ? tkey[1 + SEG * grp + cnt] : -1;
+        // ---- the one dependent trip to memory: dH rows, S rows, g_fm and the table rows, all in flight together (no
+        //      branch around a load: the in-order counter stays counted) ------------------------------------------------
+        f32x4 rh[SEG], rs[SEG], rv[SEG];
+        float g[SEG];
+#pragma unroll
+        for (int jj = 0; jj < SEG; ++jj) {
+            // (dH / S: B * 64 floats < 2^32 bytes — 32-bit offsets from the scalar base)
+            rh[jj] = V::load(dh + ((uint32_t)bs[jj] * (uint32_t)lddh + (uint32_t)c));
+            if (HAS_FM) {
+                rs[jj] = V::load(sum_in + ((uint32_t)bs[jj] * (uint32_t)D + (uint32_t)c));
+                g[jj] = gfm[(uint32_t)bs[jj]];
+            }
+            rv[jj] = V::load(arena + (int64_t)(k[jj] < 0 ? 0 : k[jj]) * D + c);
+        }
+        // ... and behind them the NEXT tile's keys (they land under the matrix passes and go to LDS after them)
+        int32_t nk0, nk1;
+        {
+            const int64_t w1 = wg0 + TILE;
+            const bool more = j + 1 < jn;
+            tile_keys(more ? w1 : 0, more ? ((w1 + TILE < fend) ? w1 + TILE : fend) : 0, nk0, nk1);
+        }
+        // ---- segment sums in registers; a piece ends where the key changes or the group's positions end.  Masks are
+        //      0 / 1 factors, not selects: a select lets the compiler sink a row's loads into a branch, and then every
+        //      wait is vmcnt(0) (rows beyond cnt read sample 0 / table row 0: real, finite data times zero) --------------
+        f32x4 E[SEG];
+        unsigned lastm = 0;
+        {
+            f32x4 accH = V::zero(), accU = V::zero();
+            float gs = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < SEG; ++jj) {
+                const bool ok = jj < cnt;
+                const float okf = ok ? 1.f : 0.f;
+                accH += okf * rh[jj];
+                if (HAS_FM) {
+                    const float gj = okf * g[jj];
+                    accU += gj * rs[jj];
+                    gs += gj;
+                }
+                const bool last = ok && k[jj + 1] != k[jj];  // (k = -1 beyond cnt and behind the group's positions)
+                lastm |= last ? (1u << jj) : 0u;
+                const float lastf = last ? 1.f : 0.f, keepf = 1.f - lastf;
+                const f32x4 tv = lastf * rv[jj];
+                V::store(&HsT[SEG * grp + jj][c], lastf * accH);
+                V::store(&VT[SEG * grp + jj][c], tv);
+                E[jj] = HAS_FM ? accU - gs * tv : V::zero();  // (used at piece ends only)
+                accH = keepf * accH;
+                if (HAS_FM) {
+                    accU = keepf * accU;
+                    gs = keepf * gs;
+                }
+            }
+        }
+        __syncthreads();  // (A) the tiles are complete; wave 0 has left the previous tile's piece merge
+        if (t == 0) {
+            pkey[grp][0] = -1;
+            pkey[grp][1] = -1;
+            pcont[grp] = 0;
+        }
+        // ---- dgrad on the matrix core: C[row, d] = sum_hidden Hs[row, hidden] W1[hidden, f*64 + d] ------------------------
+        f32x16 ag[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ag[mb][r] = 0.f;
+            const float *arow = &HsT[(TILE / 2) * mh + 32 * mb + i][8 * h];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks + 4);
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v0[e];
+                    v[4 + e] = v1[e];
+                }
+                bf16x8 a[3];
+                bf_split8<3>(v, a);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    ag[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], wp[ks][BfProd<6>::pb(pr)], ag[mb], 0, 0, 0);
+            }
+        }
+        // ---- weight gradient: dW1^T[d, hidden] += sum_row V[row, d] Hs[row, hidden]  (K = the tile's rows) ----------------
+        if (want_dw) {
+            const int dblk = wv >> 1, hblk = wv & 1;
+#pragma unroll 2
+            for (int ks = 0; ks < TILE / 16; ++ks) {
+                f32x8 va, vb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    va[e] = VT[16 * ks + 8 * h + e][32 * dblk + i];
+                    vb[e] = HsT[16 * ks + 8 * h + e][32 * hblk + i];
+                }
+                bf16x8 a[3], bq[3];
+                bf_split8<3>(va, a);
+                bf_split8<3>(vb, bq);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], dwacc, 0, 0, 0);
+            }
+        }
+        __syncthreads();  // (B) every wave is done reading the Hs tile: it becomes the C tile
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) HsT[(TILE / 2) * mh + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h][32 * nb + i] = ag[mb][r];
+        tile_keys_store(nk0, nk1);  // (this tile's keys were last read in front of barrier A)
+        __syncthreads();  // (C)
+        // ---- the pieces' gradient rows: C + u - s v; runs inside the group are stored, border pieces merged as in
+        //      embed_grad_reduce_kernel (same piece list, same finish launches) -------------------------------------------
+        {
+            bool run_head = (k[0] != kprev);
+#pragma unroll
+            for (int jj = 0; jj < SEG; ++jj) {
+                if ((lastm >> jj) & 1u) {
+                    const f32x4 val = V::load(&HsT[SEG * grp + jj][c]) + E[jj];
+                    const bool run_ends_here = (jj + 1 < cnt) ? true : (k[jj] != knext);
+                    if (run_head && run_ends_here) {
+                        float *dst = G + (int64_t)k[jj] * D + c;
+                        V::store(dst, accumulate ? V::load(dst) + val : val);  // the only writer of this row
+                    } else {
+                        const int slot = run_head ? 1 : 0;
+                        V::store(&piece[grp][slot][c], val);
+                        if (t == 0) {
+                            pkey[grp][slot] = k[jj];
+                            if (!run_ends_here) pcont[grp] = 1;
+                        }
+                    }
+                    run_head = true;
+                }
+            }
+        }
+        __syncthreads();  // (D)
+        if (grp == 0) {
+            const int64_t tile_id = tile_id0 + j;
+            float *hp = gpiece + tile_id * 2 * D, *tp = hp + D;
+            const bool head_open = pkey[0][0] >= 0;
+            int last_g = -1;
+            for (int g2 = GPB - 1; g2 >= 0; --g2)
+                if (pkey[g2][0] >= 0 || pkey[g2][1] >= 0) {
+                    last_g = g2;
+                    break;
+                }
+            const int last_active = (int)((gend - wg0 + SEG - 1) / SEG) - 1;
+            const bool tail_open = last_g >= 0 && last_g == last_active && pcont[last_g] != 0;
+            int32_t curk = -1;
+            bool cur_is_head = false;
+            f32x4 cacc = V::zero();
+            int32_t headkey = -1, tailkey = -1;
+            f32x4 headv = V::zero(), tailv = V::zero();
+            for (int g2 = 0; g2 < GPB; ++g2) {
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    const int32_t key = pkey[g2][slot];
+                    if (key < 0) continue;
+                    const f32x4 pv = V::load(&piece[g2][slot][c]);
+                    if (key == curk) {
+                        cacc += pv;
+                    } else {
+                        if (curk >= 0) {
+                            if (cur_is_head) {
+                                headkey = curk;
+                                headv = cacc;
+                            } else {
+                                float *dst = G + (int64_t)curk * D + c;
+                                V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+                            }
+                        }
+                        curk = key;
+                        cacc = pv;
+                        cur_is_head = head_open && g2 == 0 && slot == 0;
+                    }
+                }
+            }
+            if (curk >= 0) {
+                if (tail_open) {
+                    if (cur_is_head) {
+                        headkey = curk;
+                        headv = cacc;
+                        tailkey = curk;
+                    } else {
+                        tailkey = curk;
+                        tailv = cacc;
+                    }
+                } else if (cur_is_head) {
+                    headkey = curk;
+                    headv = cacc;
+                } else {
+                    float *dst = G + (int64_t)curk * D + c;
+                    V::store(dst, accumulate ? V::load(dst) + cacc : cacc);
+                }
+            }
+            V::store(hp + c, headv);
+            V::store(tp + c, tailv);
+            if (t == 0) {
+                gkey[2 * tile_id] = headkey;
+                gkey[2 * tile_id + 1] = tailkey;
+            }
+        }
+    }
+    if (want_dw) {
+        float *P = dwpart + (int64_t)chunk * (D * D);
+        const int dblk = wv >> 1, hblk = wv & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P[(32 * dblk + (r & 3) + 8 * (r >> 2) + 4 * h) * D + 32 * hblk + i] = dwacc[r];
+    }
+}
+
+// dw[hidden, f*64 + d] = the fixed-order sum of the chunk partials [d][hidden] of field f (four independent chains)
+__global__ __launch_bounds__(256) void embed_grad_seg_dw_kernel(const float *__restrict__ dwpart, SegFields sf, int cpf,
+                                                                float *__restrict__ dw, int64_t lddw) {
+    const int o = (int)blockIdx.x, f = sf.sched[o];
+    const int e = (int)blockIdx.y * 256 + (int)threadIdx.x;  // element (d = e >> 6, hidden = e & 63) of the field's block
+    const float *p = dwpart + (int64_t)o * cpf * 4096 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int cidx = 0;
+    for (; cidx + 4 <= cpf; cidx += 4) {
+        s0 += p[(int64_t)cidx * 4096];
+        s1 += p[(int64_t)(cidx + 1) * 4096];
+        s2 += p[(int64_t)(cidx + 2) * 4096];
+        s3 += p[(int64_t)(cidx + 3) * 4096];
+    }
+    for (; cidx < cpf; ++cidx) s0 += p[(int64_t)cidx * 4096];
+    dw[(int64_t)(e & 63) * lddw + (int64_t)f * 64 + (e >> 6)] = (s0 + s1) + (s2 + s3);
+}
+
+// rows per tile: 128 (two workgroups per CU) or 64 (three); RP_SEG_ROWS overrides the default
+static int seg_tile_rows() {
+    static const int rows = []() {
+        const char *e = getenv("RP_SEG_ROWS");
+        const int v = e ? atoi(e) : 0;
+        return v == 64 ? 64 : 128;
+    }();
+    return rows;
+}
+
+// tiles per chunk: ~64 chunks per field (RP_SEG_TILES overrides)
+static int seg_tiles_per_chunk(int tpf) {
+    static const int forced = []() {
+        const char *e = getenv("RP_SEG_TILES");
+        return e ? atoi(e) : 0;
+    }();
+    int T = forced > 0 ? forced : (tpf + 32) / 64;
+    T = T < 1 ? 1 : (T > 64 ? 64 : T);
+    return T > tpf ? tpf : T;
+}
+
+static int64_t seg_n_eff(int64_t n, int64_t B) {  // (the piece region is sized through rp_embed_grad_reduce's formula)
+    const int64_t F = B > 0 ? n / B : 0;
+    const int64_t tiles = F * rp_cdiv(B, seg_tile_rows());
+    return n > tiles * 32 ? n : tiles * 32;
+}
+
+extern "C" int rp_embed_grad_seg_fits(int D, int hidden, int64_t lddh) {
+    return (D == 64 && hidden == 64 && lddh % 4 == 0) ? 1 : 0;
+}
+
+extern "C" int rp_embed_grad_seg_workspace_bytes(int64_t n, int64_t B, int D, size_t *bytes) {
+    RP_REQUIRE(bytes && n >= 0 && B >= 1 && D == 64 && n % B == 0 && n / B <= 64,
+               "embed_grad_seg_workspace_bytes: needs D = 64 and field-major positions (n = F * B, F <= 64)");
+    size_t red = 0;
+    rp_embed_grad_reduce_workspace_bytes(seg_n_eff(n, B), D, &red);
+    const int tpf = (int)rp_cdiv(B, seg_tile_rows());
+    const int64_t cpf = rp_cdiv(tpf, seg_tiles_per_chunk(tpf));
+    *bytes = ((red + 255) & ~(size_t)255) + (size_t)(n / B) * cpf * 4096 * sizeof(float) + 256;
+    return RP_OK;
+}
+
+extern "C" int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
+                                 const float *dh, int64_t lddh, const float *w, int64_t ldw, const float *gfm,
+                                 const float *sum_in, const float *arena, float *grad_arena, int accumulate,
+                                 uint64_t skip_fields, const int64_t *field_rows, float *dw, int64_t lddw, void *workspace,
+                                 size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && dh && w && arena && grad_arena && workspace, "embed_grad_seg: null pointer");
+    RP_REQUIRE(B >= 1 && B < INT32_MAX && n >= 0 && n < INT32_MAX, "embed_grad_seg: bad B / n");
+    RP_REQUIRE(n % B == 0 && n / B <= 64, "embed_grad_seg: needs field-major positions (n = F * B, F <= 64)");
+    RP_REQUIRE((gfm == nullptr) == (sum_in == nullptr), "embed_grad_seg: the FM term needs both gfm and sum_in");
+    const int F = (int)(n / B);
+    RP_REQUIRE(ldw >= (int64_t)F * 64 && (dw == nullptr || lddw >= (int64_t)F * 64), "embed_grad_seg: weight rows shorter than F * 64");
+    if (!rp_embed_grad_seg_fits(D, 64, lddh) || !rp_aligned16(dh) || !rp_aligned16(grad_arena) || !rp_aligned16(arena) ||
+        (sum_in && !rp_aligned16(sum_in)))
+        return rp_fail(RP_ERR_UNSUPPORTED, "embed_grad_seg: needs D = 64, a 64-wide layer and 16-byte aligned operands");
+    if (n == 0) return RP_OK;
+    size_t need = 0;
+    if (rp_embed_grad_seg_workspace_bytes(n, B, D, &need) != RP_OK) return RP_ERR_ARG;
+    RP_REQUIRE(workspace_bytes >= need, "embed_grad_seg: workspace %zu < %zu bytes", workspace_bytes, need);
+    SegFields sf;
+    memset(&sf, 0, sizeof(sf));
+    int kept[64];
+    for (int f = 0; f < F; ++f)
+        if (!((skip_fields >> f) & 1u)) {
+            sf.rank[f] = (unsigned char)sf.n;
+            kept[sf.n++] = f;
+        }
+    if (sf.n == 0) return RP_OK;  // every field is handled elsewhere
+    // chunk blocks in the order largest table first (insertion sort, stable: ties keep the field order)
+    for (int a = 0; a < sf.n; ++a) {
+        const int f = kept[a];
+        int b = a;
+        while (b > 0 && field_rows != nullptr && field_rows[sf.sched[b - 1]] < field_rows[f]) {
+            sf.sched[b] = sf.sched[b - 1];
+            --b;
+        }
+        sf.sched[b] = (unsigned char)f;
+    }
+    const int rows = seg_tile_rows();
+    const int tpf = (int)rp_cdiv(B, rows);
+    const int T = seg_tiles_per_chunk(tpf);
+    const int cpf = (int)rp_cdiv(tpf, T);
+    const int64_t n_eff = seg_n_eff(n, B);
+    size_t red = 0;
+    rp_embed_grad_reduce_workspace_bytes(n_eff, D, &red);
+    char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const int64_t nb0 = (int64_t)sf.n * tpf;
+    float *piece0 = reinterpret_cast<float *>(wbase);
+    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
+    float *dwpart = dw ? reinterpret_cast<float *>(wbase + ((red + 255) & ~(size_t)255)) : nullptr;  // [chunks][64 d][64 hidden]
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)(sf.n * cpf);
+#define SEG_LAUNCH(FM, SG)                                                                                                  \
+    hipLaunchKernelGGL((embed_grad_seg_kernel<FM, SG>), dim3(grid), dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B, dh,  \
+                       lddh, w, ldw, gfm, sum_in, arena, grad_arena, accumulate, piece0, key0, dwpart, sf, tpf, T, cpf)
+    if (rows == 128) {
+        if (gfm != nullptr) SEG_LAUNCH(true, 8);
+        else SEG_LAUNCH(false, 8);
+    } else {
+        if (gfm != nullptr) SEG_LAUNCH(true, 4);
+        else SEG_LAUNCH(false, 4);
+    }
+#undef SEG_LAUNCH
+    RP_LAUNCH_CHECK("embed_grad_seg");
+    if (dw != nullptr) {
+        hipLaunchKernelGGL(embed_grad_seg_dw_kernel, dim3((unsigned)sf.n, 16), dim3(256), 0, s, dwpart, sf, cpf, dw, lddw);
+        RP_LAUNCH_CHECK("embed_grad_seg (weight-gradient partials)");
+    }
+    return grad_reduce_finish(n_eff, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+}
+
 extern "C" int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream) {
     RP_REQUIRE(keys && grad_arena && D >= 1, "zero_rows: bad argument");
     if (n == 0) return RP_OK;

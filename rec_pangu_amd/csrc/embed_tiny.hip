@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void embed_grad_tiny_partial_kernel(
 #define ET_FIN_PARTS 4
 __global__ __launch_bounds__(ET_COLS * ET_FIN_PARTS) void embed_grad_tiny_finish_kernel(
     const float *__restrict__ partial, int nblk, TinyTables tt, const float *__restrict__ wt, int64_t ldwt,
-    const float *__restrict__ arena, float *__restrict__ G, int accumulate, int has_fm) {
+    const float *__restrict__ arena, float *__restrict__ G, int accumulate, int has_fm, float *__restrict__ hs_out) {
     __shared__ float Sp[ET_FIN_PARTS][ET_COLS];
     __shared__ float S[ET_COLS];
     const int m = blockIdx.x, c = threadIdx.x % ET_COLS, part = threadIdx.x / ET_COLS;
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(ET_COLS * ET_FIN_PARTS) void embed_grad_tiny_finish
     __syncthreads();
     if (threadIdx.x < ET_COLS) S[c] = (Sp[0][c] + Sp[1][c]) + (Sp[2][c] + Sp[3][c]);
     __syncthreads();
+    if (hs_out != nullptr && threadIdx.x >= 64 && threadIdx.x < 128) hs_out[m * 64 + (threadIdx.x - 64)] = S[threadIdx.x - 64];
     if (threadIdx.x < 64) {
         const int d = threadIdx.x;
         const float *w = wt + ((int64_t)tt.field[slot] * 64 + d) * ldwt;  // row f 64 + d of W1^T = column of W1
@@ -204,6 +205,21 @@ __global__ __launch_bounds__(ET_COLS * ET_FIN_PARTS) void embed_grad_tiny_finish
     }
 }
 
+// The tiny tables' share of the first layer's WEIGHT gradient (round 5, the companion of rp_embed_grad_seg: the forward
+// stores no activation):  dw[hidden, f*64 + d] = sum over the table's rows r of  Sh[r, hidden] v_r[d]  with the dH row sums
+// Sh the finish launch left in the workspace — a few hundred rows in all: fp32 FMAs in row order.
+__global__ __launch_bounds__(256) void embed_grad_tiny_dw_kernel(const float *__restrict__ hs, TinyTables tt,
+                                                                 const float *__restrict__ arena, float *__restrict__ dw,
+                                                                 int64_t lddw) {
+    const int slot = (int)blockIdx.x;
+    const int e = (int)blockIdx.y * 256 + (int)threadIdx.x, d = e & 63, hh = e >> 6;  // (d fastest: coalesced row reads)
+    const float *hrow = hs + (int64_t)tt.acc0[slot] * 64 + hh;
+    const float *vrow = arena + (int64_t)tt.base[slot] * 64 + d;
+    float a = 0.f;
+    for (int r = 0; r < tt.rows[slot]; ++r) a = __builtin_fmaf(hrow[(int64_t)r * 64], vrow[(int64_t)r * 64], a);
+    dw[(int64_t)hh * lddw + (int64_t)tt.field[slot] * 64 + d] = a;
+}
+
 static int64_t tiny_per_block(int64_t B) {
     int64_t per = rp_cdiv(rp_cdiv(B, 128), ET_CHUNK) * ET_CHUNK;  // ~128 blocks, whole chunks
     return per < ET_CHUNK ? ET_CHUNK : per;
@@ -211,15 +227,15 @@ static int64_t tiny_per_block(int64_t B) {
 
 extern "C" int rp_embed_grad_tiny_workspace_bytes(int64_t B, size_t *bytes) {
     RP_REQUIRE(bytes && B >= 1, "embed_grad_tiny_workspace_bytes: bad argument");
-    *bytes = (size_t)rp_cdiv(B, tiny_per_block(B)) * ET_ROWS * ET_COLS * sizeof(float) + 256;
+    *bytes = (size_t)rp_cdiv(B, tiny_per_block(B)) * ET_ROWS * ET_COLS * sizeof(float) + (size_t)ET_ROWS * 64 * sizeof(float) + 256;
     return RP_OK;
 }
 
 extern "C" int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t *tiny_field, const int64_t *tiny_base,
                                   const int32_t *tiny_rows, int n_tiny, const float *dh, int64_t lddh, const float *wt,
                                   int64_t ldwt, const float *gfm, const float *sum_in, const float *arena,
-                                  float *grad_arena, int accumulate, void *workspace, size_t workspace_bytes,
-                                  rp_stream_t stream) {
+                                  float *grad_arena, int accumulate, float *dw, int64_t lddw, void *workspace,
+                                  size_t workspace_bytes, rp_stream_t stream) {
     RP_REQUIRE(keys && tiny_field && tiny_base && tiny_rows && dh && wt && grad_arena && workspace, "embed_grad_tiny: null pointer");
     RP_REQUIRE(n_tiny >= 1 && n_tiny <= ET_MAXF, "embed_grad_tiny: %d tables (1..%d)", n_tiny, ET_MAXF);
     RP_REQUIRE(B >= 1 && B < INT32_MAX, "embed_grad_tiny: bad B");
@@ -253,8 +269,16 @@ extern "C" int rp_embed_grad_tiny(const int32_t *keys, int64_t B, const int32_t 
     hipLaunchKernelGGL(embed_grad_tiny_partial_kernel, dim3((unsigned)nblk, 2), dim3(256), 0, s, keys, B, tt, dh, lddh, sum_in, gfm, per,
                        partial);
     RP_LAUNCH_CHECK("embed_grad_tiny (partial sums)");
+    RP_REQUIRE(dw == nullptr || arena != nullptr, "embed_grad_tiny: the weight gradient needs the arena");
+    float *hs = dw ? partial + (size_t)nblk * ET_ROWS * ET_COLS : nullptr;  // [total][64]: the rows' dH sums
     hipLaunchKernelGGL(embed_grad_tiny_finish_kernel, dim3((unsigned)total), dim3(ET_COLS * ET_FIN_PARTS), 0, s, partial, (int)nblk, tt, wt, ldwt, arena,
-                       grad_arena, accumulate, gfm != nullptr ? 1 : 0);
+                       grad_arena, accumulate, gfm != nullptr ? 1 : 0, hs);
     RP_LAUNCH_CHECK("embed_grad_tiny (finish)");
+    if (dw != nullptr) {
+        for (int j = 0; j < n_tiny; ++j)
+            RP_REQUIRE(lddw >= ((int64_t)tt.field[j] + 1) * 64, "embed_grad_tiny: dw rows shorter than field %d's columns", tt.field[j]);
+        hipLaunchKernelGGL(embed_grad_tiny_dw_kernel, dim3((unsigned)n_tiny, 16), dim3(256), 0, s, hs, tt, arena, dw, lddw);
+        RP_LAUNCH_CHECK("embed_grad_tiny (weight gradient)");
+    }
     return RP_OK;
 }

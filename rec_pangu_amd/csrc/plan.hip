@@ -48,6 +48,11 @@ struct Plan {
     hipStream_t side2 = nullptr;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     bool own_side = false, own_side2 = false;  // streams created here (else: the caller's, rp_plan_set_streams)
+    // probe (rp_plan_set_probe): ONE launch of the next replays is bracketed by a timing event pair on the stream it is
+    // issued on — the launch's duration INSIDE the replayed step, beside whatever the side streams run (bench.py)
+    int probe = -1;
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
+    bool probe_recorded = false;
 };
 
 std::atomic<Plan *> g_recording{nullptr};
@@ -182,6 +187,60 @@ extern "C" int rp_plan_inline_count(void *plan, int *n_inline) {
     return RP_OK;
 }
 
+// launch index (recorded order, join markers not counted) -> node index; -1 when there is none
+static int plan_launch_node(const Plan *p, int launch) {
+    int k = 0;
+    for (size_t i = 0; i < p->nodes.size(); ++i) {
+        if (p->nodes[i].func == nullptr) continue;
+        if (k == launch) return (int)i;
+        ++k;
+    }
+    return -1;
+}
+
+// Time launch `launch` (0 .. n_nodes - 1 of rp_plan_info, recorded order) of the following replays: a HIP-event pair on the
+// stream the launch is issued on.  -1 switches the probe off.  Two event records on one stream cost the step about as much
+// as two small kernels; everything else of the replay is unchanged, so the launch shares the device with the same
+// neighbours as in an unprobed replay.
+extern "C" int rp_plan_set_probe(void *plan, int launch) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended, "plan_set_probe: the plan was not finished with rp_plan_end");
+    RP_REQUIRE(launch < 0 || plan_launch_node(p, launch) >= 0, "plan_set_probe: launch %d does not exist", launch);
+    if (launch >= 0 && p->ev_p0 == nullptr) {
+        hipError_t e = hipEventCreate(&p->ev_p0);
+        if (e == hipSuccess) e = hipEventCreate(&p->ev_p1);
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_set_probe: %s", hipGetErrorString(e));
+    }
+    p->probe = launch < 0 ? -1 : plan_launch_node(p, launch);
+    p->probe_recorded = false;
+    return RP_OK;
+}
+
+// milliseconds between the probe's two events of the LAST replay (waits for the second one)
+extern "C" int rp_plan_probe_ms(void *plan, float *ms) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && ms != nullptr, "plan_probe_ms: null pointer");
+    RP_REQUIRE(p->probe >= 0 && p->probe_recorded, "plan_probe_ms: no probed replay yet");
+    hipError_t e = hipEventSynchronize(p->ev_p1);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, p->ev_p0, p->ev_p1);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_probe_ms: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+// the (mangled) kernel name and the section (0 main, 1 side, 2 inline) of launch `launch`
+extern "C" int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_len, int *section) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && buf != nullptr && buf_len > 1, "plan_launch_name: bad argument");
+    const int i = plan_launch_node(p, launch);
+    RP_REQUIRE(i >= 0, "plan_launch_name: launch %d does not exist", launch);
+    const char *nm = hipKernelNameRefByPtr(p->nodes[i].func, p->nodes[i].rec_stream);
+    if (nm == nullptr) nm = "?";
+    strncpy(buf, nm, (size_t)buf_len - 1);
+    buf[buf_len - 1] = 0;
+    if (section) *section = p->nodes[i].section;
+    return RP_OK;
+}
+
 extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && p->ended, "plan_replay: the plan was not finished with rp_plan_end");
@@ -217,8 +276,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             for (size_t j = 0; j < p->nodes.size(); ++j) {
                 const PlanNode &n = p->nodes[j];
                 if (n.section != 1) continue;
+                if ((int)j == p->probe) (void)hipEventRecord(p->ev_p0, p->side);
                 e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[j], n.shmem, p->side);
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", j, hipGetErrorString(e));
+                if ((int)j == p->probe) {
+                    (void)hipEventRecord(p->ev_p1, p->side);
+                    p->probe_recorded = true;
+                }
             }
             e = hipEventRecord(p->ev_join, p->side);
             if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join record: %s", hipGetErrorString(e));
@@ -258,8 +322,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         } else if (open2) {
             main_since_fork2 = true;
         }
+        if ((int)i == p->probe) (void)hipEventRecord(p->ev_p0, target);
         e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, target);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: launch %zu: %s", i, hipGetErrorString(e));
+        if ((int)i == p->probe) {
+            (void)hipEventRecord(p->ev_p1, target);
+            p->probe_recorded = true;
+        }
         rp_count_launch();
     }
     if (open2) {  // (a section that was never joined explicitly joins at the end)
@@ -286,6 +355,10 @@ extern "C" int rp_plan_destroy(void *plan) {
         (void)hipEventDestroy(p->ev_fork);
         (void)hipEventDestroy(p->ev_join);
         if (p->own_side) (void)hipStreamDestroy(p->side);
+    }
+    if (p->ev_p0 != nullptr) {
+        (void)hipEventDestroy(p->ev_p0);
+        (void)hipEventDestroy(p->ev_p1);
     }
     if (p->ev_fork2 != nullptr) {
         (void)hipStreamSynchronize(p->side2);

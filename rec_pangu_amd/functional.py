@@ -814,15 +814,22 @@ class _EmbedGatherLinear(torch.autograd.Function):
         # only the dense columns are stored.  Measured at Criteo shape: forward 0.195 -> 0.139 ms, weight gradient 0.148 ->
         # 0.248 ms (random 256-byte rows, two per wave-instruction, against a streamed activation): a net loss of 0.015 ms per
         # step, so it is OFF by default (bit-identical either way: tests/test_hip_kernels.py).
+        # "seg" (round 5, the default where it fits): NO activation is stored at all — the embedding columns of the weight
+        # gradient come out of the gather backward itself (rp_embed_grad_seg: one matrix pass per run of equal rows over the
+        # table rows it reads anyway), the dense columns from a small weight gradient over xd.  RP_GRAD_SEG=0: the stored x.
         if not need_w:
             x_mode = "none"
         elif os.environ.get("RP_WGRAD_GATHER", "0") == "1" and hip.linear_wgrad_gather_fits(B, 64, K, Kg):
             x_mode = "dense"
+        elif (need_grad and K > Kg and len(idx) <= 64 and os.environ.get("RP_GRAD_SEG", "1") != "0"
+              and store.embedding_dim == 64 and weight.shape[0] == 64):
+            x_mode = "seg"
         else:
             x_mode = "full"
         want_keys = (need_grad or x_mode == "dense") and pre is None
         x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd(store.arena, store.row_base, store.row_count, idx, dense, ldx, w16,
-                                                            bias, True, need_grad, want_keys, store.err_flag, x_mode=x_mode)
+                                                            bias, True, need_grad, want_keys, store.err_flag,
+                                                            x_mode="dense" if x_mode == "seg" else x_mode)
         ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, B, K, out_link, bias is not None
         ctx.ldx, ctx.x_mode, ctx.Kg, ctx.need_tables = ldx, x_mode, Kg, need_grad
         ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
@@ -849,7 +856,18 @@ class _EmbedGatherLinear(torch.autograd.Function):
             raise RuntimeError("the fused lookup + first layer stored no activation (the forward ran without gradients for the "
                                "layer's weight)")
 
+        seg = None
+        if need_w and ctx.x_mode == "seg":
+            # the weight gradient's three column groups come from three launches: the dense columns (+ the bias gradient)
+            # from rp_linear_wgrad over xd below, the tiny tables' from rp_embed_grad_tiny and the other tables' from
+            # rp_embed_grad_seg (both inside store.accumulate_grad)
+            dw_seg = torch.empty((64, ctx.K), dtype=torch.float32, device=dpre.device)
+            seg = (weight, dw_seg)
+
         def wgrad(keep=None):
+            if ctx.x_mode == "seg":    # x holds the dense columns only (xd [B, 64]); their columns of dw and the bias gradient
+                _, db_ = hip.linear_wgrad(dpre, x, ctx.K - ctx.Kg, dw=dw_seg[:, ctx.Kg:], want_bias=ctx.has_bias, keep=keep)
+                return dw_seg, db_
             if ctx.x_mode == "bf16":   # the activation was stored as bf16 (bf16-storage training)
                 return hip.linear_wgrad_xbf16(dpre, x, ctx.K, want_bias=ctx.has_bias, keep=keep)
             if ctx.x_mode == "dense":  # x holds the dense columns only: the embedding columns are gathered from the arena
@@ -884,7 +902,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
             wt = ctx.wt if ctx.wt is not None else hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
-                                  fused=(dpre, wt), plan_keep=keep if in_plan else None)
+                                  fused=(dpre, wt), plan_keep=keep if in_plan else None, seg=seg)
         if in_plan:
             hip.LaunchPlan.join()
             del keep

@@ -42,8 +42,12 @@ _SIGNATURES = {
     "rp_embed_grad_gemm": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
                                      C.c_uint64, _vp, _sz, _vp]),
     "rp_embed_grad_tiny_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
-    "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz,
-                                     _vp]),
+    "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64,
+                                     _vp, _sz, _vp]),
+    "rp_embed_grad_seg_fits": (C.c_int, [_i32, _i32, _i64]),
+    "rp_embed_grad_seg_workspace_bytes": (C.c_int, [_i64, _i64, _i32, C.POINTER(_sz)]),
+    "rp_embed_grad_seg": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, C.c_uint64, _vp,
+                                    _vp, _i64, _vp, _sz, _vp]),
     "rp_zero_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "rp_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_linear_fwd_rowadd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp]),
@@ -64,6 +68,9 @@ _SIGNATURES = {
     "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_plan_replay": (C.c_int, [_vp, _vp]),
     "rp_plan_set_streams": (C.c_int, [_vp, _vp, _vp]),
+    "rp_plan_set_probe": (C.c_int, [_vp, _i32]),
+    "rp_plan_probe_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
@@ -140,6 +147,7 @@ _SIGNATURES = {
     "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f64, _f64, _f64, _f64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rp_adam_step_scalars_range": (C.c_int, [_f64, _f64, _f64, _f64, _i64, _i64, _vp]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _f64, _f64,
                                     _vp, _i64, _vp, _vp]),
     "rp_lazy_adam_flush": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _f64, _f64, _f64, _vp, _i64, _vp]),
@@ -484,10 +492,11 @@ def embed_grad_gemm_fits(D: int, hidden: int, dh, wt) -> bool:
         and dh.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
 
 
-def embed_grad_tiny(keys, B: int, tiny, dh, wt, gfm, sum_in, arena, grad_arena, accumulate: bool, keep=None):
+def embed_grad_tiny(keys, B: int, tiny, dh, wt, gfm, sum_in, arena, grad_arena, accumulate: bool, keep=None, dw=None):
     """rp_embed_grad_tiny: the gradient rows of the tiny tables `tiny` = [(field, first arena row, rows), ...] from the
     unsorted pair keys [F * B] (sample-major one-hot GEMMs).  keep: a list that receives the workspace (launches that run
-    beside later ones inside a recorded plan)."""
+    beside later ones inside a recorded plan).  dw [64, K]: the tiny tables' columns of the first layer's weight gradient
+    are written into it as well (the companion of embed_grad_seg)."""
     _req(keys, torch.int32, "keys")
     _req(dh, torch.float32, "dh")
     n = len(tiny)
@@ -504,7 +513,8 @@ def embed_grad_tiny(keys, B: int, tiny, dh, wt, gfm, sum_in, arena, grad_arena, 
     with _Timed("embed_grad_tiny", f"{n} tables", B * (64 * 8 + 4 + 4 * n)):
         _check(lib().rp_embed_grad_tiny(keys.data_ptr(), B, arrs[0], arrs[1], arrs[2], n, dh.data_ptr(), _rowmajor(dh, "dh"),
                                         wt.data_ptr(), _rowmajor(wt, "wt"), _ptr(gfm), _ptr(sum_in), _ptr(arena),
-                                        grad_arena.data_ptr(), int(accumulate), ws.data_ptr(), nbytes.value, _stream()),
+                                        grad_arena.data_ptr(), int(accumulate), _ptr(dw),
+                                        _rowmajor(dw, "dw") if dw is not None else 0, ws.data_ptr(), nbytes.value, _stream()),
                "rp_embed_grad_tiny")
 
 
@@ -528,6 +538,46 @@ def embed_grad_gemm(sorted_keys, sorted_pos, B: int, D: int, dh, wt, dx, gfm, su
                                         dh.data_ptr(), _rowmajor(dh, "dh"), wt.data_ptr(), _rowmajor(wt, "wt"), _ptr(dx), ldx,
                                         _ptr(gfm), _ptr(sum_in), _ptr(arena), grad_arena.data_ptr(), int(accumulate),
                                         skip_fields, ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_gemm")
+
+
+def embed_grad_seg_fits(D: int, hidden: int, dh) -> bool:
+    return bool(lib().rp_embed_grad_seg_fits(D, hidden, _rowmajor(dh, "dh"))) and dh.data_ptr() % 16 == 0
+
+
+_SEG_ROWS: dict = {}
+
+
+def embed_grad_seg(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, arena, grad_arena, accumulate: bool,
+                   skip_fields: int = 0, field_rows=None, dw=None, keep=None):
+    """rp_embed_grad_seg: the first layer's whole backward on the embedding columns, segment-sum first — the table
+    gradient rows (dgrad of `w` [64, K] formed per run of equal keys + the FM term) AND, with dw [64, K], the embedding
+    columns of the layer's weight gradient from the table rows the launch reads anyway (no stored activation).
+    field_rows: table sizes per field (scheduling only).  Field-major positions (the single-device path)."""
+    _req(grad_arena, torch.float32, "grad_arena")
+    _req(dh, torch.float32, "dh")
+    _req(w, torch.float32, "w")
+    n = sorted_keys.numel()
+    fr = None
+    if field_rows is not None:
+        ck = tuple(field_rows)
+        fr = _SEG_ROWS.get(ck)
+        if fr is None:
+            fr = _SEG_ROWS[ck] = (C.c_int64 * len(ck))(*ck)
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_seg_workspace_bytes(n, B, D, C.byref(nbytes)), "rp_embed_grad_seg_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+    if keep is not None:
+        keep.append(ws)
+    F = n // B if B else 0
+    nk = F - bin(skip_fields).count("1")
+    # compulsory bytes: the sorted pairs, one dH / S row per pair (each field reads every sample's rows once), one table row
+    # read + one gradient row written per unique row is not known here: priced by bench.py; flops: dgrad + weight gradient
+    with _Timed("embed_grad_seg", f"D={D}", 0, 2 * 2 * nk * B * 64 * 64):
+        _check(lib().rp_embed_grad_seg(sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, B, D, dh.data_ptr(), _rowmajor(dh, "dh"),
+                                       w.data_ptr(), _rowmajor(w, "w"), _ptr(gfm), _ptr(sum_in), arena.data_ptr(),
+                                       grad_arena.data_ptr(), int(accumulate), skip_fields, fr, _ptr(dw),
+                                       _rowmajor(dw, "dw") if dw is not None else 0, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_embed_grad_seg")
 
 
 def zero_rows(keys, D: int, grad_arena):
@@ -818,7 +868,10 @@ def multi_copy(dst: Sequence[torch.Tensor], src: Sequence[torch.Tensor]) -> bool
         if not (d.is_cuda and s_.is_cuda and d.device == s_.device and d.dtype == s_.dtype and d.shape == s_.shape
                 and d.is_contiguous() and s_.is_contiguous()):
             return False
-    key = tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+    # (the byte counts are part of the key: a re-allocation at the same addresses with another shape or dtype must not
+    #  find the old sizes — ADVICE r4)
+    key = (tuple(t.data_ptr() for t in dst) + tuple(t.data_ptr() for t in src)
+           + tuple(t.numel() * t.element_size() for t in dst))
     arrs = _COPY_PLANS.get(key)
     if arrs is None:
         if len(_COPY_PLANS) >= 256:
@@ -1632,6 +1685,13 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, eps: flo
     a, b = C.c_float(0), C.c_float(0)
     _check(lib().rp_adam_step_scalars(lr, beta1, beta2, eps, step, C.byref(a), C.byref(b)), "rp_adam_step_scalars")
     return a.value, b.value
+
+
+def adam_step_scalars_range(lr: float, beta1: float, beta2: float, step0: int, n: int, eps: float = 1e-8) -> torch.Tensor:
+    """[n, 2] float32 HOST tensor: row i = adam_step_scalars(.., step0 + i) — one C call (rp_adam_step_scalars_range)"""
+    out = torch.empty((n, 2), dtype=torch.float32)
+    _check(lib().rp_adam_step_scalars_range(lr, beta1, beta2, eps, step0, n, out.data_ptr()), "rp_adam_step_scalars_range")
+    return out
 
 
 def lazy_adam_rows(sorted_keys, D: int, p, g, m, v, last, scalars, t_target: int, real_step: bool, zero_grad: bool,

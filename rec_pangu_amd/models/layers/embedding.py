@@ -274,7 +274,7 @@ class EmbeddingLayer(nn.Module):
         self.__dict__["_tiny_cache"] = (sig, out)
         return out
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None):
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None, seg=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -319,14 +319,23 @@ class EmbeddingLayer(nn.Module):
                     hip.LaunchPlan.section(2)
                 try:
                     hip.embed_grad_tiny(keys, B, tiny, fused[0], fused[1], gfm, ssum, self._arena, self._grad_arena,
-                                        accumulate=not self._grad_clean, keep=plan_keep)
+                                        accumulate=not self._grad_clean, keep=plan_keep, dw=None if seg is None else seg[1])
                 finally:
                     if in_plan:
                         hip.LaunchPlan.section(0)
                 for f, _, _ in tiny:
                     skip |= 1 << f
-            hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
-                                accumulate=not self._grad_clean, skip_fields=skip)
+            if seg is not None:
+                # (weight [64, K], dw [64, K]) of the consuming Linear: segment sums first, one matrix pass per run that also
+                # yields the embedding columns of dw — the forward stored no activation (functional._EmbedGatherLinear)
+                if keys is None or dx is not None or keys.numel() != len(self.emb_feature) * B:
+                    raise RuntimeError("the fused first layer stored no activation, but its backward is not the field-major "
+                                       "single-device form rp_embed_grad_seg covers")
+                hip.embed_grad_seg(sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena,
+                                   accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1])
+            else:
+                hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
+                                    accumulate=not self._grad_clean, skip_fields=skip)
         else:
             hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
                                   accumulate=not self._grad_clean)

@@ -86,8 +86,8 @@ class StepTables:
                 new[:old.shape[0]].copy_(old)
                 setattr(self, name, new)
             self.generation += 1
-        rows = [hip.adam_step_scalars(lr, self.betas[0], self.betas[1], s, self.eps) for s in range(t_new, hi + 1)]
-        self.sc[t_new:hi + 1].copy_(torch.tensor(rows, dtype=torch.float32))
+        # (one C call for the whole chunk: the per-step loop over ctypes cost the host ~1 ms every 1024th step)
+        self.sc[t_new:hi + 1].copy_(hip.adam_step_scalars_range(lr, self.betas[0], self.betas[1], t_new, hi + 1 - t_new, self.eps))
         j = torch.arange(t_new, hi + 1, dtype=torch.float64)
         ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
         d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
@@ -139,6 +139,7 @@ class LazyAdamRows:
         # ~372 steps old) is valid for replays that end at step `_cf_built`; -1 = a fresh buffer.  Bringing it to the next
         # step rebuilds only the youngest stamps: O(1) per training step whatever the step count
         self._cf, self._cf_built, self._cf_gen = None, -1, -1
+        self._cf_in_capture = False  # a captured step holds this state's window rebuild (set by _cf_args under device_clock)
         self.device_clock = False
         self.set_replay(replay)
 
@@ -170,6 +171,9 @@ class LazyAdamRows:
     def cf_sync(self, t_end):
         """host-clock build: the table is valid for replays that end at t_end (no launch when it already is)"""
         cf = self._cf_buffer()
+        if self._cf_built > t_end:
+            self._cf_built = -1  # the clock went BACK (an optimizer-state rollback): the youngest entries were built for a
+            #                      later end step — a fresh build (ADVICE r4)
         if self._cf_built != t_end and (t_end > self._cf_from or self._cf_built < 0):  # (a fresh buffer gets its power columns)
             hip.lazy_adam_cf_table(self.tabs.ns_d, t_end, self._cf_from, self.betas[0], self.betas[1], cf,
                                    built_to=self._cf_built)
@@ -188,6 +192,7 @@ class LazyAdamRows:
             if build:
                 hip.lazy_adam_cf_table(self.tabs.ns_d, self.tabs.capacity - 1, self._cf_from, self.betas[0], self.betas[1],
                                        cf, built_to=0, t_dev=self.tabs.t_dev)
+                self._cf_in_capture = True  # this state's window rebuild is part of the captured step (advance_host)
             return cf, self._cf_from
         if t_end <= self._cf_from:
             return None, 0
@@ -405,11 +410,16 @@ class FusedAdam(torch.optim.Optimizer):
         self._in_step, self._clock_ticks = True, []
         try:
             self._step_groups()
+        except BaseException:
+            # a step that raised part-way advanced the host counters of the groups it got through only; the device clocks
+            # are ticked on SUCCESS only (ticking all of them in `finally` let device and host clocks diverge)
+            self._clock_ticks = []
+            raise
         finally:
             self._in_step = False
-            ticks, self._clock_ticks = self._clock_ticks, []
-            for i in range(0, len(ticks), 8):  # (every lazy state and every parameter group has a clock of its own)
-                hip.counters_add(ticks[i:i + 8], 1)
+        ticks, self._clock_ticks = self._clock_ticks, []
+        for i in range(0, len(ticks), 8):  # (every lazy state and every parameter group has a clock of its own)
+            hip.counters_add(ticks[i:i + 8], 1)
         return loss
 
     def _step_groups(self):
@@ -560,8 +570,11 @@ class FusedAdam(torch.optim.Optimizer):
         for g in self.param_groups:
             g["_rp_step"] = g.get("_rp_step", 0) + 1
         for lz in self._lazies():
-            if lz.closed:
-                lz._cf_built = lz.t  # the replay in front of the captured forward brought the table to this step
+            if lz.closed and getattr(lz, "_cf_in_capture", False):
+                # the replay in front of the captured forward brought the table to this step — only where that rebuild was
+                # recorded in the capture: a state whose layer the captured step never looks up keeps its old mark and is
+                # rebuilt by the next eager cf_sync
+                lz._cf_built = lz.t
             lz.t += 1
 
     def _adopt_loaded_state(self, store, m, v, lz):
@@ -580,6 +593,8 @@ class FusedAdam(torch.optim.Optimizer):
         if any_loaded and lz is not None and lz.t > 0:
             live = (m != 0).any(dim=1) | (v != 0).any(dim=1)
             lz.last.copy_(live.to(torch.int32) * lz.t)
+        if lz is not None:
+            lz._cf_built = -1  # (whatever the closed-form table was built for, the loaded clock may differ)
 
     def load_state_dict(self, state_dict):
         """torch semantics; the moments of arena-backed tables are adopted by the arena state at the next step()."""

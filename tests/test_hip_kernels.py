@@ -937,3 +937,77 @@ def test_embed_grad_tiny_tables_vs_sorted_path_and_fp64(hip, rows, B, with_fm, a
         Gs[0][never] = init
     assert float((got - ref).abs().max()) <= 2e-5 * max(scale, 1e-6), "against fp64"
     assert float((Gs[0] - Gall).abs().max()) <= 2e-5 * max(scale, 1e-6), "against the row-sorted kernel over every field"
+
+
+@pytest.mark.parametrize("rows,B,with_fm,accumulate,with_tiny", [
+    ([8, 4, 51, 12, 3], 24, True, False, False),               # one partial tile per field, every run inside one group
+    ([3, 4, 10, 5000, 27], 4099, True, False, False),          # runs of > 1000 equal rows: pieces across groups, tiles and chunks
+    ([3, 4, 10, 5000, 27], 4099, False, False, True),          # no FM term; the tiny tables through rp_embed_grad_tiny
+    ([300, 40, 1000, 5000, 27, 90], 2048, True, True, True),   # accumulate into a non-zero arena + tiny tables
+    ([50000, 7, 2000000], 65536, True, False, False),          # full batch: mostly unique rows, a hot table, 512 tiles per field
+    ([50000, 13, 5, 700, 90], 16384 + 77, True, False, True),  # a ragged last tile
+])
+def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate, with_tiny):
+    """rp_embed_grad_seg (segment sums first, then ONE matrix pass per run piece that yields the table rows' gradient AND the
+    embedding columns of the first layer's weight gradient; the forward stores no activation) against an fp64 restatement
+    of the reference's ops (embedding.py:61-63 backward + interaction.py:38-44 backward + deep.py:62-72 dgrad / wgrad) and
+    against rp_embed_grad_gemm; bit-identical between two launches; both tile sizes when the library was started with
+    RP_SEG_ROWS (the default here)."""
+    D, H = 64, 64
+    g = torch.Generator().manual_seed(B + len(rows))
+    F = len(rows)
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    ND = 5
+    K = F * D + ND
+    ldx = (K + 63) // 64 * 64
+    W1 = torch.randn(H, K, generator=g) / K ** 0.5
+    dh = torch.randn(B, H, generator=g) * 1e-3 * (torch.rand(B, H, generator=g) < 0.6)
+    gfm = torch.randn(B, 1, generator=g) * 1e-3 if with_fm else None
+    ssum = torch.randn(B, D, generator=g) if with_fm else None
+    row_of = [base[f] + idx[f] for f in range(F)]
+    keys = torch.cat(row_of).to(torch.int32).to(DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=max(1, (arena.shape[0] - 1).bit_length()))
+    dev = lambda t_: None if t_ is None else t_.to(DEV)  # noqa: E731
+    Wd = dev(W1)
+    wt = hip.transpose(Wd, rows_out=ldx)
+    NR = arena.shape[0]
+    init = 0.5 if accumulate else 0.0
+    tiny = [(f, int(base[f]), rows[f]) for f in range(F) if rows[f] <= 254] if with_tiny else []
+    skip = sum(1 << t[0] for t in tiny)
+    outs = []
+    for _ in range(2):
+        G = torch.full((NR, D), init, device=DEV)
+        dw = torch.full((H, K), float("nan"), device=DEV)
+        if tiny:
+            hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G, accumulate, dw=dw)
+        hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G, accumulate, skip_fields=skip,
+                           field_rows=rows, dw=dw)
+        outs.append((G, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:, :F * D], outs[1][1][:, :F * D]), "two launches differ"
+    G, dw = outs[0]
+    assert bool(torch.isnan(dw[:, F * D:]).all()), "the dense columns are not this launch's"
+    # fp64 restatement
+    xr = torch.cat([arena[row_of[f].long()] for f in range(F)], dim=1).double()
+    dX = dh.double() @ W1.double()[:, :F * D]
+    ref = torch.full((NR, D), init, dtype=torch.float64)
+    for f in range(F):
+        contrib = dX[:, f * D:(f + 1) * D]
+        if with_fm:
+            contrib = contrib + gfm.double() * (ssum.double() - arena.double()[row_of[f].long()])
+        ref.index_add_(0, row_of[f].long(), contrib)
+    dw_ref = dh.double().T @ xr
+    scale = float((ref - init).abs().max())
+    assert float((G.cpu().double() - ref).abs().max()) <= 2e-5 * max(scale, 1e-6), "table gradient against fp64"
+    wscale = float(dw_ref.abs().max())
+    assert float((dw[:, :F * D].cpu().double() - dw_ref).abs().max()) <= 2e-5 * max(wscale, 1e-6), "weight gradient against fp64"
+    # the pair-form kernel over every field
+    Gall = torch.full((NR, D), init, device=DEV)
+    hip.embed_grad_gemm(sk, sp, B, D, dev(dh), wt, None, dev(gfm), dev(ssum), dev(arena), Gall, accumulate)
+    assert float((G - Gall).abs().max()) <= 2e-5 * max(scale, 1e-6)
+    # no weight gradient asked for: the same rows, nothing else written
+    G2 = torch.full((NR, D), init, device=DEV)
+    if tiny:
+        hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
+    hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
+    assert torch.equal(G2, G)
