@@ -694,7 +694,7 @@ int rp_plan_replay(void *plan, rp_stream_t stream);
  * nothing outside the library can bracket one of them).  rp_plan_set_probe(plan, k): the k-th recorded launch (0 ..
  * n_nodes - 1 of rp_plan_info, recorded order) of the following replays is bracketed by a HIP timing-event pair on the stream it
  * is issued on; -1 = off.  rp_plan_probe_ms: elapsed milliseconds of the last replay's pair (waits for it).
- * rp_plan_launch_name: the launch's (mangled) kernel name and section (0 main stream, 1 side, 2 inline side). */
+ * rp_plan_launch_name: the launch's (demangled) kernel name and section (0 main stream, 1 side, 2 inline side). */
 int rp_plan_set_probe(void *plan, int launch);
 int rp_plan_probe_ms(void *plan, float *ms);
 int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_len, int *section);

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 TAG=$1; PRE=$2; shift 2
 W=5; K=20
-FLAGS="--no-cpu-baseline --no-small-batch --pre-roll $PRE --warmup $W --steps $K $*"
+FLAGS="--no-cpu-baseline --no-small-batch --long-steps 0 --pre-roll $PRE --warmup $W --steps $K $*"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT gpurun_out/profiles
 OURS='adam_kernel|embed_|linear_|wgrad_|transpose_kernel|relu_bwd|sigmoid_bce|loss_finish|zero_rows|iota_i32|cin_|crossnet|attn_|mmoe_|lazy_|counter_add|accumulate|pool_|fm_|bn_|batchnorm|field_sort|sort_hist|sort_scan|sort_scatter|mlp_tail|dropout|route_|shard_|DeviceRadixSort|radix|onesweep|multi_copy|copy_rows|dice_'
@@ -32,7 +32,7 @@ cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc.json gpurun_out/profiles
 wc -l $(find $OUT -name "*counter_collection.csv") 2>/dev/null
 # the big raw traces stay on the box
 find $OUT -name "*.csv" -size +1M -delete; find $OUT -name "*.db" -delete
-timeout 200 python bench.py --pre-roll $PRE $* 2>/dev/null | grep "^{" > gpurun_out/profiles/${TAG}_bench.json
+timeout 400 python bench.py --pre-roll $PRE $* 2>/dev/null | grep "^{" > gpurun_out/profiles/${TAG}_bench.json
 python - gpurun_out/profiles/${TAG}_bench.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"] or {}

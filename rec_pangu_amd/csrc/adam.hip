@@ -994,6 +994,55 @@ __global__ __launch_bounds__(256) void lazy_adam_catchup_kernel(const int32_t *_
     }
 }
 
+// The same launch with the run heads COMPACTED per wave (round 5).  Above, a TPR-lane group is spent on
+// every sorted PAIR and only run heads work: 31 % of the groups at Criteo shape (0.53 M unique rows of 1.70 M pairs), so a
+// wave carries two or three live rows and as many loads in flight.  Here a wave takes 64 consecutive pairs, finds its run
+// heads with one ballot, parks their keys in LDS in rank order and walks them 64 / TPR at a time: every iteration of a wave
+// but its last is full.  Same per-row code (catchup_row_chunks), same results bit for bit.
+template <int NCH, int TPR, typename T>
+__global__ __launch_bounds__(256) void lazy_adam_catchup_wave_kernel(const int32_t *__restrict__ sk, int64_t n, int D,
+                                                                     float *__restrict__ P, float *__restrict__ G,
+                                                                     float *__restrict__ Mo, float *__restrict__ Vo,
+                                                                     int32_t *__restrict__ last,
+                                                                     const float2 *__restrict__ sc, int t_done, int mark,
+                                                                     LazyCfg c, const CfEntry *__restrict__ cf, int cf_from,
+                                                                     const int32_t *__restrict__ t_dev,
+                                                                     uint16_t *__restrict__ shadow) {
+    if (t_dev != nullptr) t_done = *t_dev;  // completed steps (graph replays)
+    __shared__ int32_t heads[4][64];
+    constexpr int RPW = 64 / TPR;  // rows a wave works on at once
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < n;
+    const int32_t key = in ? sk[i] : -1;
+    const int32_t prev = (in && i > 0) ? sk[i - 1] : -1;
+    const bool head = in && (i == 0 || prev != key);
+    const unsigned long long mask = __ballot(head);
+    const int nh = __popcll(mask);
+    if (head) heads[wv][__popcll(mask & ((1ull << lane) - 1ull))] = key;
+    __syncthreads();
+    const int g = lane / TPR, t = lane % TPR;
+    for (int it = 0; it * RPW < nh; ++it) {
+        const int q = it * RPW + g;
+        if (q >= nh) continue;
+        const int32_t row = heads[wv][q];
+        const int raw = last[row];
+        const bool pend = raw < 0;
+        const int l = pend ? -raw - 1 : raw;
+        const bool apply = pend && l + 1 <= t_done && G != nullptr;
+        const bool behind = apply || (l > 0 && l < t_done);
+        if (behind) catchup_row_chunks<NCH, TPR, T>(row, D, t, P, G, Mo, Vo, shadow, apply, mark, l, t_done, sc, c, cf, cf_from);
+        if (t == 0) {
+            int nl = raw;
+            if (!(pend && !apply)) {  // (a gradient whose step is still in progress stays pending as it is)
+                if (mark) nl = -(t_done + 1);
+                else if (behind) nl = t_done;
+            }
+            if (nl != raw) last[row] = nl;
+        }
+    }
+}
+
 // every row of the arena: what it is owed through step t_target (checkpoints, state_dict(), evaluation on raw tables)
 template <int TPR, typename T>
 __global__ __launch_bounds__(256) void lazy_adam_flush_deferred_kernel(int64_t R, int D, float *__restrict__ P,
@@ -1050,10 +1099,20 @@ extern "C" int rp_lazy_adam_catchup(const int32_t *sorted_keys, int64_t n, int D
     // column chunks per lane (catchup_row_chunks): RP_CATCHUP_CHUNKS = 1, 2 (default) or 4
     static const int chunks = getenv("RP_CATCHUP_CHUNKS") ? atoi(getenv("RP_CATCHUP_CHUNKS")) : 2;
     if ((chunks == 2 || chunks == 4) && tpr >= chunks && D == tpr * vw) tpr /= chunks;
-    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
     hipStream_t s = (hipStream_t)stream;
     const float2 *sc = reinterpret_cast<const float2 *>(step_scalars);
     const CfEntry *cf = reinterpret_cast<const CfEntry *>(cf_table);
+    // D = 64 rows as two float4 chunks per lane (the layers of every BASELINE config): run heads compacted per wave
+    // (RP_CATCHUP_WAVE=0: one lane group per sorted pair, as before)
+    static const bool wave_form = !(getenv("RP_CATCHUP_WAVE") && getenv("RP_CATCHUP_WAVE")[0] == '0');
+    if (wave_form && vw == 4 && D == 64 && tpr == 8) {
+        hipLaunchKernelGGL((lazy_adam_catchup_wave_kernel<2, 8, f32x4>), dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, s, sorted_keys,
+                           n, D, p, g, m, v, last, sc, (int)t_done, mark, c, cf, (int)cf_from, t_dev,
+                           reinterpret_cast<uint16_t *>(shadow_bf16));
+        RP_LAUNCH_CHECK("lazy_adam_catchup");
+        return RP_OK;
+    }
+    const unsigned grid = (unsigned)rp_cdiv(n, 256 / tpr);
 #define CALL(T, TY)                                                                                                      \
     hipLaunchKernelGGL((lazy_adam_catchup_kernel<T, TY>), dim3(grid), dim3(256), 0, s, sorted_keys, n, D, p, g, m, v, last, \
                        sc, (int)t_done, mark, c, cf, (int)cf_from, t_dev, reinterpret_cast<uint16_t *>(shadow_bf16))

@@ -1307,6 +1307,10 @@ struct SegFields {
 };
 // SEG = sorted positions per 16-lane group: a tile is 16 * SEG positions.  SEG = 8: 128-row tiles, two workgroups per CU
 // (LDS 77 KB, up to 256 registers); SEG = 4: 64-row tiles, three workgroups per CU (42 KB, 168 registers).
+// LDS-only barrier: every barrier of the tile loop orders LDS traffic only (each gradient row has one writer, the piece list
+// is read by later launches), and __syncthreads() would also drain the vector-memory counter — the row loads in flight across
+// the piece-count barrier, the next tile's keys, the gradient-row stores
+#define SEG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <bool HAS_FM, int SEG>
 __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,
@@ -1323,6 +1327,7 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
     __shared__ int32_t pcont[GPB];
     __shared__ int32_t tkey[TILE + 2];  // sorted keys of the tile's rows (-1 beyond its end), [0] / [TILE + 1]: the neighbours
     __shared__ int32_t tsmp[TILE];      // sample of every tile row (0 beyond the end)
+    __shared__ __attribute__((aligned(16))) int32_t gcnt[GPB];  // pieces per group (the tile's pieces are stored COMPACTED)
     const int tid = threadIdx.x, t = tid & 15, grp = tid >> 4, c = 4 * t;
     const int wv = tid >> 6, l = tid & 63, i = l & 31, h = l >> 5;
     const int chunk = (int)blockIdx.x;
@@ -1380,6 +1385,10 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
         tile_keys(wg0, (wg0 + TILE < fend) ? wg0 + TILE : fend, a0, a1);
         tile_keys_store(a0, a1);
     }
+    // (rows of the two tiles beyond a tile's pieces are read by the last k-step of the weight gradient with a zero on the
+    //  other side: they must hold finite data from the start)
+    for (int e = tid; e < TILE * SG_HT / 4; e += 256) reinterpret_cast<f32x4 *>(&HsT[0][0])[e] = V::zero();
+    for (int e = tid; e < TILE * D / 4; e += 256) reinterpret_cast<f32x4 *>(&VT[0][0])[e] = V::zero();
     __syncthreads();
     for (int j = j0; j < jn; ++j) {
         const int64_t wg0 = fbase + (int64_t)TILE * j;
@@ -1396,12 +1405,19 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
         k[SEG] = -1;
         const int32_t kprev = cnt > 0 ? tkey[SEG * grp] : -1;
         const int32_t knext = cnt > 0 ? tkey[1 + SEG * grp + cnt] : -1;
+        // a piece ends where the key changes or the group's positions end (k = -1 beyond cnt and behind the group's
+        // positions); only piece ends carry data, so they are stored COMPACTED: piece q of the tile in row q of the two LDS
+        // tiles — a field of a 10 k-row table has ~30 pieces per 128 positions, and the matrix passes then cover 32 rows
+        // (one m-block of the dgrad, two k-steps of the weight gradient) instead of 128
+        unsigned lastm = 0;
+#pragma unroll
+        for (int jj = 0; jj < SEG; ++jj) lastm |= (jj < cnt && k[jj + 1] != k[jj]) ? (1u << jj) : 0u;
+        if (t == 0) gcnt[grp] = __builtin_popcount(lastm);
         // ---- the one dependent trip to memory: dH rows, S rows, g_fm and the table rows, all in flight together (no
         //      branch around a load: the in-order counter stays counted) ------------------------------------------------
         f32x4 rh[SEG], rs[SEG], rv[SEG];
         float g[SEG];
-#pragma unroll
-        for (int jj = 0; jj < SEG; ++jj) {
+        auto issue_row = [&](int jj) {
             // (dH / S: B * 64 floats < 2^32 bytes — 32-bit offsets from the scalar base)
             rh[jj] = V::load(dh + ((uint32_t)bs[jj] * (uint32_t)lddh + (uint32_t)c));
             if (HAS_FM) {
@@ -1409,7 +1425,12 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
                 g[jj] = gfm[(uint32_t)bs[jj]];
             }
             rv[jj] = V::load(arena + (int64_t)(k[jj] < 0 ? 0 : k[jj]) * D + c);
-        }
+        };
+        // the group's last LATE rows are issued once its first LATE rows have been folded (their registers are free again:
+        // 8 rows x 3 float4 in flight at once did not fit beside the chunk's constants — 27 spilled registers)
+        constexpr int LATE = 0;  // (tried 2 at SEG = 8: the spill count did not move — the peak is in the matrix passes)
+#pragma unroll
+        for (int jj = 0; jj < SEG - LATE; ++jj) issue_row(jj);
         // ... and behind them the NEXT tile's keys (they land under the matrix passes and go to LDS after them)
         int32_t nk0, nk1;
         {
@@ -1417,31 +1438,52 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
             const bool more = j + 1 < jn;
             tile_keys(more ? w1 : 0, more ? ((w1 + TILE < fend) ? w1 + TILE : fend) : 0, nk0, nk1);
         }
-        // ---- segment sums in registers; a piece ends where the key changes or the group's positions end.  Masks are
-        //      0 / 1 factors, not selects: a select lets the compiler sink a row's loads into a branch, and then every
-        //      wait is vmcnt(0) (rows beyond cnt read sample 0 / table row 0: real, finite data times zero) --------------
+        SEG_BARRIER();  // (A0) the groups' piece counts (the row loads are in flight meanwhile)
+        int pbase = 0, P = 0;
+        {
+            const int4 *g4 = reinterpret_cast<const int4 *>(gcnt);
+#pragma unroll
+            for (int q = 0; q < GPB / 4; ++q) {
+                const int4 v4 = g4[q];
+                const int vals[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pbase += (4 * q + e < grp) ? vals[e] : 0;
+                    P += vals[e];
+                }
+            }
+        }
+        // ---- segment sums in registers.  Masks are 0 / 1 factors, not selects: a select lets the compiler sink a row's
+        //      loads into a branch, and then every wait is vmcnt(0) (rows beyond cnt read sample 0 / table row 0: real,
+        //      finite data times zero) ----------------------------------------------------------------------------------
         f32x4 E[SEG];
-        unsigned lastm = 0;
         {
             f32x4 accH = V::zero(), accU = V::zero();
             float gs = 0.f;
+            int slot = pbase;
 #pragma unroll
             for (int jj = 0; jj < SEG; ++jj) {
-                const bool ok = jj < cnt;
-                const float okf = ok ? 1.f : 0.f;
+                if (LATE > 0 && jj == LATE) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = SEG - LATE; u < SEG; ++u) issue_row(u);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float okf = (jj < cnt) ? 1.f : 0.f;
                 accH += okf * rh[jj];
                 if (HAS_FM) {
                     const float gj = okf * g[jj];
                     accU += gj * rs[jj];
                     gs += gj;
                 }
-                const bool last = ok && k[jj + 1] != k[jj];  // (k = -1 beyond cnt and behind the group's positions)
-                lastm |= last ? (1u << jj) : 0u;
-                const float lastf = last ? 1.f : 0.f, keepf = 1.f - lastf;
-                const f32x4 tv = lastf * rv[jj];
-                V::store(&HsT[SEG * grp + jj][c], lastf * accH);
-                V::store(&VT[SEG * grp + jj][c], tv);
-                E[jj] = HAS_FM ? accU - gs * tv : V::zero();  // (used at piece ends only)
+                const bool last = (lastm >> jj) & 1u;
+                const float keepf = last ? 0.f : 1.f;
+                if (last) {  // (LDS stores only: no vector-memory operation sits behind this branch)
+                    V::store(&HsT[slot][c], accH);
+                    V::store(&VT[slot][c], rv[jj]);
+                }
+                slot += last ? 1 : 0;
+                E[jj] = HAS_FM ? accU - gs * rv[jj] : V::zero();  // (used at piece ends only)
                 accH = keepf * accH;
                 if (HAS_FM) {
                     accU = keepf * accU;
@@ -1449,19 +1491,23 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
                 }
             }
         }
-        __syncthreads();  // (A) the tiles are complete; wave 0 has left the previous tile's piece merge
+        // the weight gradient's last k-step reads rows P .. (its multiple of 16): zero table rows there
+        if (grp < ((P + 15) & ~15) - P) V::store(&VT[P + grp][c], V::zero());
+        SEG_BARRIER();  // (A) the tiles are complete; wave 0 has left the previous tile's piece merge
         if (t == 0) {
             pkey[grp][0] = -1;
             pkey[grp][1] = -1;
             pcont[grp] = 0;
         }
         // ---- dgrad on the matrix core: C[row, d] = sum_hidden Hs[row, hidden] W1[hidden, f*64 + d] ------------------------
+        // (m-blocks of 32 piece rows are dealt mh, mh + 2: with P <= 64 pieces both wave pairs still have one each)
         f32x16 ag[MB];
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ag[mb][r] = 0.f;
-            const float *arow = &HsT[(TILE / 2) * mh + 32 * mb + i][8 * h];
+            if (32 * (mh + 2 * mb) >= P) continue;  // (workgroup-uniform)
+            const float *arow = &HsT[32 * (mh + 2 * mb) + i][8 * h];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks);
@@ -1482,8 +1528,10 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
         // ---- weight gradient: dW1^T[d, hidden] += sum_row V[row, d] Hs[row, hidden]  (K = the tile's rows) ----------------
         if (want_dw) {
             const int dblk = wv >> 1, hblk = wv & 1;
-#pragma unroll 2
-            for (int ks = 0; ks < TILE / 16; ++ks) {
+            const int nks = (P + 15) >> 4;
+            __builtin_amdgcn_sched_barrier(0);  // (the dgrad's fragments are dead here: do not start this loop's reads early)
+#pragma unroll 1
+            for (int ks = 0; ks < nks; ++ks) {
                 f32x8 va, vb;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -1498,21 +1546,24 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
                     dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], dwacc, 0, 0, 0);
             }
         }
-        __syncthreads();  // (B) every wave is done reading the Hs tile: it becomes the C tile
+        SEG_BARRIER();  // (B) every wave is done reading the Hs tile: it becomes the C tile
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
+            if (32 * (mh + 2 * mb) < P) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) HsT[(TILE / 2) * mh + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h][32 * nb + i] = ag[mb][r];
+                for (int r = 0; r < 16; ++r) HsT[32 * (mh + 2 * mb) + (r & 3) + 8 * (r >> 2) + 4 * h][32 * nb + i] = ag[mb][r];
+            }
         tile_keys_store(nk0, nk1);  // (this tile's keys were last read in front of barrier A)
-        __syncthreads();  // (C)
+        SEG_BARRIER();  // (C)
         // ---- the pieces' gradient rows: C + u - s v; runs inside the group are stored, border pieces merged as in
         //      embed_grad_reduce_kernel (same piece list, same finish launches) -------------------------------------------
         {
             bool run_head = (k[0] != kprev);
+            int slot = pbase;
 #pragma unroll
             for (int jj = 0; jj < SEG; ++jj) {
                 if ((lastm >> jj) & 1u) {
-                    const f32x4 val = V::load(&HsT[SEG * grp + jj][c]) + E[jj];
+                    const f32x4 val = V::load(&HsT[slot++][c]) + E[jj];
                     const bool run_ends_here = (jj + 1 < cnt) ? true : (k[jj] != knext);
                     if (run_head && run_ends_here) {
                         float *dst = G + (int64_t)k[jj] * D + c;
@@ -1529,7 +1580,7 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
                 }
             }
         }
-        __syncthreads();  // (D)
+        SEG_BARRIER();  // (D)
         if (grp == 0) {
             const int64_t tile_id = tile_id0 + j;
             float *hp = gpiece + tile_id * 2 * D, *tp = hp + D;
@@ -1605,22 +1656,34 @@ __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel
     }
 }
 
-// dw[hidden, f*64 + d] = the fixed-order sum of the chunk partials [d][hidden] of field f (four independent chains)
+// dw[hidden, f*64 + d] = the fixed-order sum of the chunk partials [d][hidden] of field f.  One workgroup = 64 consecutive
+// elements x four quarters of the chunk list (a wave each, eight loads in flight per lane: a first version — one thread per
+// element walking all chunks four loads at a time — was latency-bound at 0.6 TB/s: 60 us for 38 MB), then the quarters are
+// added in order through LDS.
 __global__ __launch_bounds__(256) void embed_grad_seg_dw_kernel(const float *__restrict__ dwpart, SegFields sf, int cpf,
                                                                 float *__restrict__ dw, int64_t lddw) {
+    __shared__ float part[4][64];
     const int o = (int)blockIdx.x, f = sf.sched[o];
-    const int e = (int)blockIdx.y * 256 + (int)threadIdx.x;  // element (d = e >> 6, hidden = e & 63) of the field's block
-    const float *p = dwpart + (int64_t)o * cpf * 4096 + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int cidx = 0;
-    for (; cidx + 4 <= cpf; cidx += 4) {
-        s0 += p[(int64_t)cidx * 4096];
-        s1 += p[(int64_t)(cidx + 1) * 4096];
-        s2 += p[(int64_t)(cidx + 2) * 4096];
-        s3 += p[(int64_t)(cidx + 3) * 4096];
+    const int q = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
+    const int e = (int)blockIdx.y * 64 + l;  // element (d = e >> 6, hidden = e & 63) of the field's block
+    const int per = (cpf + 3) / 4, c0 = q * per, c1 = (c0 + per < cpf) ? c0 + per : cpf;
+    const float *p = dwpart + ((int64_t)o * cpf) * 4096 + e;
+    float s0 = 0.f, s1 = 0.f;
+    int ci = c0;
+    for (; ci + 8 <= c1; ci += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(ci + u) * 4096];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            s0 += v[u];
+            s1 += v[u + 1];
+        }
     }
-    for (; cidx < cpf; ++cidx) s0 += p[(int64_t)cidx * 4096];
-    dw[(int64_t)(e & 63) * lddw + (int64_t)f * 64 + (e >> 6)] = (s0 + s1) + (s2 + s3);
+    for (; ci < c1; ++ci) s0 += p[(int64_t)ci * 4096];
+    part[q][l] = s0 + s1;
+    __syncthreads();
+    if (q == 0) dw[(int64_t)(e & 63) * lddw + (int64_t)f * 64 + (e >> 6)] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
 }
 
 // rows per tile: 128 (two workgroups per CU) or 64 (three); RP_SEG_ROWS overrides the default
@@ -1639,6 +1702,8 @@ static int seg_tiles_per_chunk(int tpf) {
         const char *e = getenv("RP_SEG_TILES");
         return e ? atoi(e) : 0;
     }();
+    // (measured at Criteo shape, 128-row tiles, compacted pieces: 8 tiles per chunk 0.310 ms, 4: 0.312, 2: 0.351, 16: 0.372 —
+    //  with the first, latency-bound form of the partial sum; 8 halves the partials against 4)
     int T = forced > 0 ? forced : (tpf + 32) / 64;
     T = T < 1 ? 1 : (T > 64 ? 64 : T);
     return T > tpf ? tpf : T;
@@ -1729,7 +1794,7 @@ extern "C" int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sort
 #undef SEG_LAUNCH
     RP_LAUNCH_CHECK("embed_grad_seg");
     if (dw != nullptr) {
-        hipLaunchKernelGGL(embed_grad_seg_dw_kernel, dim3((unsigned)sf.n, 16), dim3(256), 0, s, dwpart, sf, cpf, dw, lddw);
+        hipLaunchKernelGGL(embed_grad_seg_dw_kernel, dim3((unsigned)sf.n, 64), dim3(256), 0, s, dwpart, sf, cpf, dw, lddw);
         RP_LAUNCH_CHECK("embed_grad_seg (weight-gradient partials)");
     }
     return grad_reduce_finish(n_eff, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);

@@ -216,7 +216,19 @@ __global__ __launch_bounds__(256) void embed_grad_tiny_dw_kernel(const float *__
     const float *hrow = hs + (int64_t)tt.acc0[slot] * 64 + hh;
     const float *vrow = arena + (int64_t)tt.base[slot] * 64 + d;
     float a = 0.f;
-    for (int r = 0; r < tt.rows[slot]; ++r) a = __builtin_fmaf(hrow[(int64_t)r * 64], vrow[(int64_t)r * 64], a);
+    const int nr = tt.rows[slot];
+    int r = 0;
+    for (; r + 8 <= nr; r += 8) {  // (eight rows' loads in flight: the plain loop waited for every pair of loads in turn)
+        float hv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            hv[u] = hrow[(int64_t)(r + u) * 64];
+            vv[u] = vrow[(int64_t)(r + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = __builtin_fmaf(hv[u], vv[u], a);
+    }
+    for (; r < nr; ++r) a = __builtin_fmaf(hrow[(int64_t)r * 64], vrow[(int64_t)r * 64], a);
     dw[(int64_t)hh * lddw + (int64_t)tt.field[slot] * 64 + d] = a;
 }
 

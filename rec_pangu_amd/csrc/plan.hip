@@ -17,6 +17,8 @@
 // of the NEXT batch) and are re-issued on the plan's side stream, forked at the start of the replay and joined at its end —
 // the overlap the eager path gets from its side stream, which a fork inside a hipGraph does not give on this runtime.
 #include "common.h"
+#include <cxxabi.h>
+#include <cstdlib>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -227,7 +229,7 @@ extern "C" int rp_plan_probe_ms(void *plan, float *ms) {
     return RP_OK;
 }
 
-// the (mangled) kernel name and the section (0 main, 1 side, 2 inline) of launch `launch`
+// the (demangled) kernel name and the section (0 main, 1 side, 2 inline) of launch `launch`
 extern "C" int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_len, int *section) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && buf != nullptr && buf_len > 1, "plan_launch_name: bad argument");
@@ -235,8 +237,11 @@ extern "C" int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_le
     RP_REQUIRE(i >= 0, "plan_launch_name: launch %d does not exist", launch);
     const char *nm = hipKernelNameRefByPtr(p->nodes[i].func, p->nodes[i].rec_stream);
     if (nm == nullptr) nm = "?";
-    strncpy(buf, nm, (size_t)buf_len - 1);
+    int status = -1;
+    char *dem = abi::__cxa_demangle(nm, nullptr, nullptr, &status);  // (as rocprofv3 prints it)
+    strncpy(buf, (status == 0 && dem != nullptr) ? dem : nm, (size_t)buf_len - 1);
     buf[buf_len - 1] = 0;
+    if (dem != nullptr) free(dem);
     if (section) *section = p->nodes[i].section;
     return RP_OK;
 }

@@ -106,6 +106,10 @@ class GraphedTrainStep:
         self._drop_seed = None
         self.replays = 0
         self.captures = 0
+        # host time of the replay calls: `host_call_s` = inside __call__ WITHOUT the back-pressure wait (`host_wait_s`: the
+        # host blocks there once MAX_IN_FLIGHT replays are queued — device time, not host work)
+        self.host_call_s = self.host_wait_s = 0.0
+        self._last_plan = None
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
     def _eager(self, batch, nxt):
@@ -291,7 +295,29 @@ class GraphedTrainStep:
         return batch.keys() == x.keys() and all(batch[k].shape == x[k].shape and batch[k].dtype == x[k].dtype and
                                                 batch[k].device == x[k].device for k in x)
 
+    # ---- live per-launch timing inside replayed steps (launch plans only) ------------------------------------------------
+    def launch_names(self):
+        """[(kernel name, section), ...] of the captured step's launches in recorded order (None unless it replays as a plan)"""
+        pl = next((p for p in self.plans if p is not None), None)
+        return None if pl is None else [pl.launch_name(k) for k in range(pl.nodes)]
+
+    def set_probe(self, launch: int):
+        for pl in self.plans:
+            if pl is not None:
+                pl.set_probe(launch)
+
+    def last_probe_ms(self) -> float:
+        return self._last_plan.probe_ms()
+
     def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
+        import time as _time
+        t_in = _time.perf_counter()
+        try:
+            return self._call(batch, next_batch)
+        finally:
+            self.host_call_s += _time.perf_counter() - t_in
+
+    def _call(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
         if self.eager_left > 0 or next_batch is None:
             self.eager_left -= 1
             self._staged = None
@@ -328,8 +354,13 @@ class GraphedTrainStep:
             self.opt.set_device_clock(False)
         # bound how far the host runs ahead (a handful of launches in flight is all the overlap there is to win)
         if len(self._inflight) >= self.MAX_IN_FLIGHT:
+            import time as _time
             done = self._inflight.pop(0)
+            t_w = _time.perf_counter()
             done.synchronize()
+            dt_w = _time.perf_counter() - t_w
+            self.host_wait_s += dt_w
+            self.host_call_s -= dt_w  # (the wait is the device's time, not the host's)
             self._ev_pool.append(done)
         calls = self._drop_calls[P]
         if calls > 0:
@@ -340,6 +371,7 @@ class GraphedTrainStep:
             self._drop_clock_host = off + 4 * calls
         if self.plans[P] is not None:
             self.plans[P].replay()
+            self._last_plan = self.plans[P]
         else:
             self.graphs[P].replay()
         ev = self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()

@@ -568,11 +568,7 @@ def embed_grad_seg(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, 
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
     if keep is not None:
         keep.append(ws)
-    F = n // B if B else 0
-    nk = F - bin(skip_fields).count("1")
-    # compulsory bytes: the sorted pairs, one dH / S row per pair (each field reads every sample's rows once), one table row
-    # read + one gradient row written per unique row is not known here: priced by bench.py; flops: dgrad + weight gradient
-    with _Timed("embed_grad_seg", f"D={D}", 0, 2 * 2 * nk * B * 64 * 64):
+    with _Timed("embed_grad_seg", f"D={D}"):  # (algorithmic bytes / flops: bench.py knows the unique-row count)
         _check(lib().rp_embed_grad_seg(sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, B, D, dh.data_ptr(), _rowmajor(dh, "dh"),
                                        w.data_ptr(), _rowmajor(w, "w"), _ptr(gfm), _ptr(sum_in), arena.data_ptr(),
                                        grad_arena.data_ptr(), int(accumulate), skip_fields, fr, _ptr(dw),
@@ -844,6 +840,22 @@ class LaunchPlan:
         rc = lib().rp_plan_replay(self._h, _stream())
         if rc != 0:
             _check(rc, "rp_plan_replay")
+
+    # ---- live timing of one launch inside replayed steps (bench.py: a replay runs no python between its launches) ------
+    def set_probe(self, launch: int):
+        """bracket launch `launch` (0 .. nodes - 1, recorded order; -1 = off) of the following replays with a timing-event pair"""
+        _check(lib().rp_plan_set_probe(self._h, launch), "rp_plan_set_probe")
+
+    def probe_ms(self) -> float:
+        ms = C.c_float(0)
+        _check(lib().rp_plan_probe_ms(self._h, C.byref(ms)), "rp_plan_probe_ms")
+        return ms.value
+
+    def launch_name(self, launch: int):
+        """(kernel name as rocprofv3 prints it, section: 0 main stream, 1 side (next batch's sort), 2 inline side)"""
+        buf, sec = C.create_string_buffer(512), _i32()
+        _check(lib().rp_plan_launch_name(self._h, launch, buf, 512, C.byref(sec)), "rp_plan_launch_name")
+        return buf.value.decode("utf-8", "replace"), sec.value
 
     def destroy(self):
         if self._h is not None and _lib is not None:
