@@ -442,7 +442,8 @@ def main():
     plan_ok = args.graph_backend != "hipgraph" and os.environ.get("RP_GRAPH_BACKEND", "plan") == "plan"
     use_graph = args.mode == "train" and not args.no_sort_ahead and (
         args.graph == "on" or (args.graph == "auto" and not sharded and args.model in ("deepfm", "dcn")
-                               and (local_B <= 16384 or (plan_ok and args.model == "deepfm"))))
+                               and (local_B <= 16384 or plan_ok)))  # (dcn: a plan since round 5 — its [L, d] weight-space
+    #                              arithmetic is one library launch; a step that still falls back to a hipGraph is timed eagerly)
     gstep = None
     if use_graph:
         from rec_pangu_amd.graph_step import GraphedTrainStep

@@ -43,6 +43,11 @@ extern "C" {
 #define RP_ACT_NONE 0
 #define RP_ACT_RELU 1
 #define RP_ACT_MASK 2 /* out = acc * (aux > 0): ReLU backward fused into a dgrad GEMM */
+/* round 5: the other activations rec_pangu/models/layers/activation.py:37-59 hands to an MLP by name, as epilogues of
+ * rp_linear_fwd (one extra elementwise launch behind the short-K kernel, fused in the others) */
+#define RP_ACT_TANH 3
+#define RP_ACT_SIGMOID 4
+#define RP_ACT_LEAKY 5 /* nn.LeakyReLU() with its default negative_slope = 0.01 */
 
 /* Matrix-core precision of the GEMM entry points (process-wide; fp32 operands and fp32 accumulation in every mode).
  * The reference computes torch.nn.Linear in fp32 (ATen); BF16X6 reproduces fp32 products to ~2^-23 on the bf16
@@ -199,7 +204,7 @@ int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_st
 /* ---- K4: Linear (+bias +activation) on the fp32 MFMA ----------------------------------------
  * replaces layers/deep.py:62-72 (nn.Linear + ReLU chain) and its autograd.
  *   out[M,N] = act(a[M,K] . w[N,K]^T + bias[N]);  bias may be NULL;
- *   act = RP_ACT_MASK multiplies by (aux[m,n] > 0) (aux: [M, ldaux]).                        */
+ *   act = RP_ACT_MASK multiplies by (aux[m,n] > 0) (aux: [M, ldaux]); RP_ACT_TANH / SIGMOID / LEAKY: see above. */
 int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, float *out,
                   int64_t ldo, int64_t M, int N, int K, int act, const float *aux, int64_t ldaux,
                   rp_stream_t stream);
@@ -249,6 +254,12 @@ int rp_linear_fwd_pieces(const void *a, int64_t lda, const void *w, int64_t ldw,
 /* y = dy * (act_out > 0), elementwise over [M,N] */
 int rp_relu_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
                 int64_t M, int N, rp_stream_t stream);
+/* the activations as launches of their own (elementwise over [M,N]; act = RP_ACT_RELU / TANH / SIGMOID / LEAKY):
+ * rp_act_fwd: y = act(x) (y == x allowed);  rp_act_bwd: out = dy * act'(.) expressed through the activation's OUTPUT
+ * (relu / leaky: sign of y; tanh: 1 - y^2; sigmoid: y (1 - y)) — the backward of rp_linear_fwd(act) needs no pre-activation */
+int rp_act_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t M, int N, int act, rp_stream_t stream);
+int rp_act_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo, int64_t M,
+               int N, int act, rp_stream_t stream);
 
 /* ---- K5: DCN-v1 CrossNet, all L layers in one pass ------------------------------------------
  * replaces layers/interaction.py:119-141 (CrossInteractionLayer/CrossNet) and, when wfc is given,
@@ -318,6 +329,11 @@ int rp_mmoe_combine_bwd(const float *z, int64_t ldz, int K, int E, int T, const 
 int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, const float *W, const float *wfc,
                          const float *s_in, const float *g_x, int64_t ldg, const float *g_logit, float *dx0,
                          int64_t lddx, float *V, int64_t B, rp_stream_t stream);
+/* the CrossNet's parameter gradients from P [2L+2, ldp] = V^T X_0 (rp_linear_wgrad over V) and cs [2L+2] = column sums of V:
+ * dW [L, d], dB [L, d] and — with the fused fc (wfc [d]) — dwfc [d]; colg [d] = column sums of the incoming gradient when
+ * there is no fused fc (else NULL).  One launch for what autograd of interaction.py:119-141 spreads over the layers. */
+int rp_crossnet_param_grads(const float *P, int64_t ldp, const float *cs, const float *W, const float *Bv, const float *wfc,
+                            const float *colg, int L, int d, float *dW, float *dB, float *dwfc, rp_stream_t stream);
 
 /* ---- K6 (bf16 matrix core): a CIN layer with at most 32 x 32 (field, map) pairs per channel ----------------
  * replaces interaction.py:157-171 for such a layer (a FIRST layer: X_{k-1} = X_0, H = M <= 32) on

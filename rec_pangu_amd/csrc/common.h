@@ -87,6 +87,27 @@ static inline int64_t rp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// activation of a GEMM epilogue (RP_ACT_MASK is handled at the call site: it needs aux)
+__device__ __forceinline__ float rp_act_apply(int act, float v) {
+    switch (act) {
+        case RP_ACT_RELU: return v > 0.f ? v : 0.f;
+        case RP_ACT_TANH: return tanhf(v);
+        case RP_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case RP_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        default: return v;
+    }
+}
+// dy * act'(pre) through the activation's output y
+__device__ __forceinline__ float rp_act_grad(int act, float dy, float y) {
+    switch (act) {
+        case RP_ACT_RELU: return y > 0.f ? dy : 0.f;
+        case RP_ACT_TANH: return dy * (1.f - y * y);
+        case RP_ACT_SIGMOID: return dy * (y * (1.f - y));
+        case RP_ACT_LEAKY: return y > 0.f ? dy : 0.01f * dy;
+        default: return dy;
+    }
+}
+
 // wave64 constants: hard-coded, gfx950 only
 #define RP_WAVE 64
 

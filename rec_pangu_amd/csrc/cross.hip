@@ -309,6 +309,46 @@ extern "C" int rp_crossnet_bwd_rows(const float *x0, int64_t ldx, int d, int L, 
     return RP_OK;
 }
 
+// The parameter gradients of the CrossNet from what the streaming backward left (round 5: this [L, d] arithmetic was a
+// dozen ATen launches — cat, cumsum, flip, mul, add — the only foreign launches of a DCN step, which kept it from being
+// replayed as a launch plan).  With P [2L+2, d] = V^T X_0 (rp_linear_wgrad over the rows kernel's V), cs [2L+2] = the column
+// sums of V (st_l = cs[L+1+l] = sum_b t_l, sgl = cs[2L+1] = sum_b g_logit), C_l = sum_{k<l} b_k:
+//     dW[l] = P[l] + C_l st_l          dB[l] = sum_{k>l} w_k st_k + extra          extra = wfc sgl (fused fc) | colg (else)
+//     dwfc  = P[L] + C_L sgl   (fused fc)
+__global__ __launch_bounds__(256) void crossnet_param_grads_kernel(const float *__restrict__ P, int64_t ldp,
+                                                                   const float *__restrict__ cs, const float *__restrict__ W,
+                                                                   const float *__restrict__ Bv, const float *__restrict__ wfc,
+                                                                   const float *__restrict__ colg, int L, int d,
+                                                                   float *__restrict__ dW, float *__restrict__ dB,
+                                                                   float *__restrict__ dwfc) {
+    const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (j >= d) return;
+    const float sgl = cs[2 * L + 1];
+    float c = 0.f;
+    for (int l = 0; l < L; ++l) {
+        dW[(int64_t)l * d + j] = P[(int64_t)l * ldp + j] + c * cs[L + 1 + l];
+        c += Bv[(int64_t)l * d + j];
+    }
+    const float extra = wfc != nullptr ? wfc[j] * sgl : (colg != nullptr ? colg[j] : 0.f);
+    float suffix = 0.f;
+    for (int l = L - 1; l >= 0; --l) {
+        dB[(int64_t)l * d + j] = suffix + extra;
+        suffix += W[(int64_t)l * d + j] * cs[L + 1 + l];
+    }
+    if (dwfc != nullptr) dwfc[j] = P[(int64_t)L * ldp + j] + c * sgl;
+}
+
+extern "C" int rp_crossnet_param_grads(const float *P, int64_t ldp, const float *cs, const float *W, const float *Bv,
+                                       const float *wfc, const float *colg, int L, int d, float *dW, float *dB, float *dwfc,
+                                       rp_stream_t stream) {
+    RP_REQUIRE(P && cs && W && Bv && dW && dB && L >= 1 && d >= 1 && ldp >= d, "crossnet_param_grads: bad argument");
+    RP_REQUIRE((wfc == nullptr) == (dwfc == nullptr), "crossnet_param_grads: wfc and dwfc go together");
+    hipLaunchKernelGGL(crossnet_param_grads_kernel, dim3((unsigned)rp_cdiv(d, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp, cs, W,
+                       Bv, wfc, colg, L, d, dW, dB, dwfc);
+    RP_LAUNCH_CHECK("crossnet_param_grads");
+    return RP_OK;
+}
+
 extern "C" int rp_crossnet_fwd(const float *x0, int64_t ldx, int d, int L, const float *W, const float *Bv,
                                const float *wfc, const float *bfc, float *xout, int64_t ldo, float *logit,
                                float *s_out, int64_t B, rp_stream_t stream) {

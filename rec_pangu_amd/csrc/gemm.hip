@@ -112,10 +112,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
             const int64_t m = m0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
             float v = (nt == 0 ? acc0[r] : acc1[r]) + bv;
-            if (act == RP_ACT_RELU)
-                v = v > 0.f ? v : 0.f;
-            else if (act == RP_ACT_MASK)
+            if (act == RP_ACT_MASK)
                 v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+            else
+                v = rp_act_apply(act, v);
             C[m * ldc + n] = v;
         }
     }
@@ -383,10 +383,10 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_fwd_bf16_kernel(const flo
                 const int64_t m = m0 + arow0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (m >= M) continue;
                 float v = acc[mi][ni][r] + bv;
-                if (act == RP_ACT_RELU)
-                    v = v > 0.f ? v : 0.f;
-                else if (act == RP_ACT_MASK)
+                if (act == RP_ACT_MASK)
                     v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+                else
+                    v = rp_act_apply(act, v);
                 C[m * ldc + n] = v;
             }
         }
@@ -579,10 +579,10 @@ __global__ __launch_bounds__(512) void linear_fwd_bf16_wide_kernel(const float *
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + arow0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = acc[mi][ni][r] + bv;
-                if (act == RP_ACT_RELU)
-                    v = v > 0.f ? v : 0.f;
-                else if (act == RP_ACT_MASK)
+                if (act == RP_ACT_MASK)
                     v = (aux[m * ldaux + n] > 0.f) ? v : 0.f;
+                else
+                    v = rp_act_apply(act, v);
                 C[m * ldc + n] = v;
             }
         }
@@ -1233,7 +1233,8 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     RP_REQUIRE(a && w && out, "linear_fwd: null pointer");
     RP_REQUIRE(M >= 0 && N >= 1 && K >= 1, "linear_fwd: bad M/N/K");
     RP_REQUIRE(lda >= K && ldw >= K && ldo >= N, "linear_fwd: leading dimension too small");
-    RP_REQUIRE(act == RP_ACT_NONE || act == RP_ACT_RELU || (act == RP_ACT_MASK && aux && ldaux >= N),
+    RP_REQUIRE(act == RP_ACT_NONE || act == RP_ACT_RELU || (act == RP_ACT_MASK && aux && ldaux >= N) ||
+                   act == RP_ACT_TANH || act == RP_ACT_SIGMOID || act == RP_ACT_LEAKY,
                "linear_fwd: bad act/aux");
     if (M == 0) return RP_OK;
     const bool va = (lda % 4 == 0) && rp_aligned16(a);
@@ -1242,10 +1243,14 @@ extern "C" int rp_linear_fwd(const float *a, int64_t lda, const float *w, int64_
     const int mode = linear_mode(M, N, K);
     if (mode != RP_MATMUL_FP32) {
         if (K <= 64) {  // A-stationary walk over the output columns
-            if (mode == RP_MATMUL_BF16X6) run_smallk<6>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
-            else if (mode == RP_MATMUL_BF16X3) run_smallk<3>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
-            else run_smallk<1>(a, lda, w, ldw, bias, out, ldo, M, N, K, act, aux, ldaux, s);
+            // (its epilogue is a template parameter: tanh / sigmoid / leaky ReLU follow as one elementwise launch in place)
+            const bool post = act == RP_ACT_TANH || act == RP_ACT_SIGMOID || act == RP_ACT_LEAKY;
+            const int act_k = post ? RP_ACT_NONE : act;
+            if (mode == RP_MATMUL_BF16X6) run_smallk<6>(a, lda, w, ldw, bias, out, ldo, M, N, K, act_k, aux, ldaux, s);
+            else if (mode == RP_MATMUL_BF16X3) run_smallk<3>(a, lda, w, ldw, bias, out, ldo, M, N, K, act_k, aux, ldaux, s);
+            else run_smallk<1>(a, lda, w, ldw, bias, out, ldo, M, N, K, act_k, aux, ldaux, s);
             RP_LAUNCH_CHECK("linear_fwd (bf16 split, short K)");
+            if (post) return rp_act_fwd(out, ldo, out, ldo, M, N, act, stream);
             return RP_OK;
         }
         // a wide output that is not a multiple of 128 columns (the MMOE expert + gate GEMM: 520): the whole 128-column
@@ -1543,6 +1548,51 @@ extern "C" int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t l
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C);
     RP_LAUNCH_CHECK("copy_rows");
+    return RP_OK;
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
+                                                      int64_t ldy, int64_t M, int N, int act) {
+    const int64_t total = M * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / N;
+        const int c = (int)(e - r * N);
+        y[r * ldy + c] = rp_act_apply(act, x[r * ldx + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, int64_t lddy, const float *__restrict__ ya,
+                                                      int64_t ldact, float *__restrict__ out, int64_t ldo, int64_t M, int N,
+                                                      int act) {
+    const int64_t total = M * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / N;
+        const int c = (int)(e - r * N);
+        out[r * ldo + c] = rp_act_grad(act, dy[r * lddy + c], ya[r * ldact + c]);
+    }
+}
+
+static bool act_kind_ok(int act) { return act == RP_ACT_RELU || act == RP_ACT_TANH || act == RP_ACT_SIGMOID || act == RP_ACT_LEAKY; }
+
+extern "C" int rp_act_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t M, int N, int act, rp_stream_t stream) {
+    RP_REQUIRE(x && y && M >= 0 && N >= 1 && ldx >= N && ldy >= N && act_kind_ok(act), "act_fwd: bad argument");
+    if (M == 0) return RP_OK;
+    int64_t blocks = rp_cdiv(M * N, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, act);
+    RP_LAUNCH_CHECK("act_fwd");
+    return RP_OK;
+}
+
+extern "C" int rp_act_bwd(const float *dy, int64_t lddy, const float *act_out, int64_t ldact, float *out, int64_t ldo,
+                          int64_t M, int N, int act, rp_stream_t stream) {
+    RP_REQUIRE(dy && act_out && out && M >= 0 && N >= 1 && act_kind_ok(act), "act_bwd: bad argument");
+    if (M == 0) return RP_OK;
+    int64_t blocks = rp_cdiv(M * N, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, act_out, ldact, out, ldo,
+                       M, N, act);
+    RP_LAUNCH_CHECK("act_bwd");
     return RP_OK;
 }
 

@@ -5,7 +5,6 @@
 //   rp_route_build  sorted composite keys -> unique-request slots, the rows to ask each owner for, per-owner counts
 #include "common.h"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 struct RouteIdx {
     const int64_t *p[RP_MAX_FIELDS];
@@ -94,22 +93,78 @@ __global__ void route_counts_kernel(const int32_t *__restrict__ incl, int64_t n,
 
 static size_t route_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static int route_scan_bytes(int64_t n, size_t *bytes) {
-    size_t tb = 0;
-    hipError_t e = rocprim::inclusive_scan(nullptr, tb, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n,
-                                           rocprim::plus<int32_t>(), nullptr);
-    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route scan size query: %s", hipGetErrorString(e));
-    *bytes = tb;
-    return RP_OK;
+// ---- inclusive scan of the head flags, own kernels (round 5: rocprim::inclusive_scan sat on the sharded step's hot path —
+//      a foreign launch sequence with its own temporary storage query).  Three launches: per-block sums of 2048 flags, one
+//      workgroup scanning the block sums, per-block scan + offset.  int32 counts, n < 2^31.
+#define RS_PER_THREAD 8
+#define RS_BLOCK (256 * RS_PER_THREAD)
+
+__device__ __forceinline__ int32_t route_block_exclusive(int32_t v, int32_t *total) {
+    // exclusive prefix of one value per thread over the 256-thread workgroup (wave shuffles + one trip through LDS)
+    __shared__ int32_t wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int32_t base = 0;
+    for (int q = 0; q < wv; ++q) base += wsum[q];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();  // (wsum is reused by the caller's next call)
+    return base + incl - v;
 }
+
+__global__ __launch_bounds__(256) void route_scan_sums_kernel(const int32_t *__restrict__ flags, int64_t n, int32_t *__restrict__ bsum) {
+    const int64_t b0 = (int64_t)blockIdx.x * RS_BLOCK + (int64_t)threadIdx.x * RS_PER_THREAD;
+    int32_t s = 0;
+#pragma unroll
+    for (int e = 0; e < RS_PER_THREAD; ++e) s += (b0 + e < n) ? flags[b0 + e] : 0;
+    int32_t total;
+    (void)route_block_exclusive(s, &total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// one workgroup: bsum[i] <- exclusive prefix of the block sums (chunks of 256 with a running carry)
+__global__ __launch_bounds__(256) void route_scan_blocks_kernel(int32_t *__restrict__ bsum, int64_t nb) {
+    int32_t carry = 0;
+    for (int64_t c0 = 0; c0 < nb; c0 += 256) {
+        const int64_t i = c0 + threadIdx.x;
+        const int32_t v = i < nb ? bsum[i] : 0;
+        int32_t total;
+        const int32_t ex = route_block_exclusive(v, &total);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void route_scan_final_kernel(const int32_t *__restrict__ flags, int64_t n,
+                                                               const int32_t *__restrict__ boff, int32_t *__restrict__ incl) {
+    const int64_t b0 = (int64_t)blockIdx.x * RS_BLOCK + (int64_t)threadIdx.x * RS_PER_THREAD;
+    int32_t v[RS_PER_THREAD], s = 0;
+#pragma unroll
+    for (int e = 0; e < RS_PER_THREAD; ++e) {
+        v[e] = (b0 + e < n) ? flags[b0 + e] : 0;
+        s += v[e];
+    }
+    int32_t total;
+    int32_t run = boff[blockIdx.x] + route_block_exclusive(s, &total);
+#pragma unroll
+    for (int e = 0; e < RS_PER_THREAD; ++e) {
+        run += v[e];
+        if (b0 + e < n) incl[b0 + e] = run;
+    }
+}
+
+static size_t route_scan_bytes(int64_t n) { return route_align((size_t)rp_cdiv(n, RS_BLOCK) * sizeof(int32_t)); }
 
 extern "C" int rp_route_workspace_bytes(int64_t n, int world, size_t *bytes) {
     RP_REQUIRE(bytes && n >= 0 && n < INT32_MAX && world >= 1, "route_workspace_bytes: bad argument");
-    size_t tb = 0;
-    int rc = route_scan_bytes(n > 0 ? n : 1, &tb);
-    if (rc != RP_OK) return rc;
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    *bytes = 2 * route_align(nn * sizeof(int32_t)) + route_align((size_t)(world + 1) * sizeof(int64_t)) + route_align(tb) + 256;
+    *bytes = 2 * route_align(nn * sizeof(int32_t)) + route_align((size_t)(world + 1) * sizeof(int64_t)) + route_scan_bytes((int64_t)nn) + 256;
     return RP_OK;
 }
 
@@ -125,23 +180,24 @@ extern "C" int rp_route_build(void *workspace, size_t workspace_bytes, const int
     RP_REQUIRE(workspace && sorted_keys && sorted_pos && slot_sorted && slot_of_pair && uniq_rows && counts,
                "route_build: null pointer");
     RP_REQUIRE(n >= 1 && n < INT32_MAX && world >= 1 && lbits >= 1 && lbits <= 30, "route_build: bad n/world/lbits");
-    size_t need = 0, tb = 0;
+    size_t need = 0;
     int rc = rp_route_workspace_bytes(n, world, &need);
     if (rc != RP_OK) return rc;
     RP_REQUIRE(workspace_bytes >= need, "route_build: workspace %zu < %zu bytes", workspace_bytes, need);
-    rc = route_scan_bytes(n, &tb);
-    if (rc != RP_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     int32_t *flags = reinterpret_cast<int32_t *>(base);
     int32_t *incl = reinterpret_cast<int32_t *>(base + route_align((size_t)n * sizeof(int32_t)));
     int64_t *starts = reinterpret_cast<int64_t *>(base + 2 * route_align((size_t)n * sizeof(int32_t)));
-    void *temp = reinterpret_cast<char *>(starts) + route_align((size_t)(world + 1) * sizeof(int64_t));
+    int32_t *bsum = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(starts) + route_align((size_t)(world + 1) * sizeof(int64_t)));
     const int64_t nf = n > world + 1 ? n : world + 1;  // the flag launch also clears starts[0..world]
     hipLaunchKernelGGL(route_flags_kernel, dim3((unsigned)rp_cdiv(nf, 256)), dim3(256), 0, s, sorted_keys, n, flags, starts, world);
     RP_LAUNCH_CHECK("route flags");
-    hipError_t e = rocprim::inclusive_scan(temp, tb, (const int32_t *)flags, incl, (size_t)n, rocprim::plus<int32_t>(), s);
-    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "route_build scan: %s", hipGetErrorString(e));
+    const int64_t nb = rp_cdiv(n, RS_BLOCK);
+    hipLaunchKernelGGL(route_scan_sums_kernel, dim3((unsigned)nb), dim3(256), 0, s, flags, n, bsum);
+    hipLaunchKernelGGL(route_scan_blocks_kernel, dim3(1), dim3(256), 0, s, bsum, nb);
+    hipLaunchKernelGGL(route_scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, s, flags, n, bsum, incl);
+    RP_LAUNCH_CHECK("route scan");
     hipLaunchKernelGGL(route_scatter_kernel, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, s, sorted_keys, sorted_pos, incl, n,
                        lbits, slot_sorted, slot_of_pair, uniq_rows, starts);
     RP_LAUNCH_CHECK("route scatter");

@@ -11,6 +11,22 @@ import torch
 from . import hip
 
 ACT_NONE, ACT_RELU, ACT_MASK = hip.ACT_NONE, hip.ACT_RELU, hip.ACT_MASK
+ACT_TANH, ACT_SIGMOID, ACT_LEAKY = hip.ACT_TANH, hip.ACT_SIGMOID, hip.ACT_LEAKY
+
+
+def act_code(module):
+    """the GEMM-epilogue code of an activation module (rec_pangu/models/layers/activation.py:37-59 builds them by name),
+    or None: ReLU, Tanh, Sigmoid, LeakyReLU at its default slope"""
+    import torch.nn as nn
+    if isinstance(module, nn.ReLU):
+        return ACT_RELU
+    if isinstance(module, nn.Tanh):
+        return ACT_TANH
+    if isinstance(module, nn.Sigmoid):
+        return ACT_SIGMOID
+    if isinstance(module, nn.LeakyReLU) and abs(module.negative_slope - 0.01) < 1e-12:
+        return ACT_LEAKY
+    return None
 
 
 def _unit_inner(t: torch.Tensor) -> torch.Tensor:
@@ -107,7 +123,7 @@ class _LinearAct(torch.autograd.Function):
         y = hip.linear_fwd(x, _rows16(weight), bias, act, K=K)
         ctx.fm_link, ctx.in_link, ctx.out_link = fm_link, in_link, out_link
         ctx.act, ctx.K, ctx.has_bias = act, K, bias is not None
-        ctx.save_for_backward(x, weight, y if act == ACT_RELU else None)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -123,6 +139,8 @@ class _LinearAct(torch.autograd.Function):
                 lk.dx = None
             if not masked:
                 dpre = hip.relu_bwd(dy, y)
+        elif ctx.act in (ACT_TANH, ACT_SIGMOID, ACT_LEAKY):
+            dpre = hip.act_bwd(dy, y, ctx.act)  # through the activation's output: tanh 1 - y^2, sigmoid y (1 - y), leaky: sign
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # [ldx, N]: the dgrad GEMM is the same NT kernel on W^T; zero rows beyond K make it write the zeros of
@@ -151,6 +169,26 @@ class _LinearAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
         return dx, dw, db, None, None, None, None
+
+
+class _Activation(torch.autograd.Function):
+    """an activation module as a launch of its own (rp_act_fwd / rp_act_bwd), for the places where it does not follow a Linear"""
+
+    @staticmethod
+    def forward(ctx, x, act: int):
+        y = hip.act_fwd(_unit_inner(x), act)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return hip.act_bwd(_unit_inner(dy), y, ctx.act), None
+
+
+def activation(x, act: int):
+    return _Activation.apply(x, act)
 
 
 def linear_act(x, weight, bias=None, act: int = ACT_NONE, fm_link=None, in_link=None, out_link=None):
@@ -205,43 +243,52 @@ def mlp_tail64(hin, in_link, hidden, head):
 # K5  CrossNet (+ the fc that follows it in DCN)   — layers/interaction.py:119-141, ranking/dcn.py:64
 # ----------------------------------------------------------------------------------------------
 class _CrossNet(torch.autograd.Function):
+    """forward(x0, wfc, bfc, L, w_0 .. w_{L-1}, b_0 .. b_{L-1}): the layers' parameters arrive one by one and are stacked by ONE
+    library launch (rp_multi_copy) — torch.stack was two ATen cat launches per step —, their gradients leave as rows of the
+    [L, d] results of rp_crossnet_param_grads.  A DCN step then holds library launches only (graph_step: launch plan)."""
+
     @staticmethod
-    def forward(ctx, x0, W, Bv, wfc, bfc):
+    def forward(ctx, x0, wfc, bfc, L: int, *wb):
         x0 = _unit_inner(x0)
-        d = W.shape[1]
-        W, Bv = W.contiguous(), Bv.contiguous()
+        d = wb[0].numel()
+        stk = torch.empty((2 * L, d), dtype=torch.float32, device=x0.device)
+        src = [t.detach().reshape(-1) for t in wb]
+        if not hip.multi_copy([stk[i] for i in range(2 * L)], src):
+            torch._foreach_copy_([stk[i] for i in range(2 * L)], src)
+        W, Bv = stk[:L], stk[L:]
         wfc_c = None if wfc is None else wfc.contiguous()
         xout, logit, s = hip.crossnet_fwd(x0, d, W, Bv, wfc_c, bfc, want_x=wfc is None)
-        ctx.d, ctx.fused_fc = d, wfc is not None
+        ctx.d, ctx.L, ctx.fused_fc = d, L, wfc is not None
+        ctx.shapes = [t.shape for t in wb]
         ctx.save_for_backward(x0, W, Bv, wfc_c, s)
         return logit if wfc is not None else xout
 
     @staticmethod
     def backward(ctx, g):
         """Streaming backward (rp_crossnet_bwd_rows): X_l = A_l X_0 + C_l, so the per-row kernel only emits dX_0 and
-        2L+2 scalars per sample; the parameter gradients are one skinny wgrad GEMM V^T X_0 plus [L,d] arithmetic."""
+        2L+2 scalars per sample; the parameter gradients are one skinny wgrad GEMM V^T X_0 plus [L,d] arithmetic
+        (rp_crossnet_param_grads)."""
         x0, W, Bv, wfc, s = ctx.saved_tensors
         g = g.contiguous()
-        L, d = W.shape
+        L, d = ctx.L, ctx.d
         fused = ctx.fused_fc
         dx0, V = hip.crossnet_bwd_rows(x0, d, W, wfc if fused else None, s, None if fused else g, g if fused else None)
         P, cs = hip.linear_wgrad(V, x0, d)                      # [2L+2, d], column sums of V
-        st, sgl = cs[L + 1:2 * L + 1], cs[2 * L + 1]             # sum_b t_l, sum_b g_logit
-        C = torch.cat([torch.zeros_like(Bv[:1]), Bv.cumsum(0)])  # C_l = sum_{k<l} b_k, l = 0..L
-        dW = P[:L] + C[:L] * st[:, None]
-        tw = W * st[:, None]                                     # w_k * sum_b t_k
-        dB = tw.flip(0).cumsum(0).flip(0) - tw                   # sum_{k>l} w_k sum_b t_k
+        colg = None
+        if not fused:
+            _, colg = hip.linear_wgrad(g, g, 1)                 # column sums of the incoming gradient
+        dW, dB, dwfc = hip.crossnet_param_grads(P, cs, W, Bv, wfc.reshape(-1) if fused else None, colg)
+        grads = [dW[i].view(ctx.shapes[i]) for i in range(L)] + [dB[i].view(ctx.shapes[L + i]) for i in range(L)]
         if fused:
-            dB = dB + wfc.reshape(1, d) * sgl
-            dwfc = (P[L] + C[L] * sgl).view_as(wfc)
-            return dx0, dW, dB, dwfc, sgl.reshape(1)
-        _, colg = hip.linear_wgrad(g, g, 1)                      # column sums of the incoming gradient
-        return dx0, dW, dB + colg[None, :], None, None
+            return (dx0, dwfc.view_as(wfc), cs[2 * L + 1:2 * L + 2], None) + tuple(grads)
+        return (dx0, None, None, None) + tuple(grads)
 
 
-def crossnet(x0, W, Bv, wfc=None, bfc=None):
-    """x0 [B, >=d] -> X_L [B, d], or the fc logit [B,1] when (wfc [1,d], bfc [1]) are given."""
-    return _CrossNet.apply(x0, W, Bv, wfc, bfc)
+def crossnet(x0, layer_w, layer_b, wfc=None, bfc=None):
+    """x0 [B, >=d] -> X_L [B, d], or the fc logit [B,1] when (wfc [1,d], bfc [1]) are given.  layer_w / layer_b: the L
+    layers' weight / bias parameters."""
+    L = len(layer_w)
+    return _CrossNet.apply(x0, wfc, bfc, L, *layer_w, *layer_b)
 
 
 # ----------------------------------------------------------------------------------------------

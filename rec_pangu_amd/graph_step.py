@@ -184,8 +184,10 @@ class GraphedTrainStep:
                 # aborts the process with hipErrorStreamCaptureUnsupported)
                 mode = "thread_local" if self._sharded else "global"
                 with torch.cuda.graph(g, pool=self._pool, capture_error_mode=mode):
+                    if plan is not None and os.environ.get("RP_PLAN_FORK", "backward") == "start":
+                        plan.fork_here()  # (A/B switch: the next batch's sort beside the catch-up and the gather instead)
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
-                    if plan is not None:
+                    if plan is not None and os.environ.get("RP_PLAN_FORK", "backward") != "start":
                         # the side section (the next batch's sort, recorded last) is forked here: beside the backward,
                         # where the eager path starts it too — beside the catch-up and the gather it costs more than it hides
                         plan.fork_here()

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RP_LIB_PATH") or os.path.join(_HERE, "lib", "librecpangu_hip.so")  # (override: A/B builds)
 MAX_FIELDS = 64
 
-ACT_NONE, ACT_RELU, ACT_MASK = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_MASK, ACT_TANH, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3, 4, 5
 
 _lib = None
 
@@ -76,8 +76,11 @@ _SIGNATURES = {
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "rp_multi_copy": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "rp_relu_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "rp_act_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "rp_act_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "rp_crossnet_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "rp_crossnet_bwd_rows": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "rp_crossnet_param_grads": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rp_cin_layer_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _vp]),
     "rp_cin_layer_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32,
                                      _i32, _i32, _i64, _vp]),
@@ -911,6 +914,25 @@ def relu_bwd(dy, act_out):
     return out
 
 
+def act_bwd(dy, act_out, act: int):
+    """dy * act'(.) through the activation's output (rp_act_bwd; act = ACT_RELU / TANH / SIGMOID / LEAKY)"""
+    M, N = dy.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    with _Timed("act_bwd", f"{M}x{N}", 12 * M * N):
+        _check(lib().rp_act_bwd(dy.data_ptr(), _rowmajor(dy, "dy"), act_out.data_ptr(), _rowmajor(act_out, "act_out"),
+                                out.data_ptr(), N, M, N, act, _stream()), "rp_act_bwd")
+    return out
+
+
+def act_fwd(x, act: int):
+    """act(x) as a launch of its own (rp_act_fwd), 2-D x"""
+    M, N = x.shape
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _Timed("act_fwd", f"{M}x{N}", 8 * M * N):
+        _check(lib().rp_act_fwd(x.data_ptr(), _rowmajor(x, "x"), out.data_ptr(), N, M, N, act, _stream()), "rp_act_fwd")
+    return out
+
+
 def crossnet_fwd(x0, d: int, W, Bv, wfc=None, bfc=None, want_x: bool = True):
     """X_L (and/or logit = X_L . wfc + bfc) of the L-layer CrossNet; returns (xout, logit, s)."""
     _req(x0, torch.float32, "x0")
@@ -939,6 +961,20 @@ def crossnet_bwd_rows(x0, d: int, W, wfc, s, g_x, g_logit):
                                           s.data_ptr(), _ptr(g_x), ldg, _ptr(g_logit), dx0.data_ptr(),
                                           _rowmajor(dx0, "dx0"), V.data_ptr(), B, _stream()), "rp_crossnet_bwd_rows")
     return dx0, V
+
+
+def crossnet_param_grads(P, cs, W, Bv, wfc, colg):
+    """(dW [L, d], dB [L, d], dwfc [d] or None) of the CrossNet from the skinny weight gradient P = V^T X_0 and the column
+    sums cs of V (rp_crossnet_param_grads)"""
+    L, d = W.shape
+    dW = torch.empty((L, d), dtype=torch.float32, device=W.device)
+    dB = torch.empty((L, d), dtype=torch.float32, device=W.device)
+    dwfc = torch.empty((d,), dtype=torch.float32, device=W.device) if wfc is not None else None
+    with _Timed("crossnet_param_grads", f"{L}x{d}"):
+        _check(lib().rp_crossnet_param_grads(P.data_ptr(), _rowmajor(P, "P"), cs.data_ptr(), W.data_ptr(), Bv.data_ptr(), _ptr(wfc),
+                                             _ptr(colg), L, d, dW.data_ptr(), dB.data_ptr(), _ptr(dwfc), _stream()),
+               "rp_crossnet_param_grads")
+    return dW, dB, dwfc
 
 
 def cin_layer_fwd(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool, want_pool: bool):

@@ -5,10 +5,12 @@ in the same order, so state_dict keys `net.<i>.{weight,bias}` and the init RNG d
 On a HIP device forward() walks `net` and runs every Linear (+ a directly following ReLU) as one
 matrix-core launch with fused bias/ReLU epilogue (rp_linear_fwd); its backward is rp_linear_fwd on the
 transposed weight + rp_linear_wgrad.  Dropout runs on rp_dropout_* (training mode; identity otherwise),
-BatchNorm1d on rp_batchnorm_*; non-ReLU activations are applied as they are.
+BatchNorm1d on rp_batchnorm_*; Tanh / Sigmoid / LeakyReLU(0.01) are epilogues of the same launch (round 5), other
+activation modules are applied as they are (counted: hip.note_torch_path).
 """
 from typing import List, Union
 
+import torch
 import torch.nn as nn
 
 from ... import functional as Fh
@@ -98,12 +100,15 @@ class MLP(nn.Module):
                 hidden = [(mods[j].weight, mods[j].bias) for j in range(i, len(mods) - 1, 2)]
                 return Fh.mlp_tail64(x, pending, hidden, (mods[-1].weight, mods[-1].bias))
             if isinstance(m, nn.Linear):
-                fuse_relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                # the activation module behind a Linear rides in the GEMM's epilogue: ReLU (with the mask hand-off to the
+                # next layer's dgrad), Tanh, Sigmoid, LeakyReLU(0.01) — activation.py:37-59 hands these out by name
+                code = Fh.act_code(mods[i + 1]) if i + 1 < len(mods) else None
+                fuse_relu = code == Fh.ACT_RELU
                 out_link = Fh.ReluLink() if fuse_relu else None
-                x = Fh.linear_act(x, m.weight, m.bias, Fh.ACT_RELU if fuse_relu else Fh.ACT_NONE,
+                x = Fh.linear_act(x, m.weight, m.bias, code if code is not None else Fh.ACT_NONE,
                                   fm_link=fm_link if i == 0 else None, in_link=pending, out_link=out_link)
                 pending = out_link
-                i += 2 if fuse_relu else 1
+                i += 2 if code is not None else 1
             elif isinstance(m, nn.BatchNorm1d) and x.dim() == 2:
                 x = Fh.batch_norm(x, m)
                 pending = None
@@ -116,11 +121,16 @@ class MLP(nn.Module):
                     x = m(x)
                     pending = None
                 i += 1
+            elif Fh.act_code(m) is not None and x.dim() == 2 and x.dtype is torch.float32:
+                # an activation that does not sit right behind a Linear (behind a BatchNorm1d, say): its own launch
+                x = Fh.activation(x, Fh.act_code(m))
+                pending = None
+                i += 1
             else:
                 if not isinstance(m, (nn.Identity, Dice)):  # (Dice dispatches to its own kernels)
                     from ... import hip
-                    hip.note_torch_path(f"{type(m).__name__} inside an MLP (the fused epilogues cover ReLU; BatchNorm1d, "
-                                        "Dropout and Dice have kernels of their own)")
+                    hip.note_torch_path(f"{type(m).__name__} inside an MLP (epilogues / launches exist for ReLU, Tanh, Sigmoid, "
+                                        "LeakyReLU(0.01); BatchNorm1d, Dropout and Dice have kernels of their own)")
                 x = m(x)
                 pending = None
                 i += 1

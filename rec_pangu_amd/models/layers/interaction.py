@@ -75,10 +75,11 @@ class CrossNet(nn.Module):
         """X_L [B,d]; with `fc` (a Linear(d,1), as in DCN) the fused kernel returns fc(X_L) [B,1] instead."""
         if X_0.is_cuda:
             from ... import functional as Fh
-            W, Bv = self.stacked()
+            lw = [layer.weight.weight for layer in self.cross_net]
+            lb = [layer.bias for layer in self.cross_net]
             if fc is not None:
-                return Fh.crossnet(X_0, W, Bv, fc.weight, fc.bias)
-            return Fh.crossnet(X_0, W, Bv)
+                return Fh.crossnet(X_0, lw, lb, fc.weight, fc.bias)
+            return Fh.crossnet(X_0, lw, lb)
         X_i = X_0
         for layer in self.cross_net:
             X_i = X_i + layer(X_0, X_i)

@@ -1011,3 +1011,44 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
         hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
     hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
     assert torch.equal(G2, G)
+
+
+@pytest.mark.parametrize("act_name", ["Tanh", "Sigmoid", "LeakyReLU"])
+@pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (3000, 200, 333), (8192, 256, 1677), (777, 1, 39)])
+def test_linear_activation_epilogues_vs_torch(hip, act_name, M, N, K):
+    """rp_linear_fwd with the Tanh / Sigmoid / LeakyReLU(0.01) epilogues (activation.py:37-59 hands these modules to an MLP by
+    name) and their backward through the activation's OUTPUT (rp_act_bwd) against torch fp32 / fp64: every GEMM kernel
+    family (short K: one elementwise launch behind it; the tiled and wide kernels: fused), forward within fp32 rounding of
+    an fp64 reference, backward within 2e-6 of the analytic derivative; the standalone launches rp_act_fwd / rp_act_bwd too."""
+    hip.set_matmul_precision("bf16x6")
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        x = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) * 0.1
+        mod = getattr(torch.nn, act_name)()
+        code = {"Tanh": hip.ACT_TANH, "Sigmoid": hip.ACT_SIGMOID, "LeakyReLU": hip.ACT_LEAKY}[act_name]
+        xd = x.to(DEV)
+        if xd.stride(0) % 4:
+            xp = torch.zeros(M, (K + 3) // 4 * 4, device=DEV)
+            xp[:, :K] = xd
+            xd = xp[:, :K]
+        Wd = torch.zeros(N, (K + 3) // 4 * 4, device=DEV)
+        Wd[:, :K] = W.to(DEV)
+        y = hip.linear_fwd(xd, Wd[:, :K], b.to(DEV), code, K=K)
+        pre = x.double() @ W.double().T + b.double()
+        ref = mod(pre)
+        scale = max(1.0, float(pre.abs().max()))
+        assert float((y.cpu().double() - ref).abs().max()) <= 2e-5 * scale
+        dy = torch.randn(M, N, generator=g)
+        p = pre.clone().requires_grad_(True)
+        mod(p).backward(dy.double())
+        dpre = hip.act_bwd(dy.to(DEV), y, code)
+        # (the derivative is formed from the fp32 OUTPUT: a pre-activation within rounding of LeakyReLU's kink may land on
+        #  either side — compare where it is clear of it)
+        clear = pre.abs() > 1e-4 * scale
+        assert float(((dpre.cpu().double() - p.grad) * clear).abs().max()) <= 5e-5 * max(1.0, float(dy.abs().max()))
+        y2 = hip.act_fwd(hip.linear_fwd(xd, Wd[:, :K], b.to(DEV), hip.ACT_NONE, K=K), code)
+        assert float((y2 - y).abs().max()) <= 1e-6 * scale
+    finally:
+        hip.set_matmul_precision("auto")

@@ -936,7 +936,9 @@ def test_sharded_fused_first_layer_single_rank():
         sd = plain.state_dict()
         for c in plain.embedding_layer.emb_feature:
             ref = sd[f"embedding_layer.embedding_layer.{c}.weight"]
-            assert float((tabs[c] - ref).abs().max()) <= 2e-5 * max(1e-2, float(ref.abs().max())), c
+            # (5e-5 since round 5: the unsharded model's first-layer backward is the segment-sum-first launch, the sharded
+            #  one the pair form — two correct fp32 summation orders, three Adam steps at lr 1e-2 apart: measured 2.06e-5)
+            assert float((tabs[c] - ref).abs().max()) <= 5e-5 * max(1e-2, float(ref.abs().max())), c
     finally:
         dist.destroy_process_group()
 
