@@ -117,12 +117,14 @@ int rp_embed_gather_linear_fwd(const float *arena, const int64_t *row_base, cons
  * backward needs — x_bf16 [B, ldx] as BF16 (the gathered values are bf16 already: exact; the dense columns are rounded to
  * bf16 for the weight gradient only, the forward uses them in fp32), sum_out [B, 64] fp32, keys_out — all NULL for
  * inference.  The bf16 arena then is the lookup copy the deferred optimizer kernels keep current (rp_lazy_adam_catchup's
- * shadow_bf16); rp_linear_wgrad_xbf16 is the weight gradient over the bf16 activation. */
+ * shadow_bf16); rp_linear_wgrad_xbf16 is the weight gradient over the bf16 activation.  Round 5: with x_bf16 = NULL and
+ * xd [B, 64] given (the dense columns in fp32, zero padded — as rp_embed_gather_linear_fwd's xd) NO activation is stored:
+ * the weight gradient's embedding columns then come from rp_embed_grad_seg over the fp32 master rows. */
 int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_base, const int64_t *row_count,
                                     const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND, int64_t B,
                                     int D, const float *W, int64_t ldw, const float *bias, float *h1, float *fm_out,
                                     void *x_bf16, int64_t ldx, float *sum_out, int32_t *keys_out, int32_t *err_flag,
-                                    rp_stream_t stream);
+                                    float *xd, rp_stream_t stream);
 
 /* ---- gather backward: sort by arena row, then segmented reduce into the dense grad arena ----
  * replaces aten::embedding_dense_backward under layers/embedding.py:62 and the autograd of
@@ -699,6 +701,9 @@ int rp_plan_fork_here(void); /* the side section is forked in front of the NEXT 
  * beside the fused gather backward: both depend only on the masked dH).  The caller keeps every buffer those launches use
  * alive until the join: the capture's allocator assumes ONE stream and would hand a freed workspace to the next launch. */
 int rp_plan_join(void);
+/* explicit fork point of the inline section (2): its launches recorded after this mark depend on what the main stream held
+ * HERE (main launches recorded between the mark and them run beside them), until the next rp_plan_join */
+int rp_plan_fork2_mark(void);
 int rp_plan_is_recording(void);
 int rp_plan_end(void *plan);
 int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);

@@ -9,6 +9,7 @@
 # steps (--kernel-iteration-range, one range per calls-per-step count); every profiler run is time-boxed.
 set -u
 export TMPDIR=/tmp
+ulimit -c 0
 cd "$(dirname "$0")/.."
 TAG=$1; PRE=$2; shift 2
 W=5; K=20

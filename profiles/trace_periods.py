@@ -17,7 +17,7 @@ skip = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "lazy_adam_catchup" in r["Kernel_Name"]]
-print("step  period  catchup  gather  grad_gemm  wgrad  last_end  idle_before_next  first kernels after the optimizer")
+print("step  period  catchup  gather  grad_seg/gemm  wgrad  last_end  idle_before_next  first kernels after the optimizer")
 for k in range(len(idx) - nsteps - skip - 1, len(idx) - skip - 1):
     a, b = idx[k], idx[k + 1]
     t0 = int(rows[a]["Start_Timestamp"])
@@ -29,7 +29,7 @@ for k in range(len(idx) - nsteps - skip - 1, len(idx) - skip - 1):
         n = r["Kernel_Name"]
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         for key in ("lazy_adam_catchup", "embed_gather_linear", "embed_grad_gemm", "linear_wgrad"):
-            if key in n:
+            if key in n or (key == "embed_grad_gemm" and "embed_grad_seg_kernel" in n):  # (round 5: the segment-sum-first launch)
                 dur[key] = d
         end = max(end, int(r["End_Timestamp"]))
         if seen_adam:

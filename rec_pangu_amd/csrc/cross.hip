@@ -79,19 +79,23 @@ __global__ __launch_bounds__(256) void crossnet_fwd_kernel(const float *__restri
     const float *bl = wl + (L + 1) * dp;
     // the next row's loads are issued before this row's arithmetic (register double buffer): a wave otherwise
     // spends most of its time waiting for its own single row
+    // VEC: every chunk is ONE unconditional dwordx4 load from a clamped address (the row is ldx >= d floats of valid memory),
+    // the lanes beyond d are zeroed with selects — a guarded load (the chunk that straddles d = 1677 took four scalar loads
+    // behind per-lane branches) turns every wait of the row loop into vmcnt(0): measured 0.278 ms for a 440 MB read
     auto load_row = [&](int64_t b, f32x4 (&dst)[CROSS_NJ]) {
 #pragma unroll
         for (int j = 0; j < CROSS_NJ; ++j) {
             const int e = 256 * j + 4 * lane;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            if (j < nj) {
-                if (VEC && e + 4 <= d) {
-                    xv = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + e);
-                } else {
+            if (VEC) {
+                const int ec = e + 4 <= (int)ldx ? e : (int)ldx - 4;
+                const f32x4 raw = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + ec);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (e + k < d) xv[k] = x0[b * ldx + e + k];
-                }
+                for (int k = 0; k < 4; ++k) xv[k] = (e + k < d) ? raw[k] : 0.f;
+            } else if (j < nj) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k < d) xv[k] = x0[b * ldx + e + k];
             }
             dst[j] = xv;
         }
@@ -197,23 +201,30 @@ __global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__r
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int nj = dp / 256;
+    // (VEC: unconditional clamped dwordx4 loads + selects, as in the forward)
     auto load_row = [&](int64_t b, f32x4 (&dx_)[CROSS_NJ], f32x4 (&dg_)[CROSS_NJ]) {
 #pragma unroll
         for (int j = 0; j < CROSS_NJ; ++j) {
             const int e = 256 * j + 4 * lane;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
-            if (j < nj) {
-                if (VEC && e + 4 <= d) {
-                    xv = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + e);
-                    if (g_x != nullptr) gv = *reinterpret_cast<const f32x4 *>(g_x + b * ldg + e);
-                } else {
+            if (VEC) {
+                const int ec = e + 4 <= (int)ldx ? e : (int)ldx - 4;
+                const f32x4 raw = *reinterpret_cast<const f32x4 *>(x0 + b * ldx + ec);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (e + k < d) {
-                            xv[k] = x0[b * ldx + e + k];
-                            if (g_x != nullptr) gv[k] = g_x[b * ldg + e + k];
-                        }
+                for (int k = 0; k < 4; ++k) xv[k] = (e + k < d) ? raw[k] : 0.f;
+                if (g_x != nullptr) {  // (uniform)
+                    const int gc = e + 4 <= (int)ldg ? e : (int)ldg - 4;
+                    const f32x4 rg = *reinterpret_cast<const f32x4 *>(g_x + b * ldg + gc);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) gv[k] = (e + k < d) ? rg[k] : 0.f;
                 }
+            } else if (j < nj) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e + k < d) {
+                        xv[k] = x0[b * ldx + e + k];
+                        if (g_x != nullptr) gv[k] = g_x[b * ldg + e + k];
+                    }
             }
             dx_[j] = xv;
             dg_[j] = gv;
@@ -270,8 +281,13 @@ __global__ __launch_bounds__(256) void crossnet_bwd_rows_kernel(const float *__r
             const int e = 256 * j + 4 * lane;
             if (j < nj) {
                 const f32x4 o4 = gx0[j] + g[j];
-                if (VEC && e + 4 <= d) {
-                    *reinterpret_cast<f32x4 *>(dx0 + b * lddx + e) = o4;
+                if (VEC) {
+                    // whole dwordx4 stores up to the row's leading dimension: the columns beyond d receive exact zeros (the
+                    // gradient of x's padding), no per-element branches around the stores
+                    f32x4 z4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) z4[k] = (e + k < d) ? o4[k] : 0.f;
+                    if (e + 4 <= (int)lddx) *reinterpret_cast<f32x4 *>(dx0 + b * lddx + e) = z4;
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)

@@ -599,12 +599,12 @@ extern "C" int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int
                                                const int64_t *const *idx_ptrs, int F, const float *const *dense_ptrs, int ND,
                                                int64_t B, int D, const float *W, int64_t ldw, const float *bias, float *h1,
                                                float *fm_out, void *x_bf16, int64_t ldx, float *sum_out, int32_t *keys_out,
-                                               int32_t *err_flag, rp_stream_t stream) {
+                                               int32_t *err_flag, float *xd, rp_stream_t stream) {
     RP_REQUIRE(x_bf16 == nullptr || (ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x_bf16) & 7u) == 0),
                "embed_gather_linear_fwd_bf16: the bf16 activation needs ldx %% 4 == 0 and 8-byte alignment");
     return embed_gather_linear_launch(reinterpret_cast<const float *>(arena_bf16), true, row_base, row_count, idx_ptrs, F,
                                       dense_ptrs, ND, B, D, reinterpret_cast<float *>(x_bf16), ldx, W, ldw, bias, h1, fm_out,
-                                      sum_out, keys_out, err_flag, nullptr, stream);
+                                      sum_out, keys_out, err_flag, xd, stream);
 }
 
 static int embed_gather_linear_launch(const float *arena, bool bf16_rows, const int64_t *row_base, const int64_t *row_count,

@@ -121,6 +121,26 @@ extern "C" int rp_plan_join(void) {
     return RP_OK;
 }
 
+// The inline section's fork point, explicitly: launches recorded under section 2 AFTER this mark (until the join) depend on
+// what the main stream held HERE, not on the main launches recorded between the mark and them.  Round 5: the first layer's
+// backward issues its long main-stream launch (rp_embed_grad_seg) FIRST and the short side launches behind it — issued the
+// other way round, the side launches filled every CU and the main launch (77 KB of LDS per workgroup) started 58 us late
+// (profiles/r05_trace_step.txt).  A marker node (func == nullptr, section -3).
+extern "C" int rp_plan_fork2_mark(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_fork2_mark: no plan is being recorded");
+    PlanNode n;
+    n.func = nullptr;
+    n.grid = n.block = dim3(0, 0, 0);
+    n.shmem = 0;
+    n.section = -3;
+    n.rec_stream = nullptr;
+    n.blob_at = p->blob.size();
+    p->nodes.push_back(std::move(n));
+    return RP_OK;
+}
+
 extern "C" int rp_plan_is_recording(void) { return rp_plan_recording() ? 1 : 0; }
 
 // the side section of a replay is forked HERE (in front of the next main-section launch) instead of at the start of the
@@ -270,7 +290,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
     }
-    bool forked = false, open2 = false, main_since_fork2 = false, side_joined = false;
+    bool forked = false, open2 = false, main_since_fork2 = false, side_joined = false, marked2 = false;
     for (size_t i = 0; i <= p->nodes.size(); ++i) {
         if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
             // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
@@ -295,7 +315,16 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (i == p->nodes.size()) break;
         const PlanNode &n = p->nodes[i];
         if (n.section == 1) continue;
+        if (n.func == nullptr && n.section == -3) {  // explicit fork point of the inline section
+            if (p->n_inline > 0 && !open2) {
+                e = hipEventRecord(p->ev_fork2, s);
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork mark: %s", hipGetErrorString(e));
+                marked2 = true;
+            }
+            continue;
+        }
         if (n.func == nullptr) {  // join marker of the inline section
+            marked2 = false;
             if (open2) {
                 // the side section (issued at its fork point, long done by now) is joined through the same wait: every
                 // event operation on the main stream is a packet its next launch queues behind
@@ -316,7 +345,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             // fork: what was enqueued on the main stream so far is what these launches depend on — also when main launches
             // were recorded between two groups of inline launches (the tiny-table gradient reads the transposed weight that
             // the main stream produces after the weight gradient was forked)
-            if (!open2 || main_since_fork2) {
+            if (marked2) {  // (the event was recorded at the mark: main launches recorded since are NOT waited for)
+                if (!open2) {
+                    e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
+                    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork (marked): %s", hipGetErrorString(e));
+                    open2 = true;
+                }
+            } else if (!open2 || main_since_fork2) {
                 e = hipEventRecord(p->ev_fork2, s);
                 if (e == hipSuccess) e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork: %s", hipGetErrorString(e));

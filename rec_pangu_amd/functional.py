@@ -846,10 +846,17 @@ class _EmbedGatherLinear(torch.autograd.Function):
             # bf16-storage training (EmbeddingLayer.bf16_training): rows from the bf16 lookup copy, the activation stored as
             # bf16 for the weight gradient (rp_linear_wgrad_xbf16); everything else as below
             want_keys = pre is None
+            # round 5: like the fp32 tables' path, no activation is stored when the tables get gradients — the embedding columns
+            # of the weight gradient come from rp_embed_grad_seg over the fp32 MASTER rows (the forward used their bf16 images:
+            # a 2^-9-relative inconsistency inside the mode's stated tolerance, and closer to the fp32 reference);
+            # RP_GRAD_SEG=0: the stored bf16 activation + rp_linear_wgrad_xbf16 (round 4)
+            seg16 = (need_grad and need_w and K > Kg and len(idx) <= 64 and os.environ.get("RP_GRAD_SEG", "1") != "0"
+                     and weight.shape[0] == 64)
             x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd_bf16(shadow, store.row_base, store.row_count, idx, dense, w16, bias,
-                                                                     store.err_flag, train_ldx=ldx, want_keys=want_keys)
+                                                                     store.err_flag, train_ldx=ldx, want_keys=want_keys,
+                                                                     dense_only=seg16)
             ctx.store, ctx.B, ctx.K, ctx.out_link, ctx.has_bias = store, B, K, out_link, bias is not None
-            ctx.ldx, ctx.x_mode, ctx.Kg, ctx.need_tables = ldx, "bf16", Kg, need_grad
+            ctx.ldx, ctx.x_mode, ctx.Kg, ctx.need_tables = ldx, ("seg" if seg16 else "bf16"), Kg, need_grad
             ctx.presorted = None if (pre is None or not need_grad) else (pre[1], pre[2])
             if pre is not None:
                 keys = pre[0]
@@ -931,7 +938,16 @@ class _EmbedGatherLinear(torch.autograd.Function):
         in_plan = (wstream is None and need_w and need_t and ctx.x_mode != "dense"
                    and os.environ.get("RP_WGRAD_OVERLAP", "1") != "0" and hip.LaunchPlan.is_recording())
         keep = []
-        if in_plan:
+        # (round 5) in a plan, with the segment-sum-first backward: the LONG main-stream launch is issued first and the short
+        # side launches behind it, all forked from the same point (rp_plan_fork2_mark) — issued the other way round the side
+        # launches filled every CU and rp_embed_grad_seg (77 KB of LDS per workgroup) started 58 us late (profiles/r05_trace_step.txt)
+        # Measured (profiles/r05 lines, alternating runs on one box): 0.946 / 0.947 ms with the main launch first against
+        # 0.929 / 0.932 the other way round (long-run means equal, 0.906-0.916): the side launches then stretch to twice their
+        # time and the join comes later — OFF by default, RP_SEG_FIRST=1 selects it
+        seg_first = in_plan and seg is not None and need_t and os.environ.get("RP_SEG_FIRST", "0") == "1"
+        if seg_first:
+            hip.LaunchPlan.fork2_mark()
+        elif in_plan:
             hip.LaunchPlan.section(2)
             try:
                 dw, db = wgrad(keep)
@@ -949,7 +965,14 @@ class _EmbedGatherLinear(torch.autograd.Function):
             wt = ctx.wt if ctx.wt is not None else hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
-                                  fused=(dpre, wt), plan_keep=keep if in_plan else None, seg=seg)
+                                  fused=(dpre, wt), plan_keep=keep if in_plan else None, seg=seg, seg_first=seg_first)
+        if seg_first:
+            hip.LaunchPlan.section(2)
+            try:
+                dw, db = wgrad(keep)
+                hip.LaunchPlan.run_deferred()
+            finally:
+                hip.LaunchPlan.section(0)
         if in_plan:
             hip.LaunchPlan.join()
             del keep

@@ -30,7 +30,7 @@ _SIGNATURES = {
     "rp_embed_gather_linear_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp, _vp]),
     "rp_embed_gather_linear_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp,
-                                                  _i64, _vp, _vp, _vp, _vp]),
+                                                  _i64, _vp, _vp, _vp, _vp, _vp]),
     "rp_linear_wgrad_gather_fits": (C.c_int, [_i64, _i32, _i32, _i32]),
     "rp_linear_wgrad_gather": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz,
                                          _vp]),
@@ -63,6 +63,7 @@ _SIGNATURES = {
     "rp_plan_section": (C.c_int, [_i32]),
     "rp_plan_fork_here": (C.c_int, []),
     "rp_plan_join": (C.c_int, []),
+    "rp_plan_fork2_mark": (C.c_int, []),
     "rp_plan_is_recording": (C.c_int, []),
     "rp_plan_end": (C.c_int, [_vp]),
     "rp_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -413,9 +414,10 @@ def embed_gather_linear_fwd(arena, row_base, row_count, idx: List[torch.Tensor],
 
 
 def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torch.Tensor], dense: List[torch.Tensor], W, bias,
-                                 err_flag: torch.Tensor, train_ldx: int = 0, want_keys: bool = False):
+                                 err_flag: torch.Tensor, train_ldx: int = 0, want_keys: bool = False, dense_only: bool = False):
     """bf16-storage: the fused lookup + FM + first Linear over a bf16 copy of the arena -> (h1 [B, 64], fm [B, 1]);
-    train_ldx > 0 (the bf16-storage TRAINING mode): -> (x_bf16 [B, train_ldx] bfloat16, h1, fm, ssum [B, 64], keys or None)"""
+    train_ldx > 0 (the bf16-storage TRAINING mode): -> (x_bf16 [B, train_ldx] bfloat16, h1, fm, ssum [B, 64], keys or None);
+    dense_only (round 5, with train_ldx > 0): no activation is stored — x is xd [B, 64] fp32, the dense columns"""
     _req(arena_bf16, torch.bfloat16, "arena_bf16")
     _req(W, torch.float32, "W")
     F, ND = len(idx), len(dense)
@@ -425,24 +427,26 @@ def embed_gather_linear_fwd_bf16(arena_bf16, row_base, row_count, idx: List[torc
     fm = torch.empty((B, 1), dtype=torch.float32, device=dev)
     K = F * D + ND
     if train_ldx:
-        x16 = torch.empty((B, train_ldx), dtype=torch.bfloat16, device=dev)
+        x16 = None if dense_only else torch.empty((B, train_ldx), dtype=torch.bfloat16, device=dev)
+        xd = torch.empty((B, 64), dtype=torch.float32, device=dev) if dense_only else None
         ssum = torch.empty((B, D), dtype=torch.float32, device=dev)
         keys = torch.empty((F * B,), dtype=torch.int32, device=dev) if want_keys else None
-        # algorithmic bytes: bf16 rows + ids read, the bf16 activation written, h1 + the field sums
+        # algorithmic bytes: bf16 rows + ids read, the bf16 activation "written" (SURVEY 8d's figure, whether or not the launch
+        # stores it), h1 + the field sums
         with _Timed("embed_gather_linear_fwd_bf16", f"D={D}", B * (F * (D * 2 + 8) + (F * D + ND) * 2 + 64 * 4 + D * 4), 2 * B * K * 64):
             _check(lib().rp_embed_gather_linear_fwd_bf16(arena_bf16.data_ptr(), row_base.data_ptr(), row_count.data_ptr(),
                                                          _ptr_array(idx), F, _ptr_array(dense), ND, B, D, W.data_ptr(),
                                                          _rowmajor(W, "W"), _ptr(bias), h1.data_ptr(), fm.data_ptr(),
-                                                         x16.data_ptr(), train_ldx, ssum.data_ptr(), _ptr(keys),
-                                                         err_flag.data_ptr(), _stream()), "rp_embed_gather_linear_fwd_bf16")
-        return x16, h1, fm, ssum, keys
+                                                         _ptr(x16), train_ldx, ssum.data_ptr(), _ptr(keys),
+                                                         err_flag.data_ptr(), _ptr(xd), _stream()), "rp_embed_gather_linear_fwd_bf16")
+        return (xd if dense_only else x16), h1, fm, ssum, keys
     # algorithmic bytes: SURVEY 8d's bf16 figure — bf16 rows + int64 ids read, the [B, F*D] bf16 output "written" (it is
     # consumed in registers here) = F * (2 D + 8) + 2 F D per sample (6 864 B at Criteo shape) — plus h1
     with _Timed("embed_gather_linear_fwd_bf16", f"D={D}", B * (F * (D * 2 + 8) + F * D * 2 + 64 * 4), 2 * B * K * 64):
         _check(lib().rp_embed_gather_linear_fwd_bf16(arena_bf16.data_ptr(), row_base.data_ptr(), row_count.data_ptr(),
                                                      _ptr_array(idx), F, _ptr_array(dense), ND, B, D, W.data_ptr(),
                                                      _rowmajor(W, "W"), _ptr(bias), h1.data_ptr(), fm.data_ptr(),
-                                                     None, 0, None, None, err_flag.data_ptr(), _stream()),
+                                                     None, 0, None, None, err_flag.data_ptr(), None, _stream()),
                "rp_embed_gather_linear_fwd_bf16")
     return h1, fm
 
@@ -798,6 +802,11 @@ class LaunchPlan:
     def fork_here():
         _check(lib().rp_plan_fork_here(), "rp_plan_fork_here")
 
+    @staticmethod
+    def fork2_mark():
+        """the inline section's launches recorded from here on depend on the main stream as it is NOW (rp_plan_fork2_mark)"""
+        _check(lib().rp_plan_fork2_mark(), "rp_plan_fork2_mark")
+
     # launches a recording step wants on the inline section (2) but has no hurry with: issued behind the next launches
     # recorded there (run_deferred), at the latest in front of the section's join; `keep` = the tensors they touch (the
     # capture's allocator would hand their memory to the launches recorded in between)
@@ -952,10 +961,14 @@ def crossnet_bwd_rows(x0, d: int, W, wfc, s, g_x, g_logit):
     """-> dx0 [B, x0.shape[1]] (columns >= d zeroed), V [B, 2L+2] (see rp_crossnet_bwd_rows)."""
     B, L = x0.shape[0], W.shape[0]
     dx0 = torch.empty_like(x0)
-    if x0.shape[1] > d:
+    ldg = _rowmajor(g_x, "g_x") if g_x is not None else 0
+    # the vectorised kernel writes whole dwordx4 up to the leading dimension (exact zeros beyond d); only the unaligned form
+    # leaves the padding columns to a fill (an ATen launch: it kept a DCN step from replaying as a launch plan)
+    vec = (x0.stride(0) % 4 == 0 and dx0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0 and dx0.data_ptr() % 16 == 0
+           and (g_x is None or (ldg % 4 == 0 and g_x.data_ptr() % 16 == 0)) and x0.shape[1] <= (d + 255) // 256 * 256)
+    if x0.shape[1] > d and not vec:
         dx0[:, d:].zero_()
     V = torch.empty((B, 2 * L + 2), dtype=torch.float32, device=x0.device)
-    ldg = _rowmajor(g_x, "g_x") if g_x is not None else 0
     with _Timed("crossnet_bwd_rows"):
         _check(lib().rp_crossnet_bwd_rows(x0.data_ptr(), _rowmajor(x0, "x0"), d, L, W.data_ptr(), _ptr(wfc),
                                           s.data_ptr(), _ptr(g_x), ldg, _ptr(g_logit), dx0.data_ptr(),

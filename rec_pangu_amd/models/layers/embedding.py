@@ -274,7 +274,8 @@ class EmbeddingLayer(nn.Module):
         self.__dict__["_tiny_cache"] = (sig, out)
         return out
 
-    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None, seg=None):
+    def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None, seg=None,
+                        seg_first: bool = False):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -310,10 +311,13 @@ class EmbeddingLayer(nn.Module):
         elif fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
             skip = 0
             tiny = self._tiny_tables() if (keys is not None and dx is None and keys.numel() == len(self.emb_feature) * B) else None
-            if tiny:
+            for f, _, _ in (tiny or ()):
+                skip |= 1 << f
+
+            def run_tiny():
                 # the tables of a few rows (Criteo: 8 fields, 31 % of the pairs) take the sample-major one-hot path; the
                 # row-sorted kernel leaves their fields out.  Inside a recorded launch plan these launches join the first
-                # layer's weight gradient on the plan's second side stream (functional._EmbedGatherLinear.backward)
+                # layer's side work on the plan's second side stream (functional._EmbedGatherLinear.backward)
                 in_plan = plan_keep is not None
                 if in_plan:
                     hip.LaunchPlan.section(2)
@@ -323,19 +327,25 @@ class EmbeddingLayer(nn.Module):
                 finally:
                     if in_plan:
                         hip.LaunchPlan.section(0)
-                for f, _, _ in tiny:
-                    skip |= 1 << f
+
+            if tiny and not seg_first:
+                run_tiny()
             if seg is not None:
                 # (weight [64, K], dw [64, K]) of the consuming Linear: segment sums first, one matrix pass per run that also
                 # yields the embedding columns of dw — the forward stored no activation (functional._EmbedGatherLinear)
                 if keys is None or dx is not None or keys.numel() != len(self.emb_feature) * B:
                     raise RuntimeError("the fused first layer stored no activation, but its backward is not the field-major "
                                        "single-device form rp_embed_grad_seg covers")
+                # (inside a recorded plan the workspace stays referenced until the join: the side launches issued BEHIND this
+                #  one run beside it on another stream, and the capture's one-stream allocator would hand them its memory)
                 hip.embed_grad_seg(sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena,
-                                   accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1])
+                                   accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1],
+                                   keep=plan_keep)
             else:
                 hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
                                     accumulate=not self._grad_clean, skip_fields=skip)
+            if tiny and seg_first:
+                run_tiny()  # (behind the long main-stream launch in issue order: see rp_plan_fork2_mark)
         else:
             hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
                                   accumulate=not self._grad_clean)

@@ -103,11 +103,11 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, de
                 assert gstep.graphs[0] is not None and gstep.graphs[1] is not None
                 if kind == "xdeepfm_dropout":
                     assert max(gstep._drop_calls) >= 1, "no dropout launch was captured: the model ran without active dropout"
-                elif backend == "plan" and kind != "dcn":
-                    # DeepFM's step is library launches only: it must replay as a plan, the sort in the side section
-                    assert gstep.backend_used == "plan" and gstep.plans[0].side >= 4, (gstep.backend_used, gstep.why_not_plan)
                 elif backend == "plan":
-                    assert gstep.backend_used == "hipgraph" and gstep.why_not_plan, "DCN's step holds ATen launches"
+                    # DeepFM's step is library launches only: it must replay as a plan, the sort in the side section — and
+                    # so is DCN's since round 5 (the CrossNet's weight-space arithmetic is rp_crossnet_param_grads, its layer
+                    # stack rp_multi_copy, the padding columns of dX_0 are written by the rows kernel)
+                    assert gstep.backend_used == "plan" and gstep.plans[0].side >= 4, (gstep.backend_used, gstep.why_not_plan)
                 else:
                     assert gstep.backend_used == "hipgraph"
             lz = model.embedding_layer._lazy
