@@ -704,6 +704,9 @@ int rp_plan_join(void);
 /* explicit fork point of the inline section (2): its launches recorded after this mark depend on what the main stream held
  * HERE (main launches recorded between the mark and them run beside them), until the next rp_plan_join */
 int rp_plan_fork2_mark(void);
+/* a non-blocking stream of the lowest priority the device offers (side streams that should yield to the main stream's
+ * launches); the caller owns it */
+int rp_stream_create_low(void **stream_out);
 int rp_plan_is_recording(void);
 int rp_plan_end(void *plan);
 int rp_plan_info(void *plan, int *n_nodes, int *n_side, int *n_streams);

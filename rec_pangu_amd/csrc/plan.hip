@@ -202,6 +202,20 @@ extern "C" int rp_plan_set_streams(void *plan, rp_stream_t side, rp_stream_t sid
     return RP_OK;
 }
 
+// A non-blocking stream of the LOWEST priority the device offers (for the side streams of a step: the next batch's sort and
+// the side work of the first layer's backward run BESIDE the main stream's launches and should yield to them — torch only
+// hands out normal- and high-priority streams).  The caller owns it (never destroyed: streams of a process lifetime).
+extern "C" int rp_stream_create_low(void **stream_out) {
+    RP_REQUIRE(stream_out != nullptr, "stream_create_low: null pointer");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipStream_t s = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "stream_create_low: %s", hipGetErrorString(e));
+    *stream_out = s;
+    return RP_OK;
+}
+
 extern "C" int rp_plan_inline_count(void *plan, int *n_inline) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p && n_inline, "plan_inline_count: null pointer");

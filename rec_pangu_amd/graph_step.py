@@ -110,6 +110,7 @@ class GraphedTrainStep:
         # host blocks there once MAX_IN_FLIGHT replays are queued — device time, not host work)
         self.host_call_s = self.host_wait_s = 0.0
         self._last_plan = None
+        self._copy_lists = None
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
     def _eager(self, batch, nxt):
@@ -144,14 +145,20 @@ class GraphedTrainStep:
         self._one = torch.ones((), dtype=torch.float32, device=next(iter(batch.values())).device)
         self._drop_clock = torch.zeros((1,), dtype=torch.int64, device=self._one.device)
         self._keys = list(batch.keys())
+        self._copy_lists = [None, None]  # per static batch: the destination side of its staging copy, converted once
         if self._sharded:
             return
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
             self.model.embedding_layer.pin_sort(x)
 
     def _copy(self, P, batch):
-        dst = [self.X[P][k] for k in self._keys]
+        cl = self._copy_lists[P] if self._copy_lists is not None else None
+        if cl is None and self._copy_lists is not None:
+            cl = self._copy_lists[P] = hip.CopyList([self.X[P][k] for k in self._keys])
         src = [batch[k] for k in self._keys]
+        if cl is not None and cl(src):
+            return
+        dst = [self.X[P][k] for k in self._keys]
         # ONE launch for the ~40 columns of a batch: torch._foreach_copy_ issues a device-to-device copy per tensor here, and
         # 40 small copies cost the stream ~0.25 ms per step in dispatch gaps (rocprofv3: 42 x __amd_rocclr_copyBuffer per
         # step — what round 3 had read as "~10 us per graph node")
@@ -240,10 +247,10 @@ class GraphedTrainStep:
                 dev = next(iter(self.X[0].values())).device
                 side = _emb._SIDE_STREAMS.get(dev)
                 if side is None:
-                    side = _emb._SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                    side = _emb._SIDE_STREAMS[dev] = hip.make_side_stream(dev)
                 side2 = _Fh._WGRAD_STREAMS.get(dev)
                 if side2 is None:
-                    side2 = _Fh._WGRAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+                    side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev)
                 plan.set_streams(side, side2)
         self.captures += 1
         self._drop_calls[P], self._drop_seed = drop["calls"], drop["seed"]
@@ -290,6 +297,7 @@ class GraphedTrainStep:
             for x in self.X:
                 _emb.EmbeddingLayer.unpin_sorts(x)
         self.X, self._staged = None, None
+        self._copy_lists = None
 
     # ---- the step ------------------------------------------------------------------------------------------------------
     def _fits(self, batch) -> bool:

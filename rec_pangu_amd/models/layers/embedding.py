@@ -565,7 +565,7 @@ class EmbeddingLayer(nn.Module):
         dev = self._arena.device
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)  # (a high-priority stream measured no better)
+            side = _SIDE_STREAMS[dev] = hip.make_side_stream(dev)  # (a high-priority stream measured no better)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)  # the id tensors (and whatever produced them) are ordered on the caller's stream
         with torch.cuda.stream(side):
@@ -598,7 +598,7 @@ class EmbeddingLayer(nn.Module):
             return
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            side = _SIDE_STREAMS[dev] = hip.make_side_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)

@@ -482,7 +482,8 @@ class ShardedEmbeddingLayer(nn.Module):
         dev = self.local_arena.device
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            from . import hip
+            side = _SIDE_STREAMS[dev] = hip.make_side_stream(dev)
         src = tuple(X[c] for c in self.emb_feature)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

@@ -159,8 +159,12 @@ def _spawn(fn, args, timeout_s=420):
                 p.kill()
 
 
-def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model():
+def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model(monkeypatch):
     require_gpu()
+    # (the unsharded model the ranks are held against runs the PAIR-form first-layer backward here, like the sharded path:
+    #  this test is about the exchange; three Adam steps amplify the fp32 summation-order difference between the pair form
+    #  and round 5's segment-sum-first launch — which the oracle tests pin — beyond its element-count bound)
+    monkeypatch.setenv("RP_GRAD_SEG", "0")
     import bench
     from rec_pangu_amd.optim import make_adam
     mgr = mp.Manager()
