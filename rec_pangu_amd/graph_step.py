@@ -109,6 +109,7 @@ class GraphedTrainStep:
         # host time of the replay calls: `host_call_s` = inside __call__ WITHOUT the back-pressure wait (`host_wait_s`: the
         # host blocks there once MAX_IN_FLIGHT replays are queued — device time, not host work)
         self.host_call_s = self.host_wait_s = 0.0
+        self.host_call_max_s = 0.0     # the slowest single call (reset by the caller: bench.py's timed window)
         self._last_plan = None
         self._copy_lists = None
 
@@ -322,10 +323,15 @@ class GraphedTrainStep:
     def __call__(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
         import time as _time
         t_in = _time.perf_counter()
+        w0 = self.host_wait_s
         try:
             return self._call(batch, next_batch)
         finally:
-            self.host_call_s += _time.perf_counter() - t_in
+            dt = _time.perf_counter() - t_in
+            self.host_call_s += dt
+            own = dt - (self.host_wait_s - w0)  # (this call's time without its back-pressure wait)
+            if own > self.host_call_max_s:
+                self.host_call_max_s = own
 
     def _call(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
         if self.eager_left > 0 or next_batch is None:

@@ -482,8 +482,9 @@ class ShardedEmbeddingLayer(nn.Module):
         dev = self.local_arena.device
         side = _SIDE_STREAMS.get(dev)
         if side is None:
-            from . import hip
-            side = _SIDE_STREAMS[dev] = hip.make_side_stream(dev)
+            # (a plain torch stream: RCCL's collectives are issued on it — the lowest-priority ExternalStream of the
+            #  single-device path has not run under a process group with more than one rank)
+            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
         src = tuple(X[c] for c in self.emb_feature)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
