@@ -587,15 +587,34 @@ def main():
     hc0 = (gstep.host_call_s, gstep.host_wait_s) if gstep is not None else None
     if gstep is not None:
         gstep.host_call_max_s = 0.0
+        gstep.host_seg_max = {}
+        for pl in gstep.plans:
+            if pl is not None:
+                pl.slowest_call(reset=True)
+    import gc
+    gc_win = {"n": 0, "s": 0.0, "t": 0.0}
+
+    def _gc_cb(phase, info):  # collector passes inside the timed window (they stall the host's enqueue, not the device)
+        if phase == "start":
+            gc_win["t"] = time.perf_counter()
+        else:
+            gc_win["n"] += 1
+            gc_win["s"] += time.perf_counter() - gc_win["t"]
+
+    gc.callbacks.append(_gc_cb)
+    host_each = []
     for i in range(args.steps):
         hip.pause_timing(i % ev_stride != 0)
         th = time.perf_counter()
         step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None, graphed=True)
-        host_s += time.perf_counter() - th  # time the host needs to ENQUEUE a step (it runs ahead of the device)
+        host_each.append(time.perf_counter() - th)  # time the host needs to ENQUEUE a step (it runs ahead of the device)
+    host_s = sum(host_each)
     hip.pause_timing(False)
     barrier()
     dt = time.perf_counter() - t0
-    host_call_ms = host_wait_ms = host_call_max_ms = None
+    gc.callbacks.remove(_gc_cb)
+    host_slowest = max(range(args.steps), key=lambda i_: host_each[i_])
+    host_call_ms = host_wait_ms = host_call_max_ms = host_stall = None
     in_step = None
     if gstep is not None:
         assert gstep.replays - replays0 == args.steps, "every timed step must have been a graph replay"
@@ -604,6 +623,10 @@ def main():
         host_call_ms = (gstep.host_call_s - hc0[0]) / args.steps * 1e3
         host_wait_ms = (gstep.host_wait_s - hc0[1]) / args.steps * 1e3
         host_call_max_ms = gstep.host_call_max_s * 1e3
+        host_stall = {"slowest_part_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in gstep.host_seg_max.items()}}
+        if gstep.backend_used == "plan":
+            sc = max((pl.slowest_call(reset=True) for pl in gstep.plans if pl is not None), key=lambda t_: t_[2])
+            host_stall["slowest_hip_call_in_replay"] = {"kind": sc[0], "node": sc[1], "ms": round(sc[2], 4)}
         if gstep.backend_used == "plan":
             # ---- per-launch durations INSIDE the replayed step, live: the plan brackets ONE launch per replay with a HIP
             #      timing-event pair on the stream it is issued on (rp_plan_set_probe) — the launch then shares the device
@@ -1105,6 +1128,9 @@ def main():
             "host_call_ms_per_step_unblocked": None if host_call_ms is None else round(host_call_ms, 4),
             "host_wait_ms_per_step": None if host_wait_ms is None else round(host_wait_ms, 4),
             "host_call_max_ms_in_window": None if host_call_max_ms is None else round(host_call_max_ms, 4),
+            "host_stall": host_stall,
+            "host_slowest_step_in_window": {"step": host_slowest, "ms": round(host_each[host_slowest] * 1e3, 4)},
+            "gc_in_window": {"passes": gc_win["n"], "ms": round(gc_win["s"] * 1e3, 4)},
             "host_note": "host_enqueue = wall time of the step call on the host, INCLUDING the back-pressure wait once 6 replays are "
                          "queued (then it equals the device's step time and says nothing about the host); host_call_unblocked = the "
                          "same without that wait: what the host itself needs per replayed step",

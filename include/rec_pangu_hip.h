@@ -721,6 +721,17 @@ int rp_plan_replay(void *plan, rp_stream_t stream);
  * rp_plan_launch_name: the launch's (demangled) kernel name and section (0 main stream, 1 side, 2 inline side). */
 int rp_plan_set_probe(void *plan, int launch);
 int rp_plan_probe_ms(void *plan, float *ms);
+/* Completion markers for the host's run-ahead bound (graph_step.py keeps at most 6 replayed steps in flight): an event
+ * without timing and without the system-scope fence of a default event record (the host waits for it; it does not read
+ * device memory on its strength).  (No counterpart in the reference.) */
+int rp_marker_create(void **marker);
+int rp_marker_record(void *marker, rp_stream_t stream);
+int rp_marker_wait(void *marker);
+int rp_marker_destroy(void *marker);
+/* Host-side stall finder: the slowest single HIP call (kind 0 = kernel launch, 1 = event record, 2 = stream wait) issued by
+ * the replays since the last reset, the plan node it belongs to (nodes, not launches: markers count) and its host time in
+ * milliseconds.  reset != 0 starts a new window.  (No counterpart in the reference: its step is eager torch.) */
+int rp_plan_slowest_call(void *plan, int *kind, int *node, double *ms, int reset);
 int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_len, int *section);
 int rp_plan_destroy(void *plan);
 int rp_graph_node_counts(void *graph, int *n_kernel, int *n_other);

@@ -1311,6 +1311,9 @@ struct SegFields {
 // is read by later launches), and __syncthreads() would also drain the vector-memory counter — the row loads in flight across
 // the piece-count barrier, the next tile's keys, the gradient-row stores
 #define SEG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// (Round 5 A/B, removed again: ONE workgroup per CU with the whole register file — 256 VGPRs + AGPR spill space, no scratch —
+//  ran 0.344 ms inside the step against 0.329 ms for this form with its 27 scratch registers, and needs an EMPTY CU to start:
+//  it began 60 us after the tail backward ended, when the side streams' kernels had drained; profiles/r05 notes in DESIGN §6.)
 template <bool HAS_FM, int SEG>
 __global__ __launch_bounds__(256, (SEG == 8 ? 2 : 3)) void embed_grad_seg_kernel(
     const int32_t *__restrict__ sk, const int32_t *__restrict__ sp, int64_t n, int Bi, const float *__restrict__ dh,

@@ -19,6 +19,7 @@
 #include "common.h"
 #include <cxxabi.h>
 #include <cstdlib>
+#include <ctime>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -55,7 +56,25 @@ struct Plan {
     int probe = -1;
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
     bool probe_recorded = false;
+    // the slowest single HIP call (launch / event record / stream wait) of the replays since rp_plan_slowest_call reset it:
+    // a launch call that blocks inside the runtime stalls the host's run-ahead (bench.py: host_stall)
+    double slow_ms = 0.0;
+    int slow_node = -1, slow_kind = -1;  // kind: 0 launch, 1 event record, 2 stream wait
 };
+
+// Fork/join events order streams of ONE device: an agent-scope release is all their consumers need.  The default event
+// carries a system-scope fence (L2 write-back + invalidate at the record) that the next launch on the stream queues behind;
+// RP_PLAN_EVENT_FENCE=system brings it back.
+inline unsigned plan_event_flags() {
+    static const bool sys = getenv("RP_PLAN_EVENT_FENCE") && strcmp(getenv("RP_PLAN_EVENT_FENCE"), "system") == 0;
+    return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+
+inline double plan_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 std::atomic<Plan *> g_recording{nullptr};
 std::mutex g_mu;
@@ -280,6 +299,51 @@ extern "C" int rp_plan_launch_name(void *plan, int launch, char *buf, int buf_le
     return RP_OK;
 }
 
+// A completion marker for the host's run-ahead bound (graph_step.py): no timing, no system-scope fence — the host only waits
+// for it, it never reads device memory on its strength.
+extern "C" int rp_marker_create(void **marker) {
+    RP_REQUIRE(marker != nullptr, "marker_create: null pointer");
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&ev, plan_event_flags());
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "marker_create: %s", hipGetErrorString(e));
+    *marker = ev;
+    return RP_OK;
+}
+
+extern "C" int rp_marker_record(void *marker, rp_stream_t stream) {
+    RP_REQUIRE(marker != nullptr, "marker_record: null marker");
+    hipError_t e = hipEventRecord((hipEvent_t)marker, (hipStream_t)stream);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "marker_record: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+extern "C" int rp_marker_wait(void *marker) {
+    RP_REQUIRE(marker != nullptr, "marker_wait: null marker");
+    hipError_t e = hipEventSynchronize((hipEvent_t)marker);
+    if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "marker_wait: %s", hipGetErrorString(e));
+    return RP_OK;
+}
+
+extern "C" int rp_marker_destroy(void *marker) {
+    if (marker != nullptr) (void)hipEventDestroy((hipEvent_t)marker);
+    return RP_OK;
+}
+
+// the slowest HIP call inside the replays since the last reset: kind (0 launch, 1 event record, 2 stream wait), the node
+// it belongs to and its host time; reset != 0 starts a new window
+extern "C" int rp_plan_slowest_call(void *plan, int *kind, int *node, double *ms, int reset) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr, "plan_slowest_call: null plan");
+    if (kind != nullptr) *kind = p->slow_kind;
+    if (node != nullptr) *node = p->slow_node;
+    if (ms != nullptr) *ms = p->slow_ms;
+    if (reset) {
+        p->slow_ms = 0.0;
+        p->slow_node = p->slow_kind = -1;
+    }
+    return RP_OK;
+}
+
 extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && p->ended, "plan_replay: the plan was not finished with rp_plan_end");
@@ -291,8 +355,8 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
             p->own_side = true;
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, plan_event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, plan_event_flags());
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side stream: %s", hipGetErrorString(e));
     }
     if (p->n_inline > 0 && p->ev_fork2 == nullptr) {
@@ -300,30 +364,41 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             e = hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking);
             p->own_side2 = true;
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork2, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork2, plan_event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, plan_event_flags());
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
     }
     bool forked = false, open2 = false, main_since_fork2 = false, side_joined = false, marked2 = false;
+    auto timed = [p](int kind, size_t node, auto &&call) -> hipError_t {
+        const double t0 = plan_now_ms();
+        const hipError_t r = call();
+        const double d = plan_now_ms() - t0;
+        if (d > p->slow_ms) {
+            p->slow_ms = d;
+            p->slow_node = (int)node;
+            p->slow_kind = kind;
+        }
+        return r;
+    };
     for (size_t i = 0; i <= p->nodes.size(); ++i) {
         if (fork && !forked && (i >= p->fork_at || i == p->nodes.size())) {
             // the side section: it depends on nothing this replay computes, only on what was enqueued before the replay
             forked = true;
-            e = hipEventRecord(p->ev_fork, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(p->side, p->ev_fork, 0);
+            e = timed(1, i, [&] { return hipEventRecord(p->ev_fork, s); });
+            if (e == hipSuccess) e = timed(2, i, [&] { return hipStreamWaitEvent(p->side, p->ev_fork, 0); });
             if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: fork: %s", hipGetErrorString(e));
             for (size_t j = 0; j < p->nodes.size(); ++j) {
                 const PlanNode &n = p->nodes[j];
                 if (n.section != 1) continue;
                 if ((int)j == p->probe) (void)hipEventRecord(p->ev_p0, p->side);
-                e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[j], n.shmem, p->side);
+                e = timed(0, j, [&] { return hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[j], n.shmem, p->side); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: side launch %zu: %s", j, hipGetErrorString(e));
                 if ((int)j == p->probe) {
                     (void)hipEventRecord(p->ev_p1, p->side);
                     p->probe_recorded = true;
                 }
             }
-            e = hipEventRecord(p->ev_join, p->side);
+            e = timed(1, i, [&] { return hipEventRecord(p->ev_join, p->side); });
             if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join record: %s", hipGetErrorString(e));
         }
         if (i == p->nodes.size()) break;
@@ -331,7 +406,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         if (n.section == 1) continue;
         if (n.func == nullptr && n.section == -3) {  // explicit fork point of the inline section
             if (p->n_inline > 0 && !open2) {
-                e = hipEventRecord(p->ev_fork2, s);
+                e = timed(1, i, [&] { return hipEventRecord(p->ev_fork2, s); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork mark: %s", hipGetErrorString(e));
                 marked2 = true;
             }
@@ -342,13 +417,17 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             if (open2) {
                 // the side section (issued at its fork point, long done by now) is joined through the same wait: every
                 // event operation on the main stream is a packet its next launch queues behind
-                if (forked && !side_joined) {
-                    e = hipStreamWaitEvent(p->side2, p->ev_join, 0);
+                // (round 5: only on request — with the side streams at the lowest priority the sort is no longer "long done":
+                //  it ended 10 us AFTER the first layer's backward and held the optimizer up by 34 us, profiles/r05 trace; nothing
+                //  in the step needs it, so it is joined at the end of the replay below)
+                static const bool join_sort_early = getenv("RP_PLAN_JOIN_SORT") && strcmp(getenv("RP_PLAN_JOIN_SORT"), "early") == 0;
+                if (join_sort_early && forked && !side_joined) {
+                    e = timed(2, i, [&] { return hipStreamWaitEvent(p->side2, p->ev_join, 0); });
                     if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join of the side section: %s", hipGetErrorString(e));
                     side_joined = true;
                 }
-                e = hipEventRecord(p->ev_join2, p->side2);
-                if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
+                e = timed(1, i, [&] { return hipEventRecord(p->ev_join2, p->side2); });
+                if (e == hipSuccess) e = timed(2, i, [&] { return hipStreamWaitEvent(s, p->ev_join2, 0); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
                 open2 = false;
             }
@@ -361,13 +440,13 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             // the main stream produces after the weight gradient was forked)
             if (marked2) {  // (the event was recorded at the mark: main launches recorded since are NOT waited for)
                 if (!open2) {
-                    e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
+                    e = timed(2, i, [&] { return hipStreamWaitEvent(p->side2, p->ev_fork2, 0); });
                     if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork (marked): %s", hipGetErrorString(e));
                     open2 = true;
                 }
             } else if (!open2 || main_since_fork2) {
-                e = hipEventRecord(p->ev_fork2, s);
-                if (e == hipSuccess) e = hipStreamWaitEvent(p->side2, p->ev_fork2, 0);
+                e = timed(1, i, [&] { return hipEventRecord(p->ev_fork2, s); });
+                if (e == hipSuccess) e = timed(2, i, [&] { return hipStreamWaitEvent(p->side2, p->ev_fork2, 0); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork: %s", hipGetErrorString(e));
                 open2 = true;
                 main_since_fork2 = false;
@@ -377,7 +456,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
             main_since_fork2 = true;
         }
         if ((int)i == p->probe) (void)hipEventRecord(p->ev_p0, target);
-        e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, target);
+        e = timed(0, i, [&] { return hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, target); });
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: launch %zu: %s", i, hipGetErrorString(e));
         if ((int)i == p->probe) {
             (void)hipEventRecord(p->ev_p1, target);
@@ -385,13 +464,14 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         }
         rp_count_launch();
     }
+    const size_t i = p->nodes.size();
     if (open2) {  // (a section that was never joined explicitly joins at the end)
-        e = hipEventRecord(p->ev_join2, p->side2);
-        if (e == hipSuccess) e = hipStreamWaitEvent(s, p->ev_join2, 0);
+        e = timed(1, i, [&] { return hipEventRecord(p->ev_join2, p->side2); });
+        if (e == hipSuccess) e = timed(2, i, [&] { return hipStreamWaitEvent(s, p->ev_join2, 0); });
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline join: %s", hipGetErrorString(e));
     }
     if (fork && !side_joined) {
-        e = hipStreamWaitEvent(s, p->ev_join, 0);
+        e = timed(2, i, [&] { return hipStreamWaitEvent(s, p->ev_join, 0); });
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join: %s", hipGetErrorString(e));
     }
     return RP_OK;

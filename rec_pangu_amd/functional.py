@@ -816,7 +816,7 @@ def _wgrad_stream(device):
         return None
     st = _WGRAD_STREAMS.get(device)
     if st is None:
-        st = _WGRAD_STREAMS[device] = hip.make_side_stream(device)
+        st = _WGRAD_STREAMS[device] = hip.make_side_stream(device, "inline")
     return st
 
 

@@ -35,6 +35,9 @@ import torch
 from . import hip
 from .models.layers import embedding as _emb
 
+# the run-ahead bound's completion markers: hip.Marker (no system-scope fence at the record) unless RP_STEP_MARKERS=torch
+_TORCH_MARKERS = os.environ.get("RP_STEP_MARKERS", "") == "torch"
+
 
 
 class GraphedTrainStep:
@@ -109,6 +112,7 @@ class GraphedTrainStep:
         # host time of the replay calls: `host_call_s` = inside __call__ WITHOUT the back-pressure wait (`host_wait_s`: the
         # host blocks there once MAX_IN_FLIGHT replays are queued — device time, not host work)
         self.host_call_s = self.host_wait_s = 0.0
+        self.host_seg_max = {}         # slowest host time per part of a replay call (copy / prepare / replay / record / advance)
         self.host_call_max_s = 0.0     # the slowest single call (reset by the caller: bench.py's timed window)
         self._last_plan = None
         self._copy_lists = None
@@ -251,7 +255,7 @@ class GraphedTrainStep:
                     side = _emb._SIDE_STREAMS[dev] = hip.make_side_stream(dev)
                 side2 = _Fh._WGRAD_STREAMS.get(dev)
                 if side2 is None:
-                    side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev)
+                    side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev, "inline")
                 plan.set_streams(side, side2)
         self.captures += 1
         self._drop_calls[P], self._drop_seed = drop["calls"], drop["seed"]
@@ -334,6 +338,16 @@ class GraphedTrainStep:
                 self.host_call_max_s = own
 
     def _call(self, batch: Dict[str, torch.Tensor], next_batch: Optional[Dict[str, torch.Tensor]] = None):
+        import time as _time
+        seg_t = _time.perf_counter()
+
+        def seg(name):  # slowest host time per part of the call (host_seg_max: where a stalled call stalled)
+            nonlocal seg_t
+            t = _time.perf_counter()
+            if t - seg_t > self.host_seg_max.get(name, 0.0):
+                self.host_seg_max[name] = t - seg_t
+            seg_t = t
+
         if self.eager_left > 0 or next_batch is None:
             self.eager_left -= 1
             self._staged = None
@@ -348,10 +362,12 @@ class GraphedTrainStep:
             # captured step would sort it): this step runs eagerly
             self._staged = None
             return self._eager(batch, next_batch)
+        seg("fits")
         if self._staged is not batch:      # not the batch announced by the previous call: stage and sort it now
             self._stage_current(batch)
         P = self.P
         self._copy(1 - P, next_batch)
+        seg("copy")
         sig = self.opt.prepare_step()
         gen = hip.device_generator(self._drop_clock.device)
         sig = sig + (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF,)  # (the dropout seed is a frozen launch argument: re-seeding re-captures)
@@ -364,6 +380,7 @@ class GraphedTrainStep:
             self._sig = sig
         if self.graphs[P] is None:
             self._capture(P)
+        seg("signature")
         counters = self.opt.host_counters()
         if counters != self._dev:          # eager steps ran in between: bring the device counters to the host's
             self.opt.set_device_clock(True)
@@ -378,6 +395,8 @@ class GraphedTrainStep:
             self.host_wait_s += dt_w
             self.host_call_s -= dt_w  # (the wait is the device's time, not the host's)
             self._ev_pool.append(done)
+            seg_t = _time.perf_counter()
+        seg("prepare")
         calls = self._drop_calls[P]
         if calls > 0:
             off = gen.get_offset()
@@ -390,12 +409,15 @@ class GraphedTrainStep:
             self._last_plan = self.plans[P]
         else:
             self.graphs[P].replay()
-        ev = self._ev_pool.pop() if self._ev_pool else torch.cuda.Event()
+        seg("replay")
+        ev = self._ev_pool.pop() if self._ev_pool else (torch.cuda.Event() if _TORCH_MARKERS else hip.Marker())
         ev.record()
         self._inflight.append(ev)
+        seg("record")
         self.opt.advance_host()
         hip.bump_weight_epoch()
         self._dev = self.opt.host_counters()
+        seg("advance")
         self.replays += 1
         self.P, self._staged = 1 - P, next_batch
         return self.outs[P]

@@ -72,6 +72,11 @@ _SIGNATURES = {
     "rp_plan_set_streams": (C.c_int, [_vp, _vp, _vp]),
     "rp_plan_set_probe": (C.c_int, [_vp, _i32]),
     "rp_plan_probe_ms": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "rp_marker_create": (C.c_int, [C.POINTER(_vp)]),
+    "rp_marker_record": (C.c_int, [_vp, _vp]),
+    "rp_marker_wait": (C.c_int, [_vp]),
+    "rp_marker_destroy": (C.c_int, [_vp]),
+    "rp_plan_slowest_call": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
@@ -763,6 +768,29 @@ def copy_rows(w, ld_out: int):
     return buf[:, :Cc]
 
 
+class Marker:
+    """Completion marker on the current stream (rp_marker_*): an event without timing and without a default event's
+    system-scope fence.  The host may wait for it; it must not read device memory on its strength."""
+
+    def __init__(self):
+        h = _vp()
+        _check(lib().rp_marker_create(C.byref(h)), "rp_marker_create")
+        self._h = h
+
+    def record(self):
+        _check(lib().rp_marker_record(self._h, _stream()), "rp_marker_record")
+
+    def synchronize(self):
+        _check(lib().rp_marker_wait(self._h), "rp_marker_wait")
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                lib().rp_marker_destroy(self._h)
+        except Exception:
+            pass
+
+
 # ---- launch plans (csrc/plan.hip; used by graph_step.GraphedTrainStep) -------------------------------------------------
 class LaunchPlan:
     """A recorded sequence of the library's kernel launches (rp_plan_*).  `with plan.recording(): ...` records every
@@ -864,6 +892,12 @@ class LaunchPlan:
         _check(lib().rp_plan_probe_ms(self._h, C.byref(ms)), "rp_plan_probe_ms")
         return ms.value
 
+    def slowest_call(self, reset: bool = True):
+        """(kind, node, ms) of the slowest HIP call the replays issued since the last reset (kind: launch / record / wait)"""
+        k, n, ms = C.c_int(-1), C.c_int(-1), C.c_double(0)
+        _check(lib().rp_plan_slowest_call(self._h, C.byref(k), C.byref(n), C.byref(ms), 1 if reset else 0), "rp_plan_slowest_call")
+        return (("launch", "record", "wait")[k.value] if k.value >= 0 else None), n.value, ms.value
+
     def launch_name(self, launch: int):
         """(kernel name as rocprofv3 prints it, section: 0 main stream, 1 side (next batch's sort), 2 inline side)"""
         buf, sec = C.create_string_buffer(512), _i32()
@@ -885,16 +919,21 @@ class LaunchPlan:
 _COPY_PLANS: dict = {}
 
 
-def make_side_stream(device) -> "torch.cuda.Stream":
+def make_side_stream(device, role: str = "sort") -> "torch.cuda.Stream":
     """a stream for work that runs BESIDE the main stream (the next batch's sort, the side work of the first layer's backward):
     of the LOWEST priority the device offers (rp_stream_create_low, wrapped as an ExternalStream), so that the main stream's
     launches are dispatched first — measured in alternating runs on one box: 0.912 / 0.912 -> 0.903 / 0.887 ms per step in the
     20-step window, 0.879 -> 0.866 over 600 steps.  RP_SIDE_PRIORITY=normal: a plain torch stream (rounds 2-4)"""
-    if os.environ.get("RP_SIDE_PRIORITY", "low") == "low":
+    prio = os.environ.get("RP_SIDE_PRIORITY", "low")
+    if role == "inline":  # (the first layer's side work is waited for by the optimizer; the sort by nothing in its step)
+        prio = os.environ.get("RP_SIDE2_PRIORITY", prio)
+    if prio == "low":
         with torch.cuda.device(device):
             h = _vp()
             _check(lib().rp_stream_create_low(C.byref(h)), "rp_stream_create_low")
         return torch.cuda.ExternalStream(h.value, device=device)
+    if prio == "high":
+        return torch.cuda.Stream(device=device, priority=-1)
     return torch.cuda.Stream(device=device)
 
 

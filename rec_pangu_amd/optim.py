@@ -87,12 +87,26 @@ class StepTables:
                 setattr(self, name, new)
             self.generation += 1
         # (one C call for the whole chunk: the per-step loop over ctypes cost the host ~1 ms every 1024th step)
-        self.sc[t_new:hi + 1].copy_(hip.adam_step_scalars_range(lr, self.betas[0], self.betas[1], t_new, hi + 1 - t_new, self.eps))
+        self._upload(self.sc[t_new:hi + 1],
+                     hip.adam_step_scalars_range(lr, self.betas[0], self.betas[1], t_new, hi + 1 - t_new, self.eps))
         j = torch.arange(t_new, hi + 1, dtype=torch.float64)
         ns = -float(lr) / (1.0 - float(self.betas[0]) ** j)
         d = 1.0 / torch.sqrt(1.0 - float(self.betas[1]) ** j)
-        self.ns_d[t_new:hi + 1].copy_(torch.stack([ns, d], 1))
+        self._upload(self.ns_d[t_new:hi + 1], torch.stack([ns, d], 1))
         self.lr, self.lr_from, self.filled_to = lr, t_new, hi
+
+    @staticmethod
+    def _upload(dst, src):
+        """host rows -> device rows in stream order WITHOUT blocking the host: a copy from pageable memory waits for the
+        stream to drain first — every 1024th step the host lost the 6 replayed steps it was ahead (5.4 ms inside one call,
+        bench.py host_stall, round 5) and the device then idled until the next step was enqueued.  The pinned staging tensor
+        goes back to torch's host allocator, which holds it until the copy has run."""
+        if dst.is_cuda:
+            pin = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            pin.copy_(src)
+            dst.copy_(pin, non_blocking=True)
+        else:
+            dst.copy_(src)
 
 
 # RP_ADAM_NOCLEAR=0: the catch-up launch always clears the gradient rows it applies (the round-3 behaviour)
