@@ -501,6 +501,23 @@ int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_h
                           const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh, float *grads,
                           int64_t M, void *workspace, size_t workspace_bytes, int parts, rp_stream_t stream);
 
+/* The tail with the model's loss head inside (ranking/deepfm.py:61-66 on top of layers/deep.py:61-84; three launches of a
+ * DeepFM step in one each way).  Forward: pred [M] = sigmoid(addends[0][m] + .. + tail logit) (0..3 other addends, summed in
+ * that order, the tail's logit last), partial [rp_mlp_tail_loss_partials(M)] = per-workgroup sums of the BCE terms of
+ * (pred + p_eps, label), logs clamped at -100: rp_loss_finish(partial, n, weight / M, loss) gives the mean loss — term for
+ * term rp_sigmoid_bce_fwd's arithmetic (pred is bit-identical to the separate launches; the loss differs by the order of
+ * its sum).  Backward: the logit's gradient is formed per row from (pred, label, gloss[0] * weight / M) — rp_sigmoid_bce_bwd
+ * bit for bit — and written to dz_out [M] (NULL: not) for the other addends; everything else as rp_mlp_tail_bwd_parts. */
+int rp_mlp_tail_loss_partials(int64_t M);
+int rp_mlp_tail_fwd_bce(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                        const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out,
+                        const float *const *addends, int n_addends, const float *label, float p_eps, float *pred,
+                        float *partial, int64_t M, rp_stream_t stream);
+int rp_mlp_tail_bwd_bce(const float *pred, const float *label, const float *gloss, float p_eps, float weight, float *dz_out,
+                        int n_hidden, const float *const *W_hidden, const int64_t *ldw, const float *const *acts,
+                        int64_t ldact0, const float *w_out, float *dhin, int64_t lddh, float *grads, int64_t M,
+                        void *workspace, size_t workspace_bytes, int parts, rp_stream_t stream);
+
 /* ---- Dropout (layers/deep.py:66-68 inside the MLP chain; the multi-task towers, mmoe.py:55) -------------------------
  * y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10(counter = (element group, offset), key = seed): a
  * pure function of (seed, offset, element index).  mask: uint8 [M*N] (1 = kept), saved for the backward
@@ -525,6 +542,8 @@ int rp_loss_partials(int64_t B);
 int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
                        int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
                        rp_stream_t stream);
+/* loss[0] = scale * sum(partial[0..n)), fixed order (the second stage of rp_sigmoid_bce_fwd; also ends rp_mlp_tail_fwd_bce) */
+int rp_loss_finish(const float *partial, int n, float scale, float *loss, rp_stream_t stream);
 /* dz[b] = gloss[0] * weight/B * dBCE/dp * (apply_sigmoid ? p(1-p) : 1) */
 int rp_sigmoid_bce_bwd(const float *pred, const float *label, const float *gloss, int64_t B, float p_eps,
                        float weight, int apply_sigmoid, float *dz, rp_stream_t stream);
@@ -704,6 +723,9 @@ int rp_plan_join(void);
 /* explicit fork point of the inline section (2): its launches recorded after this mark depend on what the main stream held
  * HERE (main launches recorded between the mark and them run beside them), until the next rp_plan_join */
 int rp_plan_fork2_mark(void);
+/* the main stream waits HERE for the side section (1) of the replay (default: at the end of the replay) — for a step that
+ * itself consumes what the side section produces (the next batch's sorted keys: graph_step.py, catch-up ahead) */
+int rp_plan_join_side(void);
 /* a non-blocking stream of the lowest priority the device offers (side streams that should yield to the main stream's
  * launches); the caller owns it */
 int rp_stream_create_low(void **stream_out);

@@ -98,6 +98,16 @@ extern "C" int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int
     return RP_OK;
 }
 
+// loss[0] = scale * sum(partial[0..n)) in a fixed order (the second stage of rp_sigmoid_bce_fwd as an entry of its own: the
+// partials of rp_mlp_tail_fwd_bce end here; nobody on the device needs the scalar, so a recorded step issues this launch on
+// its side section)
+extern "C" int rp_loss_finish(const float *partial, int n, float scale, float *loss, rp_stream_t stream) {
+    RP_REQUIRE(partial && loss && n >= 1, "loss_finish: bad argument");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, partial, n, scale, loss);
+    RP_LAUNCH_CHECK("loss_finish");
+    return RP_OK;
+}
+
 extern "C" int rp_sigmoid_bce_bwd(const float *pred, const float *label, const float *gloss, int64_t B, float p_eps,
                                   float weight, int apply_sigmoid, float *dz, rp_stream_t stream) {
     RP_REQUIRE(pred && label && gloss && dz && B >= 1, "sigmoid_bce_bwd: bad argument");

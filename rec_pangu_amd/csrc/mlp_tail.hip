@@ -70,10 +70,23 @@ __device__ __forceinline__ void mt_stage_wt(const float *__restrict__ W, int64_t
     }
 }
 
-template <int L>
+// The loss head folded into the forward (rp_mlp_tail_fwd_bce): z = sum of the other logit addends (DeepFM: the FM term) + this
+// tail's logit, pred = sigmoid(z), and the workgroup's partial sum of the BCE terms — the arithmetic of rp_sigmoid_bce_fwd
+// (csrc/loss.hip) term by term, so pred is bit-identical to the two-launch form; only the ORDER of the loss sum differs (one
+// partial per 128 rows here).  rp_loss_finish turns the partials into the scalar.
+struct TailBce {
+    const float *add[3];
+    int n_add;
+    const float *label;
+    float p_eps;
+    float *pred;
+    float *partial;  // [workgroups]
+};
+
+template <int L, bool BCE>
 __global__ __launch_bounds__(256, 2) void mlp_tail_fwd_kernel(const float *__restrict__ hin, int64_t ldin, TailFwdArgs a,
                                                               const float *__restrict__ wout, const float *__restrict__ bout,
-                                                              float *__restrict__ logit, int64_t M) {
+                                                              float *__restrict__ logit, int64_t M, TailBce bc) {
     __shared__ __attribute__((aligned(16))) __bf16 Wt[3][64][MT_LD];
     __shared__ __attribute__((aligned(16))) float Ct[4][32][MT_CT];  // per wave: the activation tile between layers
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 31, h = l >> 5;
@@ -151,7 +164,36 @@ __global__ __launch_bounds__(256, 2) void mlp_tail_fwd_kernel(const float *__res
 #pragma unroll
         for (int e = 0; e < 8; ++e) part = __builtin_fmaf(av[ks][e], wout[ks * 16 + 8 * h + e], part);
     part += __shfl_xor(part, 32, 64);
-    if (h == 0 && row < M) logit[row] = part + (bout != nullptr ? bout[0] : 0.f);
+    const float lg = part + (bout != nullptr ? bout[0] : 0.f);
+    if constexpr (!BCE) {
+        if (h == 0 && row < M) logit[row] = lg;
+    } else {
+        __shared__ float lred[128];
+        if (h == 0) {
+            float term = 0.f;
+            if (row < M) {
+                float z = lg;
+                if (bc.n_add > 0) {  // (the addends first, this tail's logit last: the order of the model's logit list)
+                    z = bc.add[0][row];
+                    for (int q = 1; q < bc.n_add; ++q) z += bc.add[q][row];
+                    z += lg;
+                }
+                const float p = 1.f / (1.f + expf(-z));
+                bc.pred[row] = p;
+                const float pe = p + bc.p_eps, y = bc.label[row];
+                const float lp = fmaxf(logf(pe), -100.f), l1p = fmaxf(log1pf(-pe), -100.f);
+                term = -(y * lp + (1.f - y) * l1p);
+            }
+            lred[32 * wv + i] = term;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // fixed-order tree over the workgroup's 128 rows
+            float v = lred[threadIdx.x] + lred[threadIdx.x + 64];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (threadIdx.x == 0) bc.partial[blockIdx.x] = v;
+        }
+    }
 }
 
 extern "C" int rp_mlp_tail_fits(int n_hidden, int width, int64_t ldin) {
@@ -159,10 +201,10 @@ extern "C" int rp_mlp_tail_fits(int n_hidden, int width, int64_t ldin) {
 }
 
 // logit[M,1] = head(relu-chain(hin)), hidden outputs h_out[l] [M,64] saved.  W_hidden[l]: [64,64] (out,in), ldw[l] floats per row.
-extern "C" int rp_mlp_tail_fwd(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
-                               const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out,
-                               float *logit, int64_t M, rp_stream_t stream) {
-    RP_REQUIRE(hin && W_hidden && ldw && b_hidden && h_out && w_out && logit, "mlp_tail_fwd: null pointer");
+static int tail_fwd_launch(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                           const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out,
+                           float *logit, int64_t M, const TailBce *bce, rp_stream_t stream) {
+    RP_REQUIRE(hin && W_hidden && ldw && b_hidden && h_out && w_out && (logit || bce), "mlp_tail_fwd: null pointer");
     if (!rp_mlp_tail_fits(n_hidden, 64, ldin) || !rp_aligned16(hin))
         return rp_fail(RP_ERR_UNSUPPORTED, "mlp_tail_fwd: 1..3 hidden layers of width 64, 16-byte aligned rows");
     if (M == 0) return RP_OK;
@@ -183,11 +225,53 @@ extern "C" int rp_mlp_tail_fwd(const float *hin, int64_t ldin, int n_hidden, con
     }
     const dim3 grid((unsigned)rp_cdiv(M, 128));
     hipStream_t s = (hipStream_t)stream;
-    if (n_hidden == 1) hipLaunchKernelGGL((mlp_tail_fwd_kernel<1>), grid, dim3(256), 0, s, hin, ldin, a, w_out, b_out, logit, M);
-    else if (n_hidden == 2) hipLaunchKernelGGL((mlp_tail_fwd_kernel<2>), grid, dim3(256), 0, s, hin, ldin, a, w_out, b_out, logit, M);
-    else hipLaunchKernelGGL((mlp_tail_fwd_kernel<3>), grid, dim3(256), 0, s, hin, ldin, a, w_out, b_out, logit, M);
+    TailBce bc{};
+    if (bce != nullptr) bc = *bce;
+#define TAIL_FWD(LL, BB) hipLaunchKernelGGL((mlp_tail_fwd_kernel<LL, BB>), grid, dim3(256), 0, s, hin, ldin, a, w_out, b_out, logit, M, bc)
+    if (bce == nullptr) {
+        if (n_hidden == 1) TAIL_FWD(1, false);
+        else if (n_hidden == 2) TAIL_FWD(2, false);
+        else TAIL_FWD(3, false);
+    } else {
+        if (n_hidden == 1) TAIL_FWD(1, true);
+        else if (n_hidden == 2) TAIL_FWD(2, true);
+        else TAIL_FWD(3, true);
+    }
+#undef TAIL_FWD
     RP_LAUNCH_CHECK("mlp_tail_fwd");
     return RP_OK;
+}
+
+extern "C" int rp_mlp_tail_fwd(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                               const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out,
+                               float *logit, int64_t M, rp_stream_t stream) {
+    RP_REQUIRE(logit != nullptr, "mlp_tail_fwd: null pointer");
+    return tail_fwd_launch(hin, ldin, n_hidden, W_hidden, ldw, b_hidden, h_out, w_out, b_out, logit, M, nullptr, stream);
+}
+
+// partial sums the loss head writes: one per 128 rows
+extern "C" int rp_mlp_tail_loss_partials(int64_t M) { return (int)rp_cdiv(M > 0 ? M : 1, 128); }
+
+// The tail's forward with the model's loss head inside: pred [M] = sigmoid(addends[0] + .. + tail logit), partial
+// [rp_mlp_tail_loss_partials(M)] = the workgroups' sums of the BCE terms of (pred + p_eps, label) — rp_loss_finish(partial, n,
+// weight / M) gives the mean loss.  (deepfm.py:61-66 on top of layers/deep.py:61-84: three launches of the step in one.)
+extern "C" int rp_mlp_tail_fwd_bce(const float *hin, int64_t ldin, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                                   const float *const *b_hidden, float *const *h_out, const float *w_out, const float *b_out,
+                                   const float *const *addends, int n_addends, const float *label, float p_eps, float *pred,
+                                   float *partial, int64_t M, rp_stream_t stream) {
+    RP_REQUIRE(label && pred && partial, "mlp_tail_fwd_bce: null pointer");
+    RP_REQUIRE(n_addends >= 0 && n_addends <= 3 && (n_addends == 0 || addends != nullptr), "mlp_tail_fwd_bce: 0..3 other logit addends");
+    TailBce bc{};
+    for (int q = 0; q < n_addends; ++q) {
+        RP_REQUIRE(addends[q] != nullptr, "mlp_tail_fwd_bce: null addend %d", q);
+        bc.add[q] = addends[q];
+    }
+    bc.n_add = n_addends;
+    bc.label = label;
+    bc.p_eps = p_eps;
+    bc.pred = pred;
+    bc.partial = partial;
+    return tail_fwd_launch(hin, ldin, n_hidden, W_hidden, ldw, b_hidden, h_out, w_out, b_out, nullptr, M, &bc, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -204,10 +288,18 @@ struct TailBwdArgs {
 //  of LDS written with 48 two-byte stores per thread and layer: the two activation tiles are then all the LDS a workgroup
 //  holds (70 KB), TWO workgroups fit a CU and all 512 of a 65536-row launch are resident at once.  With one workgroup per
 //  CU — one wave per SIMD — nothing hid the kernel's chains of LDS round trips: 67 us for ~6 us of matrix work.)
+// the loss head's backward folded into the tail's (rp_mlp_tail_bwd_bce): dz[row] is formed from (pred, label, the loss
+// gradient) with rp_sigmoid_bce_bwd's arithmetic instead of being read, and written out for the other logit addends
+struct TailDz {
+    const float *pred, *label, *gloss;  // pred == nullptr: read dz
+    float p_eps, scale;
+    float *dz_out;
+};
+
 template <int L>
 __global__ __launch_bounds__(256, 2) void mlp_tail_bwd_kernel(const float *__restrict__ dz, TailBwdArgs a,
                                                               const float *__restrict__ wout, float *__restrict__ dhin,
-                                                              int64_t lddh, float *__restrict__ P, int64_t M, int nwg) {
+                                                              int64_t lddh, float *__restrict__ P, int64_t M, int nwg, TailDz tz) {
     __shared__ __attribute__((aligned(16))) float T0[4][32][MT_CT];      // dpre_l  (rows of the four waves back to back)
     __shared__ __attribute__((aligned(16))) float T1[4][32][MT_CT];      // a_{l-1}
     __shared__ float dzs[128];                                           // dz of the workgroup's rows (0 beyond M)
@@ -221,7 +313,16 @@ __global__ __launch_bounds__(256, 2) void mlp_tail_bwd_kernel(const float *__res
     float (*T1f)[MT_CT] = reinterpret_cast<float (*)[MT_CT]>(&T1[0][0][0]);
     float *Pg = P + (int64_t)blockIdx.x * ((int64_t)L * 64 * 64 + (int64_t)L * 64 + 64 + 1);
     // ---- head: dpre_L = dz * wout, masked by a_L > 0; dw_out, db_out partials
-    const float dzr = rok ? dz[row] : 0.f;
+    float dzr = 0.f;
+    if (tz.pred == nullptr) {
+        dzr = rok ? dz[row] : 0.f;
+    } else if (rok) {
+        const float g = tz.gloss[0] * tz.scale;
+        const float p = tz.pred[row], y = tz.label[row], pe = p + tz.p_eps;
+        dzr = (pe - y) / fmaxf((1.f - pe) * pe, 1e-12f) * g;
+        dzr *= p * (1.f - p);
+        if (h == 0 && tz.dz_out != nullptr) tz.dz_out[row] = dzr;
+    }
     if (h == 0) dzs[32 * wv + i] = dzr;
     f32x8 dp[4];  // dpre of the current layer, A layout (lane = row, k = 16 ks + 8 h ..)
     {
@@ -387,12 +488,11 @@ extern "C" int rp_mlp_tail_bwd_workspace_bytes(int64_t M, int n_hidden, size_t *
 // parts: 1 = the per-workgroup launch (dhin + partial sums into the workspace), 2 = the second stage (partials -> grads),
 // 3 = both.  The second stage depends on nothing but the workspace: a captured step issues it beside the kernels that
 // follow the first one (rec_pangu_amd/hip.py: mlp_tail_bwd inside a launch plan).
-extern "C" int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
-                                     const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
-                                     float *grads, int64_t M, void *workspace, size_t workspace_bytes, int parts,
-                                     rp_stream_t stream) {
+static int tail_bwd_launch(const float *dz, const TailDz &tz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                           const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
+                           float *grads, int64_t M, void *workspace, size_t workspace_bytes, int parts, rp_stream_t stream) {
     RP_REQUIRE(parts >= 1 && parts <= 3, "mlp_tail_bwd_parts: parts must be 1, 2 or 3");
-    RP_REQUIRE(dz && W_hidden && ldw && acts && w_out && dhin && grads && workspace, "mlp_tail_bwd: null pointer");
+    RP_REQUIRE((dz || tz.pred) && W_hidden && ldw && acts && w_out && dhin && grads && workspace, "mlp_tail_bwd: null pointer");
     if (!rp_mlp_tail_fits(n_hidden, 64, ldact0) || lddh < 64)
         return rp_fail(RP_ERR_UNSUPPORTED, "mlp_tail_bwd: 1..3 hidden layers of width 64");
     RP_REQUIRE(M >= 1, "mlp_tail_bwd: M must be positive");
@@ -420,9 +520,9 @@ extern "C" int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float 
     const int64_t per = (int64_t)n_hidden * 64 * 64 + (int64_t)n_hidden * 64 + 64 + 1;
     hipStream_t s = (hipStream_t)stream;
     if (parts & 1) {
-        if (n_hidden == 1) hipLaunchKernelGGL((mlp_tail_bwd_kernel<1>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
-        else if (n_hidden == 2) hipLaunchKernelGGL((mlp_tail_bwd_kernel<2>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
-        else hipLaunchKernelGGL((mlp_tail_bwd_kernel<3>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg);
+        if (n_hidden == 1) hipLaunchKernelGGL((mlp_tail_bwd_kernel<1>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg, tz);
+        else if (n_hidden == 2) hipLaunchKernelGGL((mlp_tail_bwd_kernel<2>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg, tz);
+        else hipLaunchKernelGGL((mlp_tail_bwd_kernel<3>), dim3(nwg), dim3(256), 0, s, dz, a, w_out, dhin, lddh, P, M, nwg, tz);
         RP_LAUNCH_CHECK("mlp_tail_bwd");
     }
     if (parts & 2) {
@@ -430,6 +530,36 @@ extern "C" int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float 
         RP_LAUNCH_CHECK("mlp_tail_bwd (partials)");
     }
     return RP_OK;
+}
+
+extern "C" int rp_mlp_tail_bwd_parts(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                                     const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
+                                     float *grads, int64_t M, void *workspace, size_t workspace_bytes, int parts,
+                                     rp_stream_t stream) {
+    RP_REQUIRE(dz != nullptr, "mlp_tail_bwd: null pointer");
+    TailDz tz{};
+    return tail_bwd_launch(dz, tz, n_hidden, W_hidden, ldw, acts, ldact0, w_out, dhin, lddh, grads, M, workspace, workspace_bytes,
+                           parts, stream);
+}
+
+// The backward of rp_mlp_tail_fwd_bce: the gradient of the logit is formed per row from (pred, label, gloss[0] * weight / M) —
+// rp_sigmoid_bce_bwd's arithmetic, bit for bit — and also written to dz_out [M] (may be NULL) for the other logit addends.
+// Everything else as rp_mlp_tail_bwd_parts.
+extern "C" int rp_mlp_tail_bwd_bce(const float *pred, const float *label, const float *gloss, float p_eps, float weight,
+                                   float *dz_out, int n_hidden, const float *const *W_hidden, const int64_t *ldw,
+                                   const float *const *acts, int64_t ldact0, const float *w_out, float *dhin, int64_t lddh,
+                                   float *grads, int64_t M, void *workspace, size_t workspace_bytes, int parts,
+                                   rp_stream_t stream) {
+    RP_REQUIRE(pred && label && gloss && M >= 1, "mlp_tail_bwd_bce: null pointer");
+    TailDz tz{};
+    tz.pred = pred;
+    tz.label = label;
+    tz.gloss = gloss;
+    tz.p_eps = p_eps;
+    tz.scale = weight / (float)M;
+    tz.dz_out = dz_out;
+    return tail_bwd_launch(nullptr, tz, n_hidden, W_hidden, ldw, acts, ldact0, w_out, dhin, lddh, grads, M, workspace,
+                           workspace_bytes, parts, stream);
 }
 
 extern "C" int rp_mlp_tail_bwd(const float *dz, int n_hidden, const float *const *W_hidden, const int64_t *ldw,

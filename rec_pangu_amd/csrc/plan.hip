@@ -160,6 +160,24 @@ extern "C" int rp_plan_fork2_mark(void) {
     return RP_OK;
 }
 
+// The main stream waits HERE for the side section (1) of the replay it is part of — for a step that consumes the next
+// batch's sort itself (the optimizer catch-up of the next batch's rows issued at the END of the step, graph_step.py
+// "catch-up ahead").  Without this marker the side section is joined at the end of the replay.  Marker node, section -4.
+extern "C" int rp_plan_join_side(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_join_side: no plan is being recorded");
+    PlanNode n;
+    n.func = nullptr;
+    n.grid = n.block = dim3(0, 0, 0);
+    n.shmem = 0;
+    n.section = -4;
+    n.rec_stream = nullptr;
+    n.blob_at = p->blob.size();
+    p->nodes.push_back(std::move(n));
+    return RP_OK;
+}
+
 extern "C" int rp_plan_is_recording(void) { return rp_plan_recording() ? 1 : 0; }
 
 // the side section of a replay is forked HERE (in front of the next main-section launch) instead of at the start of the
@@ -409,6 +427,14 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
                 e = timed(1, i, [&] { return hipEventRecord(p->ev_fork2, s); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork mark: %s", hipGetErrorString(e));
                 marked2 = true;
+            }
+            continue;
+        }
+        if (n.func == nullptr && n.section == -4) {  // the main stream needs the side section's results from here on
+            if (forked && !side_joined) {
+                e = timed(2, i, [&] { return hipStreamWaitEvent(s, p->ev_join, 0); });
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: join of the side section: %s", hipGetErrorString(e));
+                side_joined = true;
             }
             continue;
         }

@@ -116,9 +116,39 @@ class GraphedTrainStep:
         self.host_call_max_s = 0.0     # the slowest single call (reset by the caller: bench.py's timed window)
         self._last_plan = None
         self._copy_lists = None
+        # Catch-up ahead (launch plans, deferred lazy table optimizer): the captured step ends with the optimizer catch-up of
+        # the NEXT batch's rows — the step's forward then starts at the lookup, the dense Adam launch and the rest of the
+        # first layer's side work run BESIDE that catch-up instead of in front of it.  `_ahead_valid`: the static batch whose
+        # rows the last call left caught up and stamped (None: nobody's); `_ahead_noclear[P]`: plan P's catch-up left its
+        # applied gradient rows uncleared for the next backward to overwrite (LazyAdamRows.replay, mark = 2).
+        self.ahead = os.environ.get("RP_CATCHUP_AHEAD", "0") == "1"
+        self._ahead_used = False
+        self._ahead_valid = None
+        self._ahead_noclear = [False, False]
+
+    # ---- catch-up ahead --------------------------------------------------------------------------------------------------
+    def _ahead_lazy(self):
+        """the embedding layer's deferred lazy state when the step can catch up ahead, else None"""
+        if not self.ahead or self._sharded or self.backend != "plan":
+            return None
+        lz = getattr(self.model.embedding_layer, "_lazy", None)
+        return lz if (lz is not None and lz.defer and lz.t > 0 and getattr(self.opt, "defer", False)) else None
+
+    def _ahead_drop(self):
+        """the promise of the last replay is not going to be kept by a replay (an eager step follows, the static batch is
+        restaged, the captures are dropped): rows it stamped whose applied gradient rows were left uncleared read as zero
+        gradients from here on — what LazyAdamRows does when a second lookup precedes the backward"""
+        if self._ahead_valid is not None:
+            emb = self.model.embedding_layer
+            lz = getattr(emb, "_lazy", None)
+            if lz is not None:
+                lz.resolve_noclear(emb)
+            emb._ahead_done = None
+            self._ahead_valid = None
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
     def _eager(self, batch, nxt):
+        self._ahead_drop()
         if nxt is not None:
             self.model.prefetch(nxt)
         out = self.model(batch)
@@ -171,6 +201,7 @@ class GraphedTrainStep:
             torch._foreach_copy_(dst, src)
 
     def _stage_current(self, batch):
+        self._ahead_drop()  # (before the pinned key list it names is re-sorted in place)
         self._copy(self.P, batch)
         if not self._sharded:
             self.model.embedding_layer.pin_sort(self.X[self.P])
@@ -187,6 +218,11 @@ class GraphedTrainStep:
         plan = hip.LaunchPlan() if want_plan else None
         gen = hip.device_generator(self._drop_clock.device)
         drop = hip.DROPOUT_CAPTURE[0] = {"seed": gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, "clock": self._drop_clock, "calls": 0}
+        emb = self.model.embedding_layer
+        ahead = plan is not None and self._ahead_lazy() is not None and self._ahead_valid == P
+        hip.LaunchPlan.ahead = ahead
+        self.opt.side_dense = ahead
+        held = []
         try:
             if plan is not None:
                 plan.begin()
@@ -196,10 +232,13 @@ class GraphedTrainStep:
                 # aborts the process with hipErrorStreamCaptureUnsupported)
                 mode = "thread_local" if self._sharded else "global"
                 with torch.cuda.graph(g, pool=self._pool, capture_error_mode=mode):
-                    if plan is not None and os.environ.get("RP_PLAN_FORK", "backward") == "start":
-                        plan.fork_here()  # (A/B switch: the next batch's sort beside the catch-up and the gather instead)
+                    fork_start = os.environ.get("RP_PLAN_FORK", "start" if ahead else "backward") == "start"
+                    if plan is not None and fork_start:
+                        # (A/B switch: the next batch's sort beside the catch-up and the gather instead.  Catch-up ahead: the
+                        #  step itself consumes the sort at its end and starts at the lookup — the sort gets the whole step)
+                        plan.fork_here()
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
-                    if plan is not None and os.environ.get("RP_PLAN_FORK", "backward") != "start":
+                    if plan is not None and not fork_start:
                         # the side section (the next batch's sort, recorded last) is forked here: beside the backward,
                         # where the eager path starts it too — beside the catch-up and the gather it costs more than it hides
                         plan.fork_here()
@@ -211,6 +250,10 @@ class GraphedTrainStep:
                     if self.post_backward is not None:
                         self.post_backward()
                     self.opt.step()
+                    if ahead:
+                        # the dense step runs on the side section until the end of the replay: the capture's one-stream
+                        # allocator must not hand the gradients' memory to the launches recorded behind it
+                        held = [p.grad for g_ in self.opt.param_groups for p in g_["params"] if p.grad is not None]
                     self.model.zero_grad()
                     # the next batch (already staged in X[1-P] when the step is launched): keys + sort into its pinned
                     # tensors.  It depends on nothing the step computes and touches persistent buffers only: a plan
@@ -223,10 +266,17 @@ class GraphedTrainStep:
                         self.model.embedding_layer._sort_into(self.X[1 - P], self._pinned(1 - P), on_side_stream=False)
                     if plan is not None:
                         plan.section(0)
+                    if ahead:
+                        plan.join_side()  # the main stream reads the next batch's sorted keys from here on
+                        if not emb.catch_up_ahead(self._pinned(1 - P)[1]):
+                            raise RuntimeError("GraphedTrainStep: the catch-up ahead was not issued")
             finally:
                 hip.DROPOUT_CAPTURE[0] = None
+                hip.LaunchPlan.ahead = False
+                self.opt.side_dense = False
                 if plan is not None:
                     plan.end()
+                del held
         finally:
             # the capture ran the python of one step without executing a kernel: put the host counters back
             self.opt.set_host_counters(counters)
@@ -258,6 +308,11 @@ class GraphedTrainStep:
                     side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev, "inline")
                 plan.set_streams(side, side2)
         self.captures += 1
+        lz = getattr(emb, "_lazy", None)
+        self._ahead_used = ahead  # (also when the step fell back to a hipGraph: the captured launches are the same)
+        self._ahead_noclear[P] = ahead and lz is not None and lz._noclear is not None
+        if lz is not None:
+            lz._cf_ahead = self._ahead_used
         self._drop_calls[P], self._drop_seed = drop["calls"], drop["seed"]
         self.graphs[P], self.plans[P] = g, plan
         self.backend_used = "plan" if plan is not None else "hipgraph"
@@ -287,6 +342,8 @@ class GraphedTrainStep:
         raise RuntimeError("GraphedTrainStep: the static batch lost its pinned sort buffers")
 
     def _drop_captures(self):
+        self._ahead_drop()
+        self._ahead_used = False
         for pl in self.plans:
             if pl is not None:
                 pl.destroy()
@@ -378,6 +435,13 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 self._drop_captures()
             self._sig = sig
+        lz_a = self._ahead_lazy()
+        if lz_a is not None and self._ahead_valid != P and (self.graphs[P] is None or self._ahead_used):
+            # the step before this one was not a replay that caught X[P]'s rows up (the first replay, an eager step in
+            # between, a restaged batch): the same launch, eagerly, in front of the replay that counts on it
+            self._ahead_drop()
+            if self.model.embedding_layer.catch_up_ahead(self._pinned(P)[1]):
+                self._ahead_valid = P
         if self.graphs[P] is None:
             self._capture(P)
         seg("signature")
@@ -417,6 +481,15 @@ class GraphedTrainStep:
         self.opt.advance_host()
         hip.bump_weight_epoch()
         self._dev = self.opt.host_counters()
+        if self._ahead_used:
+            # host mirror of what the replay's last launch did: the next batch's rows are caught up and stamped for the step
+            # that follows (LazyAdamRows.replay's bookkeeping, which no python ran for)
+            emb = self.model.embedding_layer
+            lz, sk_next = emb._lazy, self._pinned(1 - P)[1]
+            lz._marked_for = lz.t + 1
+            lz._noclear = (lz.t + 1, sk_next) if self._ahead_noclear[P] else None
+            emb._ahead_done = sk_next
+            self._ahead_valid = 1 - P
         seg("advance")
         self.replays += 1
         self.P, self._staged = 1 - P, next_batch

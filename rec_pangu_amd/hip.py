@@ -78,6 +78,7 @@ _SIGNATURES = {
     "rp_marker_destroy": (C.c_int, [_vp]),
     "rp_plan_slowest_call": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
+    "rp_plan_join_side": (C.c_int, []),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
@@ -140,6 +141,11 @@ _SIGNATURES = {
     "rp_mlp_tail_bwd_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_mlp_tail_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _vp]),
     "rp_mlp_tail_bwd_parts": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _sz, _i32, _vp]),
+    "rp_mlp_tail_loss_partials": (C.c_int, [_i64]),
+    "rp_mlp_tail_fwd_bce": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _i64, _vp]),
+    "rp_mlp_tail_bwd_bce": (C.c_int, [_vp, _vp, _vp, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp,
+                                      _sz, _i32, _vp]),
+    "rp_loss_finish": (C.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "rp_dropout_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp]),
     "rp_dropout_fwd_dev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _f32, C.c_uint64, C.c_uint64, _vp, _vp]),
     "rp_counter_add_u64": (C.c_int, [_vp, C.c_uint64, _vp]),
@@ -809,7 +815,7 @@ class LaunchPlan:
     def end(self):
         if LaunchPlan._deferred and LaunchPlan.is_recording():
             LaunchPlan.join()  # (nobody joined the inline section after the last deferred launch was queued)
-        LaunchPlan._deferred, LaunchPlan._kept = [], []
+        LaunchPlan._deferred, LaunchPlan._kept, LaunchPlan._ahead_keep = [], [], []
         _check(lib().rp_plan_end(self._h), "rp_plan_end")
         a, b, c = _i32(), _i32(), _i32()
         _check(lib().rp_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)), "rp_plan_info")
@@ -872,6 +878,22 @@ class LaunchPlan:
         cls.run_deferred()
         _check(lib().rp_plan_join(), "rp_plan_join")
         cls._kept = []
+
+    @classmethod
+    def join_only(cls):
+        """join the inline section as it stands: deferred launches stay queued, what they keep alive stays alive"""
+        _check(lib().rp_plan_join(), "rp_plan_join")
+
+    @staticmethod
+    def join_side():
+        """the main stream waits here for the side section (rp_plan_join_side)"""
+        _check(lib().rp_plan_join_side(), "rp_plan_join_side")
+
+    # "catch-up ahead" (graph_step.GraphedTrainStep, recording only): the step catches up the NEXT batch's rows at its end,
+    # beside the dense optimizer step — the first layer's backward then joins only what that launch must not overtake (the
+    # tiny tables' gradient, which reads their rows) and leaves the rest of its side work for the optimizer's side section
+    ahead = False
+    _ahead_keep: list = []
 
     @staticmethod
     def is_recording() -> bool:
@@ -1722,16 +1744,61 @@ def mlp_tail_fwd(hin, Ws, bs, w_out, b_out):
     return logit, hs
 
 
-def mlp_tail_bwd(dz, Ws, acts, w_out):
-    """-> (dhin [M,64] masked by hin > 0, [dW_l], [db_l], dw_out [1,64], db_out [1]) (rp_mlp_tail_bwd)."""
-    M, L = dz.shape[0], len(Ws)
-    dev = dz.device
+def mlp_tail_fwd_bce(hin, Ws, bs, w_out, b_out, addends, label, p_eps: float = 0.0, weight: float = 1.0):
+    """the tail's forward with the loss head inside (rp_mlp_tail_fwd_bce): -> (pred [M,1], loss [] , hidden outputs).
+    The scalar is the only thing the partial sums are for and nobody on the device reads it: inside a recorded launch plan
+    rp_loss_finish is issued on the plan's inline side section (deferred behind the next launches recorded there)."""
+    _req(hin, torch.float32, "hin")
+    _req(label, torch.float32, "label")
+    M, L = hin.shape[0], len(Ws)
+    dev = hin.device
+    hs = [torch.empty((M, 64), dtype=torch.float32, device=dev) for _ in range(L)]
+    pred = torch.empty((M, 1), dtype=torch.float32, device=dev)
+    n_part = lib().rp_mlp_tail_loss_partials(M)
+    partial = torch.empty((n_part,), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    for t in addends:
+        _req(t, torch.float32, "addend")
+        if t.numel() != M or not t.is_contiguous():
+            raise RuntimeError("mlp_tail_fwd_bce: every addend is a contiguous [M] / [M, 1] logit")
+    if label.numel() != M or not label.is_contiguous():
+        raise RuntimeError("mlp_tail_fwd_bce: label must be a contiguous [M]")
+    with _Timed("mlp_tail_fwd", f"{M}x64x{L}+bce", 4 * M * (64 * (L + 1) + 3), 2 * M * (64 * 64 * L + 64)):
+        _check(lib().rp_mlp_tail_fwd_bce(hin.data_ptr(), _rowmajor(hin, "hin"), L, _ptr_array(Ws),
+                                         _i64_array([_rowmajor(w, "W") for w in Ws]), _opt_ptr_array(bs), _ptr_array(hs),
+                                         w_out.data_ptr(), _ptr(b_out), _ptr_array(addends) if addends else None, len(addends),
+                                         label.data_ptr(), p_eps, pred.data_ptr(), partial.data_ptr(), M, _stream()),
+               "rp_mlp_tail_fwd_bce")
+
+    def finish():
+        _check(lib().rp_loss_finish(partial.data_ptr(), n_part, weight / M, loss.data_ptr(), _stream()), "rp_loss_finish")
+
+    if LaunchPlan.is_recording() and os.environ.get("RP_TAIL_REDUCE_SIDE", "1") != "0":
+        LaunchPlan.defer_side(finish, (partial, loss))
+    else:
+        finish()
+    return pred, loss, hs
+
+
+def mlp_tail_bwd(dz, Ws, acts, w_out, bce=None):
+    """-> (dhin [M,64] masked by hin > 0, [dW_l], [db_l], dw_out [1,64], db_out [1]) (rp_mlp_tail_bwd).
+    bce = (pred, label, gloss, p_eps, weight, dz_out): the loss head's backward inside the launch (rp_mlp_tail_bwd_bce) —
+    `dz` is then None and the logit's gradient is written to dz_out [M] for the other logit addends."""
+    M, L = (dz.shape[0] if bce is None else bce[0].shape[0]), len(Ws)
+    dev = dz.device if bce is None else bce[0].device
     dhin = torch.empty((M, 64), dtype=torch.float32, device=dev)
     grads = torch.empty((L * 4096 + L * 64 + 65,), dtype=torch.float32, device=dev)
     nbytes = _sz(0)
     _check(lib().rp_mlp_tail_bwd_workspace_bytes(M, L, C.byref(nbytes)), "rp_mlp_tail_bwd_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
     def launch(parts):
+        if bce is not None:
+            pred, label, gloss, p_eps, weight, dz_out = bce
+            _check(lib().rp_mlp_tail_bwd_bce(pred.data_ptr(), label.data_ptr(), gloss.data_ptr(), p_eps, weight, _ptr(dz_out), L,
+                                             _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]), _ptr_array(acts),
+                                             _rowmajor(acts[0], "hin"), w_out.data_ptr(), dhin.data_ptr(), 64, grads.data_ptr(),
+                                             M, ws.data_ptr(), nbytes.value, parts, _stream()), "rp_mlp_tail_bwd_bce")
+            return
         _check(lib().rp_mlp_tail_bwd_parts(dz.data_ptr(), L, _ptr_array(Ws), _i64_array([_rowmajor(w, "W") for w in Ws]),
                                            _ptr_array(acts), _rowmajor(acts[0], "hin"), w_out.data_ptr(), dhin.data_ptr(), 64,
                                            grads.data_ptr(), M, ws.data_ptr(), nbytes.value, parts, _stream()),

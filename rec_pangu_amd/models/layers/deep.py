@@ -8,6 +8,7 @@ transposed weight + rp_linear_wgrad.  Dropout runs on rp_dropout_* (training mod
 BatchNorm1d on rp_batchnorm_*; Tanh / Sigmoid / LeakyReLU(0.01) are epilogues of the same launch (round 5), other
 activation modules are applied as they are (counted: hip.note_torch_path).
 """
+import os
 from typing import List, Union
 
 import torch
@@ -76,6 +77,21 @@ class MLP(nn.Module):
         if x.dim() != 2 or hip.get_matmul_precision() == "fp32":
             return -1
         return j
+
+    def tail_bce(self, x, start: int, pending, addends, label, p_eps: float = 0.0, weight: float = 1.0):
+        """(pred, loss) of BCE(sigmoid(sum(addends) + rest of the MLP from module `start` on), label) when that rest is exactly
+        the fused tail ([Linear 64x64 + ReLU] x 1..3 -> Linear 64 -> 1 behind a Linear+ReLU whose ReluLink is `pending`) and
+        there are at most 3 other addends: the loss head then rides inside the tail's two launches (Fh.mlp_tail64_bce).
+        None otherwise — the caller runs the MLP and the loss separately."""
+        if not x.is_cuda or pending is None or len(addends) > 3 or os.environ.get("RP_TAIL_BCE", "1") == "0":
+            return None
+        mods = list(self.net)
+        if start <= 0 or self._tail64_start(mods, x) != start:
+            return None
+        if any(a.numel() != x.shape[0] or a.dtype is not torch.float32 for a in addends) or label.numel() != x.shape[0]:
+            return None
+        hidden = [(mods[j].weight, mods[j].bias) for j in range(start, len(mods) - 1, 2)]
+        return Fh.mlp_tail64_bce(x, pending, hidden, (mods[-1].weight, mods[-1].bias), addends, label, p_eps, weight)
 
     def first_linear_relu(self):
         """the first Linear when it is directly followed by a ReLU (what the fused gather + Linear launch replaces)"""

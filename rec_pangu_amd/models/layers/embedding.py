@@ -489,7 +489,7 @@ class EmbeddingLayer(nn.Module):
         shadow = self._shadow_for_training()  # (before the replay below: a rebuild flushes)
         if self._lazy is not None and self._lazy.t > 0:
             keys, sk, sp = self._sorted_keys(idx, self.row_base, self.row_count, src)
-            self._lazy.replay(self, sk)
+            self._replay_rows(sk)
             self._presorted = (keys, sk, sp)
         elif torch.is_grad_enabled():
             self._presorted = self._sorted_keys(idx, self.row_base, self.row_count, src, lookup_only=True)
@@ -498,6 +498,27 @@ class EmbeddingLayer(nn.Module):
         if self.check_indices == "sync":
             self.raise_if_bad_index()
         return out
+
+    def _replay_rows(self, sk) -> None:
+        """the rows of this batch are brought up to date before they are read (LazyAdamRows.replay) — unless the step before
+        this one already did that for exactly this key list (catch_up_ahead)"""
+        done, self._ahead_done = self.__dict__.get("_ahead_done"), None
+        if done is not None and done is sk:
+            return
+        self._lazy.replay(self, sk)
+
+    def catch_up_ahead(self, sk) -> bool:
+        """graph_step's "catch-up ahead": the optimizer catch-up of the NEXT batch's rows (`sk`: its sorted keys, the very
+        tensor its forward will find), issued at the end of the step in progress — after the optimizer step, beside the dense
+        Adam launch.  Same launch, same inputs, earlier: a second catch-up of rows that are already stamped leaves them alone
+        (csrc/adam.hip "DEFERRED execution"), so a forward that does not find this promise just runs its own."""
+        lz = self._lazy
+        if lz is None or not lz.defer or lz.t <= 0:
+            return False
+        with torch.enable_grad():  # (stamps the rows for the step whose backward will write their gradients)
+            lz.replay(self, sk)
+        self._ahead_done = sk
+        return True
 
     def _sorted_keys(self, idx, row_base, row_count, src, lookup_only: bool = False):
         """(keys, sorted keys, positions) of this batch's row requests.  Two layers with the same vocabularies fed the
@@ -651,7 +672,7 @@ class EmbeddingLayer(nn.Module):
             # exact lazy dense Adam: the rows this batch reads must first replay the zero-gradient steps they
             # skipped.  The (row, position) sort the backward needs anyway is done here and reused there.
             keys, sk, sp = self._sorted_keys(idx, row_base, row_count, src if meta is None else None)
-            self._lazy.replay(self, sk)
+            self._replay_rows(sk)
             self._presorted = (keys, sk, sp)
         elif src is not None and meta is None and torch.is_grad_enabled():
             # no replay to do (dense Adam / first step): the backward sorts — unless another layer already has

@@ -9,7 +9,7 @@ from typing import Dict, List
 import torch
 
 from ... import functional as Fh
-from ..base_model import BaseModel, build_loss
+from ..base_model import BaseModel, _is_plain_bce as is_plain_bce, build_loss
 from ..layers import FM_Layer, MLP
 from ..utils import get_dnn_input_dim, get_linear_input
 
@@ -35,6 +35,12 @@ class DeepFM(BaseModel):
                 # lookup + dense concat + FM second order + dnn.net.0 (+ ReLU) in ONE launch; the rest of the MLP follows
                 link = Fh.ReluLink()
                 h1, fm_out = self.embedding_layer.gather_linear(data, dense, first, link)
+                if is_training and is_plain_bce(self.loss_fun):
+                    # sigmoid + BCE (deepfm.py:61-66) inside the fused MLP tail's launches: pred and the gradients are
+                    # bit-identical to the separate launches, the loss is the same sum in another order
+                    out = self.dnn.tail_bce(h1, 2, link, [fm_out], data["label"].float())
+                    if out is not None:
+                        return {"pred": out[0], "loss": out[1]}
                 return self._finish([fm_out, self.dnn(h1, start=2, pending=link)], data, is_training, self.loss_fun)
             x, fm_out = self.embedding_layer.gather_concat(data, dense, want_fm=True)
             link = getattr(self.embedding_layer, "_fm_link", None)

@@ -314,6 +314,9 @@ class LazyAdamRows:
             store.grads_were_zeroed()
 
     def flush(self, store):
+        # (a stamping launch whose rows were never written by a backward — the catch-up ahead of a step that was not taken —
+        #  left applied gradient rows uncleared: they must read as zero before anything applies them again)
+        self.resolve_noclear(store)
         if self.flushed_t == self.t:
             return
         self._check_table(self.t)
@@ -432,9 +435,28 @@ class FusedAdam(torch.optim.Optimizer):
         finally:
             self._in_step = False
         ticks, self._clock_ticks = self._clock_ticks, []
+        if self._side_dense():
+            # catch-up ahead (graph_step): the table clocks tick on the main stream, in front of the next batch's catch-up; the
+            # dense clocks behind the dense step, on the plan's inline side section
+            table = {id(lz.tabs.t_dev) for lz in self._lazies()}
+            mine = [t for t in ticks if id(t) in table]
+            rest = [t for t in ticks if id(t) not in table]
+            for i in range(0, len(mine), 8):
+                hip.counters_add(mine[i:i + 8], 1)
+            hip.LaunchPlan.section(2)
+            try:
+                for i in range(0, len(rest), 8):
+                    hip.counters_add(rest[i:i + 8], 1)
+            finally:
+                hip.LaunchPlan.section(0)
+            return loss
         for i in range(0, len(ticks), 8):  # (every lazy state and every parameter group has a clock of its own)
             hip.counters_add(ticks[i:i + 8], 1)
         return loss
+
+    def _side_dense(self) -> bool:
+        """the dense step of a recorded launch plan goes to the plan's inline side section (graph_step's catch-up ahead)"""
+        return bool(getattr(self, "side_dense", False)) and self._device_clock and hip.LaunchPlan.is_recording()
 
     def _step_groups(self):
         for group in self.param_groups:
@@ -506,8 +528,15 @@ class FusedAdam(torch.optim.Optimizer):
                 tabs = self._dense_tabs.get(id(group)) if self._device_clock else None
                 if tabs is not None:
                     assert tabs.covers(step, lr), "graphed step: the dense step table was not prepared for this step / lr"
-                    hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad, scalars=tabs.sc,
-                                  t_dev=tabs.t_dev)
+                    side = self._side_dense()
+                    if side:
+                        hip.LaunchPlan.section(2)
+                    try:
+                        hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad, scalars=tabs.sc,
+                                      t_dev=tabs.t_dev)
+                    finally:
+                        if side:
+                            hip.LaunchPlan.section(0)
                     self._clock_ticks.append(tabs.t_dev)
                 else:
                     hip.adam_step(ps, gs, ms, vs, lr, b1, b2, eps, step, self.fuse_zero_grad)
@@ -590,6 +619,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # rebuilt by the next eager cf_sync
                 lz._cf_built = lz.t
             lz.t += 1
+            if lz.closed and getattr(lz, "_cf_in_capture", False) and getattr(lz, "_cf_ahead", False):
+                lz._cf_built = lz.t  # (catch-up ahead: the rebuild recorded BEHIND the step brought the table to the new step)
 
     def _adopt_loaded_state(self, store, m, v, lz):
         """Moments that load_state_dict() put into self.state for the table Parameters (optimizer resume) are copied

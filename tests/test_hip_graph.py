@@ -172,6 +172,68 @@ def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch
         assert torch.equal(finals["eager"][k], finals["graph"][k]), k
 
 
+@pytest.mark.parametrize("kind", ["deepfm64", "deepfm16", "dcn"])
+def test_catch_up_ahead_with_everything_that_can_come_between_two_steps(kind, monkeypatch):
+    """RP_CATCHUP_AHEAD=1: a replayed step ends with the optimizer catch-up of the NEXT batch's rows (graph_step.py) — the
+    rows are then stamped 'gradient coming' across the step boundary.  Everything a training loop does between two steps
+    must leave the run bit-identical to the eager loop: an unannounced batch (the promise is dropped: the stamped rows must
+    read as zero gradients), the last batch of an epoch (no next batch: an eager step), an evaluation forward of other rows,
+    a state_dict() (flushes the lazy state), a change of the learning rate."""
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.optim import FusedAdam
+    from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+    monkeypatch.setenv("RP_CATCHUP_AHEAD", "1")
+    monkeypatch.setenv("RP_GRAPH_BACKEND", "plan")
+    enc = _enc(3, [500, 9, 4000, 30, 12000])
+    batches = _batches(enc, 320, 40, seed=11)
+    # (current, announced next, what happens AFTER the step)
+    order = [(i, i + 1, None) for i in range(6)] + [(6, 7, "eval"), (7, 8, None), (8, 9, "state_dict"), (9, 10, None),
+             (10, 30, None),        # announces 30 ...
+             (11, 12, None),        # ... but 11 arrives: the promise for 30's rows is dropped
+             (12, 13, "lr"), (13, 14, None), (14, None, None),  # end of an epoch
+             (20, 21, None), (21, 22, "eval"), (22, 23, None), (23, 24, None)]
+    finals, preds = {}, {}
+    try:
+        for mode in ("eager", "graph"):
+            model = _build(kind, enc)
+            opt = FusedAdam(model.parameters(), lr=2e-3, fuse_zero_grad=True, lazy_tables=True, replay="closed", defer=True)
+            gstep = GraphedTrainStep(model, opt) if mode == "graph" else None
+            seen = []
+            for cur, nxt, after in order:
+                nb = batches[nxt] if nxt is not None else None
+                if gstep is not None:
+                    out = gstep(batches[cur], nb)
+                else:
+                    if nb is not None:
+                        model.prefetch(nb)
+                    out = model(batches[cur])
+                    out["loss"].backward()
+                    opt.step()
+                    model.zero_grad()
+                seen.append(out["loss"].detach().clone())
+                if after == "eval":
+                    model.eval()
+                    with torch.no_grad():
+                        seen.append(model(batches[35])["pred"].detach().clone())
+                    model.train()
+                elif after == "state_dict":
+                    seen.append(torch.cat([v.detach().reshape(-1).float()[:64] for v in model.state_dict().values()]))
+                elif after == "lr":
+                    for grp in opt.param_groups:
+                        grp["lr"] *= 0.5
+            finals[mode] = {k: v.clone() for k, v in model.state_dict().items()}
+            preds[mode] = seen
+            if gstep is not None:
+                assert gstep._ahead_used and gstep.backend_used == "plan", (gstep._ahead_used, gstep.backend_used, gstep.why_not_plan)
+                assert gstep.replays >= len(order) - 2 - 3
+    finally:
+        EmbeddingLayer.unpin_sorts()
+    for i, (a, b) in enumerate(zip(preds["eager"], preds["graph"])):
+        assert torch.equal(a, b), f"observation {i} differs"
+    for k in finals["eager"]:
+        assert torch.equal(finals["eager"][k], finals["graph"][k]), k
+
+
 def test_graphed_step_above_a_million_pairs(backend):
     """1.2 M (sample, field) pairs per batch: the size at which rocPRIM's onesweep sort faulted under unsynchronised
     replays (GraphedTrainStep.MAX_PAIRS_ROCPRIM).  The own radix sort has no memset nodes: 60 replays without a

@@ -781,6 +781,48 @@ def test_mlp_tail_fused_vs_fp64(hip, M, L):
     close(dbo, bo64.grad, "db_out")
 
 
+@pytest.mark.parametrize("M,L,n_add", [(65536, 2, 1), (1000, 1, 0), (4099, 3, 2), (128, 2, 3)])
+def test_mlp_tail_with_the_loss_head_inside_vs_separate_launches(hip, M, L, n_add):
+    """rp_mlp_tail_fwd_bce / rp_mlp_tail_bwd_bce (deepfm.py:61-66 folded into the MLP tail's two launches) against
+    mlp_tail64 + sigmoid_bce on the same inputs: the predictions and EVERY gradient bit-identical (the same arithmetic per
+    row), the loss within fp32 rounding of its sum (another order) and of an fp64 evaluation of the reference's formula."""
+    from rec_pangu_amd import functional as Fh
+    g = torch.Generator().manual_seed(7 * M + L)
+    dev = lambda t_: t_.to(DEV)
+    hin0 = dev(torch.randn(M, 64, generator=g).relu())
+    Ws0 = [dev(torch.randn(64, 64, generator=g) / 8) for _ in range(L)]
+    bs0 = [dev(torch.randn(64, generator=g) * 0.1) for _ in range(L)]
+    wo0, bo0 = dev(torch.randn(1, 64, generator=g) / 8), dev(torch.randn(1, generator=g))
+    adds0 = [dev(torch.randn(M, 1, generator=g)) for _ in range(n_add)]
+    label = dev((torch.rand(M, generator=g) < 0.3).float())
+    seed = dev(torch.tensor(0.75))  # (a loss gradient that is not 1: it is read on the device)
+    res = {}
+    for mode in ("separate", "fused"):
+        hin = hin0.clone().requires_grad_(True)
+        Ws = [w.clone().requires_grad_(True) for w in Ws0]
+        bs = [b.clone().requires_grad_(True) for b in bs0]
+        wo, bo = wo0.clone().requires_grad_(True), bo0.clone().requires_grad_(True)
+        adds = [a.clone().requires_grad_(True) for a in adds0]
+        link = Fh.ReluLink()
+        if mode == "separate":
+            logit = Fh.mlp_tail64(hin, link, list(zip(Ws, bs)), (wo, bo))
+            pred, loss = Fh.sigmoid_bce(adds + [logit], label)
+        else:
+            pred, loss = Fh.mlp_tail64_bce(hin, link, list(zip(Ws, bs)), (wo, bo), adds, label)
+        loss.backward(gradient=seed)
+        res[mode] = (pred.detach(), loss.detach(), [t.grad for t in (hin, *Ws, *bs, wo, bo, *adds)], link.dx)
+    a, b = res["separate"], res["fused"]
+    assert torch.equal(a[0], b[0]), "pred differs"
+    for i, (x, y) in enumerate(zip(a[2], b[2])):
+        assert x is not None and y is not None and torch.equal(x, y), f"gradient {i} differs"
+    assert torch.equal(a[3], b[3]), "the masked input gradient handed to the producing layer differs"
+    p64 = a[0].double().reshape(-1).cpu()
+    y64 = label.double().cpu()
+    ref = -(y64 * p64.log().clamp_min(-100) + (1 - y64) * (1 - p64).log().clamp_min(-100)).mean()
+    assert abs(float(b[1]) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(a[1]) - float(b[1])) <= 2e-6 * max(1.0, abs(float(ref)))
+
+
 @pytest.mark.parametrize("rows,ND,B,biased", [
     ([8, 4, 51, 12, 3], 5, 24, True),          # one partial workgroup
     ([3, 4, 10, 5000, 27], 13, 4099, True),    # 32 full workgroups + a 3-sample tail, the Criteo dense count
