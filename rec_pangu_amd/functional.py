@@ -1004,7 +1004,8 @@ class _EmbedGatherLinear(torch.autograd.Function):
         # (re-measured at the end of round 5, after the loss head moved into the MLP tail and the side streams went to the
         #  lowest priority: main launch first 0.8324 / 0.8375 ms against 0.8369 / 0.8384 in the 20-step window, 0.8086 / 0.8099
         #  against 0.8152 / 0.8161 over 600 steps — ON by default now; RP_SEG_FIRST=0: the side launches first)
-        seg_first = in_plan and seg is not None and need_t and os.environ.get("RP_SEG_FIRST", "1") == "1"
+        seg_first = (in_plan and seg is not None and need_t and not hip.LaunchPlan.ahead
+                     and os.environ.get("RP_SEG_FIRST", "1") == "1")
         # catch-up ahead (graph_step): the step's last main-stream launch rewrites table rows, so only the tiny tables' gradient
         # (which READS their rows) runs beside rp_embed_grad_seg and is joined behind it; the weight gradient's dense columns
         # and the deferred side launches are issued after that join and run beside the catch-up, joined at the end of the replay
