@@ -441,9 +441,10 @@ def main():
     # batch size; a step that must fall back to a hipGraph (dcn: ATen launches inside) only where the host is the limit.
     plan_ok = args.graph_backend != "hipgraph" and os.environ.get("RP_GRAPH_BACKEND", "plan") == "plan"
     use_graph = args.mode == "train" and not args.no_sort_ahead and (
-        args.graph == "on" or (args.graph == "auto" and not sharded and args.model in ("deepfm", "dcn")
-                               and (local_B <= 16384 or plan_ok)))  # (dcn: a plan since round 5 — its [L, d] weight-space
-    #                              arithmetic is one library launch; a step that still falls back to a hipGraph is timed eagerly)
+        args.graph == "on" or (args.graph == "auto" and not sharded and args.model in ("deepfm", "dcn", "mmoe")
+                               and (local_B <= 16384 or plan_ok)))  # (dcn, mmoe: plans since round 5 — their weight-space
+    #                              arithmetic, BatchNorm statistics and loss sum are library launches; a step that still
+    #                              falls back to a hipGraph is timed eagerly)
     gstep = None
     if use_graph:
         from rec_pangu_amd.graph_step import GraphedTrainStep

@@ -467,6 +467,11 @@ int rp_dice_gate_bwd(const float *x, int64_t ldx, const float *xhat, int64_t ldh
  *   rp_batchnorm_bwd_sums   dbeta[n] = sum_m dy, dgamma[n] = sum_m dy * xhat  (xhat from the given mean / rstd)
  *   rp_batchnorm_bwd_apply  dx = gamma * rstd * (dy - mean_dy - xhat * mean_dyx) with the given (global) means
  * workspace: rp_batchnorm_workspace_bytes(M, N). */
+/* nn.BatchNorm1d's running statistics of one training forward in ONE launch (mmoe.py:54 towers; torch/nn/modules/batchnorm.py):
+ * num_batches_tracked (int64[1], may be NULL) += 1; running_x = (1 - m) running_x + m batch_x, the variance unbiased by
+ * M / (M - 1); momentum < 0 = None: the cumulative average m = 1 / num_batches_tracked. */
+int rp_batchnorm_update_running(const float *mean, const float *var, float *running_mean, float *running_var,
+                                int64_t *num_batches_tracked, float momentum, int64_t M, int N, rp_stream_t stream);
 int rp_batchnorm_colsum(const float *x, int64_t ldx, const float *center, float *out, int64_t M, int N, void *workspace,
                         size_t workspace_bytes, rp_stream_t stream);
 int rp_batchnorm_bwd_sums(const float *x, int64_t ldx, const float *dy, int64_t lddy, const float *mean,
@@ -542,6 +547,11 @@ int rp_loss_partials(int64_t B);
 int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
                        int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
                        rp_stream_t stream);
+/* rp_sigmoid_bce_fwd with loss[0] += instead of = : the second .. last task of a multi-task loss (mmoe.py:127: the sum of the
+ * tasks' weighted means, added in task order like the reference's python sum) */
+int rp_sigmoid_bce_fwd_accum(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
+                             int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
+                             rp_stream_t stream);
 /* loss[0] = scale * sum(partial[0..n)), fixed order (the second stage of rp_sigmoid_bce_fwd; also ends rp_mlp_tail_fwd_bce) */
 int rp_loss_finish(const float *partial, int n, float scale, float *loss, rp_stream_t stream);
 /* dz[b] = gloss[0] * weight/B * dBCE/dp * (apply_sigmoid ? p(1-p) : 1) */

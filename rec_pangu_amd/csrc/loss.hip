@@ -44,13 +44,18 @@ __global__ __launch_bounds__(LOSS_BLOCK) void sigmoid_bce_fwd_kernel(ZPtrs z, in
     if (threadIdx.x == 0 && partial != nullptr) partial[blockIdx.x] = tot;
 }
 
+// accumulate: loss[0] += (a multi-task loss: sum of the tasks' weighted means, multi_task/mmoe.py:127 — each task's launch adds
+// its term, in task order: the same fp32 additions as the reference's python sum)
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_finish_kernel(const float *__restrict__ partial, int n, float scale,
-                                                                 float *__restrict__ loss) {
+                                                                 float *__restrict__ loss, int accumulate) {
     __shared__ float sh[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += LOSS_BLOCK) acc += partial[i];
     const float tot = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) loss[0] = tot * scale;
+    if (threadIdx.x == 0) {
+        const float term = __fmul_rn(tot, scale);  // (no contraction into an fma: the python sum rounds the product first)
+        loss[0] = accumulate ? __fadd_rn(loss[0], term) : term;
+    }
 }
 
 __global__ __launch_bounds__(LOSS_BLOCK) void sigmoid_bce_bwd_kernel(const float *__restrict__ pred,
@@ -75,9 +80,9 @@ static int loss_blocks(int64_t B) {
 
 extern "C" int rp_loss_partials(int64_t B) { return loss_blocks(B); }
 
-extern "C" int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
+static int sigmoid_bce_fwd_launch(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
                                   int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
-                                  rp_stream_t stream) {
+                                  int accumulate, rp_stream_t stream) {
     RP_REQUIRE(z_ptrs && n_addends >= 1 && n_addends <= 4, "sigmoid_bce_fwd: 1..4 logit addends");
     RP_REQUIRE(B >= 1, "sigmoid_bce_fwd: empty batch");
     RP_REQUIRE(loss == nullptr || (label && partial), "sigmoid_bce_fwd: loss needs label and partial");
@@ -92,10 +97,24 @@ extern "C" int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int
                        loss ? label : nullptr, B, p_eps, pred, loss ? partial : nullptr);
     RP_LAUNCH_CHECK("sigmoid_bce_fwd");
     if (loss != nullptr) {
-        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, s, partial, nb, weight / (float)B, loss);
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, s, partial, nb, weight / (float)B, loss, accumulate);
         RP_LAUNCH_CHECK("loss_finish");
     }
     return RP_OK;
+}
+
+extern "C" int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
+                                  int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
+                                  rp_stream_t stream) {
+    return sigmoid_bce_fwd_launch(z_ptrs, n_addends, apply_sigmoid, label, B, p_eps, weight, pred, partial, loss, 0, stream);
+}
+
+// the same with loss[0] += instead of = (the second .. last task of a multi-task loss)
+extern "C" int rp_sigmoid_bce_fwd_accum(const float *const *z_ptrs, int n_addends, int apply_sigmoid, const float *label,
+                                        int64_t B, float p_eps, float weight, float *pred, float *partial, float *loss,
+                                        rp_stream_t stream) {
+    RP_REQUIRE(loss != nullptr, "sigmoid_bce_fwd_accum: null loss");
+    return sigmoid_bce_fwd_launch(z_ptrs, n_addends, apply_sigmoid, label, B, p_eps, weight, pred, partial, loss, 1, stream);
 }
 
 // loss[0] = scale * sum(partial[0..n)) in a fixed order (the second stage of rp_sigmoid_bce_fwd as an entry of its own: the
@@ -103,7 +122,7 @@ extern "C" int rp_sigmoid_bce_fwd(const float *const *z_ptrs, int n_addends, int
 // its side section)
 extern "C" int rp_loss_finish(const float *partial, int n, float scale, float *loss, rp_stream_t stream) {
     RP_REQUIRE(partial && loss && n >= 1, "loss_finish: bad argument");
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, partial, n, scale, loss);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, partial, n, scale, loss, 0);
     RP_LAUNCH_CHECK("loss_finish");
     return RP_OK;
 }

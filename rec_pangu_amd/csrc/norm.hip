@@ -369,6 +369,33 @@ extern "C" int rp_batchnorm_apply_bwd(const float *dy, int64_t lddy, const float
 //                           out[n] = sum_m (x[m,n] - center[n])^2     (center given: variance around the global mean)
 //   rp_batchnorm_bwd_sums   dbeta[n] = sum_m dy, dgamma[n] = sum_m dy * xhat   (xhat from the given mean / rstd)
 //   rp_batchnorm_bwd_apply  dx = gamma * rstd * (dy - mean_dy - xhat * mean_dyx)  with the given (global) means
+
+// nn.BatchNorm1d's running statistics of one training forward (torch/nn/modules/batchnorm.py: exponential with `momentum`, or
+// the cumulative average 1 / num_batches_tracked when momentum < 0 stands for None), as ONE launch instead of six ATen ones:
+//   num_batches_tracked += 1;  running_mean = (1 - m) running_mean + m mean;  running_var = (1 - m) running_var + m var M/(M-1)
+__global__ __launch_bounds__(256) void bn_running_kernel(const float *__restrict__ mean, const float *__restrict__ var,
+                                                         float *__restrict__ rmean, float *__restrict__ rvar,
+                                                         long long *__restrict__ tracked, float momentum, float unbias, int N) {
+    const long long seen = tracked != nullptr ? tracked[0] + 1 : 1;
+    const float m = momentum >= 0.f ? momentum : 1.f / (float)seen;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        rmean[i] = __builtin_fmaf(m, mean[i], rmean[i] * (1.f - m));
+        rvar[i] = __builtin_fmaf(m, var[i] * unbias, rvar[i] * (1.f - m));
+    }
+    __syncthreads();  // (every thread has read the counter)
+    if (threadIdx.x == 0 && tracked != nullptr) tracked[0] = seen;
+}
+
+extern "C" int rp_batchnorm_update_running(const float *mean, const float *var, float *running_mean, float *running_var,
+                                           int64_t *num_batches_tracked, float momentum, int64_t M, int N, rp_stream_t stream) {
+    RP_REQUIRE(mean && var && running_mean && running_var && N >= 1 && M >= 1, "batchnorm_update_running: bad argument");
+    const float unbias = (float)M / (float)(M > 1 ? M - 1 : 1);
+    hipLaunchKernelGGL(bn_running_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, var, running_mean, running_var,
+                       reinterpret_cast<long long *>(num_batches_tracked), momentum, unbias, N);
+    RP_LAUNCH_CHECK("batchnorm_update_running");
+    return RP_OK;
+}
+
 extern "C" int rp_batchnorm_colsum(const float *x, int64_t ldx, const float *center, float *out, int64_t M, int N,
                                    void *workspace, size_t workspace_bytes, rp_stream_t stream) {
     RP_REQUIRE(x && out && workspace && M >= 1 && N >= 1 && ldx >= N, "batchnorm_colsum: bad argument");

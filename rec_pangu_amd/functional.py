@@ -593,8 +593,71 @@ class _LinearInputMajor(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dW, _ = hip.linear_wgrad(x[:, :h], dz, N, want_bias=False)  # roles swapped: x^T @ dz -> [h, N]
         if ctx.needs_input_grad[2]:
-            _, db = hip.linear_wgrad(dz, dz, 1)  # column sums of dz ride on the wgrad kernel (K=1)
+            # column sums of dz: the deterministic two-stage column-sum kernel (they rode on the wgrad kernel with K = 1 until
+            # round 5: 0.137 ms at [65536, 520], 8x the time of streaming dz once)
+            db = hip.batchnorm_colsum(dz)
         return dx, dW, db
+
+
+class _MMOEProject(torch.autograd.Function):
+    """z = x[:, :h] @ [experts | gate_1 | .. | gate_T] + [experts_bias | gate biases]  (multi_task/mmoe.py:86-104 as ONE GEMM)
+    straight from the model's parameters: forward(x, pack, T, experts [h,K,E], experts_bias, *gates [h,E], *gate_biases [E]).
+    `pack` [rows of x, N] is a persistent buffer of the model whose rows beyond h are zero (the dgrad's weight operand: it
+    writes exact zeros into x's padding columns): the parameters are copied into their column blocks by rp_copy_rows /
+    rp_multi_copy and their gradients leave as contiguous blocks the same way — torch.cat (x2), the padded copy and its
+    zero fill, and autograd's strided-gradient clones were 6+ ATen launches per step."""
+
+    @staticmethod
+    def forward(ctx, x, pack, T: int, experts, experts_bias, *gw):
+        x = _unit_inner(x)
+        h, K, E = experts.shape
+        gates, gbias = gw[:T], gw[T:]
+        N = K * E + T * E
+        hip.copy_rows_to(experts.detach().reshape(h, K * E), pack[:h, :K * E])
+        for t in range(T):
+            hip.copy_rows_to(gates[t].detach(), pack[:h, K * E + t * E:K * E + (t + 1) * E])
+        bias = torch.empty((N,), dtype=torch.float32, device=x.device)
+        dst = [bias[:K * E]] + [bias[K * E + t * E:K * E + (t + 1) * E] for t in range(T)]
+        src = [experts_bias.detach().reshape(-1)] + [b.detach() for b in gbias]
+        if not hip.multi_copy(dst, src):
+            torch._foreach_copy_(dst, src)
+        Wm = pack[:h]
+        z = hip.linear_fwd(x, hip.transpose(Wm), bias, ACT_NONE, K=h)
+        ctx.cfg = (h, K, E, T)
+        ctx.save_for_backward(x, pack)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, pack = ctx.saved_tensors
+        h, K, E, T = ctx.cfg
+        dz = _unit_inner(dz)
+        N = K * E + T * E
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            hip.linear_fwd(dz, pack, None, ACT_NONE, out=dx)  # dz @ Wm^T (the zero rows of pack give the padding columns of dx)
+        need = ctx.needs_input_grad  # (x, pack, T, experts, experts_bias, gates.., gate biases..: the reference's gates are
+        #                               plain tensors, not parameters — buffers here — and take no gradient)
+        dexp, dgates = None, [None] * T
+        if need[3] or any(need[5:5 + T]):
+            dW, _ = hip.linear_wgrad(x[:, :h], dz, N, want_bias=False)  # roles swapped: x^T @ dz -> [h, N]
+            if need[3]:
+                dexp = hip.copy_rows_to(dW[:, :K * E], torch.empty((h, K * E), dtype=torch.float32, device=x.device)).view(h, K, E)
+            for t in range(T):
+                if need[5 + t]:
+                    dgates[t] = hip.copy_rows_to(dW[:, K * E + t * E:K * E + (t + 1) * E],
+                                                 torch.empty((h, E), dtype=torch.float32, device=x.device))
+        dbe, dbias = None, [None] * T
+        if need[4] or any(need[5 + T:5 + 2 * T]):
+            db = hip.batchnorm_colsum(dz)
+            dbe = db[:K * E].view(K, E) if need[4] else None
+            dbias = [db[K * E + t * E:K * E + (t + 1) * E] if need[5 + T + t] else None for t in range(T)]
+        return (dx, None, None, dexp, dbe, *dgates, *dbias)
+
+
+def mmoe_project(x, pack, experts, experts_bias, gates, gate_biases):
+    return _MMOEProject.apply(x, pack, len(gates), experts, experts_bias, *gates, *gate_biases)
 
 
 def linear_input_major(x, Wm, bias):
@@ -608,13 +671,23 @@ class _MMOECombine(torch.autograd.Function):
         out, gate = hip.mmoe_combine_fwd(z, K, E, T)
         ctx.cfg = (K, E, T)
         ctx.save_for_backward(z, gate)
-        return out
+        ctx.set_materialize_grads(False)
+        # T outputs, one per task (the rows of one [T, B, K] buffer): handed out as ONE tensor, the towers' slices came back
+        # through autograd as T zero-filled [T, B, K] gradients plus their sum — 2T + 1 ATen launches over 67 MB each
+        return tuple(out[t] for t in range(T))
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         z, gate = ctx.saved_tensors
         K, E, T = ctx.cfg
-        dz = hip.mmoe_combine_bwd(z, K, E, T, gate, dout.contiguous())
+        dout = torch.empty((T, z.shape[0], K), dtype=torch.float32, device=z.device)
+        have = [t for t in range(T) if douts[t] is not None]
+        for t in range(T):
+            if douts[t] is None:
+                dout[t].zero_()  # (a task whose mixture nobody used)
+        if have and not hip.multi_copy([dout[t] for t in have], [douts[t].contiguous() for t in have]):
+            torch._foreach_copy_([dout[t] for t in have], [douts[t] for t in have])
+        dz = hip.mmoe_combine_bwd(z, K, E, T, gate, dout)
         if z.shape[1] != dz.shape[1]:
             full = torch.zeros_like(z)
             full[:, :dz.shape[1]] = dz
@@ -623,7 +696,7 @@ class _MMOECombine(torch.autograd.Function):
 
 
 def mmoe_combine(z, K: int, E: int, T: int):
-    """z [B, K*E + T*E] (experts | gate logits) -> [T, B, K] gate-weighted expert mixtures."""
+    """z [B, K*E + T*E] (experts | gate logits) -> T gate-weighted expert mixtures [B, K] (the rows of one [T, B, K] buffer)."""
     return _MMOECombine.apply(z, K, E, T)
 
 
@@ -663,11 +736,14 @@ class _BatchNormTrain(torch.autograd.Function):
         y, mean, var, rstd = hip.batchnorm_train_fwd(x, gamma, beta, eps)
         ctx.save_for_backward(x, mean, rstd, gamma)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)  # (the statistics' gradients were materialised as zero fills: 2 ATen launches per BN)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _gm, _gv):
         x, mean, rstd, gamma = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None
         dx, dgamma, dbeta = hip.batchnorm_train_bwd(x, _unit_inner(dy), mean, rstd, gamma)
         # (affine=False — Dice's BatchNorm — has neither: a gradient for a None input is an autograd error)
         return dx, (dgamma if gamma is not None else None), (dbeta if ctx.needs_input_grad[2] else None), None
@@ -701,12 +777,8 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d):
     if use_batch:
         y, mean, var = _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.eps)
         if bn.training and bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                M = x.shape[0]
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var * (M / max(M - 1, 1)), alpha=mom)
+            # one launch (six ATen launches per BatchNorm until round 5: 24 per MMOE step); in place, like nn.BatchNorm1d
+            hip.batchnorm_update_running(mean, var, bn, x.shape[0])
         return y
     rstd = torch.rsqrt(bn.running_var + bn.eps)
     return _BatchNormApply.apply(x, bn.running_mean, rstd, bn.weight, bn.bias)
@@ -794,6 +866,49 @@ class _SigmoidBCE(torch.autograd.Function):
 def sigmoid_bce(addends: Sequence[torch.Tensor], label: torch.Tensor, apply_sigmoid=True, p_eps=0.0, weight=1.0):
     """pred [B,1] = sigmoid(sum(addends)); loss = weight * mean BCE(pred + p_eps, label)."""
     return _SigmoidBCE.apply(label, apply_sigmoid, p_eps, weight, *addends)
+
+
+class _SigmoidBCEMulti(torch.autograd.Function):
+    """The multi-task loss (multi_task/mmoe.py:127, towers.py): forward(T, apply_sigmoid, p_eps, weights, *labels, *logits) ->
+    (pred_1 .. pred_T, loss) with loss = sum_i weights[i] * mean BCE(pred_i + p_eps, label_i): every task's launch adds its
+    term to ONE device scalar, in task order — the fp32 additions of the reference's python sum without its ATen launches."""
+
+    @staticmethod
+    def forward(ctx, T: int, apply_sigmoid: bool, p_eps: float, weights, *rest):
+        ctx.set_materialize_grads(False)
+        labels = [t.contiguous() for t in rest[:T]]
+        logits = [t.contiguous() for t in rest[T:]]
+        preds, loss = [], None
+        for i in range(T):
+            pred, loss = hip.sigmoid_bce_fwd([logits[i]], labels[i], apply_sigmoid, p_eps, float(weights[i]), add_to=loss)
+            preds.append(pred)
+        ctx.cfg = (T, apply_sigmoid, p_eps, [float(w) for w in weights], [tuple(t.shape) for t in rest[T:]])
+        ctx.save_for_backward(*preds, *labels)
+        return (*preds, loss)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        T, apply_sigmoid, p_eps, weights, shapes = ctx.cfg
+        saved = ctx.saved_tensors
+        preds, labels = saved[:T], saved[T:]
+        dloss = grads[T]
+        outs = []
+        for i in range(T):
+            dz = None
+            if dloss is not None:
+                dz = hip.sigmoid_bce_bwd(preds[i], labels[i], dloss, apply_sigmoid, p_eps, weights[i])
+            if grads[i] is not None:  # someone differentiated through a prediction itself (rare): torch ops on device
+                extra = grads[i] * (preds[i] * (1 - preds[i]) if apply_sigmoid else 1.0)
+                dz = extra if dz is None else dz + extra
+            outs.append(None if dz is None else dz.reshape(shapes[i]))
+        return (None, None, None, None) + (None,) * T + tuple(outs)
+
+
+def sigmoid_bce_multi(logits: Sequence[torch.Tensor], labels: Sequence[torch.Tensor], weights, apply_sigmoid=True, p_eps=0.0):
+    """([pred_i [B,1]], loss) with loss = sum_i weights[i] * mean BCE(sigmoid(logits[i]) + p_eps, labels[i])"""
+    T = len(logits)
+    out = _SigmoidBCEMulti.apply(T, apply_sigmoid, float(p_eps), tuple(float(w) for w in weights), *labels, *logits)
+    return list(out[:T]), out[T]
 
 
 class _SigmoidSum(torch.autograd.Function):

@@ -131,6 +131,7 @@ _SIGNATURES = {
                                          _vp]),
     "rp_batchnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rp_batchnorm_apply_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "rp_batchnorm_update_running": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _vp]),
     "rp_batchnorm_colsum": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_sums": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_batchnorm_bwd_apply": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
@@ -152,6 +153,7 @@ _SIGNATURES = {
     "rp_dropout_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _f32, _vp]),
     "rp_loss_partials": (C.c_int, [_i64]),
     "rp_sigmoid_bce_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "rp_sigmoid_bce_fwd_accum": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rp_sigmoid_bce_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp]),
     "rp_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _f64, _f64, _f64, _f64, _i64, _i32, _vp, _vp, _vp]),
     "rp_counter_add": (C.c_int, [_vp, _i32, _vp]),
@@ -772,6 +774,19 @@ def copy_rows(w, ld_out: int):
     with _Timed("copy_rows", f"{R}x{Cc}", 8 * R * Cc):
         _check(lib().rp_copy_rows(w.data_ptr(), _rowmajor(w, "w"), buf.data_ptr(), ld_out, R, Cc, _stream()), "rp_copy_rows")
     return buf[:, :Cc]
+
+
+def copy_rows_to(src, dst):
+    """dst[r, :] = src[r, :] for 2-D fp32 tensors of one shape with unit inner stride, any row strides (rp_copy_rows): packs a
+    matrix into a column block of a wider one, or a column block out into a contiguous matrix"""
+    _req(src, torch.float32, "src")
+    _req(dst, torch.float32, "dst")
+    if src.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1:
+        raise RuntimeError("copy_rows_to: two 2-D tensors of one shape with unit inner stride")
+    R, Cc = src.shape
+    with _Timed("copy_rows", f"{R}x{Cc}", 8 * R * Cc):
+        _check(lib().rp_copy_rows(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), R, Cc, _stream()), "rp_copy_rows")
+    return dst
 
 
 class Marker:
@@ -1552,7 +1567,7 @@ def batchnorm_apply_bwd(dy, rstd, gamma):
 
 
 def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tensor], apply_sigmoid: bool = True,
-                    p_eps: float = 0.0, weight: float = 1.0):
+                    p_eps: float = 0.0, weight: float = 1.0, add_to: Optional[torch.Tensor] = None):
     B = addends[0].numel()
     for z in addends:
         _req(z, torch.float32, "logit")
@@ -1566,11 +1581,14 @@ def sigmoid_bce_fwd(addends: Sequence[torch.Tensor], label: Optional[torch.Tenso
         if label.numel() != B or not label.is_contiguous():
             raise RuntimeError("label must be contiguous float32 with B elements")
         partial = torch.empty((lib().rp_loss_partials(B),), dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev) if add_to is None else add_to
+    elif add_to is not None:
+        raise RuntimeError("sigmoid_bce_fwd: add_to needs a label")
     with _Timed("sigmoid_bce_fwd"):
-        _check(lib().rp_sigmoid_bce_fwd(_ptr_array(addends), len(addends), int(apply_sigmoid), _ptr(label), B, p_eps,
-                                    weight, pred.data_ptr(), _ptr(partial), _ptr(loss), _stream()),
-           "rp_sigmoid_bce_fwd")
+        # add_to: the loss scalar of the tasks before this one (a multi-task loss): this launch ADDS its weighted mean
+        fn = lib().rp_sigmoid_bce_fwd if add_to is None else lib().rp_sigmoid_bce_fwd_accum
+        _check(fn(_ptr_array(addends), len(addends), int(apply_sigmoid), _ptr(label), B, p_eps, weight, pred.data_ptr(),
+                  _ptr(partial), _ptr(loss), _stream()), "rp_sigmoid_bce_fwd")
     return pred, loss
 
 
@@ -1679,6 +1697,18 @@ def route_pad(sorted_keys, sorted_pos, world: int, lbits: int, capacity: int, co
                                   counts.data_ptr(), slot_sorted.data_ptr(), slot_of_pair.data_ptr(),
                                   rows_padded.data_ptr(), err_flag.data_ptr(), _stream()), "rp_route_pad")
     return rows_padded
+
+
+def batchnorm_update_running(mean, var, bn, M: int):
+    """bn.running_mean / running_var / num_batches_tracked after one training forward over M rows (rp_batchnorm_update_running)"""
+    for t in (mean, var, bn.running_mean, bn.running_var):
+        _req(t, torch.float32, "statistics")
+    nbt = bn.num_batches_tracked
+    if nbt is not None and (nbt.dtype is not torch.int64 or not nbt.is_cuda):
+        raise RuntimeError("batchnorm_update_running: num_batches_tracked must be an int64 device tensor")
+    _check(lib().rp_batchnorm_update_running(mean.data_ptr(), var.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                             _ptr(nbt), -1.0 if bn.momentum is None else float(bn.momentum), M, mean.numel(),
+                                             _stream()), "rp_batchnorm_update_running")
 
 
 def batchnorm_colsum(x, center=None):

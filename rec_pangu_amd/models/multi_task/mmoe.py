@@ -85,9 +85,19 @@ class MMOE(BaseModel):
         -> towers (Linear on the MFMA kernel, BatchNorm1d on rp_batchnorm_*; Dropout as it is) -> sigmoid+BCE(p+1e-6) kernel."""
         x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
         h, K, E, T = self.experts.shape[0], self.mmoe_hidden_dim, self.n_expert, self.num_task
-        w_cat = torch.cat([self.experts.reshape(h, K * E)] + self.gates, dim=1)
-        b_cat = torch.cat([self.experts_bias.reshape(-1)] + self.gates_bias)
-        mix = Fh.mmoe_combine(Fh.linear_input_major(x, w_cat, b_cat), K, E, T)  # [T, B, K]
+        N = K * E + T * E
+        pack = self.__dict__.get("_pack")
+        if pack is None or pack.shape != (x.shape[1], N) or pack.device != x.device:
+            # [experts | gates] in the input-major layout the reference keeps them in, rows beyond h zero: filled from the
+            # parameters by library launches every step (Fh.mmoe_project); created once, outside any captured step
+            pack = self.__dict__["_pack"] = torch.zeros((x.shape[1], N), dtype=torch.float32, device=x.device)
+        if all(g.shape == (h, E) for g in self.gates) and self.experts_bias.numel() == K * E:
+            z = Fh.mmoe_project(x, pack, self.experts, self.experts_bias, list(self.gates), list(self.gates_bias))
+        else:
+            w_cat = torch.cat([self.experts.reshape(h, K * E)] + self.gates, dim=1)
+            b_cat = torch.cat([self.experts_bias.reshape(-1)] + self.gates_bias)
+            z = Fh.linear_input_major(x, w_cat, b_cat)
+        mix = Fh.mmoe_combine(z, K, E, T)  # [T, B, K]
         return run_towers(self, [mix[i] for i in range(T)], data, is_training, p_eps=1e-6)
 
     def loss(self, task_outputs, data, weight=None):

@@ -33,6 +33,9 @@ def weighted_bce(task_outputs, data, num_task: int, p_eps: float = 0.0, weight=N
     if weight is None:
         weight = np.ones(num_task) / num_task
     total = 0
+    if len(task_outputs) and all(p.is_cuda for p in task_outputs):
+        labels = [data[f'task{i + 1}_label'].float() for i in range(len(task_outputs))]
+        return Fh.sigmoid_bce_multi(list(task_outputs), labels, weight, apply_sigmoid=False, p_eps=p_eps)[1]
     for i, p in enumerate(task_outputs):
         y = data[f'task{i + 1}_label']
         if p.is_cuda:
@@ -59,7 +62,7 @@ def run_towers(model: nn.Module, inputs, data, is_training: bool, p_eps: float =
         if is_training:
             output_dict['loss'] = model.loss(task_outputs, data)
         return output_dict
-    total = 0
+    logits = []
     for i in range(T):
         x_t = inputs[i]
         for mod in getattr(model, 'task_{}_dnn'.format(i + 1)):
@@ -79,12 +82,13 @@ def run_towers(model: nn.Module, inputs, data, is_training: bool, p_eps: float =
                 hip.note_torch_path(f"{type(mod).__name__} inside a task tower")
                 x_t = mod(x_t)
         if is_training:
-            pred, l_i = Fh.sigmoid_bce([x_t], data[f'task{i + 1}_label'].float(), apply_sigmoid=True, p_eps=p_eps,
-                                       weight=1.0 / T)
-            total = total + l_i
+            logits.append(x_t)
         else:
-            pred = Fh.sigmoid_sum([x_t])
-        output_dict[f'task{i + 1}_pred'] = pred
+            output_dict[f'task{i + 1}_pred'] = Fh.sigmoid_sum([x_t])
     if is_training:
-        output_dict['loss'] = total
+        # one loss scalar for all tasks: every task's launch adds its weighted mean to it, in task order
+        labels = [data[f'task{i + 1}_label'].float() for i in range(T)]
+        preds, output_dict['loss'] = Fh.sigmoid_bce_multi(logits, labels, [1.0 / T] * T, apply_sigmoid=True, p_eps=p_eps)
+        for i in range(T):
+            output_dict[f'task{i + 1}_pred'] = preds[i]
     return output_dict

@@ -232,7 +232,7 @@ def test_mmoe_expert_gemm_and_combine_vs_oracle(B, h, ld, K, E, T):
     dx, de, db = x.to(DEV).requires_grad_(True), experts.to(DEV).requires_grad_(True), ebias.to(DEV).requires_grad_(True)
     w_cat = torch.cat([de.reshape(h, K * E)] + [t.to(DEV) for t in gates], dim=1)
     b_cat = torch.cat([db.reshape(-1)] + [t.to(DEV) for t in gbias])
-    mix = Fh.mmoe_combine(Fh.linear_input_major(dx, w_cat, b_cat), K, E, T)
+    mix = torch.stack(Fh.mmoe_combine(Fh.linear_input_major(dx, w_cat, b_cat), K, E, T))  # (one [B, K] output per task)
     _close(mix.detach().cpu(), ref.detach(), what="mixtures")
     (mix * coef.to(DEV)).sum().backward()
     _close(dx.grad[:, :h].cpu(), rx.grad, rel=2e-4, what="d hidden")
