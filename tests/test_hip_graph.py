@@ -37,6 +37,8 @@ def _batches(enc, B, n, seed):
         b = {k: (torch.rand(B, generator=gen) if "min" in v else torch.randint(0, v["vocab_size"] + 1, (B,), generator=gen))
              for k, v in enc.items()}
         b["label"] = (torch.rand(B, generator=gen) < 0.3).float()
+        b["task1_label"] = (torch.rand(B, generator=gen) < 0.3).float()
+        b["task2_label"] = (torch.rand(B, generator=gen) < 0.1).float()
         out.append({k: v.to(DEV) for k, v in b.items()})
     return out
 
@@ -51,6 +53,9 @@ def _build(kind, enc):
     elif kind == "xdeepfm_dropout":  # the reference's default: dropout 0.1 inside the MLP — ACTIVE in the captured step
         from rec_pangu_amd.models.ranking import xDeepFM
         model = xDeepFM(embedding_dim=16, dnn_hidden_units=[32, 16], cin_layer_units=[8, 8], enc_dict=enc)
+    elif kind == "mmoe":  # the reference's defaults: BatchNorm1d + Dropout(0.2) towers, two tasks (round 5: a launch plan)
+        from rec_pangu_amd.models.multi_task import MMOE
+        model = MMOE(enc_dict=enc, embedding_dim=16, device=None)
     elif kind == "deepfm16":
         model = DeepFM(embedding_dim=16, hidden_units=[32, 16], enc_dict=enc)
     else:
@@ -65,7 +70,7 @@ def _build(kind, enc):
 @pytest.mark.parametrize("kind,replay,steps,defer", [("deepfm64", "closed", 330, False), ("deepfm64", "exact", 60, False),
                                                      ("deepfm16", "closed", 300, False), ("dcn", "closed", 60, False),
                                                      ("deepfm32tail", "closed", 40, True), ("xdeepfm_dropout", "closed", 40, True),
-                                                     ("deepfm64", "closed", 300, True)])
+                                                     ("deepfm64", "closed", 300, True), ("mmoe", "closed", 40, True)])
 def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, defer, backend):
     """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
     in-place extensions of the step tables; the learning rate changes twice on the way)"""
@@ -96,7 +101,7 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, de
                     opt.step()
                     model.zero_grad()
                 if i % 7 == 0 or i > steps - 4:
-                    preds.append(out["pred"].detach().clone())
+                    preds.append(out["pred" if "pred" in out else "task1_pred"].detach().clone())
                     losses.append(out["loss"].detach().clone())
             if gstep is not None:
                 assert gstep.replays == steps - 2, "every step after the two eager ones must have been a graph replay"
