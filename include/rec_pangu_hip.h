@@ -239,6 +239,9 @@ int rp_transpose_copy(const float *in, int64_t ldin, float *out, int64_t ldout, 
                       int64_t ldcopy, rp_stream_t stream);
 /* out[r, 0:C] = in[r, 0:C], r < R, with another row stride (staging copy of a weight with unaligned rows) */
 int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
+/* out[r, 0:C] += in[r, 0:C] (independent row strides): the gradient of a column block of the gathered activation that a
+ * second consumer produced (AutoInt's attention over x[:, :F*D], autoint.py:44-46) added into the first consumer's dX */
+int rp_add_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream);
 /* ---- nn.Linear forward on PRE-SPLIT bf16 operands (csrc/gemm_pieces.hip; round 4) ---------------------------------
  * Same contract as rp_linear_fwd (deep.py:62-72: out = act(a . w^T + bias)), but both operands arrive as bf16 PIECES in
  * the "interleaved" layout: a row is a sequence of 128-byte k-tiles,

@@ -1551,6 +1551,27 @@ extern "C" int rp_copy_rows(const float *in, int64_t ldin, float *out, int64_t l
     return RP_OK;
 }
 
+// out[r, 0:C] += in[r, 0:C] with independent row strides (a second consumer's gradient of a column block of x added into the
+// first consumer's: autograd would sum two full-width tensors with an ATen launch and a zero-filled slice gradient)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float *__restrict__ in, int64_t ldin, float *__restrict__ out,
+                                                       int64_t ldout, int R, int C) {
+    const int64_t total = (int64_t)R * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / C;
+        const int c = (int)(e - r * C);
+        out[r * ldout + c] += in[r * ldin + c];
+    }
+}
+
+extern "C" int rp_add_rows(const float *in, int64_t ldin, float *out, int64_t ldout, int R, int C, rp_stream_t stream) {
+    RP_REQUIRE(in && out && R >= 1 && C >= 1 && ldin >= C && ldout >= C, "add_rows: bad argument");
+    int64_t blocks = rp_cdiv((int64_t)R * C, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, ldin, out, ldout, R, C);
+    RP_LAUNCH_CHECK("add_rows");
+    return RP_OK;
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float *__restrict__ x, int64_t ldx, float *__restrict__ y,
                                                       int64_t ldy, int64_t M, int N, int act) {
     const int64_t total = M * N;

@@ -73,13 +73,73 @@ class FMFold:
     embedding gradient, g_fm[b] * S[b, :] added to every field's slice of dX[b], is folded into the dgrad GEMM that
     produces dX (rp_linear_fwd_rowadd) instead of being applied per (sample, field) pair in the segmented reduce.
     `dfm` is recorded by _GradTap (tap_fm_grad) when the loss backward produces it, before any Linear runs."""
-    __slots__ = ("ssum", "ncols", "dfm", "folded", "dgrad", "D", "fused")
+    __slots__ = ("ssum", "ncols", "dfm", "folded", "dgrad", "D", "fused", "extra")
 
     def __init__(self, ssum, ncols, D=0):
         self.ssum, self.ncols, self.dfm, self.folded = ssum, ncols, None, False
+        # the gradient of x[:, :ncols] from a consumer that read the embedding block as [B, F, D] tokens (token_view: AutoInt's
+        # attention): left here by its backward, added into the other consumers' dX by the gather's backward
+        self.extra = None
         # (dH, W^T) of the first Linear when its dgrad is left to the gather backward (rp_embed_grad_gemm): dX is then
         # never materialised; the Linear returns a stride-0 zero in its place
         self.dgrad, self.D, self.fused = None, D, False
+
+
+class _TokenView(torch.autograd.Function):
+    """x [B, ldx] (embedding block | dense | padding) -> a contiguous [B, F, D] copy of its first F*D columns (rp_copy_rows), for
+    a consumer that reads the fields as tokens (AutoInt, autoint.py:44-46).  The slice + unflatten + reshape it replaces made a
+    strided view whose re-pack was an ATen clone, and in the backward a zero-filled [B, ldx] slice gradient plus the ATen sum
+    of the two consumers' gradients of x.  Here the token gradient is parked in the gather's link and the gather's backward
+    adds it into the other consumer's dX with one library launch (rp_add_rows) — so x needs another consumer (the MLP)."""
+
+    @staticmethod
+    def forward(ctx, x, F: int, D: int, link):
+        x = _unit_inner(x)
+        out = torch.empty((x.shape[0], F * D), dtype=torch.float32, device=x.device)
+        hip.copy_rows_to(x[:, :F * D], out)
+        ctx.link = link
+        return out.view(x.shape[0], F, D)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        ctx.link.extra = dtok.reshape(dtok.shape[0], -1).contiguous()
+        return None, None, None, None
+
+
+def token_view(x, F: int, D: int, link):
+    return _TokenView.apply(x, F, D, link)
+
+
+class _StackRows(torch.autograd.Function):
+    """cat(ws, dim=0) of 2-D matrices with one column count, as ONE library launch (rp_multi_copy into the row blocks of a fresh
+    buffer); the gradients leave as the row blocks (contiguous views) of the incoming one."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        rows = [w.shape[0] for w in ws]
+        out = torch.empty((sum(rows), ws[0].shape[1]), dtype=torch.float32, device=ws[0].device)
+        dst, r0 = [], 0
+        for r in rows:
+            dst.append(out[r0:r0 + r])
+            r0 += r
+        src = [w.detach().contiguous() for w in ws]
+        if not hip.multi_copy(dst, src):
+            torch._foreach_copy_(dst, src)
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        outs, r0 = [], 0
+        for r in ctx.rows:
+            outs.append(g[r0:r0 + r])
+            r0 += r
+        return tuple(outs)
+
+
+def stack_rows(ws):
+    return _StackRows.apply(*ws)
 
 
 class _GradTap(torch.autograd.Function):
@@ -971,6 +1031,11 @@ class _EmbedGather(torch.autograd.Function):
                 dx = None  # the placeholder of the fused Linear: no other consumer of x contributed
         if dx is not None:
             dx = _unit_inner(dx)
+        if ctx.link is not None and ctx.link.extra is not None:
+            extra, ctx.link.extra = ctx.link.extra, None
+            if dx is None or fused is not None:
+                raise RuntimeError("token_view: the gathered activation needs a consumer that materialises its gradient")
+            hip.add_rows_to(extra, dx[:, :extra.shape[1]])
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
         if ctx.link is not None and ctx.link.folded:
             ssum = None  # g_fm * S is already inside dx (rp_linear_fwd_rowadd)

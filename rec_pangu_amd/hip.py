@@ -55,6 +55,7 @@ _SIGNATURES = {
     "rp_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "rp_transpose": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "rp_copy_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "rp_add_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     "rp_transpose_copy": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "rp_pieces_ld": (C.c_int64, [_i32, _i32]),
     "rp_pieces_pack": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
@@ -786,6 +787,18 @@ def copy_rows_to(src, dst):
     R, Cc = src.shape
     with _Timed("copy_rows", f"{R}x{Cc}", 8 * R * Cc):
         _check(lib().rp_copy_rows(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), R, Cc, _stream()), "rp_copy_rows")
+    return dst
+
+
+def add_rows_to(src, dst):
+    """dst[r, :] += src[r, :] for 2-D fp32 tensors of one shape with unit inner stride, any row strides (rp_add_rows)"""
+    _req(src, torch.float32, "src")
+    _req(dst, torch.float32, "dst")
+    if src.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1:
+        raise RuntimeError("add_rows_to: two 2-D tensors of one shape with unit inner stride")
+    R, Cc = src.shape
+    with _Timed("add_rows", f"{R}x{Cc}", 12 * R * Cc):
+        _check(lib().rp_add_rows(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), R, Cc, _stream()), "rp_add_rows")
     return dst
 
 

@@ -91,7 +91,7 @@ class MultiHeadAttention(nn.Module):
         if self.W_res is not None:
             ws.append(self.W_res.weight)
         from ... import hip
-        W = torch.cat(ws, dim=0)
+        W = Fh.stack_rows(ws) if all(w.dim() == 2 and w.dtype is torch.float32 for w in ws) else torch.cat(ws, dim=0)
         if hip.attention_core_fits(T, self.num_heads, self.attention_dim):
             # projections on the matrix core as one GEMM over all B*T tokens + the T x T core per sample
             return Fh.field_attention_split(X, W, T, Din, self.num_heads, self.attention_dim, self.W_res is not None,

@@ -34,7 +34,14 @@ class AutoInt(BaseModel):
         if self.on_hip:
             x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
             F, D = self.num_sparse, self.embedding_dim
-            att = self.self_attention(x[:, :F * D].unflatten(1, (F, D))).flatten(start_dim=1)
+            link = getattr(self.embedding_layer, "_fm_link", None)
+            if self.dnn is not None and link is not None and x.requires_grad and torch.is_grad_enabled():
+                # the fields as [B, F, D] tokens: a packed copy by a library launch; its gradient joins the MLP's dX inside the
+                # gather's backward (Fh.token_view) instead of through autograd's zero-filled slice gradient and ATen sum
+                tokens = Fh.token_view(x, F, D, link)
+            else:
+                tokens = x[:, :F * D].unflatten(1, (F, D))
+            att = self.self_attention(tokens).flatten(start_dim=1)
             logits = [Fh.linear_act(att, self.fc.weight, self.fc.bias, Fh.ACT_NONE)]
             if self.dnn is not None:
                 logits.append(self.dnn(x))

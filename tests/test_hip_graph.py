@@ -56,6 +56,9 @@ def _build(kind, enc):
     elif kind == "mmoe":  # the reference's defaults: BatchNorm1d + Dropout(0.2) towers, two tasks (round 5: a launch plan)
         from rec_pangu_amd.models.multi_task import MMOE
         model = MMOE(enc_dict=enc, embedding_dim=16, device=None)
+    elif kind == "autoint":  # the fields as tokens beside the MLP (Fh.token_view), dropout 0.1, the LR layer's own tables
+        from rec_pangu_amd.models.ranking import AutoInt
+        model = AutoInt(embedding_dim=16, dnn_hidden_units=[32, 16], attention_layers=1, num_heads=2, attention_dim=4, enc_dict=enc)
     elif kind == "deepfm16":
         model = DeepFM(embedding_dim=16, hidden_units=[32, 16], enc_dict=enc)
     else:
@@ -70,7 +73,8 @@ def _build(kind, enc):
 @pytest.mark.parametrize("kind,replay,steps,defer", [("deepfm64", "closed", 330, False), ("deepfm64", "exact", 60, False),
                                                      ("deepfm16", "closed", 300, False), ("dcn", "closed", 60, False),
                                                      ("deepfm32tail", "closed", 40, True), ("xdeepfm_dropout", "closed", 40, True),
-                                                     ("deepfm64", "closed", 300, True), ("mmoe", "closed", 40, True)])
+                                                     ("deepfm64", "closed", 300, True), ("mmoe", "closed", 40, True),
+                                                     ("autoint", "closed", 40, True)])
 def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, defer, backend):
     """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
     in-place extensions of the step tables; the learning rate changes twice on the way)"""
@@ -110,7 +114,8 @@ def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, de
                     assert max(gstep._drop_calls) >= 1, "no dropout launch was captured: the model ran without active dropout"
                 elif backend == "plan":
                     # DeepFM's step is library launches only: it must replay as a plan, the sort in the side section — and
-                    # so is DCN's since round 5 (the CrossNet's weight-space arithmetic is rp_crossnet_param_grads, its layer
+                    # so are MMOE's and AutoInt's (BatchNorm statistics, loss sum, weight packing, token view: library
+                    # launches) and DCN's since round 5 (the CrossNet's weight-space arithmetic is rp_crossnet_param_grads, its layer
                     # stack rp_multi_copy, the padding columns of dX_0 are written by the rows kernel)
                     assert gstep.backend_used == "plan" and gstep.plans[0].side >= 4, (gstep.backend_used, gstep.why_not_plan)
                 else:
