@@ -736,6 +736,12 @@ int rp_plan_join(void);
 /* explicit fork point of the inline section (2): its launches recorded after this mark depend on what the main stream held
  * HERE (main launches recorded between the mark and them run beside them), until the next rp_plan_join */
 int rp_plan_fork2_mark(void);
+/* Input rebinding: after rp_plan_end, name the addresses of the static input buffers the step was recorded on (n of them);
+ * every 8-byte word of the recorded launch arguments that holds one is remembered (n_sites).  rp_plan_set_inputs(addrs[n])
+ * then makes the next replays read buffer i from addrs[i] instead — the current batch's own tensors (same shape, dtype,
+ * contiguity; alive until the replay has run), no staging copy. */
+int rp_plan_bind_inputs(void *plan, const uint64_t *addrs, int n, int *n_sites);
+int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n);
 /* the main stream waits HERE for the side section (1) of the replay (default: at the end of the replay) — for a step that
  * itself consumes what the side section produces (the next batch's sorted keys: graph_step.py, catch-up ahead) */
 int rp_plan_join_side(void);

@@ -19,6 +19,7 @@
 #include "common.h"
 #include <cxxabi.h>
 #include <cstdlib>
+#include <cstring>
 #include <ctime>
 #include <atomic>
 #include <mutex>
@@ -56,6 +57,9 @@ struct Plan {
     int probe = -1;
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
     bool probe_recorded = false;
+    // input rebinding (rp_plan_bind_inputs): 8-byte words of the packed arguments that hold the address of one of the caller's
+    // static input buffers -> (offset into blob, input index); rp_plan_set_inputs writes other addresses there
+    std::vector<std::pair<size_t, int>> binds;
     // the slowest single HIP call (launch / event record / stream wait) of the replays since rp_plan_slowest_call reset it:
     // a launch call that blocks inside the runtime stalls the host's run-ahead (bench.py: host_stall)
     double slow_ms = 0.0;
@@ -204,6 +208,41 @@ extern "C" int rp_plan_end(void *plan) {
         if (n.offs.empty()) p->ptrs.push_back(nullptr);
     }
     p->ended = true;
+    return RP_OK;
+}
+
+// Input rebinding.  A recorded step reads its batch through pointers frozen in the launch arguments; graph_step.py used to keep
+// two sets of static input buffers and copy every batch into one of them (one launch + 18 MB per step).  Instead: after
+// rp_plan_end the caller names the addresses of those static buffers; every 8-byte word of the packed arguments that holds one
+// of them is remembered, and rp_plan_set_inputs writes the addresses of the CURRENT batch's tensors there before a replay (the
+// launch copies its arguments when it is issued).  Same shapes, dtypes and contiguity are the caller's business; so is keeping
+// the tensors alive until the replay has run.  n_sites: how many words were found (0 = nothing to rebind).
+extern "C" int rp_plan_bind_inputs(void *plan, const uint64_t *addrs, int n, int *n_sites) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended && addrs != nullptr && n >= 1, "plan_bind_inputs: a finished plan and >= 1 address");
+    p->binds.clear();
+    const size_t words = p->blob.size() / 8;
+    for (size_t w = 0; w < words; ++w) {
+        uint64_t v;
+        memcpy(&v, p->blob.data() + 8 * w, 8);
+        if (v == 0) continue;
+        for (int i = 0; i < n; ++i)
+            if (v == addrs[i]) {
+                p->binds.emplace_back(8 * w, i);
+                break;
+            }
+    }
+    if (n_sites != nullptr) *n_sites = (int)p->binds.size();
+    return RP_OK;
+}
+
+extern "C" int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended && addrs != nullptr, "plan_set_inputs: null pointer");
+    for (const auto &b : p->binds) {
+        RP_REQUIRE(b.second < n, "plan_set_inputs: %d addresses, input %d is bound", n, b.second);
+        memcpy(p->blob.data() + b.first, &addrs[b.second], 8);
+    }
     return RP_OK;
 }
 

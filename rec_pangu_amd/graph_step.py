@@ -121,6 +121,14 @@ class GraphedTrainStep:
         # first layer's side work run BESIDE that catch-up instead of in front of it.  `_ahead_valid`: the static batch whose
         # rows the last call left caught up and stamped (None: nobody's); `_ahead_noclear[P]`: plan P's catch-up left its
         # applied gradient rows uncleared for the next backward to overwrite (LazyAdamRows.replay, mark = 2).
+        # Input rebinding (launch plans): instead of copying every batch into a static input buffer, the recorded launch
+        # arguments that point at those buffers are re-pointed at the batch's own tensors before each replay
+        # (rp_plan_bind_inputs / _set_inputs).  `_x_valid[Q]`: static batch Q holds the content of the batch it stands for
+        # (false after a step that read the tensors directly); `_held`: the batches of the replays that may still be in flight.
+        self.rebind = os.environ.get("RP_PLAN_REBIND", "1") != "0"
+        self._bind_sites = [0, 0]
+        self._x_valid = [False, False]
+        self._held = []
         self.ahead = os.environ.get("RP_CATCHUP_AHEAD", "0") == "1"
         self._ahead_used = False
         self._ahead_valid = None
@@ -181,6 +189,7 @@ class GraphedTrainStep:
         self._drop_clock = torch.zeros((1,), dtype=torch.int64, device=self._one.device)
         self._keys = list(batch.keys())
         self._copy_lists = [None, None]  # per static batch: the destination side of its staging copy, converted once
+        self._x_valid, self._bind_sites, self._held = [False, False], [0, 0], []
         if self._sharded:
             return
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
@@ -203,6 +212,7 @@ class GraphedTrainStep:
     def _stage_current(self, batch):
         self._ahead_drop()  # (before the pinned key list it names is re-sorted in place)
         self._copy(self.P, batch)
+        self._x_valid[self.P] = True
         if not self._sharded:
             self.model.embedding_layer.pin_sort(self.X[self.P])
         self._staged = batch
@@ -307,6 +317,9 @@ class GraphedTrainStep:
                 if side2 is None:
                     side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev, "inline")
                 plan.set_streams(side, side2)
+                if self.rebind:
+                    self._bind_sites[P] = plan.bind_inputs([self.X[P][k].data_ptr() for k in self._keys]
+                                                           + [self.X[1 - P][k].data_ptr() for k in self._keys])
         self.captures += 1
         lz = getattr(emb, "_lazy", None)
         self._ahead_used = ahead  # (also when the step fell back to a hipGraph: the captured launches are the same)
@@ -344,6 +357,7 @@ class GraphedTrainStep:
     def _drop_captures(self):
         self._ahead_drop()
         self._ahead_used = False
+        self._bind_sites = [0, 0]
         for pl in self.plans:
             if pl is not None:
                 pl.destroy()
@@ -423,8 +437,6 @@ class GraphedTrainStep:
         if self._staged is not batch:      # not the batch announced by the previous call: stage and sort it now
             self._stage_current(batch)
         P = self.P
-        self._copy(1 - P, next_batch)
-        seg("copy")
         sig = self.opt.prepare_step()
         gen = hip.device_generator(self._drop_clock.device)
         sig = sig + (gen.initial_seed() & 0xFFFFFFFFFFFFFFFF,)  # (the dropout seed is a frozen launch argument: re-seeding re-captures)
@@ -445,6 +457,25 @@ class GraphedTrainStep:
         if self.graphs[P] is None:
             self._capture(P)
         seg("signature")
+        # (staged here, behind the capture: a re-capture a few lines up may have replaced the plan this call started with)
+        plan = self.plans[P]
+        direct = (self.rebind and plan is not None and self._bind_sites[P] > 0
+                  and all(t.is_contiguous() for t in batch.values()) and all(t.is_contiguous() for t in next_batch.values()))
+        if direct:
+            # the replay reads this batch and sorts the next one straight from the caller's tensors: no staging copy
+            plan.set_inputs([batch[k] for k in self._keys] + [next_batch[k] for k in self._keys])
+            self._x_valid[1 - P] = False
+            self._held.append((batch, next_batch))
+            del self._held[:-(self.MAX_IN_FLIGHT + 2)]
+        else:
+            if not self._x_valid[P]:  # (the step before read this batch from the caller's tensors: X[P] was never filled)
+                self._copy(P, batch)
+                self._x_valid[P] = True
+            self._copy(1 - P, next_batch)
+            self._x_valid[1 - P] = True
+            if plan is not None and self._bind_sites[P] > 0:
+                plan.set_inputs([self.X[P][k] for k in self._keys] + [self.X[1 - P][k] for k in self._keys])
+        seg("copy")
         counters = self.opt.host_counters()
         if counters != self._dev:          # eager steps ran in between: bring the device counters to the host's
             self.opt.set_device_clock(True)

@@ -80,6 +80,8 @@ _SIGNATURES = {
     "rp_plan_slowest_call": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
     "rp_plan_join_side": (C.c_int, []),
+    "rp_plan_bind_inputs": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
+    "rp_plan_set_inputs": (C.c_int, [_vp, _vp, _i32]),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
     "rp_graph_node_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
@@ -941,6 +943,23 @@ class LaunchPlan:
         ms = C.c_float(0)
         _check(lib().rp_plan_probe_ms(self._h, C.byref(ms)), "rp_plan_probe_ms")
         return ms.value
+
+    def bind_inputs(self, addrs) -> int:
+        """remember where the recorded launch arguments hold the addresses `addrs` (the static input buffers the step was
+        recorded on); -> number of argument words found (rp_plan_bind_inputs)"""
+        arr = (C.c_uint64 * len(addrs))(*addrs)
+        n = _i32()
+        _check(lib().rp_plan_bind_inputs(self._h, arr, len(addrs), C.byref(n)), "rp_plan_bind_inputs")
+        self._n_inputs = len(addrs)
+        self._in_arr = (C.c_uint64 * len(addrs))()
+        return n.value
+
+    def set_inputs(self, tensors):
+        """the next replays read input i from tensors[i] (rp_plan_set_inputs)"""
+        a = self._in_arr
+        for i, t in enumerate(tensors):
+            a[i] = t.data_ptr()
+        _check(lib().rp_plan_set_inputs(self._h, a, self._n_inputs), "rp_plan_set_inputs")
 
     def slowest_call(self, reset: bool = True):
         """(kind, node, ms) of the slowest HIP call the replays issued since the last reset (kind: launch / record / wait)"""
