@@ -200,6 +200,37 @@ int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int
                       int64_t lddh, const float *w, int64_t ldw, const float *gfm, const float *sum_in, const float *arena,
                       float *grad_arena, int accumulate, uint64_t skip_fields, const int64_t *field_rows, float *dw,
                       int64_t lddw, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+/* The same backward for the BIG tables, SAMPLE-major (csrc/embed_smp.hip, round 6; reference ops as rp_embed_grad_seg:
+ * rec_pangu/models/layers/embedding.py:61-63 backward, layers/interaction.py:38-44 backward, layers/deep.py:62-72 dgrad and
+ * the embedding columns of the weight gradient).  For a table whose runs in the sorted pair list are mostly singletons the
+ * sort buys nothing and the (field, row) order re-gathers every sample's dh / sum_in row once per field; this launch walks
+ * the batch in sample order instead (a unit = 64 samples x one field: dh staged once in LDS, the table rows gathered into
+ * the matrix core's accumulator layout, dgrad + FM term + the field's weight-gradient columns from the same registers):
+ *     pair (f, b), r = keys[f * B + b]:   row = dh[b, :] . w[:, f*64:(f+1)*64] + gfm[b] (sum_in[b, :] - arena[r, :])
+ *     grad_arena[r, :] (+)= row                       when the pair is alone in its run of the sorted list (one writer), else
+ *     the row goes to a side buffer at its sorted index and rp_embed_grad_reduce_rows sums the runs in list order;
+ *     dw[:, f*64:(f+1)*64] = sum_b dh[b, :]^T (x) arena[r, :]                      (dw != NULL; written, not added)
+ * rp_embed_grad_smp_mark (from the sorted list; may run ahead of the backward: it depends on the batch's ids only):
+ *     dupq[fi * B + b] = fi * B + j if pair (fields[fi], b) is entry j of its field's sorted range AND its run has >= 2
+ *     pairs, else -1;  dupkeys[fi * B + j] = that entry's key, else -1.  Both [n_fields * B] int32, caller-owned.
+ * fields: host array, ascending, <= 16; field_base / field_rows: host arrays [n_fields], first arena row and row count of each
+ * field's table (< 2^24 rows: 32-bit row offsets; n_fields * B < 2^24); FIELD-MAJOR positions (n = F * B, F <= 64).
+ * rp_embed_grad_seg(skip_fields = their bits) covers the other fields.  phases: 1 = the main launch, 2 = the launches behind it
+ * (the partial sums of dw, the duplicate runs: they touch no row of another launch and may run beside rp_embed_grad_seg on a
+ * second stream, ordered behind phase 1 on the same workspace), 3 = both.  Deterministic.  Workspace: rp_embed_grad_smp_workspace_bytes(B, n_fields).
+ * rp_embed_grad_reduce_rows: grad_arena[key, :] (+)= sum of rows[i, :] over the entries i of a key-sorted list with
+ * keys[i] == key; key -1 = no entry (its row is not read).  Workspace: rp_embed_grad_reduce_workspace_bytes(n, D). */
+int rp_embed_grad_smp_fits(int D, int hidden, int64_t lddh);
+int rp_embed_grad_smp_workspace_bytes(int64_t B, int n_fields, size_t *bytes);
+int rp_embed_grad_smp_mark(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
+                           const int32_t *fields, int n_fields, int32_t *dupq, int32_t *dupkeys, rp_stream_t stream);
+int rp_embed_grad_smp(const int32_t *keys, const int32_t *dupq, const int32_t *dupkeys, int64_t B, int F,
+                      const int32_t *fields, const int64_t *field_base, const int64_t *field_rows, int n_fields,
+                      const float *dh, int64_t lddh, const float *w, int64_t ldw,
+                      const float *gfm, const float *sum_in, const float *arena, float *grad_arena, int accumulate,
+                      float *dw, int64_t lddw, int phases, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+int rp_embed_grad_reduce_rows(const int32_t *keys, const float *rows, int64_t n, int D, float *grad_arena, int accumulate,
+                              void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
 

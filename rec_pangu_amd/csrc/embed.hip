@@ -1161,6 +1161,36 @@ extern "C" int rp_embed_grad_reduce(const int32_t *sorted_keys, const int32_t *s
     return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }
 
+// grad_arena[key] (+)= the sum of rows[i, :] over the entries i of a KEY-SORTED list with keys[i] == key; entries with key -1
+// carry nothing and are not read (round 6: the duplicate pairs of rp_embed_grad_smp — a list over ALL pairs of its fields in
+// sorted order where only the pairs of runs of two and more carry a key).  The LEVEL1 form of the segmented reduce above:
+// same determinism (one writer per row, fixed order), same workspace as rp_embed_grad_reduce(n, D).
+extern "C" int rp_embed_grad_reduce_rows(const int32_t *keys, const float *rows, int64_t n, int D, float *grad_arena,
+                                         int accumulate, void *workspace, size_t workspace_bytes, rp_stream_t stream) {
+    RP_REQUIRE(keys && rows && grad_arena && workspace, "embed_grad_reduce_rows: null pointer");
+    RP_REQUIRE(D >= 1 && n >= 0 && n < INT32_MAX, "embed_grad_reduce_rows: bad n / D");
+    if (n == 0) return RP_OK;
+    size_t need = 0;
+    rp_embed_grad_reduce_workspace_bytes(n, D, &need);
+    RP_REQUIRE(workspace_bytes >= need, "embed_grad_reduce_rows: workspace %zu < %zu bytes", workspace_bytes, need);
+    char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const bool v4 = (D % 4 == 0) && rp_aligned16(rows) && rp_aligned16(grad_arena);
+    const int vec = v4 ? 4 : 1;
+    const int tpr = pick_tpr(D, vec);
+    const int64_t nb0 = grad_reduce_blocks(n, D, vec);
+    float *piece0 = reinterpret_cast<float *>(wbase);
+    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
+    hipStream_t s = (hipStream_t)stream;
+    const float *no_f = nullptr;
+#define CALL(T, VV)                                                                                                   \
+    hipLaunchKernelGGL((embed_grad_reduce_kernel<T, VV, true>), dim3((unsigned)nb0), dim3(256), 0, s, keys, keys, n, (int)n, D, \
+                       rows, (int64_t)D, no_f, no_f, no_f, grad_arena, accumulate, piece0, key0)
+    RP_DISPATCH_TPR(tpr, vec, CALL);
+#undef CALL
+    RP_LAUNCH_CHECK("embed_grad_reduce_rows");
+    return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+}
+
 // Backward of rp_embed_gather_pool_fwd (pool.hip): grad_arena[key] (+)= sum over the ids p with that key of
 // g[bag(p), :] (* scale[bag(p), :]); bag(p) = bag_of[p] (CSR bags) or p / L (dense bags of L ids).  sorted_keys /
 // sorted_pos: the (arena row, flat id position) pairs sorted by row.  Same determinism, accumulate semantics and

@@ -1191,7 +1191,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
         # and the deferred side launches are issued after that join and run beside the catch-up, joined at the end of the replay
         ahead = in_plan and hip.LaunchPlan.ahead and seg is not None and need_t and not seg_first
         if seg_first:
-            hip.LaunchPlan.fork2_mark()
+            pass  # (the fork is marked inside accumulate_grad, behind the sample-major launch: round 6)
         elif ahead:
             pass
         elif in_plan:
@@ -1212,7 +1212,8 @@ class _EmbedGatherLinear(torch.autograd.Function):
             wt = ctx.wt if ctx.wt is not None else hip.transpose(weight, rows_out=ctx.ldx)
             gfm = dfm.contiguous() if dfm is not None else None
             store.accumulate_grad(keys, ctx.B, None, gfm, ssum if gfm is not None else None, presorted=ctx.presorted,
-                                  fused=(dpre, wt), plan_keep=keep if in_plan else None, seg=seg, seg_first=seg_first)
+                                  fused=(dpre, wt), plan_keep=keep if in_plan else None, seg=seg, seg_first=seg_first,
+                                  fork2=hip.LaunchPlan.fork2_mark if seg_first else None)
         if seg_first:
             hip.LaunchPlan.section(2)
             try:

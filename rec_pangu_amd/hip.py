@@ -44,6 +44,12 @@ _SIGNATURES = {
     "rp_embed_grad_tiny_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64,
                                      _vp, _sz, _vp]),
+    "rp_embed_grad_smp_fits": (C.c_int, [_i32, _i32, _i64]),
+    "rp_embed_grad_smp_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_embed_grad_smp_mark": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "rp_embed_grad_smp": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
+                                    _vp, _i64, _i32, _vp, _sz, _vp]),
+    "rp_embed_grad_reduce_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_seg_fits": (C.c_int, [_i32, _i32, _i64]),
     "rp_embed_grad_seg_workspace_bytes": (C.c_int, [_i64, _i64, _i32, C.POINTER(_sz)]),
     "rp_embed_grad_seg": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, C.c_uint64, _vp,
@@ -598,6 +604,79 @@ def embed_grad_seg(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, 
                                        grad_arena.data_ptr(), int(accumulate), skip_fields, fr, _ptr(dw),
                                        _rowmajor(dw, "dw") if dw is not None else 0, ws.data_ptr(), nbytes.value, _stream()),
                "rp_embed_grad_seg")
+
+
+_SMP_FIELDS: dict = {}
+
+
+def embed_grad_smp_fits(D: int, hidden: int, dh) -> bool:
+    return bool(lib().rp_embed_grad_smp_fits(D, hidden, _rowmajor(dh, "dh"))) and dh.data_ptr() % 16 == 0
+
+
+def _smp_fields(fields):
+    """`fields` = [(field, first arena row, rows), ...] (or plain field indices for the mark launch) -> ctypes arrays"""
+    ck = tuple((int(f[0]), int(f[1]), int(f[2])) if isinstance(f, (tuple, list)) else (int(f), 0, 0) for f in fields)
+    arr = _SMP_FIELDS.get(ck)
+    if arr is None:
+        n = len(ck)
+        arr = _SMP_FIELDS[ck] = ((C.c_int32 * n)(*[t[0] for t in ck]), (C.c_int64 * n)(*[t[1] for t in ck]),
+                                 (C.c_int64 * n)(*[t[2] for t in ck]))
+    return arr
+
+
+def embed_grad_smp_mark(sorted_keys, sorted_pos, B: int, fields, out=None):
+    """rp_embed_grad_smp_mark: (dupq, dupkeys), both [len(fields) * B] int32 — which pairs of the big tables `fields` share
+    their table row with another pair of the batch, from the sorted pair list (depends on the batch's ids only)."""
+    _req(sorted_keys, torch.int32, "sorted_keys")
+    _req(sorted_pos, torch.int32, "sorted_pos")
+    nf = len(fields)
+    if out is None:
+        out = (torch.empty((nf * B,), dtype=torch.int32, device=sorted_keys.device),
+               torch.empty((nf * B,), dtype=torch.int32, device=sorted_keys.device))
+    with _Timed("embed_grad_smp_mark", f"{nf} fields", 16 * nf * B):
+        _check(lib().rp_embed_grad_smp_mark(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B,
+                                            _smp_fields(fields)[0], nf, out[0].data_ptr(), out[1].data_ptr(), _stream()),
+               "rp_embed_grad_smp_mark")
+    return out
+
+
+def embed_grad_smp(keys, marks, B: int, F: int, fields, dh, w, gfm, sum_in, arena, grad_arena, accumulate: bool, dw=None,
+                   keep=None, phases: int = 3, ws=None):
+    """rp_embed_grad_smp: the first layer's backward on the embedding columns of the big tables `fields`, sample-major (the
+    table rows' gradient incl. the FM term + those fields' columns of dw [64, K]); `fields` = [(field, first arena row,
+    rows), ...] ascending; `marks` = embed_grad_smp_mark's pair.  phases = 1: the main launch only, 2: the launches behind
+    it (same `ws`, returned by the phase-1 call), 3: both.  -> the workspace."""
+    _req(keys, torch.int32, "keys")
+    _req(dh, torch.float32, "dh")
+    _req(w, torch.float32, "w")
+    _req(grad_arena, torch.float32, "grad_arena")
+    nf = len(fields)
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_smp_workspace_bytes(B, nf, C.byref(nbytes)), "rp_embed_grad_smp_workspace_bytes")
+    if ws is None:
+        ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+        if keep is not None:
+            keep.append(ws)
+    fa = _smp_fields(fields)
+    with _Timed("embed_grad_smp" if phases & 1 else "embed_grad_smp_behind", f"{nf} fields"):
+        _check(lib().rp_embed_grad_smp(keys.data_ptr(), marks[0].data_ptr(), marks[1].data_ptr(), B, F, fa[0], fa[1], fa[2], nf,
+                                       dh.data_ptr(), _rowmajor(dh, "dh"), w.data_ptr(), _rowmajor(w, "w"), _ptr(gfm),
+                                       _ptr(sum_in), arena.data_ptr(), grad_arena.data_ptr(), int(accumulate), _ptr(dw),
+                                       _rowmajor(dw, "dw") if dw is not None else 0, phases, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_embed_grad_smp")
+    return ws
+
+
+def embed_grad_reduce_rows(keys, rows, grad_arena, accumulate: bool):
+    """rp_embed_grad_reduce_rows: grad_arena[key] (+)= the sum of rows[i] over a key-sorted list (key -1: no entry)"""
+    _req(keys, torch.int32, "keys")
+    _req(rows, torch.float32, "rows")
+    n, D = keys.numel(), rows.shape[1]
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_reduce_workspace_bytes(n, D, C.byref(nbytes)), "rp_embed_grad_reduce_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+    _check(lib().rp_embed_grad_reduce_rows(keys.data_ptr(), rows.data_ptr(), n, D, grad_arena.data_ptr(), int(accumulate),
+                                           ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_reduce_rows")
 
 
 def zero_rows(keys, D: int, grad_arena):

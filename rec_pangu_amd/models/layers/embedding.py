@@ -38,6 +38,11 @@ _SORT_PINNED: list = []
 # launches may be re-issued on a side stream, where memory of the capture's pool could alias the step's temporaries)
 _PINNED_WS: dict = {}
 
+# id(sorted-keys tensor) -> [weakref(sorted keys), (B, fields), (dupq, dupkeys)]: the marks rp_embed_grad_smp wants, made
+# right behind the sort that made the keys (EmbeddingLayer._mark_sorted: on the sort's stream, one step ahead when the sort
+# is) and re-made in place when a pinned entry is re-sorted in place
+_SMP_MARKS: dict = {}
+
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
 _SHARD_SPEC = None
@@ -274,8 +279,54 @@ class EmbeddingLayer(nn.Module):
         self.__dict__["_tiny_cache"] = (sig, out)
         return out
 
+    def _smp_tables(self, B: int):
+        """[(field, first arena row, rows), ...] of the BIG tables rp_embed_grad_smp takes (round 6: the sample-major form of
+        the first layer's backward — tables of at least RP_SMP_MIN x B rows, where most runs of the sorted pair list are
+        single pairs; not rp_embed_grad_tiny's; < 2^24 rows each; the 16 largest), or None; RP_GRAD_SMP=0 turns the path off"""
+        hit = self.__dict__.get("_smp_cache")
+        sig = self._rows_sig()
+        if hit is not None and hit[0] is sig and hit[1] == B:
+            return hit[2]
+        out = None
+        if self.embedding_dim == 64 and os.environ.get("RP_GRAD_SMP", "1") != "0" and len(sig) <= 64:
+            tiny = {t[0] for t in (self._tiny_tables() or ())}
+            need = float(os.environ.get("RP_SMP_MIN", "1.0")) * B
+            pick = sorted((f for f in range(len(sig)) if f not in tiny and need <= sig[f] < (1 << 24)),
+                          key=lambda f: -sig[f])[:16]
+            if pick and len(pick) * B < (1 << 24) and sum(sig) < (1 << 31):
+                out = [(f, sum(sig[:f]), sig[f]) for f in sorted(pick)]
+        self.__dict__["_smp_cache"] = (sig, B, out)
+        return out
+
+    def _mark_sorted(self, sk, sp) -> None:
+        """behind a sort of this layer's pairs (on the stream that sorted them): the duplicate marks of the big tables"""
+        from ... import hip
+        F = len(self.emb_feature)
+        if sk.numel() == 0 or sk.numel() % F:
+            return
+        B = sk.numel() // F
+        smp = self._smp_tables(B)
+        if smp is None:
+            return
+        ent = _SMP_MARKS.get(id(sk))
+        sig = (B, tuple(smp))
+        out = ent[2] if (ent is not None and ent[0]() is sk and ent[1] == sig) else None
+        marks = hip.embed_grad_smp_mark(sk, sp, B, [t[0] for t in smp], out=out)
+        if out is None:
+            if len(_SMP_MARKS) >= 8:
+                for k in [k for k, e in _SMP_MARKS.items() if e[0]() is None] or list(_SMP_MARKS)[:4]:
+                    _SMP_MARKS.pop(k, None)
+            _SMP_MARKS[id(sk)] = [weakref.ref(sk), sig, marks]
+
+    def _marks_of(self, sk, sp, smp, B: int):
+        ent = _SMP_MARKS.get(id(sk))
+        if ent is None or ent[0]() is not sk or ent[1] != (B, tuple(smp)):
+            self._mark_sorted(sk, sp)  # (a sort nobody marked: an eager backward that sorted for itself)
+            ent = _SMP_MARKS[id(sk)]
+        return ent[2]
+
     def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None, seg=None,
-                        seg_first: bool = False):
+                        seg_first: bool = False, fork2=None):
         """Called from the autograd node of the gather: dense table gradients, reference semantics
         (aten::embedding_dense_backward: every table gets a full [V+1, D] gradient, zeros where no
         sample looked).  Invariant kept between steps: the gradient arena is zero everywhere except
@@ -336,16 +387,53 @@ class EmbeddingLayer(nn.Module):
                 if keys is None or dx is not None or keys.numel() != len(self.emb_feature) * B:
                     raise RuntimeError("the fused first layer stored no activation, but its backward is not the field-major "
                                        "single-device form rp_embed_grad_seg covers")
+                # round 6: the BIG tables (runs of the sorted list are mostly single pairs: the sort buys nothing and the
+                # (field, row) order re-gathers every dH / S row once per field) go through the batch in sample order
+                # instead (rp_embed_grad_smp); its main launch first, then — forked from that point inside a recorded plan —
+                # rp_embed_grad_seg over the remaining fields with the launches behind the sample-major one (the weight
+                # gradient's partial sums, the duplicate runs: other rows than anything beside them) on the second stream
+                smp = self._smp_tables(B) if hip.embed_grad_smp_fits(D, 64, fused[0]) else None
+                smp_ws = None
+                if smp:
+                    for f, _, _ in smp:
+                        skip |= 1 << f
+                    marks = self._marks_of(sk, sp, smp, B)
+                    smp_args = (keys, marks, B, len(self.emb_feature), smp, fused[0], seg[0], gfm, ssum, self._arena,
+                                self._grad_arena)
+                    smp_ws = hip.embed_grad_smp(*smp_args, accumulate=not self._grad_clean, dw=seg[1], keep=plan_keep,
+                                                phases=1)
+                if fork2 is not None:
+                    fork2()
                 # (inside a recorded plan the workspace stays referenced until the join: the side launches issued BEHIND this
                 #  one run beside it on another stream, and the capture's one-stream allocator would hand them its memory)
-                hip.embed_grad_seg(sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena,
-                                   accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1],
-                                   keep=plan_keep)
+                if skip != (1 << len(self.emb_feature)) - 1:
+                    hip.embed_grad_seg(sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena,
+                                       accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1],
+                                       keep=plan_keep)
+                if smp:
+                    in_plan = plan_keep is not None
+                    if in_plan:
+                        hip.LaunchPlan.section(2)
+                    try:
+                        hip.embed_grad_smp(*smp_args, accumulate=not self._grad_clean, dw=seg[1], phases=2, ws=smp_ws)
+                    finally:
+                        if in_plan:
+                            hip.LaunchPlan.section(0)
             else:
+                if fork2 is not None:
+                    fork2()
                 hip.embed_grad_gemm(sk, sp, B, D, fused[0], fused[1], dx, gfm, ssum, self._arena, self._grad_arena,
                                     accumulate=not self._grad_clean, skip_fields=skip)
             if tiny and seg_first:
-                run_tiny()  # (behind the long main-stream launch in issue order: see rp_plan_fork2_mark)
+                # (behind the long main-stream launch in issue order: see rp_plan_fork2_mark.  Round 6, with the sample-major
+                #  launch in front: on the MAIN stream — the second stream's launches cannot run beside rp_embed_grad_smp /
+                #  _seg, whose workgroups hold all of every CU's LDS, so whatever sits there runs in the step's tail one short
+                #  launch after another while the main stream idles at the join: the tail is split over both streams)
+                if smp and os.environ.get("RP_TINY_MAIN", "1") == "1":
+                    hip.embed_grad_tiny(keys, B, tiny, fused[0], fused[1], gfm, ssum, self._arena, self._grad_arena,
+                                        accumulate=not self._grad_clean, keep=plan_keep, dw=None if seg is None else seg[1])
+                else:
+                    run_tiny()
         else:
             hip.embed_grad_reduce(sk, sp, B, D, dx, gfm, ssum, self._arena, self._grad_arena,
                                   accumulate=not self._grad_clean)
@@ -545,6 +633,8 @@ class EmbeddingLayer(nn.Module):
             return None
         keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
         sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        if row_base is self.row_base and torch.is_grad_enabled():
+            self._mark_sorted(sk, sp)
         out = (keys, sk, sp)
         if src is not None:
             self._cache_sort(src, sig, out, None)
@@ -595,6 +685,7 @@ class EmbeddingLayer(nn.Module):
             # (its own gather checks the same ids again when its turn comes) — they get a scratch flag
             keys = hip.embed_keys(self.row_base, self.row_count, idx, self._ahead_flag())
             sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            self._mark_sorted(sk, sp)
             event = torch.cuda.Event()
             event.record(side)
         for t in src:
@@ -616,6 +707,7 @@ class EmbeddingLayer(nn.Module):
         if not on_side_stream:
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
             hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp), workspace=_PINNED_WS.get(id(keys)))
+            self._mark_sorted(sk, sp)
             return
         side = _SIDE_STREAMS.get(dev)
         if side is None:
@@ -624,6 +716,7 @@ class EmbeddingLayer(nn.Module):
         with torch.cuda.stream(side):
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
             hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp))
+            self._mark_sorted(sk, sp)
 
     def pin_sort(self, X) -> None:
         """graph_step: X holds STATIC id tensors (refilled in place from now on).  Sort their current content into

@@ -1055,6 +1055,129 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
     assert torch.equal(G2, G)
 
 
+@pytest.mark.parametrize("rows,B,with_fm,accumulate,smp,with_tiny", [
+    ([8, 400000, 51, 90000], 24, True, False, [1, 3], False),                  # one ragged unit per field, no duplicates at all
+    ([3, 2000000, 10, 5000, 70000], 4099, True, False, [1, 4], False),         # ragged last unit, a few duplicate pairs
+    ([3, 2000000, 10, 5000, 70000], 4099, False, True, [1, 4], True),          # no FM term, accumulate, tiny tables beside
+    ([300, 40, 1000, 5000, 27, 90], 2048, True, True, [0, 2, 3], True),        # EVERY pair of the launch's fields a duplicate
+    ([50000, 7, 2000000, 300000], 65536, True, False, [0, 2, 3], False),       # full batch: 1024 units per field, hot + big
+    ([50000, 13, 5, 700, 9000000, 90], 16384 + 77, True, False, [0, 4], True),  # keys beyond 2^23 rows, ragged
+])
+def test_embed_grad_smp_vs_fp64_and_seg(hip, rows, B, with_fm, accumulate, smp, with_tiny):
+    """rp_embed_grad_smp_mark + rp_embed_grad_smp (round 6: the big tables' share of the first layer's backward, SAMPLE-major:
+    a pair that is alone in its run writes its table row's gradient directly, the pairs of longer runs go through a side
+    buffer and rp_embed_grad_reduce_rows) composed with rp_embed_grad_seg (the other fields) and rp_embed_grad_tiny, against an
+    fp64 restatement of the reference's ops (embedding.py:61-63 backward + interaction.py:38-44 backward + deep.py:62-72
+    dgrad / wgrad) and against rp_embed_grad_seg over every field; the marks against a host restatement (index work:
+    exact); bit-identical between two launches."""
+    D, H = 64, 64
+    g = torch.Generator().manual_seed(B + len(rows) + 6)
+    F = len(rows)
+    arena, base = _tables(rows, D, g)
+    idx = [torch.randint(0, r, (B,), generator=g) for r in rows]
+    ND = 5
+    K = F * D + ND
+    ldx = (K + 63) // 64 * 64
+    W1 = torch.randn(H, K, generator=g) / K ** 0.5
+    dh = torch.randn(B, H, generator=g) * 1e-3 * (torch.rand(B, H, generator=g) < 0.6)
+    gfm = torch.randn(B, 1, generator=g) * 1e-3 if with_fm else None
+    ssum = torch.randn(B, D, generator=g) if with_fm else None
+    row_of = [base[f] + idx[f] for f in range(F)]
+    keys = torch.cat(row_of).to(torch.int32).to(DEV)
+    sk, sp = hip.sort_pairs(keys, end_bit=max(1, (arena.shape[0] - 1).bit_length()))
+    dev = lambda t_: None if t_ is None else t_.to(DEV)  # noqa: E731
+    Wd = dev(W1)
+    wt = hip.transpose(Wd, rows_out=ldx)
+    NR = arena.shape[0]
+    init = 0.5 if accumulate else 0.0
+    tiny = [(f, int(base[f]), rows[f]) for f in range(F) if rows[f] <= 254 and f not in smp] if with_tiny else []
+    skip = sum(1 << t[0] for t in tiny) | sum(1 << f for f in smp)
+    # ---- the marks: index work, exact against a host restatement
+    smp_t = [(f, int(base[f]), rows[f]) for f in smp]
+    marks = hip.embed_grad_smp_mark(sk, sp, B, smp)
+    skc, spc = sk.cpu().long(), sp.cpu().long()
+    dupq_ref = torch.full((len(smp) * B,), -1, dtype=torch.int64)
+    dupk_ref = torch.full((len(smp) * B,), -1, dtype=torch.int64)
+    for fi, f in enumerate(smp):
+        ks, ps = skc[f * B:(f + 1) * B], spc[f * B:(f + 1) * B]
+        assert bool(((ps >= f * B) & (ps < (f + 1) * B)).all())
+        dup = torch.zeros(B, dtype=torch.bool)
+        dup[1:] |= ks[1:] == ks[:-1]
+        dup[:-1] |= ks[:-1] == ks[1:]
+        j = torch.arange(B)
+        dupq_ref[fi * B + (ps - f * B)] = torch.where(dup, fi * B + j, torch.full_like(j, -1))
+        dupk_ref[fi * B:(fi + 1) * B] = torch.where(dup, ks, torch.full_like(ks, -1))
+    assert torch.equal(marks[0].cpu().long(), dupq_ref) and torch.equal(marks[1].cpu().long(), dupk_ref)
+    outs = []
+    for _ in range(2):
+        G = torch.full((NR, D), init, device=DEV)
+        dw = torch.full((H, K), float("nan"), device=DEV)
+        if tiny:
+            hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G, accumulate, dw=dw)
+        hip.embed_grad_smp(keys, marks, B, F, smp_t, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G, accumulate, dw=dw)
+        if skip != (1 << F) - 1:
+            hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G, accumulate, skip_fields=skip,
+                               field_rows=rows, dw=dw)
+        outs.append((G, dw))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:, :F * D], outs[1][1][:, :F * D]), "two launches differ"
+    G, dw = outs[0]
+    xr = torch.cat([arena[row_of[f].long()] for f in range(F)], dim=1).double()
+    dX = dh.double() @ W1.double()[:, :F * D]
+    ref = torch.full((NR, D), init, dtype=torch.float64)
+    for f in range(F):
+        contrib = dX[:, f * D:(f + 1) * D]
+        if with_fm:
+            contrib = contrib + gfm.double() * (ssum.double() - arena.double()[row_of[f].long()])
+        ref.index_add_(0, row_of[f].long(), contrib)
+    dw_ref = dh.double().T @ xr
+    scale = float((ref - init).abs().max())
+    assert float((G.cpu().double() - ref).abs().max()) <= 2e-5 * max(scale, 1e-6), "table gradient against fp64"
+    wscale = float(dw_ref.abs().max())
+    assert float((dw[:, :F * D].cpu().double() - dw_ref).abs().max()) <= 2e-5 * max(wscale, 1e-6), "weight gradient against fp64"
+    # rows nobody looked up are untouched
+    touched = torch.zeros(NR, dtype=torch.bool)
+    touched[torch.cat(row_of).long()] = True
+    assert bool((G.cpu()[~touched] == init).all())
+    # rp_embed_grad_seg over every field
+    Gall = torch.full((NR, D), init, device=DEV)
+    hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), Gall, accumulate, skip_fields=0, field_rows=rows)
+    assert float((G - Gall).abs().max()) <= 2e-5 * max(scale, 1e-6)
+    # no weight gradient asked for: the same rows
+    G2 = torch.full((NR, D), init, device=DEV)
+    if tiny:
+        hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
+    hip.embed_grad_smp(keys, marks, B, F, smp_t, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
+    if skip != (1 << F) - 1:
+        hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
+    assert torch.equal(G2, G)
+
+
+def test_embed_grad_reduce_rows_vs_host(hip):
+    """rp_embed_grad_reduce_rows: sums of the rows of a key-sorted list per key, key -1 = no entry (never read: NaN rows
+    there), runs across workgroups and a run of thousands of entries; against an fp64 index_add; accumulate on top."""
+    g = torch.Generator().manual_seed(61)
+    n, D, NR = 70000, 64, 5000
+    keys = torch.sort(torch.randint(0, NR, (n,), generator=g)).values
+    keys[20000:29000] = keys[20000]                     # one run of 9000 entries
+    keys = torch.sort(keys).values
+    # (holes cover WHOLE runs: the entries of one key stay contiguous — the list rp_embed_grad_smp_mark writes)
+    hole = (torch.rand(NR, generator=g) < 0.4)[keys]
+    rows = torch.randn(n, D, generator=g)
+    rows[hole] = float("nan")
+    k32 = torch.where(hole, torch.full_like(keys, -1), keys).to(torch.int32)
+    for accumulate in (False, True):
+        init = 0.25 if accumulate else 0.0
+        G = torch.full((NR, D), init, device=DEV)
+        hip.embed_grad_reduce_rows(k32.to(DEV), rows.to(DEV), G, accumulate)
+        ref = torch.full((NR, D), init, dtype=torch.float64)
+        ref.index_add_(0, keys[~hole], rows[~hole].double())
+        live = torch.zeros(NR, dtype=torch.bool)
+        live[keys[~hole]] = True
+        got = G.cpu().double()
+        assert float((got[live] - ref[live]).abs().max()) <= 1e-4
+        assert bool((got[~live] == init).all())
+
+
 @pytest.mark.parametrize("act_name", ["Tanh", "Sigmoid", "LeakyReLU"])
 @pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (3000, 200, 333), (8192, 256, 1677), (777, 1, 39)])
 def test_linear_activation_epilogues_vs_torch(hip, act_name, M, N, K):
