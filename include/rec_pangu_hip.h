@@ -200,6 +200,20 @@ int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int
                       int64_t lddh, const float *w, int64_t ldw, const float *gfm, const float *sum_in, const float *arena,
                       float *grad_arena, int accumulate, uint64_t skip_fields, const int64_t *field_rows, float *dw,
                       int64_t lddw, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+/* rp_embed_grad_seg's work in two launches (csrc/embed_ss.hip, round 6; the same reference ops, contract and results up to
+ * fp32 summation order): a STREAMING segment-sum pass with no LDS and no barrier (a 16-lane group per 32 sorted positions
+ * writes one record [sum dh | sum gfm sum_in | sum gfm | key] per run piece) and a matrix pass over the UNIQUE rows of every
+ * tile of 128 sorted positions (the pieces of one key merged first).  The one-launch form keeps its gathers in flight during
+ * a fifth of its tile loop and moves 2.3 TB/s out of the Infinity Cache; this form is for the tables whose runs are long
+ * (the mid-size ones: rp_embed_grad_smp takes the big tables, rp_embed_grad_tiny the tiny ones).
+ * phases: 1 = the segment-sum launch (reads dh / sum_in / gfm and the sorted pairs only: it may run beside
+ * rp_embed_grad_smp's main launch on another stream), 2 = the launches behind it (same workspace, ordered behind phase 1),
+ * 3 = both.  Workspace: rp_embed_grad_ss_workspace_bytes(n, B, D, skip_fields). */
+int rp_embed_grad_ss_workspace_bytes(int64_t n, int64_t B, int D, uint64_t skip_fields, size_t *bytes);
+int rp_embed_grad_ss(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D, const float *dh,
+                     int64_t lddh, const float *w, int64_t ldw, const float *gfm, const float *sum_in, const float *arena,
+                     float *grad_arena, int accumulate, uint64_t skip_fields, const int64_t *field_rows, float *dw,
+                     int64_t lddw, int phases, void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* The same backward for the BIG tables, SAMPLE-major (csrc/embed_smp.hip, round 6; reference ops as rp_embed_grad_seg:
  * rec_pangu/models/layers/embedding.py:61-63 backward, layers/interaction.py:38-44 backward, layers/deep.py:62-72 dgrad and
  * the embedding columns of the weight gradient).  For a table whose runs in the sorted pair list are mostly singletons the
@@ -208,11 +222,13 @@ int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int
  * the matrix core's accumulator layout, dgrad + FM term + the field's weight-gradient columns from the same registers):
  *     pair (f, b), r = keys[f * B + b]:   row = dh[b, :] . w[:, f*64:(f+1)*64] + gfm[b] (sum_in[b, :] - arena[r, :])
  *     grad_arena[r, :] (+)= row                       when the pair is alone in its run of the sorted list (one writer), else
- *     the row goes to a side buffer at its sorted index and rp_embed_grad_reduce_rows sums the runs in list order;
+ *     the row goes to a side buffer at its number among such pairs and rp_embed_grad_reduce_rows sums the runs in list order;
  *     dw[:, f*64:(f+1)*64] = sum_b dh[b, :]^T (x) arena[r, :]                      (dw != NULL; written, not added)
- * rp_embed_grad_smp_mark (from the sorted list; may run ahead of the backward: it depends on the batch's ids only):
- *     dupq[fi * B + b] = fi * B + j if pair (fields[fi], b) is entry j of its field's sorted range AND its run has >= 2
- *     pairs, else -1;  dupkeys[fi * B + j] = that entry's key, else -1.  Both [n_fields * B] int32, caller-owned.
+ * rp_embed_grad_smp_mark (from the sorted list; may run ahead of the backward: it depends on the batch's ids only): the
+ *     pairs whose run has >= 2 pairs are numbered c = 0, 1, ... in sorted order (field by field);
+ *     dupq[fi * B + b] = c of pair (fields[fi], b), or -1 for a pair alone in its run;  dupkeys[c] = the key of pair c, -1
+ *     from the number of such pairs on.  Both [n_fields * B] int32, caller-owned; scratch: rp_embed_grad_smp_mark_scratch
+ *     int32 words.
  * fields: host array, ascending, <= 16; field_base / field_rows: host arrays [n_fields], first arena row and row count of each
  * field's table (< 2^24 rows: 32-bit row offsets; n_fields * B < 2^24); FIELD-MAJOR positions (n = F * B, F <= 64).
  * rp_embed_grad_seg(skip_fields = their bits) covers the other fields.  phases: 1 = the main launch, 2 = the launches behind it
@@ -222,8 +238,10 @@ int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int
  * keys[i] == key; key -1 = no entry (its row is not read).  Workspace: rp_embed_grad_reduce_workspace_bytes(n, D). */
 int rp_embed_grad_smp_fits(int D, int hidden, int64_t lddh);
 int rp_embed_grad_smp_workspace_bytes(int64_t B, int n_fields, size_t *bytes);
+int rp_embed_grad_smp_mark_scratch(int64_t B, int n_fields, size_t *n_int32);
 int rp_embed_grad_smp_mark(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
-                           const int32_t *fields, int n_fields, int32_t *dupq, int32_t *dupkeys, rp_stream_t stream);
+                           const int32_t *fields, int n_fields, int32_t *dupq, int32_t *dupkeys, int32_t *scratch,
+                           rp_stream_t stream);
 int rp_embed_grad_smp(const int32_t *keys, const int32_t *dupq, const int32_t *dupkeys, int64_t B, int F,
                       const int32_t *fields, const int64_t *field_base, const int64_t *field_rows, int n_fields,
                       const float *dh, int64_t lddh, const float *w, int64_t ldw,
@@ -776,6 +794,9 @@ int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n);
 /* the main stream waits HERE for the side section (1) of the replay (default: at the end of the replay) — for a step that
  * itself consumes what the side section produces (the next batch's sorted keys: graph_step.py, catch-up ahead) */
 int rp_plan_join_side(void);
+/* the inline section (2) waits here for what the main stream holds at this point (a second dependency edge for a section
+ * forked earlier; the fork mark while the section is not open yet) */
+int rp_plan_side2_sync(void);
 /* a non-blocking stream of the lowest priority the device offers (side streams that should yield to the main stream's
  * launches); the caller owns it */
 int rp_stream_create_low(void **stream_out);

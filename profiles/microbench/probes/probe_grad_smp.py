@@ -73,6 +73,8 @@ timed("embed_grad_smp_mark", lambda: hip.embed_grad_smp_mark(sk, sp, B, smp, out
 timed("embed_grad_smp (+ dw partial sum + duplicate reduce)", lambda: hip.embed_grad_smp(keys, marks, B, F, smp_t, dh, W, gfm, ssum, arena, G, False, dw=dw))
 timed("embed_grad_smp without dw", lambda: hip.embed_grad_smp(keys, marks, B, F, smp_t, dh, W, gfm, ssum, arena, G, False))
 timed("embed_grad_seg over the remaining fields (+ dw)", lambda: hip.embed_grad_seg(sk, sp, B, D, dh, W, gfm, ssum, arena, G, False, skip_fields=skip_tiny | skip_smp, field_rows=rows, dw=dw))
+timed("embed_grad_ss over the remaining fields (+ dw)", lambda: hip.embed_grad_ss(sk, sp, B, D, dh, W, gfm, ssum, arena, G, False, skip_fields=skip_tiny | skip_smp, field_rows=rows, dw=dw))
+timed("embed_grad_ss over the remaining AND the tiny fields (+ dw)", lambda: hip.embed_grad_ss(sk, sp, B, D, dh, W, gfm, ssum, arena, G, False, skip_fields=skip_smp, field_rows=rows, dw=dw))
 timed("embed_grad_tiny (+ dw)", lambda: hip.embed_grad_tiny(keys, B, tiny, dh, wt, gfm, ssum, arena, G, False, dw=dw))
 
 
@@ -92,3 +94,11 @@ hip.embed_grad_seg(sk, sp, B, D, dh, W, gfm, ssum, arena, Gb, False, skip_fields
 torch.cuda.synchronize()
 print("max |G_smp+seg - G_seg| =", float((Ga - Gb).abs().max()), " scale", float(Ga.abs().max()))
 print("max |dw - dw| =", float((dwa - dwb)[:, :F * 64].abs().max()), " scale", float(dwa[:, :F * 64].abs().max()))
+
+Gc = torch.zeros(R, D, device=dev)
+dwc = torch.zeros(64, K, device=dev)
+hip.embed_grad_smp(keys, marks, B, F, smp_t, dh, W, gfm, ssum, arena, Gc, False, dw=dwc)
+hip.embed_grad_ss(sk, sp, B, D, dh, W, gfm, ssum, arena, Gc, False, skip_fields=skip_tiny | skip_smp, field_rows=rows, dw=dwc)
+torch.cuda.synchronize()
+print("max |G_smp+ss - G_seg| =", float((Ga - Gc).abs().max()))
+print("max |dw_ss - dw| =", float((dwa - dwc)[:, :F * 64].abs().max()))

@@ -116,3 +116,7 @@ __device__ __forceinline__ float rp_act_grad(int act, float dy, float y) {
 // matrix-core bound even at 3 products (flops x 3 / algorithmic bytes above the MFMA/HBM ridge) and 6 (fp32-faithful)
 // otherwise — HBM-bound launches get the exact products for free.
 int rp_matmul_products(double flops, double bytes);
+
+// embed.hip: second pass over a (head, tail) piece list of `nb0` tiles + the sequential walk (rp_embed_grad_reduce's finish)
+int rp_int_grad_reduce_finish(int64_t n, int D, int64_t nb0, char *wbase, float *piece0, int32_t *key0, float *grad_arena,
+                              int accumulate, hipStream_t s);

@@ -142,6 +142,20 @@ __global__ __launch_bounds__(256) void embed_grad_reduce_kernel(
     }
     const int32_t kprev = (active && start > 0) ? sk[start - 1] : -1;
     const int32_t knext = (active && start + cnt < n) ? sk[start + cnt] : -1;
+    if (LEVEL1) {
+        // a workgroup of "no entry" keys (round 6: the tail of rp_embed_grad_smp's duplicate list, most of it): nothing to sum,
+        // nothing to hand on — its two piece entries say so and it is done
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < RP_SEG; ++j) any |= k[j] >= 0;
+        if (!__syncthreads_or((int)any)) {
+            if (threadIdx.x == 0) {
+                gkey[2 * (int64_t)blockIdx.x] = -1;
+                gkey[2 * (int64_t)blockIdx.x + 1] = -1;
+            }
+            return;
+        }
+    }
     // the global piece list is written once per workgroup (all column passes fill the same two rows)
     float *hp = gpiece + (int64_t)blockIdx.x * 2 * D, *tp = hp + D;
     for (int c0 = 0; c0 < D; c0 += W) {
@@ -1831,6 +1845,12 @@ extern "C" int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sort
         RP_LAUNCH_CHECK("embed_grad_seg (weight-gradient partials)");
     }
     return grad_reduce_finish(n_eff, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+}
+
+// (embed_ss.hip shares the piece-list finish of the segmented reduce)
+int rp_int_grad_reduce_finish(int64_t n, int D, int64_t nb0, char *wbase, float *piece0, int32_t *key0, float *grad_arena,
+                              int accumulate, hipStream_t s) {
+    return grad_reduce_finish(n, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
 }
 
 extern "C" int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream) {

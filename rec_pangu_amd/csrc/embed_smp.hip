@@ -15,8 +15,9 @@
 // in — so v, S and the gradient rows never pass through LDS, no wave waits for another one inside a unit (one LDS-only
 // barrier per unit for the double-buffered dH stage), and the row of a pair goes
 //     * straight to grad_arena[key] when the pair is the only one of its table row in the batch (one writer per row), or
-//     * to row q of a side buffer when its run in the sorted pair list has two or more pairs (q = its sorted index; marked
-//       by rp_embed_grad_smp_mark from the sorted list), which rp_embed_grad_reduce_rows then sums per run in list order.
+//     * to row c of a side buffer when its run in the sorted pair list has two or more pairs (c = its number among those
+//       pairs in sorted order; rp_embed_grad_smp_mark, from the sorted list), which rp_embed_grad_reduce_rows then sums per
+//       run in list order.
 // Deterministic: fixed summation orders, no atomics.  Split-bf16 x6 products (fp32-faithful), as rp_embed_grad_seg.
 #include "common.h"
 #include "bfsplit.h"
@@ -31,25 +32,88 @@ struct SmpFields {
 };
 #define SM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// dupq[fi * B + b]    = fi * B + j  if pair (field[fi], sample b) sits at index j of its field's sorted range inside a run of
-//                       two or more equal keys, else -1
-// dupkeys[fi * B + j] = the key of that sorted entry if it is part of such a run, else -1
+// The duplicate marks, COMPACT (three short launches; they depend on the batch's ids only and run with the sort, a step ahead):
+//   entry j of field fi's sorted range is a DUPLICATE when its run has two or more pairs; the duplicates are numbered
+//   c = 0, 1, ... in (fi, j) order — sorted order, so the pairs of a run are consecutive —
+//   dupq[fi * B + b] = c of pair (field[fi], sample b), or -1 when the pair is alone in its run
+//   dupkeys[c]       = the key of duplicate c; -1 from the number of duplicates on (the reduce behind the main launch walks
+//                      this list: with all n_fields * B entries in it — 14 % duplicates at Criteo shape — that reduce was a
+//                      30 us launch over 4096 workgroups of "no entry" keys, 100 us beside the step's other launches)
+__device__ __forceinline__ bool smp_is_dup(const int32_t *__restrict__ sk, int64_t n, int64_t q, int32_t k) {
+    return (q > 0 && sk[q - 1] == k) || (q + 1 < n && sk[q + 1] == k);
+}
+
+// counts[fi * nbk + blk] = duplicates among the 256 entries of block blk of field fi
+__global__ __launch_bounds__(256) void embed_grad_smp_count_kernel(const int32_t *__restrict__ sk, int64_t n, int Bi,
+                                                                   SmpFields sf, int nbk, int32_t *__restrict__ counts) {
+    __shared__ int32_t wc[4];
+    const int fi = (int)blockIdx.y, j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    bool dup = false;
+    if (j < Bi) {
+        const int64_t q = (int64_t)sf.field[fi] * Bi + j;
+        dup = smp_is_dup(sk, n, q, sk[q]);
+    }
+    const uint64_t bal = __ballot(dup);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __builtin_popcountll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[fi * nbk + (int)blockIdx.x] = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+}
+
+// counts -> exclusive offsets in place; counts[nblocks] = the total (one workgroup)
+__global__ __launch_bounds__(256) void embed_grad_smp_scan_kernel(int32_t *__restrict__ counts, int nblocks) {
+    __shared__ int32_t part[256];
+    const int t = (int)threadIdx.x;
+    const int per = (nblocks + 255) / 256, a = t * per, b = (a + per < nblocks) ? a + per : nblocks;
+    int s = 0;
+    for (int e = a; e < b; ++e) s += counts[e];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // (Hillis-Steele over 256 partial sums)
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = (t > 0) ? part[t - 1] : 0;
+    for (int e = a; e < b; ++e) {
+        const int c = counts[e];
+        counts[e] = run;
+        run += c;
+    }
+    if (t == 255) counts[nblocks] = part[255];
+}
+
 __global__ __launch_bounds__(256) void embed_grad_smp_mark_kernel(const int32_t *__restrict__ sk, const int32_t *__restrict__ sp,
-                                                                  int64_t n, int Bi, SmpFields sf, int32_t *__restrict__ dupq,
+                                                                  int64_t n, int Bi, SmpFields sf, int nbk,
+                                                                  const int32_t *__restrict__ offs, int32_t *__restrict__ dupq,
                                                                   int32_t *__restrict__ dupkeys) {
-    const int fi = (int)blockIdx.y;
-    const int j = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (j >= Bi) return;
+    __shared__ int32_t wc[4];
+    const int fi = (int)blockIdx.y, j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int wv = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
     const int f = sf.field[fi];
-    const int64_t q = (int64_t)f * Bi + j;
-    const int32_t k = sk[q];
-    const bool dup = (q > 0 && sk[q - 1] == k) || (q + 1 < n && sk[q + 1] == k);
-    const int32_t p = sp[q];
-    int b = p - f * Bi;
-    b = b < 0 ? 0 : (b >= Bi ? Bi - 1 : b);  // (a position outside the field's range would be a caller error)
-    const int32_t slot = fi * Bi + j;
-    dupq[(int64_t)fi * Bi + b] = dup ? slot : -1;
-    dupkeys[slot] = dup ? k : -1;
+    bool dup = false;
+    int32_t k = -1, p = 0;
+    if (j < Bi) {
+        const int64_t q = (int64_t)f * Bi + j;
+        k = sk[q];
+        p = sp[q];
+        dup = smp_is_dup(sk, n, q, k);
+    }
+    const uint64_t bal = __ballot(dup);
+    if (l == 0) wc[wv] = __builtin_popcountll(bal);
+    __syncthreads();
+    const int nblocks = sf.n * nbk;
+    const int total = offs[nblocks];
+    if (j < Bi) {
+        int c = offs[fi * nbk + (int)blockIdx.x] + __builtin_popcountll(bal & ((l == 0) ? 0ull : (~0ull >> (64 - l))));
+        for (int w2 = 0; w2 < wv; ++w2) c += wc[w2];
+        int b = p - f * Bi;
+        b = b < 0 ? 0 : (b >= Bi ? Bi - 1 : b);  // (a position outside the field's range would be a caller error)
+        dupq[(int64_t)fi * Bi + b] = dup ? c : -1;
+        if (dup) dupkeys[c] = k;
+        const int g = fi * Bi + j;  // the list's tail: "no entry"
+        if (g >= total) dupkeys[g] = -1;
+    }
 }
 
 #define SM_ROWS 64  // samples per unit
@@ -348,17 +412,30 @@ extern "C" int rp_embed_grad_smp_fits(int D, int hidden, int64_t lddh) {
     return (D == 64 && hidden == 64 && lddh % 4 == 0) ? 1 : 0;
 }
 
+extern "C" int rp_embed_grad_smp_mark_scratch(int64_t B, int n_fields, size_t *n_int32) {
+    RP_REQUIRE(n_int32 && B >= 1 && n_fields >= 1 && n_fields <= SM_MAXF, "embed_grad_smp_mark_scratch: bad argument");
+    *n_int32 = (size_t)n_fields * (size_t)rp_cdiv(B, 256) + 8;
+    return RP_OK;
+}
+
 extern "C" int rp_embed_grad_smp_mark(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B,
-                                      const int32_t *fields, int n_fields, int32_t *dupq, int32_t *dupkeys,
+                                      const int32_t *fields, int n_fields, int32_t *dupq, int32_t *dupkeys, int32_t *scratch,
                                       rp_stream_t stream) {
-    RP_REQUIRE(sorted_keys && sorted_pos && dupq && dupkeys, "embed_grad_smp_mark: null pointer");
+    RP_REQUIRE(sorted_keys && sorted_pos && dupq && dupkeys && scratch, "embed_grad_smp_mark: null pointer");
     RP_REQUIRE(B >= 1 && B < INT32_MAX && n >= 0 && n < INT32_MAX && n % B == 0 && n / B <= 64,
                "embed_grad_smp_mark: needs field-major positions (n = F * B, F <= 64)");
     RP_REQUIRE((int64_t)n_fields * B < INT32_MAX, "embed_grad_smp_mark: n_fields * B overflows int32");
     SmpFields sf;
     if (int rc = smp_fields(fields, n_fields, (int)(n / B), nullptr, nullptr, &sf)) return rc;
-    hipLaunchKernelGGL(embed_grad_smp_mark_kernel, dim3((unsigned)rp_cdiv(B, 256), (unsigned)n_fields), dim3(256), 0,
-                       (hipStream_t)stream, sorted_keys, sorted_pos, n, (int)B, sf, dupq, dupkeys);
+    const int nbk = (int)rp_cdiv(B, 256);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)nbk, (unsigned)n_fields);
+    hipLaunchKernelGGL(embed_grad_smp_count_kernel, grid, dim3(256), 0, s, sorted_keys, n, (int)B, sf, nbk, scratch);
+    RP_LAUNCH_CHECK("embed_grad_smp_mark (counts)");
+    hipLaunchKernelGGL(embed_grad_smp_scan_kernel, dim3(1), dim3(256), 0, s, scratch, n_fields * nbk);
+    RP_LAUNCH_CHECK("embed_grad_smp_mark (scan)");
+    hipLaunchKernelGGL(embed_grad_smp_mark_kernel, grid, dim3(256), 0, s, sorted_keys, sorted_pos, n, (int)B, sf, nbk, scratch, dupq,
+                       dupkeys);
     RP_LAUNCH_CHECK("embed_grad_smp_mark");
     return RP_OK;
 }

@@ -50,7 +50,7 @@ struct Plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_inline = 0;               // launches of section 2 (forked where they were recorded, joined at rp_plan_join)
     hipStream_t side2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_sync2 = nullptr;
     bool own_side = false, own_side2 = false;  // streams created here (else: the caller's, rp_plan_set_streams)
     // probe (rp_plan_set_probe): ONE launch of the next replays is bracketed by a timing event pair on the stream it is
     // issued on — the launch's duration INSIDE the replayed step, beside whatever the side streams run (bench.py)
@@ -176,6 +176,25 @@ extern "C" int rp_plan_join_side(void) {
     n.grid = n.block = dim3(0, 0, 0);
     n.shmem = 0;
     n.section = -4;
+    n.rec_stream = nullptr;
+    n.blob_at = p->blob.size();
+    p->nodes.push_back(std::move(n));
+    return RP_OK;
+}
+
+// The inline section (2) waits HERE for what the main stream holds at this point — a second dependency edge for a section
+// that was forked earlier (round 6: the tiny tables' gradient is forked in front of the sample-major launch and runs beside
+// it; the launches behind the sample-major one follow on the same side stream and need that launch).  While the section is
+// not open yet this is the fork mark.  Marker node, section -5.
+extern "C" int rp_plan_side2_sync(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_side2_sync: no plan is being recorded");
+    PlanNode n;
+    n.func = nullptr;
+    n.grid = n.block = dim3(0, 0, 0);
+    n.shmem = 0;
+    n.section = -5;
     n.rec_stream = nullptr;
     n.blob_at = p->blob.size();
     p->nodes.push_back(std::move(n));
@@ -423,6 +442,7 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork2, plan_event_flags());
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join2, plan_event_flags());
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_sync2, plan_event_flags());
         if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: second side stream: %s", hipGetErrorString(e));
     }
     bool forked = false, open2 = false, main_since_fork2 = false, side_joined = false, marked2 = false;
@@ -466,6 +486,20 @@ extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
                 e = timed(1, i, [&] { return hipEventRecord(p->ev_fork2, s); });
                 if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline fork mark: %s", hipGetErrorString(e));
                 marked2 = true;
+            }
+            continue;
+        }
+        if (n.func == nullptr && n.section == -5) {  // the inline section needs the main stream's results from here on
+            if (p->n_inline > 0) {
+                if (open2) {
+                    e = timed(1, i, [&] { return hipEventRecord(p->ev_sync2, s); });
+                    if (e == hipSuccess) e = timed(2, i, [&] { return hipStreamWaitEvent(p->side2, p->ev_sync2, 0); });
+                    main_since_fork2 = false;
+                } else {
+                    e = timed(1, i, [&] { return hipEventRecord(p->ev_fork2, s); });
+                    marked2 = true;
+                }
+                if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay: inline sync: %s", hipGetErrorString(e));
             }
             continue;
         }
@@ -563,6 +597,7 @@ extern "C" int rp_plan_destroy(void *plan) {
         (void)hipStreamSynchronize(p->side2);
         (void)hipEventDestroy(p->ev_fork2);
         (void)hipEventDestroy(p->ev_join2);
+        if (p->ev_sync2) (void)hipEventDestroy(p->ev_sync2);
         if (p->own_side2) (void)hipStreamDestroy(p->side2);
     }
     delete p;

@@ -44,9 +44,13 @@ _SIGNATURES = {
     "rp_embed_grad_tiny_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64,
                                      _vp, _sz, _vp]),
+    "rp_embed_grad_ss_workspace_bytes": (C.c_int, [_i64, _i64, _i32, C.c_uint64, C.POINTER(_sz)]),
+    "rp_embed_grad_ss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, C.c_uint64, _vp,
+                                   _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_smp_fits": (C.c_int, [_i32, _i32, _i64]),
     "rp_embed_grad_smp_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
-    "rp_embed_grad_smp_mark": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "rp_embed_grad_smp_mark_scratch": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_embed_grad_smp_mark": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "rp_embed_grad_smp": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
                                     _vp, _i64, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_reduce_rows": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
@@ -86,6 +90,7 @@ _SIGNATURES = {
     "rp_plan_slowest_call": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
     "rp_plan_join_side": (C.c_int, []),
+    "rp_plan_side2_sync": (C.c_int, []),
     "rp_plan_bind_inputs": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
     "rp_plan_set_inputs": (C.c_int, [_vp, _vp, _i32]),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
@@ -625,18 +630,21 @@ def _smp_fields(fields):
 
 
 def embed_grad_smp_mark(sorted_keys, sorted_pos, B: int, fields, out=None):
-    """rp_embed_grad_smp_mark: (dupq, dupkeys), both [len(fields) * B] int32 — which pairs of the big tables `fields` share
-    their table row with another pair of the batch, from the sorted pair list (depends on the batch's ids only)."""
+    """rp_embed_grad_smp_mark: (dupq, dupkeys, scratch) — which pairs of the big tables `fields` share their table row with
+    another pair of the batch, numbered compactly in sorted order, from the sorted pair list (depends on the batch's ids only)."""
     _req(sorted_keys, torch.int32, "sorted_keys")
     _req(sorted_pos, torch.int32, "sorted_pos")
     nf = len(fields)
     if out is None:
+        nsc = _sz(0)
+        _check(lib().rp_embed_grad_smp_mark_scratch(B, nf, C.byref(nsc)), "rp_embed_grad_smp_mark_scratch")
         out = (torch.empty((nf * B,), dtype=torch.int32, device=sorted_keys.device),
-               torch.empty((nf * B,), dtype=torch.int32, device=sorted_keys.device))
+               torch.empty((nf * B,), dtype=torch.int32, device=sorted_keys.device),
+               torch.empty((nsc.value,), dtype=torch.int32, device=sorted_keys.device))
     with _Timed("embed_grad_smp_mark", f"{nf} fields", 16 * nf * B):
         _check(lib().rp_embed_grad_smp_mark(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), B,
-                                            _smp_fields(fields)[0], nf, out[0].data_ptr(), out[1].data_ptr(), _stream()),
-               "rp_embed_grad_smp_mark")
+                                            _smp_fields(fields)[0], nf, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                            _stream()), "rp_embed_grad_smp_mark")
     return out
 
 
@@ -677,6 +685,36 @@ def embed_grad_reduce_rows(keys, rows, grad_arena, accumulate: bool):
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
     _check(lib().rp_embed_grad_reduce_rows(keys.data_ptr(), rows.data_ptr(), n, D, grad_arena.data_ptr(), int(accumulate),
                                            ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_reduce_rows")
+
+
+def embed_grad_ss(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, arena, grad_arena, accumulate: bool,
+                  skip_fields: int = 0, field_rows=None, dw=None, keep=None, phases: int = 3, ws=None):
+    """rp_embed_grad_ss: embed_grad_seg's work as a streaming segment-sum launch + a matrix launch over the unique rows (the
+    mid-size tables' share of the first layer's backward); same arguments and results up to fp32 summation order.
+    phases = 1: the segment-sum launch only, 2: the launches behind it (same `ws`), 3: both.  -> the workspace."""
+    _req(grad_arena, torch.float32, "grad_arena")
+    _req(dh, torch.float32, "dh")
+    _req(w, torch.float32, "w")
+    n = sorted_keys.numel()
+    fr = None
+    if field_rows is not None:
+        ck = tuple(field_rows)
+        fr = _SEG_ROWS.get(ck)
+        if fr is None:
+            fr = _SEG_ROWS[ck] = (C.c_int64 * len(ck))(*ck)
+    nbytes = _sz(0)
+    _check(lib().rp_embed_grad_ss_workspace_bytes(n, B, D, skip_fields, C.byref(nbytes)), "rp_embed_grad_ss_workspace_bytes")
+    if ws is None:
+        ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=grad_arena.device)
+        if keep is not None:
+            keep.append(ws)
+    with _Timed("embed_grad_ss" if phases & 2 else "embed_grad_segsum", f"D={D}"):
+        _check(lib().rp_embed_grad_ss(sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, B, D, dh.data_ptr(), _rowmajor(dh, "dh"),
+                                      w.data_ptr(), _rowmajor(w, "w"), _ptr(gfm), _ptr(sum_in), arena.data_ptr(),
+                                      grad_arena.data_ptr(), int(accumulate), skip_fields, fr, _ptr(dw),
+                                      _rowmajor(dw, "dw") if dw is not None else 0, phases, ws.data_ptr(), nbytes.value, _stream()),
+               "rp_embed_grad_ss")
+    return ws
 
 
 def zero_rows(keys, D: int, grad_arena):
@@ -992,6 +1030,11 @@ class LaunchPlan:
     def join_only(cls):
         """join the inline section as it stands: deferred launches stay queued, what they keep alive stays alive"""
         _check(lib().rp_plan_join(), "rp_plan_join")
+
+    @staticmethod
+    def side2_sync():
+        """the inline section waits here for what the main stream holds at this point (rp_plan_side2_sync)"""
+        _check(lib().rp_plan_side2_sync(), "rp_plan_side2_sync")
 
     @staticmethod
     def join_side():

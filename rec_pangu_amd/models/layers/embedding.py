@@ -361,6 +361,7 @@ class EmbeddingLayer(nn.Module):
                                accumulate=not self._grad_clean)
         elif fused is not None:  # (dH, W^T) of the Linear that consumes x: its dgrad is formed inside the reduce
             skip = 0
+            smp = None
             tiny = self._tiny_tables() if (keys is not None and dx is None and keys.numel() == len(self.emb_feature) * B) else None
             for f, _, _ in (tiny or ()):
                 skip |= 1 << f
@@ -393,29 +394,53 @@ class EmbeddingLayer(nn.Module):
                 # rp_embed_grad_seg over the remaining fields with the launches behind the sample-major one (the weight
                 # gradient's partial sums, the duplicate runs: other rows than anything beside them) on the second stream
                 smp = self._smp_tables(B) if hip.embed_grad_smp_fits(D, 64, fused[0]) else None
-                smp_ws = None
+                in_plan = plan_keep is not None
+                acc = not self._grad_clean
                 if smp:
                     for f, _, _ in smp:
                         skip |= 1 << f
+                rest = skip != (1 << len(self.emb_feature)) - 1   # fields left for the row-sorted form
+                # ... and the row-sorted form for the remaining (mid-size) tables in two launches (rp_embed_grad_ss: a streaming
+                # segment-sum launch, then the matrix launch over the unique rows).  (The segment-sum launch uses no LDS, but it
+                # cannot run BESIDE the sample-major launch on a second stream: 4 x 112 and 2 x 240 registers per SIMD lane do
+                # not fit the file of 512 together — one after the other on the main stream.)
+                ss = bool(smp) and rest and os.environ.get("RP_GRAD_SS", "1") != "0"
+                seg_args = (sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena)
+                seg_kw = dict(accumulate=acc, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1], keep=plan_keep)
+                smp_ws = None
+                # RP_TINY_EARLY=1 (a recorded plan only): the tiny tables' launches are forked IN FRONT of the sample-major
+                # launch and run beside it on the second stream; the launches behind the sample-major one follow them there
+                # (rp_plan_side2_sync: that stream waits for the sample-major launch at that point)
+                tiny_early = bool(smp and tiny and seg_first and in_plan and fork2 is not None
+                                  and os.environ.get("RP_TINY_EARLY", "1") == "1")
+                if tiny_early:
+                    fork2()
+                if smp:
                     marks = self._marks_of(sk, sp, smp, B)
                     smp_args = (keys, marks, B, len(self.emb_feature), smp, fused[0], seg[0], gfm, ssum, self._arena,
                                 self._grad_arena)
-                    smp_ws = hip.embed_grad_smp(*smp_args, accumulate=not self._grad_clean, dw=seg[1], keep=plan_keep,
-                                                phases=1)
-                if fork2 is not None:
+                    smp_ws = hip.embed_grad_smp(*smp_args, accumulate=acc, dw=seg[1], keep=plan_keep, phases=1)
+                if tiny_early:
+                    run_tiny()
+                    hip.LaunchPlan.side2_sync()
+                    tiny = None
+                elif fork2 is not None:
                     fork2()
-                # (inside a recorded plan the workspace stays referenced until the join: the side launches issued BEHIND this
-                #  one run beside it on another stream, and the capture's one-stream allocator would hand them its memory)
-                if skip != (1 << len(self.emb_feature)) - 1:
-                    hip.embed_grad_seg(sk, sp, B, D, fused[0], seg[0], gfm, ssum, self._arena, self._grad_arena,
-                                       accumulate=not self._grad_clean, skip_fields=skip, field_rows=self._rows_sig(), dw=seg[1],
-                                       keep=plan_keep)
+                # (inside a recorded plan the workspaces stay referenced until the join: the side launches issued BEHIND these
+                #  run beside them on another stream, and the capture's one-stream allocator would hand them their memory)
+                if ss:
+                    hip.embed_grad_ss(*seg_args, **seg_kw)
+                elif rest:
+                    hip.embed_grad_seg(*seg_args, **seg_kw)
                 if smp:
-                    in_plan = plan_keep is not None
+                    # the launches behind the sample-major one: other rows than anything beside them — on the second stream,
+                    # forked at the mark above (behind the sample-major launch), beside the launches of the row-sorted form; in
+                    # ISSUE order behind those: issued in front of them, the 4096 short workgroups of the duplicate reduce held
+                    # the segment-sum launch up by 56 us (profiles/r06 trace notes)
                     if in_plan:
                         hip.LaunchPlan.section(2)
                     try:
-                        hip.embed_grad_smp(*smp_args, accumulate=not self._grad_clean, dw=seg[1], phases=2, ws=smp_ws)
+                        hip.embed_grad_smp(*smp_args, accumulate=acc, dw=seg[1], phases=2, ws=smp_ws)
                     finally:
                         if in_plan:
                             hip.LaunchPlan.section(0)

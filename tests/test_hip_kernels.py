@@ -989,13 +989,15 @@ def test_embed_grad_tiny_tables_vs_sorted_path_and_fp64(hip, rows, B, with_fm, a
     ([50000, 7, 2000000], 65536, True, False, False),          # full batch: mostly unique rows, a hot table, 512 tiles per field
     ([50000, 13, 5, 700, 90], 16384 + 77, True, False, True),  # a ragged last tile
 ])
-def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate, with_tiny):
+@pytest.mark.parametrize("impl", ["seg", "ss"])
+def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate, with_tiny, impl):
     """rp_embed_grad_seg (segment sums first, then ONE matrix pass per run piece that yields the table rows' gradient AND the
     embedding columns of the first layer's weight gradient; the forward stores no activation) against an fp64 restatement
     of the reference's ops (embedding.py:61-63 backward + interaction.py:38-44 backward + deep.py:62-72 dgrad / wgrad) and
     against rp_embed_grad_gemm; bit-identical between two launches; both tile sizes when the library was started with
     RP_SEG_ROWS (the default here)."""
     D, H = 64, 64
+    seg_fn = hip.embed_grad_seg if impl == "seg" else hip.embed_grad_ss  # (round 6: the two-launch form, same contract)
     g = torch.Generator().manual_seed(B + len(rows))
     F = len(rows)
     arena, base = _tables(rows, D, g)
@@ -1023,7 +1025,7 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
         dw = torch.full((H, K), float("nan"), device=DEV)
         if tiny:
             hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G, accumulate, dw=dw)
-        hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G, accumulate, skip_fields=skip,
+        seg_fn(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G, accumulate, skip_fields=skip,
                            field_rows=rows, dw=dw)
         outs.append((G, dw))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1][:, :F * D], outs[1][1][:, :F * D]), "two launches differ"
@@ -1051,7 +1053,7 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
     G2 = torch.full((NR, D), init, device=DEV)
     if tiny:
         hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
-    hip.embed_grad_seg(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
+    seg_fn(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
     assert torch.equal(G2, G)
 
 
@@ -1098,15 +1100,17 @@ def test_embed_grad_smp_vs_fp64_and_seg(hip, rows, B, with_fm, accumulate, smp, 
     skc, spc = sk.cpu().long(), sp.cpu().long()
     dupq_ref = torch.full((len(smp) * B,), -1, dtype=torch.int64)
     dupk_ref = torch.full((len(smp) * B,), -1, dtype=torch.int64)
+    c0 = 0  # the duplicates are numbered in sorted order, field by field; the key list is compact, -1 behind them
     for fi, f in enumerate(smp):
         ks, ps = skc[f * B:(f + 1) * B], spc[f * B:(f + 1) * B]
         assert bool(((ps >= f * B) & (ps < (f + 1) * B)).all())
         dup = torch.zeros(B, dtype=torch.bool)
         dup[1:] |= ks[1:] == ks[:-1]
         dup[:-1] |= ks[:-1] == ks[1:]
-        j = torch.arange(B)
-        dupq_ref[fi * B + (ps - f * B)] = torch.where(dup, fi * B + j, torch.full_like(j, -1))
-        dupk_ref[fi * B:(fi + 1) * B] = torch.where(dup, ks, torch.full_like(ks, -1))
+        c = c0 + torch.cumsum(dup.long(), 0) - 1
+        dupq_ref[fi * B + (ps - f * B)] = torch.where(dup, c, torch.full_like(c, -1))
+        dupk_ref[c[dup]] = ks[dup]
+        c0 += int(dup.sum())
     assert torch.equal(marks[0].cpu().long(), dupq_ref) and torch.equal(marks[1].cpu().long(), dupk_ref)
     outs = []
     for _ in range(2):

@@ -1044,7 +1044,7 @@ def test_bf16_storage_training_mode():
     # (round 5: no stored activation — the weight gradient's embedding columns come out of rp_embed_grad_seg; RP_GRAD_SEG=0
     #  brings back the bf16 activation + rp_linear_wgrad_xbf16)
     assert any(k.startswith("embed_gather_linear_fwd_bf16") for k in rows)
-    assert any(k.startswith(("embed_grad_seg", "linear_wgrad_xbf16")) for k in rows)
+    assert any(k.startswith(("embed_grad_seg", "embed_grad_smp", "embed_grad_ss", "linear_wgrad_xbf16")) for k in rows)
     assert hip.launch_count() > n0
     z = lambda p: torch.log(p.clamp(1e-7, 1 - 1e-7)) - torch.log1p(-p.clamp(1e-7, 1 - 1e-7))  # noqa: E731
     dz = float((z(o["pred"]) - z(o_ref["pred"])).abs().max())
