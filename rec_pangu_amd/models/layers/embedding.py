@@ -437,12 +437,15 @@ class EmbeddingLayer(nn.Module):
                     # forked at the mark above (behind the sample-major launch), beside the launches of the row-sorted form; in
                     # ISSUE order behind those: issued in front of them, the 4096 short workgroups of the duplicate reduce held
                     # the segment-sum launch up by 56 us (profiles/r06 trace notes)
-                    if in_plan:
+                    # (RP_SMP_BEHIND=main: on the main stream behind everything else of this phase — with the tiny tables'
+                    #  launches in front of them the second stream is the longer one, the main stream idles at the join)
+                    side = in_plan and os.environ.get("RP_SMP_BEHIND", "side") != "main"
+                    if side:
                         hip.LaunchPlan.section(2)
                     try:
                         hip.embed_grad_smp(*smp_args, accumulate=acc, dw=seg[1], phases=2, ws=smp_ws)
                     finally:
-                        if in_plan:
+                        if side:
                             hip.LaunchPlan.section(0)
             else:
                 if fork2 is not None:
