@@ -29,6 +29,16 @@ CRITEO_CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; v_mfma_f32_32x32x16_bf16)
 HBM_COPY_GBS = 6300.0  # device-to-device copy ceiling measured on this part
+# Measured ceilings of RANDOM 256-B row traffic on this part (profiles/microbench/rowgather.hip -> profiles/r06_rowgather.txt;
+# every dominant launch of this path moves table rows, not streams): row bytes per second with the best
+# loads-in-flight / waves-per-SIMD setting of the sweep
+ROW_GATHER_HBM_GBS = 5900.0   # reads of distinct rows of the 8.6 GB arena (HBM)
+ROW_GATHER_MALL_GBS = 8000.0  # reads of rows of a 33.5 MB buffer (L2 miss, Infinity-Cache hit)
+ROW_RW_HBM_GBS = 4780.0       # 4 row reads + 3 row writes per row (the lazy optimizer's catch-up; 4 arenas = one 1 KB record)
+ROW_PEAK_OF = {"lazy_adam_catchup": ROW_RW_HBM_GBS, "lazy_adam_rows_step": ROW_RW_HBM_GBS, "lazy_adam_rows_replay": ROW_RW_HBM_GBS,
+               "embed_grad_smp": ROW_RW_HBM_GBS, "embed_gather_linear_fwd": ROW_GATHER_HBM_GBS, "embed_gather_fwd": ROW_GATHER_HBM_GBS,
+               "embed_gather_linear_fwd_bf16": ROW_GATHER_HBM_GBS, "embed_grad_seg": ROW_GATHER_MALL_GBS,
+               "embed_grad_ss": ROW_GATHER_MALL_GBS, "embed_grad_gemm": ROW_GATHER_MALL_GBS}
 # The replay's arithmetic floor, measured (profiles/microbench/valubench.hip, 8 waves per SIMD, operands in registers,
 # reported in SIMD clocks at the nominal 2.4 GHz): v_fma_f32 2.7, v_pk_fma_f32 7.3, v_rcp_f32 8.0 per wave-instruction; one
 # zero-gradient element-step of a wave (4 fma/mul issued as v_pk_*_f32 over two rows + one v_rcp_f32 per row) 17.2 clocks
@@ -120,12 +130,16 @@ KERNELS_OF = {
     "linear_wgrad": ("linear_wgrad_bf16_kernel", "linear_wgrad_partial_kernel"),
     "lazy_adam_rows_replay": ("lazy_replay_wave_kernel", "lazy_adam_rows_kernel"),
     "lazy_adam_rows_step": ("lazy_adam_rows_kernel",),
-    "lazy_adam_catchup": ("lazy_adam_catchup_kernel",),
+    "lazy_adam_catchup": ("lazy_adam_catchup_kernel", "lazy_adam_catchup_wave_kernel"),
     "lazy_adam_flush": ("lazy_flush_wave_kernel", "lazy_adam_flush_kernel"),
     "sort_pairs_i32": ("sort_hist", "sort_scan", "sort_scatter", "rocprim", "radix"),
     "embed_gather_linear_fwd": ("embed_gather_linear_kernel",),
     "embed_grad_tiny": ("embed_grad_tiny_partial_kernel", "embed_grad_tiny_finish_kernel", "embed_grad_tiny_dw_kernel"),
     "embed_grad_seg": ("embed_grad_seg_kernel",),
+    "embed_grad_smp": ("embed_grad_smp_kernel",),
+    "embed_grad_smp_behind": ("embed_grad_smp_dw_kernel",),
+    "embed_grad_smp_mark": ("embed_grad_smp_count_kernel", "embed_grad_smp_scan_kernel", "embed_grad_smp_mark_kernel"),
+    "embed_grad_ss": ("embed_segsum_kernel", "embed_ss_rows_kernel", "embed_ss_dw_kernel"),
     "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
     "attention_core_fwd": ("attn_core_fwd_kernel",),
     "attention_core_bwd": ("attn_core_bwd_kernel",),
@@ -242,7 +256,7 @@ def full_size_parity(oracle, dev):
     pre-activations lies within 1e-5 (of the layer's scale) of ZERO: fp32 rounding may put such a unit on either side in
     two correct implementations (measured: 1 sample of 65536; both the segment-sum-first and the pair-form backward show the
     same row, profiles/microbench/probes/diag_fullsize.py), which changes that one sample's gradient rows by a fraction of a
-    per cent.  Those samples are found with an fp64 forward of the MLP on the host and their rows held to 5e-2 instead."""
+    per cent.  Those samples are found with an fp64 forward of the MLP on the host and their rows held to 2e-3 instead (2.5 x the measured worst, 8e-4)."""
     from rec_pangu_amd.models.ranking import DeepFM
     enc, first, st = oracle["enc"], oracle["first"], oracle["state0"]
     with torch.device(dev):
@@ -288,17 +302,17 @@ def full_size_parity(oracle, dev):
             gd = max(gd, err)
         if worst is None or err > worst[1]:
             worst = (k, err)
-    ok = dp <= 1e-4 and dl <= 1e-4 and gd <= 1e-4 and gt <= 1e-4 and gt_near <= 5e-2
+    ok = dp <= 1e-4 and dl <= 1e-4 and gd <= 1e-4 and gt <= 1e-4 and gt_near <= 2e-3
     return {"ok": bool(ok), "B": int(first["pred"].shape[0]), "tolerance": 1e-4, "max_abs_pred_diff": dp, "abs_loss_diff": dl,
             "max_dense_grad_err_of_scale": gd, "max_table_grad_row_err_of_scale": gt, "table_rows_outside_tolerance": n_out,
             "samples_with_a_relu_preactivation_at_zero": int(near.sum()),
-            "max_table_grad_row_err_of_scale_on_those_samples_rows": gt_near, "tolerance_on_those_rows": 5e-2,
+            "max_table_grad_row_err_of_scale_on_those_samples_rows": gt_near, "tolerance_on_those_rows": 2e-3,
             "worst_gradient": worst[0] if worst else None,
             "note": "HIP DeepFM (fwd + bwd through the library's kernels, auto matrix-core mode) against the CPU oracle port on "
                     "the same initial weights and the same batch: B = 65536, 26 fields x D = 64 + 13 dense, vocabulary / 16 "
                     "(the oracle leg's bounded table size); gradients: max |g - g_ref| / max |g_ref| per tensor (per row for "
                     "tables); rows of samples with a ReLU pre-activation within 1e-5 of zero (either side is a correct "
-                    "rounding) are held to 5e-2 instead of 1e-4"}
+                    "rounding) are held to 2e-3 (2.5 x the measured worst, 8e-4) instead of 1e-4"}
 
 
 def main():
@@ -584,9 +598,12 @@ def main():
         # idle device in front of it: the --warmup steps are therefore REPEATED here as replays, right in front of the timed
         # region (the eager warm-up above was the per-kernel profiling pass; without these the first timed steps run on a
         # device that has just sat idle — the 20-step window then reads 1.5-4 % above the long-run mean of the same replays)
+        # (on batches of their own — never the timed ones; the last one announces the first timed batch)
         n_pre = 3 + args.warmup
+        pw = [gen(n_seen + 500000 + i) for i in range(n_pre)] + [batches[0]]
         for i in range(n_pre):
-            step(batches[(n_batches - n_pre + i) % n_batches], batches[(n_batches - n_pre + 1 + i) % n_batches], graphed=True)
+            step(pw[i], pw[i + 1], graphed=True)
+        del pw
         barrier()
         t0 = time.perf_counter()
     replays0 = gstep.replays if gstep is not None else 0
@@ -619,9 +636,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.callbacks.remove(_gc_cb)
+    # the lazy optimizer's owed work at the END of the timed window, read before anything else runs (read
+    # after the probes' ~125 further steps over the window's own 20 batches it said something else)
+    backlog1 = lazy_backlog() if lazy else None
+    pending1 = pending_real_steps() if (lazy and getattr(opt, "defer", False)) else None
     host_slowest = max(range(args.steps), key=lambda i_: host_each[i_])
     host_call_ms = host_wait_ms = host_call_max_ms = host_stall = None
     in_step = None
+    # everything behind the timed window (per-launch probes, the eager event passes) runs on batches of its OWN, distinct and
+    # never the timed ones: 48 of them, cycled
+    xb = [gen(n_seen + 600000 + i) for i in range(48)] if gstep is not None else None
     if gstep is not None:
         assert gstep.replays - replays0 == args.steps, "every timed step must have been a graph replay"
         # the host's own work per replayed step (python + ctypes + the plan's launches) and, apart from it, the time it sat
@@ -641,14 +665,14 @@ def main():
             REP = 3
             ctr = 0
             for _ in range(2):
-                step(batches[ctr % n_batches], batches[(ctr + 1) % n_batches], graphed=True)
+                step(xb[ctr % 48], xb[(ctr + 1) % 48], graphed=True)
                 ctr += 1
             in_step = []
             for k_, (kname, sec) in enumerate(names):
                 gstep.set_probe(k_)
                 acc = []
                 for _ in range(REP):
-                    step(batches[ctr % n_batches], batches[(ctr + 1) % n_batches], graphed=True)
+                    step(xb[ctr % 48], xb[(ctr + 1) % 48], graphed=True)
                     ctr += 1
                     acc.append(gstep.last_probe_ms())
                 short = kname.replace("void ", "").replace("(anonymous namespace)::", "")
@@ -661,8 +685,9 @@ def main():
         else:
             hip.enable_timing(True)
         for i in range(8):
-            step(batches[(args.steps + i) % n_batches], batches[(args.steps + i + 1) % n_batches] if ahead else None)
+            step(xb[i], xb[i + 1] if ahead else None)
         barrier()
+        del xb
     timing = hip.timing_summary()
     meta = hip.timing_meta()
     hip.enable_timing(False)
@@ -679,8 +704,6 @@ def main():
     value = B * args.steps / dt
     # ---- (5) the lazy optimizer's deferred work: equal at both ends of the timed region in the long-run state (nothing
     #          was pushed out of the window); the flush that a checkpoint would trigger is timed separately
-    backlog1 = lazy_backlog() if lazy else None
-    pending1 = pending_real_steps() if (lazy and getattr(opt, "defer", False)) else None
     flush_ms = None
     replay_elem_steps = None
     if lazy:
@@ -950,6 +973,11 @@ def main():
         r = {"kernel": key, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_vs_measured_copy_peak": round(gbs / HBM_COPY_GBS, 4),
              "traffic": pmc_traffic(key, mean_ms) if world == 1 else None, "algorithmic_bytes_per_launch": int(nbytes)}
+        rp_ = ROW_PEAK_OF.get(key.split("[")[0])
+        if rp_:
+            # the ceiling this launch is actually against: random 256-B rows, not a stream (profiles/r06_rowgather.txt)
+            r["row_peak_GBps"] = rp_
+            r["frac_vs_measured_row_gather_peak"] = round(gbs / rp_, 4)
         if r["traffic"]:
             # (state the fraction on the bytes that actually moved as well, and where they were counted)
             r["traffic_source"] = f"RECORDED rocprofv3 FETCH_SIZE + WRITE_SIZE of this workload ({PMC_FILE}), matched by kernel " \
@@ -1056,11 +1084,13 @@ def main():
         # the first layer's backward PHASE: the main-stream launches between the inline fork and its join, and what runs
         # beside them on the second side stream (the dense columns' weight gradient, the MLP tail's second stage, the tiny
         # tables); algorithmic bytes of the three gradient launches together
-        mainp = [r_ for r_ in in_step if r_["stream"] == "main" and r_["kernel"].startswith(("embed_grad_seg", "embed_grad_gemm", "embed_grad_reduce_kernel", "embed_grad_fix_kernel"))]
+        mainp = [r_ for r_ in in_step if r_["stream"] == "main" and r_["kernel"].startswith(("embed_grad_", "embed_segsum", "embed_ss_"))
+                 and not r_["kernel"].startswith(("embed_grad_smp_count", "embed_grad_smp_scan", "embed_grad_smp_mark"))]
         side2 = [r_ for r_ in in_step if r_["stream"] == "side2"]
         if mainp and side2:
             pb = sum((alg(k_)[0] if (k_ in kernels and alg(k_)) else 0) for k_ in kernels
-                     if k_.split("[")[0] in ("embed_grad_seg", "embed_grad_gemm", "embed_grad_tiny") or k_.startswith("linear_wgrad"))
+                     if k_.split("[")[0] in ("embed_grad_seg", "embed_grad_gemm", "embed_grad_tiny", "embed_grad_smp", "embed_grad_ss")
+                     or k_.startswith("linear_wgrad"))
             pm, ps = sum(r_["ms"] for r_ in mainp), sum(r_["ms"] for r_ in side2)
             phase = {"name": "first layer's backward (table rows + dW1 + tiny tables + dense columns)",
                      "main_stream_ms": round(pm, 4), "side2_stream_ms": round(ps, 4), "phase_ms": round(max(pm, ps), 4),
@@ -1078,6 +1108,20 @@ def main():
     gkeys = (f"embed_gather_fwd[D={D}]", f"embed_gather_linear_fwd[D={D}]", f"embed_gather_linear_fwd_bf16[D={D}]")
     gkey = next((k for k in (gkeys[::-1] if sharded else gkeys) if k in timing), None)
     gather = roofline_of(gkey, timing[gkey][1]) if gkey else None
+    if gather is not None and gather.get("traffic") and gather.get("bound") == "hbm":
+        # `frac` = the bytes rocprofv3 SEES over the launch's duration (north_star: "rocprof HBM GB/s on the
+        # gather"); SURVEY 8(d)'s 13 520 B/sample accounting figure — which includes an output store the fused launch does not
+        # do and row reads the caches absorb — stays beside it under its own name
+        sec_ = timing[gkey][1] * 1e-3
+        gather["frac_on_survey_bytes"] = gather["frac"]
+        gather["achieved_on_survey_bytes_GBps"] = gather["achieved"]
+        gather["achieved"] = round(gather["traffic"] / sec_ / 1e9, 1)
+        gather["frac"] = round(gather["traffic"] / sec_ / 1e9 / HBM_PEAK_GBS, 4)
+        gather["frac_vs_measured_row_gather_peak"] = round(gather["traffic"] / sec_ / 1e9 / ROW_GATHER_HBM_GBS, 4)
+        gather["note"] = ("achieved / frac = recorded rocprofv3 counter bytes (FETCH_SIZE + WRITE_SIZE, gfx950-corrected) of this "
+                          "launch / its live duration; *_on_survey_bytes = SURVEY 8(d)'s accounting figure (13 520 B per sample: "
+                          "every looked-up row + a [B, F*D] output the fused launch never stores); the launch also runs the "
+                          "first Linear (1677 x 64, split-bf16 x6) on the matrix core")
     gemm = None
     if args.model == "deepfm" and hidden != (64, 64, 64):
         # MFMA-bound variant: the heaviest GEMM row against the dense bf16 matrix-core peak
@@ -1168,9 +1212,14 @@ def main():
                                      "tables are still being touched for the FIRST time it grows, i.e. that many real "
                                      "steps (of the steps x unique rows the window owes) run after the window"}
                    if pending0 is not None else {}),
-                "note": "no flush inside the timed region: in the long-run state the deferred zero-gradient work is the "
-                        "same at both ends of the window (the two figures above), so none of it is pushed out of the "
-                        "measurement; flush_ms is what state_dict()/a checkpoint pays to bring every row to the last step"}
+                "owed_after_over_before": (round(backlog1 / backlog0, 4) if backlog0 else None),
+                "note": "no flush inside the timed region.  owed_element_steps = sum over rows of (t - row's last step) x D, read "
+                        "before the pre-window replays (8 steps on batches of their own, directly in front of the first timed step: a host read-back "
+                        "there would leave the device idle at the window's start) and immediately after the last timed step (the "
+                        "probes and the eager passes behind it run on batches of their own too): in the long-run state it is stationary up to "
+                        "the batch-to-batch fluctuation (owed_after_over_before ~ 1), i.e. the window pushes no zero-gradient "
+                        "work out of the measurement; flush_ms is what state_dict() / a checkpoint pays to bring every row to "
+                        "the last step"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"], oracle_leg = cpu_baseline()
             if args.model == "deepfm" and not sharded:

@@ -791,6 +791,10 @@ int rp_plan_fork2_mark(void);
  * contiguity; alive until the replay has run), no staging copy. */
 int rp_plan_bind_inputs(void *plan, const uint64_t *addrs, int n, int *n_sites);
 int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n);
+/* what rp_plan_bind_inputs would find, per input: sites[i] = argument words holding exactly addrs[i]; *n_interior = words that
+ * point INSIDE buffer i (addrs[i] < word < addrs[i] + nbytes[i]): arguments derived from an input, which rp_plan_set_inputs
+ * cannot re-point — the caller keeps its staging copy then (graph_step.py) */
+int rp_plan_bind_report(void *plan, const uint64_t *addrs, const uint64_t *nbytes, int n, int32_t *sites, int *n_interior);
 /* the main stream waits HERE for the side section (1) of the replay (default: at the end of the replay) — for a step that
  * itself consumes what the side section produces (the next batch's sorted keys: graph_step.py, catch-up ahead) */
 int rp_plan_join_side(void);

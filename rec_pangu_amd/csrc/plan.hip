@@ -255,6 +255,37 @@ extern "C" int rp_plan_bind_inputs(void *plan, const uint64_t *addrs, int n, int
     return RP_OK;
 }
 
+// What rp_plan_bind_inputs found, per input: sites[i] = argument words that hold EXACTLY addrs[i] (re-pointed by
+// rp_plan_set_inputs), *n_interior = words that point INSIDE one of the buffers [addrs[i] + 1, addrs[i] + nbytes[i]) — a
+// launch argument derived from an input (an offset view, a column of a packed buffer) that rp_plan_set_inputs can NOT
+// re-point: the caller must keep the staging copy when there is one.
+extern "C" int rp_plan_bind_report(void *plan, const uint64_t *addrs, const uint64_t *nbytes, int n, int32_t *sites,
+                                   int *n_interior) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended && addrs != nullptr && nbytes != nullptr && n >= 1 && sites != nullptr && n_interior != nullptr,
+               "plan_bind_report: a finished plan, >= 1 address, output pointers");
+    for (int i = 0; i < n; ++i) sites[i] = 0;
+    int interior = 0;
+    const size_t words = p->blob.size() / 8;
+    for (size_t w = 0; w < words; ++w) {
+        uint64_t v;
+        memcpy(&v, p->blob.data() + 8 * w, 8);
+        if (v == 0) continue;
+        for (int i = 0; i < n; ++i) {
+            if (v == addrs[i]) {
+                ++sites[i];
+                break;
+            }
+            if (v > addrs[i] && v < addrs[i] + nbytes[i]) {
+                ++interior;
+                break;
+            }
+        }
+    }
+    *n_interior = interior;
+    return RP_OK;
+}
+
 extern "C" int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && p->ended && addrs != nullptr, "plan_set_inputs: null pointer");

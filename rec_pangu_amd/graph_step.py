@@ -47,7 +47,16 @@ class GraphedTrainStep:
     returned dict holds detached, STATIC tensors ('pred', 'loss', ...) that the next call on the same graph overwrites
     (do not keep an autograd graph of an earlier eager step alive across the first captured call: its AccumulateGrad nodes
     are bound to the eager stream).  `post_backward`: a hook run
-    between backward and optimizer step (eager and captured alike)."""
+    between backward and optimizer step (eager and captured alike).
+
+    CONTRACT for the batches (launch plans re-point the recorded launches at the caller's own tensors, no staging copy):
+    a batch handed in as `next_batch` is read TWICE — by that call's replay (its keys + row sort, a step ahead) and by the next
+    call's (the step itself) — and both reads happen on the device after the calls have returned.  Its tensors must
+    therefore stay alive and UNCHANGED from the call that announces them until MAX_IN_FLIGHT + 2 further calls have been
+    made (the step holds references that long).  A loader that refills a device buffer in place is detected where torch can
+    see it — the tensor's data pointer or version counter differs from what was announced — and the batch is then staged
+    and re-sorted on the spot (correct, one copy + one sort slower); a refill torch cannot see (a raw kernel writing through
+    data_ptr()) is the caller's responsibility.  RP_PLAN_REBIND=0 restores the staging copy (a snapshot at call time)."""
 
     MAX_IN_FLIGHT = 6
 
@@ -95,6 +104,7 @@ class GraphedTrainStep:
         self.P = 0
         self._inflight, self._ev_pool = [], []  # completion events of the replays not yet known to have finished
         self._staged = None      # the caller's batch object whose content X[P] holds (sorted and pinned)
+        self._staged_sig = None  # (data_ptr, version) of its tensors when it was announced (a recycled buffer re-stages)
         self._sig = None
         self._pool = None
         self._dev = None         # host mirror of the device counters
@@ -126,6 +136,7 @@ class GraphedTrainStep:
         # (rp_plan_bind_inputs / _set_inputs).  `_x_valid[Q]`: static batch Q holds the content of the batch it stands for
         # (false after a step that read the tensors directly); `_held`: the batches of the replays that may still be in flight.
         self.rebind = os.environ.get("RP_PLAN_REBIND", "1") != "0"
+        self.bind_report = None   # {"sites": {input: argument words}, "interior": derived pointers} of the last capture
         self._bind_sites = [0, 0]
         self._x_valid = [False, False]
         self._held = []
@@ -209,6 +220,10 @@ class GraphedTrainStep:
         if not hip.multi_copy(dst, src):
             torch._foreach_copy_(dst, src)
 
+    def _sig_of(self, batch):
+        """what torch can see of a batch's buffers: (address, version counter) per tensor"""
+        return [(t.data_ptr(), t._version) for t in batch.values()]
+
     def _stage_current(self, batch):
         self._ahead_drop()  # (before the pinned key list it names is re-sorted in place)
         self._copy(self.P, batch)
@@ -218,6 +233,11 @@ class GraphedTrainStep:
         self._staged = batch
 
     def _capture(self, P):
+        if self.graphs[1 - P] is None:
+            # the flags describe the captures in use: with none left, a layer this capture no longer looks up must not keep
+            # "a captured step rebuilds my window" from an earlier one (the capture below sets them again)
+            for lz in self._lazy_states():
+                lz._cf_in_capture = False
         counters = self.opt.host_counters()
         self.opt.set_device_clock(True)
         self._dev = counters
@@ -318,8 +338,17 @@ class GraphedTrainStep:
                     side2 = _Fh._WGRAD_STREAMS[dev] = hip.make_side_stream(dev, "inline")
                 plan.set_streams(side, side2)
                 if self.rebind:
-                    self._bind_sites[P] = plan.bind_inputs([self.X[P][k].data_ptr() for k in self._keys]
-                                                           + [self.X[1 - P][k].data_ptr() for k in self._keys])
+                    # an argument that points INSIDE a static input (a derived pointer: an offset view, a column of
+                    # a packed buffer) cannot be re-pointed — such a step keeps the staging copy.  (An input no launch reads
+                    # at all has no site and needs none; a launch that is not the library's would have refused the plan.)
+                    ins = [self.X[P][k] for k in self._keys] + [self.X[1 - P][k] for k in self._keys]
+                    sites, interior = plan.bind_report(ins)
+                    self.bind_report = {"sites": dict(zip([f"cur:{k}" for k in self._keys] + [f"next:{k}" for k in self._keys], sites)),
+                                        "interior": interior}
+                    if interior == 0:
+                        self._bind_sites[P] = plan.bind_inputs([t.data_ptr() for t in ins])
+                    else:
+                        self._bind_sites[P] = 0
         self.captures += 1
         lz = getattr(emb, "_lazy", None)
         self._ahead_used = ahead  # (also when the step fell back to a hipGraph: the captured launches are the same)
@@ -354,9 +383,15 @@ class GraphedTrainStep:
                 return c_out
         raise RuntimeError("GraphedTrainStep: the static batch lost its pinned sort buffers")
 
+    def _lazy_states(self):
+        return [st._lazy for st in getattr(self.opt, "_stores", {}).values() if getattr(st, "_lazy", None) is not None]
+
     def _drop_captures(self):
         self._ahead_drop()
         self._ahead_used = False
+        for lz in self._lazy_states():  # (no capture in use rebuilds these states' closed-form windows any more)
+            lz._cf_in_capture = False
+            lz._cf_ahead = False
         self._bind_sites = [0, 0]
         for pl in self.plans:
             if pl is not None:
@@ -434,7 +469,9 @@ class GraphedTrainStep:
             self._staged = None
             return self._eager(batch, next_batch)
         seg("fits")
-        if self._staged is not batch:      # not the batch announced by the previous call: stage and sort it now
+        # not the batch announced by the previous call — or its tensors are not the ones (or no longer hold what) that call
+        # sorted: stage and sort it now
+        if self._staged is not batch or self._staged_sig != self._sig_of(batch):
             self._stage_current(batch)
         P = self.P
         sig = self.opt.prepare_step()
@@ -523,5 +560,5 @@ class GraphedTrainStep:
             self._ahead_valid = 1 - P
         seg("advance")
         self.replays += 1
-        self.P, self._staged = 1 - P, next_batch
+        self.P, self._staged, self._staged_sig = 1 - P, next_batch, self._sig_of(next_batch)
         return self.outs[P]

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "rp_plan_join_side": (C.c_int, []),
     "rp_plan_side2_sync": (C.c_int, []),
     "rp_plan_bind_inputs": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
+    "rp_plan_bind_report": (C.c_int, [_vp, _vp, _vp, _i32, _vp, C.POINTER(_i32)]),
     "rp_plan_set_inputs": (C.c_int, [_vp, _vp, _i32]),
     "rp_plan_inline_count": (C.c_int, [_vp, C.POINTER(_i32)]),
     "rp_plan_destroy": (C.c_int, [_vp]),
@@ -1075,6 +1076,18 @@ class LaunchPlan:
         self._n_inputs = len(addrs)
         self._in_arr = (C.c_uint64 * len(addrs))()
         return n.value
+
+    def bind_report(self, tensors):
+        """(sites per input, interior words): how often the recorded launch arguments hold exactly tensors[i].data_ptr(), and
+        how many hold an address INSIDE one of the tensors — derived pointers that set_inputs cannot re-point
+        (rp_plan_bind_report)"""
+        n = len(tensors)
+        addrs = (C.c_uint64 * n)(*[t.data_ptr() for t in tensors])
+        sizes = (C.c_uint64 * n)(*[t.numel() * t.element_size() for t in tensors])
+        sites = (C.c_int32 * n)()
+        inner = _i32()
+        _check(lib().rp_plan_bind_report(self._h, addrs, sizes, n, sites, C.byref(inner)), "rp_plan_bind_report")
+        return list(sites), inner.value
 
     def set_inputs(self, tensors):
         """the next replays read input i from tensors[i] (rp_plan_set_inputs)"""

@@ -182,6 +182,55 @@ def test_graphed_step_falls_back_to_eager_for_the_unannounced_and_the_last_batch
         assert torch.equal(finals["eager"][k], finals["graph"][k]), k
 
 
+def test_graphed_step_with_a_loader_that_refills_its_buffers_in_place():
+    """a launch plan reads the caller's tensors when the replay RUNS, and the sort of a batch is made one call
+    earlier from the same tensors.  A loader that recycles device buffers — here: the announced buffer is refilled in place
+    with another batch between the call that announces it and the call that consumes it, every other step — must not make
+    ids and sort disagree: the step sees the changed version counter and stages + re-sorts that batch.  Also: every input of
+    the captured step has an argument site, and no recorded argument points inside an input."""
+    from rec_pangu_amd.graph_step import GraphedTrainStep
+    from rec_pangu_amd.optim import FusedAdam
+    from rec_pangu_amd.models.layers.embedding import EmbeddingLayer
+    enc = _enc(3, [500, 9, 4000])
+    content = _batches(enc, 256, 16, seed=31)
+    decoys = _batches(enc, 256, 16, seed=32)
+    finals = {}
+    try:
+        for mode in ("eager", "graph"):
+            model = _build("deepfm16", enc)
+            opt = FusedAdam(model.parameters(), lr=2e-3, fuse_zero_grad=True, lazy_tables=True, replay="closed")
+            if mode == "eager":
+                for b in content[:-1]:
+                    model(b)["loss"].backward()
+                    opt.step()
+                    model.zero_grad()
+            else:
+                gstep = GraphedTrainStep(model, opt, backend="plan")
+                bufs = [{k: v.clone() for k, v in content[0].items()}, {k: torch.empty_like(v) for k, v in content[0].items()}]
+                restaged = 0
+                for i in range(len(content) - 1):
+                    cur, nxt = bufs[i % 2], bufs[(i + 1) % 2]
+                    late = i % 2 == 1
+                    for k in nxt:  # the loader fills the buffer it announces ...
+                        nxt[k].copy_((decoys if late else content)[i + 1][k])
+                    before = gstep._staged_sig
+                    gstep(cur, nxt)
+                    if late:       # ... and, every other step, changes its mind afterwards: the same buffer, refilled in place
+                        for k in nxt:
+                            nxt[k].copy_(content[i + 1][k])
+                        restaged += 1
+                assert gstep.replays >= len(content) - 1 - 2 - 2 and restaged >= 6
+                assert gstep.backend_used == "plan" and gstep.bind_report["interior"] == 0
+                used = [k for k in gstep.bind_report["sites"]  # the step reads everything of its batch, the ids of the next one
+                        if (k.startswith("cur:") and (k[4:] in enc or k == "cur:label")) or (k.startswith("next:C"))]
+                assert used and all(gstep.bind_report["sites"][k] > 0 for k in used), gstep.bind_report
+            finals[mode] = {k: v.clone() for k, v in model.state_dict().items()}
+    finally:
+        EmbeddingLayer.unpin_sorts()
+    for k in finals["eager"]:
+        assert torch.equal(finals["eager"][k], finals["graph"][k]), k
+
+
 @pytest.mark.parametrize("kind", ["deepfm64", "deepfm16", "dcn"])
 def test_catch_up_ahead_with_everything_that_can_come_between_two_steps(kind, monkeypatch):
     """RP_CATCHUP_AHEAD=1: a replayed step ends with the optimizer catch-up of the NEXT batch's rows (graph_step.py) — the
