@@ -139,7 +139,8 @@ KERNELS_OF = {
     "embed_grad_smp": ("embed_grad_smp_kernel",),
     "embed_grad_smp_behind": ("embed_grad_smp_dw_kernel",),
     "embed_grad_smp_mark": ("embed_grad_smp_count_kernel", "embed_grad_smp_scan_kernel", "embed_grad_smp_mark_kernel"),
-    "embed_grad_ss": ("embed_segsum_kernel", "embed_ss_rows_kernel", "embed_ss_dw_kernel"),
+    "embed_grad_ss": ("embed_segsum_kernel", "embed_ss_urows_kernel", "embed_ss_dw_kernel"),
+    "embed_grad_ss_mark": ("embed_ss_count_kernel", "embed_ss_scan_kernel", "embed_ss_mark_kernel"),
     "embed_gather_linear_fwd_bf16": ("embed_gather_linear_kernel",),
     "attention_core_fwd": ("attn_core_fwd_kernel",),
     "attention_core_bwd": ("attn_core_bwd_kernel",),

@@ -202,18 +202,24 @@ int rp_embed_grad_seg(const int32_t *sorted_keys, const int32_t *sorted_pos, int
                       int64_t lddw, void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* rp_embed_grad_seg's work in two launches (csrc/embed_ss.hip, round 6; the same reference ops, contract and results up to
  * fp32 summation order): a STREAMING segment-sum pass with no LDS and no barrier (a 16-lane group per 32 sorted positions
- * writes one record [sum dh | sum gfm sum_in | sum gfm | key] per run piece) and a matrix pass over the UNIQUE rows of every
- * tile of 128 sorted positions (the pieces of one key merged first).  The one-launch form keeps its gathers in flight during
- * a fifth of its tile loop and moves 2.3 TB/s out of the Infinity Cache; this form is for the tables whose runs are long
- * (the mid-size ones: rp_embed_grad_smp takes the big tables, rp_embed_grad_tiny the tiny ones).
- * phases: 1 = the segment-sum launch (reads dh / sum_in / gfm and the sorted pairs only: it may run beside
- * rp_embed_grad_smp's main launch on another stream), 2 = the launches behind it (same workspace, ordered behind phase 1),
- * 3 = both.  Workspace: rp_embed_grad_ss_workspace_bytes(n, B, D, skip_fields). */
+ * writes one record [sum dh | sum gfm sum_in | sum gfm] per run piece) and a matrix pass over tiles of 128 UNIQUE rows of a
+ * field (a row's pieces summed in position order first; one writer per row, no run is cut at a tile border).  This form is
+ * for the tables whose runs are long (the mid-size ones: rp_embed_grad_smp takes the big tables, rp_embed_grad_tiny the
+ * tiny ones).
+ * The matrix pass reads the fields' unique-row lists (ustart, ukey, offs): rp_embed_grad_ss_mark makes them from the sorted
+ * keys alone (three short launches — with the sort, a step ahead); NULL x 3 = made inside this call (workspace).  Sizes in
+ * int32 elements: rp_embed_grad_ss_mark_sizes(B, kept fields) -> n_rows (ustart and ukey each), n_offs.
+ * phases: 1 = the segment-sum launch (reads dh / sum_in / gfm and the sorted pairs only), 2 = the launches behind it (same
+ * workspace, ordered behind phase 1), 3 = both.  Workspace: rp_embed_grad_ss_workspace_bytes(n, B, D, skip_fields). */
 int rp_embed_grad_ss_workspace_bytes(int64_t n, int64_t B, int D, uint64_t skip_fields, size_t *bytes);
+int rp_embed_grad_ss_mark_sizes(int64_t B, int n_kept, size_t *n_rows, size_t *n_offs);
+int rp_embed_grad_ss_mark(const int32_t *sorted_keys, int64_t n, int64_t B, uint64_t skip_fields, int32_t *ustart, int32_t *ukey,
+                          int32_t *offs, rp_stream_t stream);
 int rp_embed_grad_ss(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D, const float *dh,
                      int64_t lddh, const float *w, int64_t ldw, const float *gfm, const float *sum_in, const float *arena,
                      float *grad_arena, int accumulate, uint64_t skip_fields, const int64_t *field_rows, float *dw,
-                     int64_t lddw, int phases, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+                     int64_t lddw, const int32_t *ustart, const int32_t *ukey, const int32_t *offs, int phases,
+                     void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* The same backward for the BIG tables, SAMPLE-major (csrc/embed_smp.hip, round 6; reference ops as rp_embed_grad_seg:
  * rec_pangu/models/layers/embedding.py:61-63 backward, layers/interaction.py:38-44 backward, layers/deep.py:62-72 dgrad and
  * the embedding columns of the weight gradient).  For a table whose runs in the sorted pair list are mostly singletons the

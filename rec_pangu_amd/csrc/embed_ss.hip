@@ -11,12 +11,17 @@
 //      at a time: dH row, S row and g_fm of eight pairs in flight per lane, segment sums in registers, and one RECORD
 //      [sum dH | sum g S | sum g | key] per run PIECE (a run cut at chunk borders) stored at the sorted index of the piece's
 //      last position; every other position gets key -1.  Sixteen waves per CU keep the gathers in flight.
-//   2. embed_ss_rows_kernel: per tile of 128 sorted positions — compact the tile's pieces (two ballots), merge the pieces
-//      of equal keys (the records are linear: a run of 215 positions of a 305-row table is ~7 chunk pieces), then exactly
-//      rp_embed_grad_seg's second half over the tile's UNIQUE rows: dgrad  Hs . W1_f  and the weight gradient  V^T . Hs  on
-//      the matrix core (split-bf16 x6), C + u - s v -> one writer per row; the tile's first / last row goes to the
-//      (head, tail) piece list when its run continues in the neighbour tile (rp_embed_grad_reduce's finish, shared).
-// Same contract, determinism and workspace protocol as rp_embed_grad_seg (field-major positions, skip_fields).
+//   2. embed_ss_urows_kernel: one workgroup per tile of 128 UNIQUE rows of a field, taken from the field's unique-row list
+//      (first sorted position + key of every run: rp_embed_grad_ss_mark — three short launches that depend on the batch's ids
+//      only and run with the sort, a step ahead; made inside this call when the caller has none).  The pieces of a row (the
+//      records are linear: a run of 215 positions of a 305-row table is ~7 chunk pieces) are summed in position order — every
+//      row's e-th piece in flight together; a run of more than SS_LONG pieces by the whole workgroup —, then
+//      rp_embed_grad_seg's second half over the 128 rows: dgrad  Hs . W1_f  and the weight gradient  V^T . Hs  on the matrix
+//      core (split-bf16 x6), C + u - s v -> the row's ONE writer.  No run is cut at a tile border: no piece list, no finish
+//      launches.  (The first form of this pass walked tiles of 256 sorted POSITIONS: a 305-row table's tile held one or two
+//      rows — 2560 mostly empty matrix tiles, eight barriers and three dependent trips each, head / tail pieces for the runs
+//      cut at tile borders and two more launches to sum those: 88 + 22 + 5 us inside the step for 47 k unique rows.)
+// Same contract and determinism as rp_embed_grad_seg (field-major positions, skip_fields).
 #include "common.h"
 #include "bfsplit.h"
 
@@ -25,7 +30,13 @@
 struct SsFields {
     int n;                    // kept fields
     unsigned char sched[64];  // chunk block -> field: the kept fields, largest table first
-    unsigned char rank[64];   // field -> its ordinal among the kept fields in ascending order (record / tile index base)
+    unsigned char rank[64];   // field -> its ordinal among the kept fields in ascending order (record / mark index base)
+    unsigned char kept[64];   // ordinal -> field (ascending)
+};
+#define SS_RB 128    // unique rows per workgroup of the second pass
+#define SS_LONG 16   // a row of more pieces than this is summed by the whole workgroup
+struct SsTiles {
+    int base[65];  // first tile of sched[o]; base[n] = the tile count (static bound: cdiv(min(B, table rows), SS_RB) per field)
 };
 #define SS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -108,34 +119,160 @@ __global__ __launch_bounds__(256, 4) void embed_segsum_kernel(const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// pass 2: the unique rows of a tile of SS_TILE sorted positions on the matrix core, 128 rows at a time.  The rows and their
-// pieces come straight from the sorted keys: a row = a maximal run inside the tile (one ballot + prefix count over the
-// positions); its pieces end at the chunk borders inside it and at its last position — no piece list is read.
+// the unique-row lists of the kept fields, from the sorted keys (they depend on the batch's ids only).  Kept field r (ascending
+// ordinal): a run STARTS at position x of the field's sorted range where the key differs from the one in front of it (or
+// x = 0); the runs are numbered j = 0, 1, ... in position order:
+//     ustart[r * B + j] = x,  ukey[r * B + j] = the run's key,  offs[r * nbk + blk] = runs in front of block blk of 256
+//     positions (over ALL kept fields in ordinal order): the field's run count = offs[(r + 1) * nbk] - offs[r * nbk]
 // ---------------------------------------------------------------------------------------------------------------------
-#define SS_TILE 256
+__device__ __forceinline__ bool ss_is_start(const int32_t *__restrict__ sk, int64_t q, int j) { return j == 0 || sk[q] != sk[q - 1]; }
+
+__global__ __launch_bounds__(256) void embed_ss_count_kernel(const int32_t *__restrict__ sk, int Bi, SsFields sf, int nbk,
+                                                             int32_t *__restrict__ counts) {
+    __shared__ int32_t wc[4];
+    const int r = (int)blockIdx.y, j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    bool st = false;
+    if (j < Bi) st = ss_is_start(sk, (int64_t)sf.kept[r] * Bi + j, j);
+    const uint64_t bal = __ballot(st);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __builtin_popcountll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[r * nbk + (int)blockIdx.x] = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+}
+
+// counts -> exclusive offsets in place; counts[nblocks] = the total (one workgroup)
+__global__ __launch_bounds__(256) void embed_ss_scan_kernel(int32_t *__restrict__ counts, int nblocks) {
+    __shared__ int32_t part[256];
+    const int t = (int)threadIdx.x;
+    const int per = (nblocks + 255) / 256, a = t * per, b = (a + per < nblocks) ? a + per : nblocks;
+    int s = 0;
+    for (int e = a; e < b; ++e) s += counts[e];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = (t > 0) ? part[t - 1] : 0;
+    for (int e = a; e < b; ++e) {
+        const int c = counts[e];
+        counts[e] = run;
+        run += c;
+    }
+    if (t == 255) counts[nblocks] = part[255];
+}
+
+__global__ __launch_bounds__(256) void embed_ss_mark_kernel(const int32_t *__restrict__ sk, int Bi, SsFields sf, int nbk,
+                                                            const int32_t *__restrict__ offs, int32_t *__restrict__ ustart,
+                                                            int32_t *__restrict__ ukey) {
+    __shared__ int32_t wc[4];
+    const int r = (int)blockIdx.y, j = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int wv = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
+    bool st = false;
+    int32_t k = -1;
+    if (j < Bi) {
+        const int64_t q = (int64_t)sf.kept[r] * Bi + j;
+        k = sk[q];
+        st = ss_is_start(sk, q, j);
+    }
+    const uint64_t bal = __ballot(st);
+    if (l == 0) wc[wv] = __builtin_popcountll(bal);
+    __syncthreads();
+    if (st) {
+        int c = offs[r * nbk + (int)blockIdx.x] - offs[r * nbk] + __builtin_popcountll(bal & ((l == 0) ? 0ull : (~0ull >> (64 - l))));
+        for (int w2 = 0; w2 < wv; ++w2) c += wc[w2];
+        ustart[(int64_t)r * Bi + c] = j;
+        ukey[(int64_t)r * Bi + c] = k;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pass 2: 128 unique rows of one field per workgroup, on the matrix core
+// ---------------------------------------------------------------------------------------------------------------------
 template <bool HAS_FM>
-__global__ __launch_bounds__(256, 2) void embed_ss_rows_kernel(
-    const float *__restrict__ rh, const float *__restrict__ ru, const float *__restrict__ rs, const int32_t *__restrict__ sk,
-    int Bi, const float *__restrict__ w, int64_t ldw, const float *__restrict__ arena, float *__restrict__ G, int accumulate,
-    float *__restrict__ gpiece, int32_t *__restrict__ gkey, float *__restrict__ dwpart, SsFields sf, int tpf, int T, int cpf) {
-    constexpr int D = 64, TILE = SS_TILE, RB = 128, MB = 2;
+__global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
+    const float *__restrict__ rh, const float *__restrict__ ru, const float *__restrict__ rs, const int32_t *__restrict__ ustart,
+    const int32_t *__restrict__ ukey, const int32_t *__restrict__ offs, int nbk, int Bi, const float *__restrict__ w, int64_t ldw,
+    const float *__restrict__ arena, float *__restrict__ G, int accumulate, float *__restrict__ dwpart, SsFields sf, SsTiles st) {
+    constexpr int D = 64, RB = SS_RB, MB = 2;
     __shared__ __attribute__((aligned(16))) float HsT[RB][SS_HT];  // the rows' dH sums; after the matrix passes: the C tile
     __shared__ __attribute__((aligned(16))) float VT[RB][D];       // the rows' table rows (zero rows behind them)
-    __shared__ int32_t rxs[TILE + 1];  // row -> its first position inside the tile ([M]: the tile's end)
-    __shared__ int32_t rowkey[TILE];
-    __shared__ int32_t wcnt[4];
+    __shared__ __attribute__((aligned(16))) float red[16][2 * D + 4];  // a long row's partial sums per group
+    __shared__ int32_t longrow[RB];
+    __shared__ int32_t nlong;
     const int tid = threadIdx.x, t = tid & 15, grp = tid >> 4, c = 4 * t;
     const int wv = tid >> 6, l = tid & 63, i = l & 31, h = l >> 5;
-    const int chunk = (int)blockIdx.x;
-    const int o = chunk / cpf;
-    const int f = sf.sched[o];
-    const int j0 = (chunk - o * cpf) * T;
-    const int jn = (j0 + T < tpf) ? j0 + T : tpf;
-    const int64_t fbase = (int64_t)f * Bi;
-    const int64_t ob = (int64_t)sf.rank[f] * Bi;
-    const int64_t tile_id0 = (int64_t)sf.rank[f] * tpf;
+    const int tile = (int)blockIdx.x;
+    int o = 0;
+    while (o + 1 < sf.n && tile >= st.base[o + 1]) ++o;  // (scalar: <= 63 steps)
+    const int f = sf.sched[o], r = sf.rank[f];
+    const int ucount = offs[(r + 1) * nbk] - offs[r * nbk];
+    const int j0 = (tile - st.base[o]) * RB;
+    if (j0 >= ucount) return;  // (workgroup-uniform: the tile count is a static bound)
+    const int Mb = (ucount - j0 < RB) ? ucount - j0 : RB;
+    const int64_t ob = (int64_t)r * Bi;  // record / mark index base of the field
     const bool want_dw = dwpart != nullptr;
     const int nb = wv & 1, mh = wv >> 1;
+    // the rows of this group: m = grp + 16 u — their position ranges and keys first (everything else depends on them)
+    int xs[8], xe[8], npc[8];
+    int32_t rk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = grp + 16 * u;
+        const bool ok = m < Mb;
+        const int64_t at = ob + j0 + (ok ? m : 0);
+        xs[u] = ustart[at];
+        rk[u] = ukey[at];
+        const int nx = (ok && j0 + m + 1 < ucount) ? ustart[at + 1] : Bi;
+        xe[u] = nx - 1;
+        npc[u] = ok ? (xe[u] >> 5) - (xs[u] >> 5) + 1 : 0;  // pieces: one per chunk of SS_CH = 32 positions the run touches
+    }
+    for (int e = tid; e < RB * SS_HT / 4; e += 256) reinterpret_cast<f32x4 *>(&HsT[0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < RB * D / 4; e += 256) reinterpret_cast<f32x4 *>(&VT[0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) nlong = 0;
+    __syncthreads();
+    // ---- (a) the rows' sums: piece e of each of this group's (up to 8) rows in flight together, e = 0, 1, ... in position
+    //      order; a row of more than SS_LONG pieces is left to the whole workgroup (b) --------------------------------------
+    f32x4 aH[8], aU[8], vv[8];
+    float aS[8];
+    int maxnp = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        aH[u] = aU[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        aS[u] = 0.f;
+        vv[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)((npc[u] > 0) ? rk[u] : 0) * D + c);
+        const bool lg = npc[u] > SS_LONG;
+        if (lg && t == 0) longrow[atomicAdd(&nlong, 1)] = grp + 16 * u;
+        if (lg) npc[u] = -npc[u];  // (marked: skipped below)
+        maxnp = npc[u] > maxnp ? npc[u] : maxnp;
+    }
+    for (int e = 0; e < maxnp; ++e) {
+        f32x4 vh[8], vu[8];
+        float s1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e < npc[u]) {
+                const int pe = (xs[u] | (SS_CH - 1)) + SS_CH * e;
+                const int64_t at = ob + (pe < xe[u] ? pe : xe[u]);
+                vh[u] = *reinterpret_cast<const f32x4 *>(rh + at * D + c);
+                if (HAS_FM) {
+                    vu[u] = *reinterpret_cast<const f32x4 *>(ru + at * D + c);
+                    s1[u] = rs[at];
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e < npc[u]) {
+                aH[u] += vh[u];
+                if (HAS_FM) {
+                    aU[u] += vu[u];
+                    aS[u] += s1[u];
+                }
+            }
+    }
+    __syncthreads();
+    // (the field's W1 slice as bf16 pieces — loaded here, behind the piece loop: in front of it the 48 registers spilled)
     bf16x8 wp[4][3];
     {
         const float *wsrc = w + (int64_t)f * D + 32 * nb + i;
@@ -147,194 +284,162 @@ __global__ __launch_bounds__(256, 2) void embed_ss_rows_kernel(
             bf_split8<3>(v, wp[ks]);
         }
     }
-    f32x16 dwacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dwacc[r] = 0.f;
-    for (int e = tid; e < RB * SS_HT / 4; e += 256) reinterpret_cast<f32x4 *>(&HsT[0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < RB * D / 4; e += 256) reinterpret_cast<f32x4 *>(&VT[0][0])[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    const uint64_t lt_mask = (l == 0) ? 0ull : (~0ull >> (64 - l));
-    for (int j = j0; j < jn; ++j) {
-        const int x0 = TILE * j;
-        const int npos = (Bi - x0 < TILE) ? Bi - x0 : TILE;
-        // ---- (a) the tile's rows: position tid starts one where its key differs from the key in front of it ---------------
-        const bool in = tid < npos;
-        const int32_t mykey = in ? sk[fbase + x0 + tid] : -1;
-        const int32_t prevkey = (in && x0 + tid > 0) ? sk[fbase + x0 + tid - 1] : -1;
-        const bool newrow = in && (tid == 0 || mykey != prevkey);
-        const uint64_t bal = __ballot(newrow);
-        if (l == 0) wcnt[wv] = __builtin_popcountll(bal);
-        // the keys in front of and behind the tile (the runs that cross its borders)
-        const int32_t kfront = (x0 > 0) ? sk[fbase + x0 - 1] : -1;
-        const int32_t kback = (x0 + TILE < Bi) ? sk[fbase + x0 + TILE] : -1;
-        SS_BARRIER();
-        const int M = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        if (newrow) {
-            int m = __builtin_popcountll(bal & lt_mask);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) m += (q < wv) ? wcnt[q] : 0;
-            rxs[m] = tid;
-            rowkey[m] = mykey;
+    // ---- (b) long rows: group g sums pieces g, g + 16, ... (four in flight), the owner adds the 16 partial sums in order ----
+    const int nl = nlong;
+    for (int q = 0; q < nl; ++q) {
+        // (the list's order depends on which group's atomic came first; the sums do not: every row is summed the same way)
+        const int m = longrow[q], og = m & 15, ou = m >> 4;
+        int lxs = 0, lxe = 0;
+        {
+            const int64_t at = ob + j0 + m;
+            lxs = ustart[at];
+            lxe = ((j0 + m + 1 < ucount) ? ustart[at + 1] : Bi) - 1;
         }
-        if (tid == 0) rxs[M] = npos;
-        SS_BARRIER();
-        const int32_t key0r = rowkey[0], keyLr = rowkey[M - 1];
-        const bool head_open = kfront >= 0 && kfront == key0r;
-        const bool tail_open = kback >= 0 && kback == keyLr;
-        const bool both = M == 1 && head_open && tail_open;  // one run over the whole tile: the head entry carries it
-        const int64_t tile_id = tile_id0 + j;
-        float *hp = gpiece + tile_id * 2 * D, *tp = hp + D;
-        for (int m0 = 0; m0 < M; m0 += RB) {
-            const int Mb = (M - m0 < RB) ? M - m0 : RB;  // rows of this batch
-            // ---- (b) the rows' sums: the first piece of each of this group's (up to 8) rows in flight together, the
-            //      further pieces of a row (a run across chunk borders) behind them ------------------------------------------
-            f32x4 E[8];
-            {
-                f32x4 vh[8], vu[8], vv[8];
-                float s1[8];
-                int xs[8], xe[8];
-                int32_t rk[8];
+        const int np = (lxe >> 5) - (lxs >> 5) + 1;
+        f32x4 pH = {0.f, 0.f, 0.f, 0.f}, pU = {0.f, 0.f, 0.f, 0.f};
+        float pS = 0.f;
+        for (int e0 = grp; e0 < np; e0 += 64) {
+            f32x4 vh[4], vu[4];
+            float s1[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = grp + 16 * u;
-                    const bool ok = m < Mb;
-                    xs[u] = ok ? rxs[m0 + m] : 0;
-                    xe[u] = ok ? rxs[m0 + m + 1] - 1 : 0;
-                    rk[u] = ok ? rowkey[m0 + m] : 0;
-                    const int p0 = (xs[u] | (SS_CH - 1)) < xe[u] ? (xs[u] | (SS_CH - 1)) : xe[u];  // the first piece's end
-                    const int64_t at = ob + x0 + p0;
-                    vh[u] = *reinterpret_cast<const f32x4 *>(rh + at * D + c);
-                    if (HAS_FM) {
-                        vu[u] = *reinterpret_cast<const f32x4 *>(ru + at * D + c);
-                        s1[u] = rs[at];
-                    }
-                    vv[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)rk[u] * D + c);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = grp + 16 * u;
-                    const bool ok = m < Mb;  // (a row beyond Mb read record 0 of the tile: possibly never written — selects, not factors)
-                    f32x4 aH = vh[u], aU = HAS_FM ? vu[u] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    float aS = HAS_FM ? s1[u] : 0.f;
-                    for (int p = (xs[u] | (SS_CH - 1)) + SS_CH; p - SS_CH < xe[u]; p += SS_CH) {  // (rare: the run's other chunks)
-                        const int64_t at = ob + x0 + (p < xe[u] ? p : xe[u]);
-                        aH += *reinterpret_cast<const f32x4 *>(rh + at * D + c);
-                        if (HAS_FM) {
-                            aU += *reinterpret_cast<const f32x4 *>(ru + at * D + c);
-                            aS += rs[at];
-                        }
-                    }
-                    if (ok) {  // (LDS stores only)
-                        *reinterpret_cast<f32x4 *>(&HsT[m][c]) = aH;
-                        *reinterpret_cast<f32x4 *>(&VT[m][c]) = vv[u];
-                    }
-                    E[u] = HAS_FM ? aU - aS * vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 16 * k;
+                const int pe = (lxs | (SS_CH - 1)) + SS_CH * (e < np ? e : 0);
+                const int64_t at = ob + (pe < lxe ? pe : lxe);
+                vh[k] = *reinterpret_cast<const f32x4 *>(rh + at * D + c);
+                if (HAS_FM) {
+                    vu[k] = *reinterpret_cast<const f32x4 *>(ru + at * D + c);
+                    s1[k] = rs[at];
                 }
             }
-            // the weight gradient's last k-step reads rows Mb .. (its multiple of 16): zero table rows there
-            if (grp < ((Mb + 15) & ~15) - Mb) *reinterpret_cast<f32x4 *>(&VT[Mb + grp][c]) = f32x4{0.f, 0.f, 0.f, 0.f};
-            SS_BARRIER();  // (A) the tiles are complete
-            // ---- dgrad on the matrix core: C[row, d] = sum_hidden Hs[row, hidden] W1[hidden, f*64 + d] ------------------------
-            f32x16 ag[MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ag[mb][r] = 0.f;
-                if (32 * (mh + 2 * mb) >= Mb) continue;  // (workgroup-uniform)
-                const float *arow = &HsT[32 * (mh + 2 * mb) + i][8 * h];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks + 4);
-                    f32x8 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = v0[e];
-                        v[4 + e] = v1[e];
-                    }
-                    bf16x8 a[3];
-                    bf_split8<3>(v, a);
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
-                        ag[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], wp[ks][BfProd<6>::pb(pr)], ag[mb], 0, 0, 0);
+            for (int k = 0; k < 4; ++k) {
+                const float okf = (e0 + 16 * k < np) ? 1.f : 0.f;
+                pH += okf * vh[k];
+                if (HAS_FM) {
+                    pU += okf * vu[k];
+                    pS += okf * s1[k];
                 }
             }
-            // ---- weight gradient: dW1^T[d, hidden] += sum_row V[row, d] Hs[row, hidden]  (K = the batch's rows) ------------
-            if (want_dw) {
-                const int dblk = wv >> 1, hblk = wv & 1;
-                const int nks = (Mb + 15) >> 4;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-                for (int ks = 0; ks < nks; ++ks) {
-                    f32x8 va, vb;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        va[e] = VT[16 * ks + 8 * h + e][32 * dblk + i];
-                        vb[e] = HsT[16 * ks + 8 * h + e][32 * hblk + i];
-                    }
-                    bf16x8 a[3], bq[3];
-                    bf_split8<3>(va, a);
-                    bf_split8<3>(vb, bq);
-#pragma unroll
-                    for (int pr = 0; pr < 6; ++pr)
-                        dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], dwacc, 0, 0, 0);
-                }
-            }
-            SS_BARRIER();  // (B) every wave is done reading the Hs tile: it becomes the C tile
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                if (32 * (mh + 2 * mb) < Mb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) HsT[32 * (mh + 2 * mb) + (r & 3) + 8 * (r >> 2) + 4 * h][32 * nb + i] = ag[mb][r];
-                }
-            SS_BARRIER();  // (C)
-            // ---- the rows' gradient: C + u - s v.  A run that continues in the neighbour tile goes to the tile's (head, tail)
-            //      entry of the piece list instead (the finish launches sum the chains); everything else has one writer ----------
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int m = grp + 16 * u;
-                if (m < Mb) {
-                    const f32x4 val = *reinterpret_cast<const f32x4 *>(&HsT[m][c]) + E[u];
-                    const bool is_head = m0 + m == 0 && head_open;
-                    const bool is_tail = m0 + m == M - 1 && tail_open && !both;
-                    if (is_head) {
-                        *reinterpret_cast<f32x4 *>(hp + c) = val;
-                    } else if (is_tail) {
-                        *reinterpret_cast<f32x4 *>(tp + c) = val;
-                    } else {
-                        float *dst = G + (int64_t)rowkey[m0 + m] * D + c;
-                        const f32x4 out = accumulate ? *reinterpret_cast<const f32x4 *>(dst) + val : val;
-                        *reinterpret_cast<f32x4 *>(dst) = out;
-                    }
-                }
-            }
-            SS_BARRIER();  // (D) the C tile is free (the index arrays stay until the tile's last batch is through)
         }
-        // entries nobody filled: zero rows (the finish adds them to nothing: key -1)
-        if (grp == 1 && !head_open) *reinterpret_cast<f32x4 *>(hp + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (grp == 2 && (!tail_open || both)) *reinterpret_cast<f32x4 *>(tp + c) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tid == 0) {
-            gkey[2 * tile_id] = head_open ? key0r : -1;
-            gkey[2 * tile_id + 1] = tail_open ? keyLr : -1;
+        *reinterpret_cast<f32x4 *>(&red[grp][c]) = pH;
+        *reinterpret_cast<f32x4 *>(&red[grp][D + c]) = pU;
+        if (t == 0) red[grp][2 * D] = pS;
+        __syncthreads();
+        if (grp == og) {
+            f32x4 sH = {0.f, 0.f, 0.f, 0.f}, sU = {0.f, 0.f, 0.f, 0.f};
+            float sS = 0.f;
+            for (int g2 = 0; g2 < 16; ++g2) {
+                sH += *reinterpret_cast<const f32x4 *>(&red[g2][c]);
+                sU += *reinterpret_cast<const f32x4 *>(&red[g2][D + c]);
+                sS += red[g2][2 * D];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (u == ou) {
+                    aH[u] = sH;
+                    aU[u] = sU;
+                    aS[u] = sS;
+                }
+        }
+        __syncthreads();
+    }
+    f32x4 E[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = grp + 16 * u;
+        if (m < Mb) {  // (LDS stores only)
+            *reinterpret_cast<f32x4 *>(&HsT[m][c]) = aH[u];
+            *reinterpret_cast<f32x4 *>(&VT[m][c]) = vv[u];
+        }
+        E[u] = HAS_FM ? aU[u] - aS[u] * vv[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    SS_BARRIER();  // (A) the tiles are complete
+    // ---- dgrad on the matrix core: C[row, d] = sum_hidden Hs[row, hidden] W1[hidden, f*64 + d] ------------------------
+    f32x16 ag[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) ag[mb][r2] = 0.f;
+        if (32 * (mh + 2 * mb) >= Mb) continue;  // (workgroup-uniform)
+        const float *arow = &HsT[32 * (mh + 2 * mb) + i][8 * h];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(arow + 16 * ks + 4);
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = v0[e];
+                v[4 + e] = v1[e];
+            }
+            bf16x8 a[3];
+            bf_split8<3>(v, a);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+                ag[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], wp[ks][BfProd<6>::pb(pr)], ag[mb], 0, 0, 0);
         }
     }
+    // ---- weight gradient: dW1^T[d, hidden] = sum_row V[row, d] Hs[row, hidden]  (K = the tile's rows) ------------------
     if (want_dw) {
-        float *P = dwpart + (int64_t)chunk * (D * D);
-        const int dblk = wv >> 1, hblk = wv & 1;
+        f32x16 dwacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) P[(32 * dblk + (r & 3) + 8 * (r >> 2) + 4 * h) * D + 32 * hblk + i] = dwacc[r];
+        for (int r2 = 0; r2 < 16; ++r2) dwacc[r2] = 0.f;
+        const int dblk = wv >> 1, hblk = wv & 1;
+        const int nks = (Mb + 15) >> 4;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ++ks) {
+            f32x8 va, vb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                va[e] = VT[16 * ks + 8 * h + e][32 * dblk + i];
+                vb[e] = HsT[16 * ks + 8 * h + e][32 * hblk + i];
+            }
+            bf16x8 a[3], bq[3];
+            bf_split8<3>(va, a);
+            bf_split8<3>(vb, bq);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+                dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[BfProd<6>::pa(pr)], bq[BfProd<6>::pb(pr)], dwacc, 0, 0, 0);
+        }
+        float *P = dwpart + (int64_t)tile * (D * D);  // [d][hidden]
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) P[(32 * dblk + (r2 & 3) + 8 * (r2 >> 2) + 4 * h) * D + 32 * hblk + i] = dwacc[r2];
+    }
+    SS_BARRIER();  // (B) every wave is done reading the Hs tile: it becomes the C tile
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+        if (32 * (mh + 2 * mb) < Mb) {
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) HsT[32 * (mh + 2 * mb) + (r2 & 3) + 8 * (r2 >> 2) + 4 * h][32 * nb + i] = ag[mb][r2];
+        }
+    SS_BARRIER();  // (C)
+    // ---- the rows' gradient: C + u - s v, one writer per row ---------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = grp + 16 * u;
+        if (m < Mb) {
+            const f32x4 val = *reinterpret_cast<const f32x4 *>(&HsT[m][c]) + E[u];
+            float *dst = G + (int64_t)rk[u] * D + c;
+            const f32x4 out = accumulate ? *reinterpret_cast<const f32x4 *>(dst) + val : val;
+            *reinterpret_cast<f32x4 *>(dst) = out;
+        }
     }
 }
 
-// dw[hidden, f*64 + d] = the fixed-order sum of the chunk partials [d][hidden] of field f (as embed_grad_seg_dw_kernel)
-__global__ __launch_bounds__(256) void embed_ss_dw_kernel(const float *__restrict__ dwpart, SsFields sf, int cpf,
-                                                          float *__restrict__ dw, int64_t lddw) {
+// dw[hidden, f*64 + d] = the fixed-order sum of the field's tile partials [d][hidden] (as many as the field has unique rows for)
+__global__ __launch_bounds__(256) void embed_ss_dw_kernel(const float *__restrict__ dwpart, SsFields sf, SsTiles st,
+                                                          const int32_t *__restrict__ offs, int nbk, float *__restrict__ dw,
+                                                          int64_t lddw) {
     __shared__ float part[4][64];
-    const int o = (int)blockIdx.x, f = sf.sched[o];
+    const int o = (int)blockIdx.x, f = sf.sched[o], r = sf.rank[f];
     const int q = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
     const int e = (int)blockIdx.y * 64 + l;  // element (d = e >> 6, hidden = e & 63) of the field's block
+    const int ucount = offs[(r + 1) * nbk] - offs[r * nbk];
+    const int cpf = (ucount + SS_RB - 1) / SS_RB;
     const int per = (cpf + 3) / 4, c0 = q * per, c1 = (c0 + per < cpf) ? c0 + per : cpf;
-    const float *p = dwpart + ((int64_t)o * cpf) * 4096 + e;
+    const float *p = dwpart + (int64_t)st.base[o] * 4096 + e;
     float s0 = 0.f, s1 = 0.f;
     int ci = c0;
     for (; ci + 8 <= c1; ci += 8) {
@@ -353,104 +458,134 @@ __global__ __launch_bounds__(256) void embed_ss_dw_kernel(const float *__restric
     if (q == 0) dw[(int64_t)(e & 63) * lddw + (int64_t)f * 64 + (e >> 6)] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
 }
 
-extern "C" int rp_embed_grad_reduce_workspace_bytes(int64_t n, int D, size_t *bytes);
-
-static int ss_tiles_per_chunk(int tpf) {
-    static const int forced = []() {
-        const char *e = getenv("RP_SS_TILES");
-        return e ? atoi(e) : 0;
-    }();
-    int T = forced > 0 ? forced : (tpf + 32) / 64;  // ~64 chunks per field
-    T = T < 1 ? 1 : (T > 64 ? 64 : T);
-    return T > tpf ? tpf : T;
+static int ss_fields(int F, uint64_t skip_fields, const int64_t *field_rows, int64_t B, SsFields *sf, SsTiles *st) {
+    memset(sf, 0, sizeof(*sf));
+    memset(st, 0, sizeof(*st));
+    for (int f = 0; f < F; ++f)
+        if (!((skip_fields >> f) & 1u)) {
+            sf->rank[f] = (unsigned char)sf->n;
+            sf->kept[sf->n++] = (unsigned char)f;
+        }
+    for (int a = 0; a < sf->n; ++a) {  // largest table first (stable)
+        const int f = sf->kept[a];
+        int b = a;
+        while (b > 0 && field_rows != nullptr && field_rows[sf->sched[b - 1]] < field_rows[f]) {
+            sf->sched[b] = sf->sched[b - 1];
+            --b;
+        }
+        sf->sched[b] = (unsigned char)f;
+    }
+    for (int o = 0; o < sf->n; ++o) {
+        int64_t rows = B;  // unique rows of a field <= min(B, table rows)
+        if (field_rows != nullptr && field_rows[sf->sched[o]] >= 1 && field_rows[sf->sched[o]] < rows) rows = field_rows[sf->sched[o]];
+        st->base[o + 1] = st->base[o] + (int)rp_cdiv(rows, SS_RB);
+    }
+    return sf->n;
 }
 
-static int64_t ss_n_eff(int64_t n, int64_t B) {  // (the piece region is sized through rp_embed_grad_reduce's formula)
-    const int64_t F = B > 0 ? n / B : 0;
-    const int64_t tiles = F * rp_cdiv(B, SS_TILE);
-    return n > tiles * 32 ? n : tiles * 32;
+// the marks: ustart / ukey [n_kept * B] int32, offs [n_kept * cdiv(B, 256) + 8] int32
+extern "C" int rp_embed_grad_ss_mark_sizes(int64_t B, int n_kept, size_t *n_rows, size_t *n_offs) {
+    RP_REQUIRE(n_rows && n_offs && B >= 1 && n_kept >= 0 && n_kept <= 64, "embed_grad_ss_mark_sizes: bad argument");
+    *n_rows = (size_t)(n_kept > 0 ? n_kept : 1) * (size_t)B;
+    *n_offs = (size_t)n_kept * (size_t)rp_cdiv(B, 256) + 8;
+    return RP_OK;
 }
 
-// workspace: [the reduce's piece lists][weight-gradient partials][records: rh, ru, rs, pk over n_kept * B positions]
-static void ss_layout(int64_t n, int64_t B, int n_kept, size_t *o_dw, size_t *o_rec, size_t *total) {
-    size_t red = 0;
-    rp_embed_grad_reduce_workspace_bytes(ss_n_eff(n, B), 64, &red);
-    const int tpf = (int)rp_cdiv(B, SS_TILE);
-    const int64_t cpf = rp_cdiv(tpf, ss_tiles_per_chunk(tpf));
-    size_t off = (red + 255) & ~(size_t)255;
-    *o_dw = off;
-    off += ((size_t)(n / B) * cpf * 4096 * sizeof(float) + 255) & ~(size_t)255;
+static int ss_mark_launch(const int32_t *sorted_keys, int64_t B, const SsFields &sf, int32_t *ustart, int32_t *ukey, int32_t *offs,
+                          hipStream_t s) {
+    const int nbk = (int)rp_cdiv(B, 256);
+    const dim3 grid((unsigned)nbk, (unsigned)sf.n);
+    hipLaunchKernelGGL(embed_ss_count_kernel, grid, dim3(256), 0, s, sorted_keys, (int)B, sf, nbk, offs);
+    RP_LAUNCH_CHECK("embed_grad_ss_mark (counts)");
+    hipLaunchKernelGGL(embed_ss_scan_kernel, dim3(1), dim3(256), 0, s, offs, sf.n * nbk);
+    RP_LAUNCH_CHECK("embed_grad_ss_mark (scan)");
+    hipLaunchKernelGGL(embed_ss_mark_kernel, grid, dim3(256), 0, s, sorted_keys, (int)B, sf, nbk, (const int32_t *)offs, ustart, ukey);
+    RP_LAUNCH_CHECK("embed_grad_ss_mark");
+    return RP_OK;
+}
+
+extern "C" int rp_embed_grad_ss_mark(const int32_t *sorted_keys, int64_t n, int64_t B, uint64_t skip_fields, int32_t *ustart,
+                                     int32_t *ukey, int32_t *offs, rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && ustart && ukey && offs, "embed_grad_ss_mark: null pointer");
+    RP_REQUIRE(B >= 1 && B < INT32_MAX && n >= 0 && n < INT32_MAX && n % B == 0 && n / B <= 64,
+               "embed_grad_ss_mark: needs field-major positions (n = F * B, F <= 64)");
+    SsFields sf;
+    SsTiles st;
+    if (ss_fields((int)(n / B), skip_fields, nullptr, B, &sf, &st) == 0) return RP_OK;
+    return ss_mark_launch(sorted_keys, B, sf, ustart, ukey, offs, (hipStream_t)stream);
+}
+
+// workspace: [weight-gradient partials: one per tile][records: rh, ru, rs over n_kept * B positions][marks made here]
+static void ss_layout(int64_t B, const SsFields &sf, const SsTiles &st, size_t *o_rec, size_t *o_mark, size_t *total) {
+    size_t off = ((size_t)st.base[sf.n] * 4096 * sizeof(float) + 255) & ~(size_t)255;
     *o_rec = off;
-    const size_t np = (size_t)n_kept * (size_t)B;
-    off += 2 * ((np * 64 * sizeof(float) + 255) & ~(size_t)255) + 2 * ((np * 4 + 255) & ~(size_t)255);
+    const size_t np = (size_t)sf.n * (size_t)B;
+    off += 2 * ((np * 64 * sizeof(float) + 255) & ~(size_t)255) + ((np * 4 + 255) & ~(size_t)255);
+    *o_mark = off;
+    size_t nr = 0, no = 0;
+    rp_embed_grad_ss_mark_sizes(B, sf.n, &nr, &no);
+    off += 2 * ((nr * 4 + 255) & ~(size_t)255) + ((no * 4 + 255) & ~(size_t)255);
     *total = off + 256;
 }
 
 extern "C" int rp_embed_grad_ss_workspace_bytes(int64_t n, int64_t B, int D, uint64_t skip_fields, size_t *bytes) {
     RP_REQUIRE(bytes && n >= 0 && B >= 1 && D == 64 && n % B == 0 && n / B <= 64,
                "embed_grad_ss_workspace_bytes: needs D = 64 and field-major positions (n = F * B, F <= 64)");
-    int kept = 0;
-    for (int f = 0; f < (int)(n / B); ++f) kept += ((skip_fields >> f) & 1u) ? 0 : 1;
+    SsFields sf;
+    SsTiles st;
+    ss_fields((int)(n / B), skip_fields, nullptr, B, &sf, &st);  // (no table sizes: the bound of B rows per field)
     size_t a, b;
-    ss_layout(n, B, kept, &a, &b, bytes);
+    ss_layout(B, sf, st, &a, &b, bytes);
     return RP_OK;
 }
 
 extern "C" int rp_embed_grad_ss(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int64_t B, int D,
                                 const float *dh, int64_t lddh, const float *w, int64_t ldw, const float *gfm,
                                 const float *sum_in, const float *arena, float *grad_arena, int accumulate,
-                                uint64_t skip_fields, const int64_t *field_rows, float *dw, int64_t lddw, int phases,
+                                uint64_t skip_fields, const int64_t *field_rows, float *dw, int64_t lddw,
+                                const int32_t *ustart, const int32_t *ukey, const int32_t *offs, int phases,
                                 void *workspace, size_t workspace_bytes, rp_stream_t stream) {
     RP_REQUIRE(sorted_keys && sorted_pos && dh && w && arena && grad_arena && workspace, "embed_grad_ss: null pointer");
     RP_REQUIRE(phases >= 1 && phases <= 3, "embed_grad_ss: phases = 1 (the segment-sum launch), 2 (the launches behind it) or 3 (both)");
     RP_REQUIRE(B >= 1 && B < INT32_MAX && n >= 0 && n < INT32_MAX, "embed_grad_ss: bad B / n");
     RP_REQUIRE(n % B == 0 && n / B <= 64, "embed_grad_ss: needs field-major positions (n = F * B, F <= 64)");
     RP_REQUIRE((gfm == nullptr) == (sum_in == nullptr), "embed_grad_ss: the FM term needs both gfm and sum_in");
+    RP_REQUIRE((ustart == nullptr) == (ukey == nullptr) && (ustart == nullptr) == (offs == nullptr),
+               "embed_grad_ss: the marks are (ustart, ukey, offs) of rp_embed_grad_ss_mark, all three or none");
     const int F = (int)(n / B);
     RP_REQUIRE(ldw >= (int64_t)F * 64 && (dw == nullptr || lddw >= (int64_t)F * 64), "embed_grad_ss: weight rows shorter than F * 64");
     if (D != 64 || lddh % 4 != 0 || !rp_aligned16(dh) || !rp_aligned16(grad_arena) || !rp_aligned16(arena) ||
         (sum_in && !rp_aligned16(sum_in)))
         return rp_fail(RP_ERR_UNSUPPORTED, "embed_grad_ss: needs D = 64, a 64-wide layer and 16-byte aligned operands");
     if (n == 0) return RP_OK;
-    SsFields sf;
-    memset(&sf, 0, sizeof(sf));
-    int kept[64];
-    for (int f = 0; f < F; ++f)
-        if (!((skip_fields >> f) & 1u)) {
-            sf.rank[f] = (unsigned char)sf.n;
-            kept[sf.n++] = f;
-        }
-    if (sf.n == 0) return RP_OK;  // every field is handled elsewhere
-    for (int a = 0; a < sf.n; ++a) {  // largest table first (stable)
-        const int f = kept[a];
-        int b = a;
-        while (b > 0 && field_rows != nullptr && field_rows[sf.sched[b - 1]] < field_rows[f]) {
-            sf.sched[b] = sf.sched[b - 1];
-            --b;
-        }
-        sf.sched[b] = (unsigned char)f;
-    }
-    size_t o_dw, o_rec, need;
-    ss_layout(n, B, sf.n, &o_dw, &o_rec, &need);
+    SsFields sf, sf0;
+    SsTiles st, st0;
+    if (ss_fields(F, skip_fields, field_rows, B, &sf, &st) == 0) return RP_OK;  // every field is handled elsewhere
+    ss_fields(F, skip_fields, nullptr, B, &sf0, &st0);  // (the workspace is sized without the table sizes)
+    size_t o_rec, o_mark, need;
+    ss_layout(B, sf0, st0, &o_rec, &o_mark, &need);
     RP_REQUIRE(workspace_bytes >= need, "embed_grad_ss: workspace %zu < %zu bytes", workspace_bytes, need);
     char *wbase = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
-    const int tpf = (int)rp_cdiv(B, SS_TILE);
-    const int T = ss_tiles_per_chunk(tpf);
-    const int cpf = (int)rp_cdiv(tpf, T);
-    const int64_t n_eff = ss_n_eff(n, B);
-    const int64_t nb0 = (int64_t)sf.n * tpf;
-    float *piece0 = reinterpret_cast<float *>(wbase);
-    int32_t *key0 = reinterpret_cast<int32_t *>(piece0 + nb0 * 2 * D);
-    float *dwpart = dw ? reinterpret_cast<float *>(wbase + o_dw) : nullptr;  // [chunks][64 d][64 hidden]
+    float *dwpart = dw ? reinterpret_cast<float *>(wbase) : nullptr;  // [tiles][64 d][64 hidden]
     const size_t np = (size_t)sf.n * (size_t)B;
     const size_t rowb = (np * 64 * sizeof(float) + 255) & ~(size_t)255;
     float *rh = reinterpret_cast<float *>(wbase + o_rec);
     float *ru = reinterpret_cast<float *>(wbase + o_rec + rowb);
     float *rs = reinterpret_cast<float *>(wbase + o_rec + 2 * rowb);
     hipStream_t s = (hipStream_t)stream;
+    const int nbk = (int)rp_cdiv(B, 256);
     const int wpf = (int)rp_cdiv(B, 16 * SS_CH);  // workgroups of the first pass per field
-    const unsigned grid1 = (unsigned)(sf.n * wpf), grid2 = (unsigned)(sf.n * cpf);
+    const unsigned grid1 = (unsigned)(sf.n * wpf), grid2 = (unsigned)st.base[sf.n];
     if (phases & 1) {
+        if (ustart == nullptr) {  // nobody marked this sort: here, in front of the pass that needs the marks least
+            size_t nr = 0, no = 0;
+            rp_embed_grad_ss_mark_sizes(B, sf.n, &nr, &no);
+            const size_t mb = (nr * 4 + 255) & ~(size_t)255;
+            if (int rc = ss_mark_launch(sorted_keys, B, sf, reinterpret_cast<int32_t *>(wbase + o_mark),
+                                        reinterpret_cast<int32_t *>(wbase + o_mark + mb),
+                                        reinterpret_cast<int32_t *>(wbase + o_mark + 2 * mb), s))
+                return rc;
+        }
         if (gfm != nullptr)
             hipLaunchKernelGGL((embed_segsum_kernel<true>), dim3(grid1), dim3(256), 0, s, sorted_keys, sorted_pos, (int)B, dh, lddh,
                                gfm, sum_in, sf, wpf, rh, ru, rs);
@@ -460,16 +595,24 @@ extern "C" int rp_embed_grad_ss(const int32_t *sorted_keys, const int32_t *sorte
         RP_LAUNCH_CHECK("embed_grad_ss (segment sums)");
     }
     if (!(phases & 2)) return RP_OK;
+    if (ustart == nullptr) {
+        size_t nr = 0, no = 0;
+        rp_embed_grad_ss_mark_sizes(B, sf.n, &nr, &no);
+        const size_t mb = (nr * 4 + 255) & ~(size_t)255;
+        ustart = reinterpret_cast<const int32_t *>(wbase + o_mark);
+        ukey = reinterpret_cast<const int32_t *>(wbase + o_mark + mb);
+        offs = reinterpret_cast<const int32_t *>(wbase + o_mark + 2 * mb);
+    }
     if (gfm != nullptr)
-        hipLaunchKernelGGL((embed_ss_rows_kernel<true>), dim3(grid2), dim3(256), 0, s, rh, ru, rs, sorted_keys, (int)B, w, ldw,
-                           arena, grad_arena, accumulate, piece0, key0, dwpart, sf, tpf, T, cpf);
+        hipLaunchKernelGGL((embed_ss_urows_kernel<true>), dim3(grid2), dim3(256), 0, s, rh, ru, rs, ustart, ukey, offs, nbk, (int)B, w,
+                           ldw, arena, grad_arena, accumulate, dwpart, sf, st);
     else
-        hipLaunchKernelGGL((embed_ss_rows_kernel<false>), dim3(grid2), dim3(256), 0, s, rh, ru, rs, sorted_keys, (int)B, w, ldw,
-                           arena, grad_arena, accumulate, piece0, key0, dwpart, sf, tpf, T, cpf);
+        hipLaunchKernelGGL((embed_ss_urows_kernel<false>), dim3(grid2), dim3(256), 0, s, rh, ru, rs, ustart, ukey, offs, nbk, (int)B, w,
+                           ldw, arena, grad_arena, accumulate, dwpart, sf, st);
     RP_LAUNCH_CHECK("embed_grad_ss (rows)");
     if (dw != nullptr) {
-        hipLaunchKernelGGL(embed_ss_dw_kernel, dim3((unsigned)sf.n, 64), dim3(256), 0, s, dwpart, sf, cpf, dw, lddw);
+        hipLaunchKernelGGL(embed_ss_dw_kernel, dim3((unsigned)sf.n, 64), dim3(256), 0, s, dwpart, sf, st, offs, nbk, dw, lddw);
         RP_LAUNCH_CHECK("embed_grad_ss (weight-gradient partials)");
     }
-    return rp_int_grad_reduce_finish(n_eff, D, nb0, wbase, piece0, key0, grad_arena, accumulate, s);
+    return RP_OK;
 }

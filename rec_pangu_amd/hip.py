@@ -45,8 +45,10 @@ _SIGNATURES = {
     "rp_embed_grad_tiny": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _i64,
                                      _vp, _sz, _vp]),
     "rp_embed_grad_ss_workspace_bytes": (C.c_int, [_i64, _i64, _i32, C.c_uint64, C.POINTER(_sz)]),
+    "rp_embed_grad_ss_mark_sizes": (C.c_int, [_i64, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
+    "rp_embed_grad_ss_mark": (C.c_int, [_vp, _i64, _i64, C.c_uint64, _vp, _vp, _vp, _vp]),
     "rp_embed_grad_ss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, C.c_uint64, _vp,
-                                   _vp, _i64, _i32, _vp, _sz, _vp]),
+                                   _vp, _i64, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_smp_fits": (C.c_int, [_i32, _i32, _i64]),
     "rp_embed_grad_smp_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_embed_grad_smp_mark_scratch": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
@@ -688,10 +690,30 @@ def embed_grad_reduce_rows(keys, rows, grad_arena, accumulate: bool):
                                            ws.data_ptr(), nbytes.value, _stream()), "rp_embed_grad_reduce_rows")
 
 
+def embed_grad_ss_mark(sorted_keys, B: int, skip_fields: int, out=None):
+    """rp_embed_grad_ss_mark: (ustart, ukey, offs) — the unique-row lists of the fields rp_embed_grad_ss keeps (every field
+    whose bit in skip_fields is clear), from the sorted keys alone"""
+    _req(sorted_keys, torch.int32, "sorted_keys")
+    n = sorted_keys.numel()
+    F = n // B
+    kept = sum(1 for f in range(F) if not (skip_fields >> f) & 1)
+    if out is None:
+        nr, no = _sz(0), _sz(0)
+        _check(lib().rp_embed_grad_ss_mark_sizes(B, kept, C.byref(nr), C.byref(no)), "rp_embed_grad_ss_mark_sizes")
+        out = (torch.empty((nr.value,), dtype=torch.int32, device=sorted_keys.device),
+               torch.empty((nr.value,), dtype=torch.int32, device=sorted_keys.device),
+               torch.empty((no.value,), dtype=torch.int32, device=sorted_keys.device))
+    with _Timed("embed_grad_ss_mark", f"{kept} fields", 12 * kept * B):
+        _check(lib().rp_embed_grad_ss_mark(sorted_keys.data_ptr(), n, B, skip_fields, out[0].data_ptr(), out[1].data_ptr(),
+                                           out[2].data_ptr(), _stream()), "rp_embed_grad_ss_mark")
+    return out
+
+
 def embed_grad_ss(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, arena, grad_arena, accumulate: bool,
-                  skip_fields: int = 0, field_rows=None, dw=None, keep=None, phases: int = 3, ws=None):
+                  skip_fields: int = 0, field_rows=None, dw=None, keep=None, phases: int = 3, ws=None, marks=None):
     """rp_embed_grad_ss: embed_grad_seg's work as a streaming segment-sum launch + a matrix launch over the unique rows (the
     mid-size tables' share of the first layer's backward); same arguments and results up to fp32 summation order.
+    marks: embed_grad_ss_mark's triple for this sort and skip_fields (None: made inside the call).
     phases = 1: the segment-sum launch only, 2: the launches behind it (same `ws`), 3: both.  -> the workspace."""
     _req(grad_arena, torch.float32, "grad_arena")
     _req(dh, torch.float32, "dh")
@@ -713,7 +735,9 @@ def embed_grad_ss(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, a
         _check(lib().rp_embed_grad_ss(sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, B, D, dh.data_ptr(), _rowmajor(dh, "dh"),
                                       w.data_ptr(), _rowmajor(w, "w"), _ptr(gfm), _ptr(sum_in), arena.data_ptr(),
                                       grad_arena.data_ptr(), int(accumulate), skip_fields, fr, _ptr(dw),
-                                      _rowmajor(dw, "dw") if dw is not None else 0, phases, ws.data_ptr(), nbytes.value, _stream()),
+                                      _rowmajor(dw, "dw") if dw is not None else 0,
+                                      None if marks is None else marks[0].data_ptr(), None if marks is None else marks[1].data_ptr(),
+                                      None if marks is None else marks[2].data_ptr(), phases, ws.data_ptr(), nbytes.value, _stream()),
                "rp_embed_grad_ss")
     return ws
 

@@ -43,6 +43,51 @@ _PINNED_WS: dict = {}
 # is) and re-made in place when a pinned entry is re-sorted in place
 _SMP_MARKS: dict = {}
 
+
+
+class DeferredGradView(torch.Tensor):
+    """`.grad` of an embedding table while FusedAdam(defer=True) drives it (the contract was prose).
+
+    Under the deferred execution a row's real optimizer step waits in the gradient arena until the row is next looked up, so
+    between backward() and step() a table's gradient rows hold THIS step's gradients AND gradients of earlier steps that are
+    still waiting — not the reference's dense gradient (rec_pangu/trainer.py:60-76 never reads it).  Anything that computes
+    with such a tensor (gradient clipping, a norm, an in-place rescale) would silently read or damage waiting gradients:
+    every torch operation on it RAISES instead.  Addresses, shapes and dtypes stay readable (the library checks that a
+    table's .grad is still its arena view that way); `with rec_pangu_amd.models.layers.embedding.deferred_grad_reads():`
+    opens the view for code that knows what the rows hold (tests, diagnostics); make_adam(..., defer=False) /
+    RP_ADAM_DEFER=0 gives plain dense gradients."""
+    _open = 0
+    _META = {"data_ptr", "size", "stride", "dim", "numel", "nelement", "element_size", "is_contiguous", "storage_offset",
+             "__get__", "__repr__", "__str__", "__format__", "__len__", "__hash__", "__reduce_ex__", "__deepcopy__",
+             "is_floating_point", "is_complex", "get_device", "untyped_storage", "type", "requires_grad_", "_is_view"}
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", "")
+        if cls._open > 0 or name in cls._META:
+            with torch._C.DisableTorchFunctionSubclass():
+                out = func(*args, **(kwargs or {}))
+            return out
+        raise RuntimeError(
+            f"torch.{name} on the .grad of an embedding table driven by FusedAdam(defer=True): its rows hold this step's "
+            "gradients AND gradients of earlier steps whose optimizer step is still waiting (rec_pangu_amd/optim.py, deferred "
+            "execution) — not a dense gradient.  Use make_adam(model, lr, defer=False) (or RP_ADAM_DEFER=0) when table gradients "
+            "are read or rewritten between backward() and step() (gradient clipping), or wrap a knowing read in "
+            "rec_pangu_amd.models.layers.embedding.deferred_grad_reads()")
+
+
+class deferred_grad_reads:
+    """context manager: table .grad views behave as plain tensors inside (see DeferredGradView)"""
+
+    def __enter__(self):
+        DeferredGradView._open += 1
+        return self
+
+    def __exit__(self, *exc):
+        DeferredGradView._open -= 1
+        return False
+
+
 # set by rec_pangu_amd.sharded.sharded_construction(): models built inside it get row-sharded embedding layers that
 # only ever allocate their own shard (see make_embedding_layer)
 _SHARD_SPEC = None
@@ -223,10 +268,13 @@ class EmbeddingLayer(nn.Module):
     # ------------------------------------------------------------------ gradients (HIP path)
     def _attach_grads(self):
         off = 0
+        guard = self._lazy is not None and bool(getattr(self._lazy, "defer", False)) and os.environ.get("RP_GRAD_GUARD", "1") != "0"
         for p in self._tables():
             r = p.shape[0]
             if p.requires_grad:  # a frozen table (set_weights(trainable=False)) never shows a gradient
-                p.grad = self._grad_arena[off:off + r]
+                view = self._grad_arena[off:off + r]
+                # (deferred lazy Adam: the rows of other steps wait in this arena — computing with the view raises)
+                p.grad = view.as_subclass(DeferredGradView) if guard else view
             off += r
 
     @property
@@ -310,13 +358,24 @@ class EmbeddingLayer(nn.Module):
             return
         ent = _SMP_MARKS.get(id(sk))
         sig = (B, tuple(smp))
-        out = ent[2] if (ent is not None and ent[0]() is sk and ent[1] == sig) else None
+        same = ent is not None and ent[0]() is sk and ent[1] == sig
+        out = ent[2] if same else None
         marks = hip.embed_grad_smp_mark(sk, sp, B, [t[0] for t in smp], out=out)
+        # ... and the unique-row lists of the mid-size tables (every field that is neither tiny nor big: rp_embed_grad_ss)
+        skip = 0
+        for f, _, _ in list(self._tiny_tables() or ()) + list(smp):
+            skip |= 1 << f
+        ss = None
+        if skip != (1 << F) - 1 and os.environ.get("RP_GRAD_SS", "1") != "0" and os.environ.get("RP_SS_MARK_AHEAD", "1") != "0":
+            ss_out = ent[3][1] if (same and len(ent) > 3 and ent[3] is not None and ent[3][0] == skip) else None
+            ss = (skip, hip.embed_grad_ss_mark(sk, B, skip, out=ss_out))
         if out is None:
             if len(_SMP_MARKS) >= 8:
                 for k in [k for k, e in _SMP_MARKS.items() if e[0]() is None] or list(_SMP_MARKS)[:4]:
                     _SMP_MARKS.pop(k, None)
-            _SMP_MARKS[id(sk)] = [weakref.ref(sk), sig, marks]
+            _SMP_MARKS[id(sk)] = [weakref.ref(sk), sig, marks, ss]
+        else:
+            ent[3:] = [ss]
 
     def _marks_of(self, sk, sp, smp, B: int):
         ent = _SMP_MARKS.get(id(sk))
@@ -324,6 +383,13 @@ class EmbeddingLayer(nn.Module):
             self._mark_sorted(sk, sp)  # (a sort nobody marked: an eager backward that sorted for itself)
             ent = _SMP_MARKS[id(sk)]
         return ent[2]
+
+    def _ss_marks_of(self, sk, skip: int):
+        """the unique-row lists made with the sort for exactly these kept fields, or None (rp_embed_grad_ss makes its own)"""
+        ent = _SMP_MARKS.get(id(sk))
+        if ent is None or ent[0]() is not sk or len(ent) < 4 or ent[3] is None or ent[3][0] != skip:
+            return None
+        return ent[3][1]
 
     def accumulate_grad(self, keys, B: int, dx, gfm, ssum, presorted=None, fused=None, pool=None, plan_keep=None, seg=None,
                         seg_first: bool = False, fork2=None):
@@ -420,6 +486,8 @@ class EmbeddingLayer(nn.Module):
                     smp_args = (keys, marks, B, len(self.emb_feature), smp, fused[0], seg[0], gfm, ssum, self._arena,
                                 self._grad_arena)
                     smp_ws = hip.embed_grad_smp(*smp_args, accumulate=acc, dw=seg[1], keep=plan_keep, phases=1)
+                if ss:  # (the unique-row lists made with the sort — or just now, by _marks_of, for a sort nobody had marked)
+                    seg_kw["marks"] = self._ss_marks_of(sk, skip)
                 if tiny_early:
                     run_tiny()
                     hip.LaunchPlan.side2_sync()

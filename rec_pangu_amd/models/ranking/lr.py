@@ -1,8 +1,9 @@
 """LR — counterpart of rec_pangu/models/ranking/lr.py:12-51: pred = sigmoid(LR_Layer(data)).
 
-The reference class cannot be constructed: it calls `BaseModel.__init__()` without the two required arguments
-(lr.py:23 vs base_model.py:15) and raises TypeError.  This one implements what that file intends — no
-`embedding_layer`, a single `lr_layer` — so BenchmarkTrainer's default ranking list can run it.
+The reference class cannot be constructed: it subclasses `nn.Module` (lr.py:12), not BaseModel, and its constructor ends
+with `self.reset_parameters()` (lr.py:28) — a method nn.Module does not have: AttributeError.  This one implements what that
+file intends — no `embedding_layer`, a single `lr_layer`, BaseModel's initialisation — so BenchmarkTrainer's default ranking
+list can run it.
 """
 from typing import Dict
 

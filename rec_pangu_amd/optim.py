@@ -682,7 +682,9 @@ def make_adam(model, lr, lazy_tables=True, replay=None, defer=None):
     defer: run a row's real step at its next touch, in the one launch that also replays its skipped steps (identical
     results after a flush — tests/test_hip_deferred_adam.py; one optimizer launch per step on the tables instead of two).
     Table .grad rows then hold gradients that are still waiting after step(), so anything that READS or rewrites table
-    gradients between backward and step (gradient clipping on the tables) must use defer=False.  Default ON since round 4
+    gradients between backward and step (gradient clipping on the tables) must use defer=False — and is told so: a table's
+    .grad is a DeferredGradView in this mode, every torch operation on it raises (models/layers/embedding.py;
+    tests/test_hip_deferred_adam.py::test_reading_table_gradients_under_the_deferred_step_raises).  Default ON since round 4
     (the whole -m gpu suite runs in it; environment variable RP_ADAM_DEFER=0 turns it off)."""
     params = list(model.parameters())
     if params and params[0].is_cuda:

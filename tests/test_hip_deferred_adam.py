@@ -243,3 +243,38 @@ def test_uncleared_catchup_rows_when_the_promised_backward_does_not_come():
         assert torch.equal(a, b), f"prediction {i} differs"
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_reading_table_gradients_under_the_deferred_step_raises():
+    """under FusedAdam(defer=True) a table's gradient rows hold this step's gradients AND earlier steps'
+    waiting ones.  Computing with a table's .grad between backward() and step() (gradient clipping) therefore RAISES instead
+    of silently reading them; addresses and shapes stay readable, a knowing read goes through deferred_grad_reads(), and the
+    immediate execution (defer=False) hands out plain dense gradients as the reference's loop would see them."""
+    from rec_pangu_amd.optim import FusedAdam
+    from rec_pangu_amd.models.layers.embedding import DeferredGradView, deferred_grad_reads
+    enc = _enc(2, [300, 7, 2000])
+    batches = _batches(enc, 128, 4, seed=5)
+    for defer in (True, False):
+        m = _model("deepfm8", enc)
+        opt = FusedAdam(m.parameters(), lr=1e-2, fuse_zero_grad=True, lazy_tables=True, replay="closed", defer=defer)
+        for b in batches[:3]:
+            m(b)["loss"].backward()
+            opt.step()
+            m.zero_grad()
+        m(batches[3])["loss"].backward()
+        tables = [p for n, p in m.named_parameters() if "embedding_layer" in n]
+        assert tables and all(p.grad is not None for p in tables)
+        if defer:
+            assert all(isinstance(p.grad, DeferredGradView) for p in tables)
+            assert all(p.grad.shape == p.shape and p.grad.data_ptr() != 0 for p in tables)   # metadata stays readable
+            with pytest.raises(RuntimeError, match="defer"):
+                torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            with pytest.raises(RuntimeError, match="defer"):
+                tables[0].grad.mul_(0.5)
+            with deferred_grad_reads():
+                assert float(sum(p.grad.abs().sum() for p in tables)) > 0.0
+        else:
+            assert not any(isinstance(p.grad, DeferredGradView) for p in tables)
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()   # the step itself is unaffected by the guard
+        m.zero_grad()

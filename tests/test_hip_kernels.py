@@ -1055,6 +1055,33 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
         hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G2, accumulate)
     seg_fn(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G2, accumulate, skip_fields=skip)
     assert torch.equal(G2, G)
+    if impl == "ss":
+        # the unique-row lists made ahead (rp_embed_grad_ss_mark: with the sort, from the sorted keys alone) — index work, exact
+        # against a host restatement — and the launch fed with them: the same bits as with the lists it makes itself
+        marks = hip.embed_grad_ss_mark(sk, B, skip)
+        kept = [f for f in range(F) if not (skip >> f) & 1]
+        nbk = (B + 255) // 256
+        skc = sk.cpu().long()
+        offs = marks[2].cpu().long()
+        run = 0
+        for r_, f in enumerate(kept):
+            ks = skc[f * B:(f + 1) * B]
+            start = torch.ones(B, dtype=torch.bool)
+            start[1:] = ks[1:] != ks[:-1]
+            xs = torch.nonzero(start).flatten()
+            assert torch.equal(marks[0].cpu().long()[r_ * B:r_ * B + xs.numel()], xs), f
+            assert torch.equal(marks[1].cpu().long()[r_ * B:r_ * B + xs.numel()], ks[xs]), f
+            per_blk = torch.zeros(nbk, dtype=torch.int64).index_add_(0, xs // 256, torch.ones_like(xs))
+            assert torch.equal(offs[r_ * nbk:(r_ + 1) * nbk], run + torch.cumsum(per_blk, 0) - per_blk), f
+            run += xs.numel()
+        assert int(offs[len(kept) * nbk]) == run
+        G3 = torch.full((NR, D), init, device=DEV)
+        dw3 = torch.full((H, K), float("nan"), device=DEV)
+        if tiny:
+            hip.embed_grad_tiny(keys, B, tiny, dev(dh), wt, dev(gfm), dev(ssum), dev(arena), G3, accumulate, dw=dw3)
+        seg_fn(sk, sp, B, D, dev(dh), Wd, dev(gfm), dev(ssum), dev(arena), G3, accumulate, skip_fields=skip, field_rows=rows, dw=dw3,
+               marks=marks)
+        assert torch.equal(G3, G) and torch.equal(dw3[:, :F * D], dw[:, :F * D])
 
 
 @pytest.mark.parametrize("rows,B,with_fm,accumulate,smp,with_tiny", [
