@@ -257,6 +257,9 @@ int rp_embed_grad_reduce_rows(const int32_t *keys, const float *rows, int64_t n,
                               void *workspace, size_t workspace_bytes, rp_stream_t stream);
 /* grad_arena[keys[i], :] = 0 for i < n (duplicates allowed) */
 int rp_zero_rows(const int32_t *keys, int64_t n, int D, float *grad_arena, rp_stream_t stream);
+/* dst[0 .. n_words) = value, 32-bit words, 16-byte aligned buffer: the library's own fill (a recorded step must hold no
+ * ATen fill kernel / memset node: csrc/plan.hip) */
+int rp_fill_words(void *dst, int64_t n_words, uint32_t value, rp_stream_t stream);
 
 /* ---- K4: Linear (+bias +activation) on the fp32 MFMA ----------------------------------------
  * replaces layers/deep.py:62-72 (nn.Linear + ReLU chain) and its autograd.
@@ -801,6 +804,14 @@ int rp_plan_set_inputs(void *plan, const uint64_t *addrs, int n);
  * point INSIDE buffer i (addrs[i] < word < addrs[i] + nbytes[i]): arguments derived from an input, which rp_plan_set_inputs
  * cannot re-point — the caller keeps its staging copy then (graph_step.py) */
 int rp_plan_bind_report(void *plan, const uint64_t *addrs, const uint64_t *nbytes, int n, int32_t *sites, int *n_interior);
+/* HOST MARKS: a step interleaved with work the library does not issue (the collectives of the row-sharded path) is recorded
+ * as segments — rp_plan_host_mark() at each such point while recording (*index_out = 0, 1, ...; the foreign work is NOT
+ * issued under the capture), rp_plan_replay_segment(plan, k, stream) for the launches between mark k - 1 and mark k, the
+ * foreign work issued by the caller in between on the same stream (every launch of the segment on that one stream, in
+ * recorded order, whatever section it was recorded under). */
+int rp_plan_host_mark(int *index_out);
+int rp_plan_host_marks(void *plan, int *n_marks);
+int rp_plan_replay_segment(void *plan, int seg, rp_stream_t stream);
 /* the main stream waits HERE for the side section (1) of the replay (default: at the end of the replay) — for a step that
  * itself consumes what the side section produces (the next batch's sorted keys: graph_step.py, catch-up ahead) */
 int rp_plan_join_side(void);

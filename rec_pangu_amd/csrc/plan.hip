@@ -49,6 +49,7 @@ struct Plan {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_inline = 0;               // launches of section 2 (forked where they were recorded, joined at rp_plan_join)
+    int n_marks = 0;                // host marks (rp_plan_host_mark): the plan replays as n_marks + 1 segments
     hipStream_t side2 = nullptr;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_sync2 = nullptr;
     bool own_side = false, own_side2 = false;  // streams created here (else: the caller's, rp_plan_set_streams)
@@ -198,6 +199,37 @@ extern "C" int rp_plan_side2_sync(void) {
     n.rec_stream = nullptr;
     n.blob_at = p->blob.size();
     p->nodes.push_back(std::move(n));
+    return RP_OK;
+}
+
+// HOST MARKS (round 6: row-sharded steps).  A step whose launches are interleaved with work the library does not issue — the
+// collectives of the row-sharded path: RCCL's all-to-alls and the dense all-reduce — is recorded as SEGMENTS: the caller marks
+// every such point while recording (and does not issue the foreign work under the capture), replays segment k with
+// rp_plan_replay_segment and issues the foreign work itself between two segments, on the same stream, with the same
+// (capture-pool) buffers.  The device then sees the eager stream of kernels with the collectives where they were; the host
+// pays a few microseconds per launch instead of the eager step's autograd / ctypes time.  Marker node, section -6;
+// *index_out = the mark's number (0, 1, ...): segment k = the launches between mark k - 1 and mark k.
+extern "C" int rp_plan_host_mark(int *index_out) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Plan *p = g_recording.load();
+    RP_REQUIRE(p != nullptr, "plan_host_mark: no plan is being recorded");
+    PlanNode n;
+    n.func = nullptr;
+    n.grid = n.block = dim3(0, 0, 0);
+    n.shmem = 0;
+    n.section = -6;
+    n.rec_stream = nullptr;
+    n.blob_at = p->blob.size();
+    p->nodes.push_back(std::move(n));
+    if (index_out != nullptr) *index_out = p->n_marks;
+    p->n_marks++;
+    return RP_OK;
+}
+
+extern "C" int rp_plan_host_marks(void *plan, int *n_marks) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p && n_marks, "plan_host_marks: null pointer");
+    *n_marks = p->n_marks;
     return RP_OK;
 }
 
@@ -451,9 +483,46 @@ extern "C" int rp_plan_slowest_call(void *plan, int *kind, int *node, double *ms
     return RP_OK;
 }
 
+// segment `seg` (0 .. n_marks) of a plan with host marks: its launches, in RECORDED order, all on `stream` — the launches of
+// the side / inline sections too (the recording order is the issue order on the one capture stream: a valid serial order; the
+// sections' fork / join events would have to straddle the caller's foreign work).
+extern "C" int rp_plan_replay_segment(void *plan, int seg, rp_stream_t stream) {
+    Plan *p = reinterpret_cast<Plan *>(plan);
+    RP_REQUIRE(p != nullptr && p->ended, "plan_replay_segment: the plan was not finished with rp_plan_end");
+    RP_REQUIRE(seg >= 0 && seg <= p->n_marks, "plan_replay_segment: segment %d of %d", seg, p->n_marks + 1);
+    hipStream_t s = (hipStream_t)stream;
+    int cur = 0;
+    for (size_t i = 0; i < p->nodes.size(); ++i) {
+        const PlanNode &n = p->nodes[i];
+        if (n.func == nullptr) {
+            if (n.section == -6) ++cur;
+            if (cur > seg) break;
+            continue;
+        }
+        if (cur != seg) continue;
+        if ((int)i == p->probe) (void)hipEventRecord(p->ev_p0, s);
+        const double t0 = plan_now_ms();
+        const hipError_t e = hipLaunchKernel(n.func, n.grid, n.block, p->ptrs.data() + p->ptrs_at[i], n.shmem, s);
+        const double d = plan_now_ms() - t0;
+        if (d > p->slow_ms) {
+            p->slow_ms = d;
+            p->slow_node = (int)i;
+            p->slow_kind = 0;
+        }
+        if (e != hipSuccess) return rp_fail(RP_ERR_LAUNCH, "plan_replay_segment: launch %zu: %s", i, hipGetErrorString(e));
+        if ((int)i == p->probe) {
+            (void)hipEventRecord(p->ev_p1, s);
+            p->probe_recorded = true;
+        }
+        rp_count_launch();
+    }
+    return RP_OK;
+}
+
 extern "C" int rp_plan_replay(void *plan, rp_stream_t stream) {
     Plan *p = reinterpret_cast<Plan *>(plan);
     RP_REQUIRE(p != nullptr && p->ended, "plan_replay: the plan was not finished with rp_plan_end");
+    RP_REQUIRE(p->n_marks == 0, "plan_replay: this plan has %d host marks — replay it segment by segment (rp_plan_replay_segment)", p->n_marks);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipSuccess;
     const bool fork = p->n_side > 0;

@@ -258,3 +258,25 @@ extern "C" int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_po
     RP_LAUNCH_CHECK("route_pad");
     return RP_OK;
 }
+
+// dst[0 .. n_words) = value (32-bit words) — the zero fill of a buffer inside a recorded step (an ATen fill kernel or a memset
+// node there would keep the step from replaying as a launch plan): the padded request list of rp_route_pad, the
+// requester's per-slot gradient rows
+__global__ __launch_bounds__(256) void fill_words_kernel(uint32_t *__restrict__ dst, int64_t n_words, uint32_t value) {
+    const int64_t n4 = n_words >> 2;
+    const uint4 v4 = {value, value, value, value};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) reinterpret_cast<uint4 *>(dst)[i] = v4;
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * 256) dst[i] = value;
+}
+
+extern "C" int rp_fill_words(void *dst, int64_t n_words, uint32_t value, rp_stream_t stream) {
+    RP_REQUIRE(n_words >= 0 && (n_words == 0 || dst != nullptr), "fill_words: null pointer");
+    RP_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 15u) == 0, "fill_words: the buffer must be 16-byte aligned");
+    if (n_words == 0) return RP_OK;
+    int64_t g = rp_cdiv(n_words, 256 * 4 * 4);
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<uint32_t *>(dst),
+                       n_words, value);
+    RP_LAUNCH_CHECK("fill_words");
+    return RP_OK;
+}

@@ -109,6 +109,7 @@ class GraphedTrainStep:
         self._pool = None
         self._dev = None         # host mirror of the device counters
         self._one = None         # the seed gradient of captured backward passes (see _seed_grad)
+        self._seed, self._seed_value = None, 1.0
         # active dropout inside the step (the reference's default for xDeepFM / AutoInt / MMOE): the generator offset of a
         # step's start lives on the device (`_drop_clock`, advanced by the step's last launch), every dropout launch adds
         # its place in the step; the host generator is advanced after each replay, so eager and captured steps draw from
@@ -232,7 +233,7 @@ class GraphedTrainStep:
             self.model.embedding_layer.pin_sort(self.X[self.P])
         self._staged = batch
 
-    def _capture(self, P):
+    def _capture(self, P, force_graph: bool = False):
         if self.graphs[1 - P] is None:
             # the flags describe the captures in use: with none left, a layer this capture no longer looks up must not keep
             # "a captured step rebuilds my window" from an earlier one (the capture below sets them again)
@@ -242,7 +243,14 @@ class GraphedTrainStep:
         self.opt.set_device_clock(True)
         self._dev = counters
         torch.cuda.synchronize()
-        want_plan = self.backend == "plan" and not self._sharded
+        # Row-sharded steps (round 6): recorded as a launch plan too — the collectives are NOT issued under the capture, the
+        # plan is cut at each of them (sharded._recorded -> rp_plan_host_mark) and a replay issues them itself between two
+        # segments.  A step that turns out to hold foreign launches is captured AGAIN, collectives included, as a hipGraph.
+        want_plan = self.backend == "plan" and not force_graph
+        world = getattr(self.model.embedding_layer, "world", 1) if self._sharded else 1
+        seed_scaled = want_plan and self._sharded and world > 1
+        if seed_scaled and (self._seed is None or self._seed_value != 1.0 / world):
+            self._seed, self._seed_value = torch.full_like(self._one, 1.0 / world), 1.0 / world  # (outside the capture)
         # (keep_graph: the hipGraph_t stays inspectable — rp_graph_node_counts — and is only instantiated if it is replayed)
         g = torch.cuda.CUDAGraph(keep_graph=True) if want_plan else torch.cuda.CUDAGraph()
         plan = hip.LaunchPlan() if want_plan else None
@@ -261,7 +269,8 @@ class GraphedTrainStep:
                 # thread captures — legal only in thread-local capture mode; in the default global mode its hipEventQuery
                 # aborts the process with hipErrorStreamCaptureUnsupported)
                 mode = "thread_local" if self._sharded else "global"
-                with torch.cuda.graph(g, pool=self._pool, capture_error_mode=mode):
+                from .sharded import seed_scaled as _seed_scaled
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode=mode), _seed_scaled(seed_scaled):
                     fork_start = os.environ.get("RP_PLAN_FORK", "start" if ahead else "backward") == "start"
                     if plan is not None and fork_start:
                         # (A/B switch: the next batch's sort beside the catch-up and the gather instead.  Catch-up ahead: the
@@ -274,7 +283,7 @@ class GraphedTrainStep:
                         plan.fork_here()
                     # the seed gradient is a persistent 1.0: loss.backward() would create it with an ATen fill kernel — the
                     # one launch of a DeepFM step that is not the library's (a launch plan must hold them all)
-                    out["loss"].backward(gradient=self._seed_grad(out["loss"]))
+                    out["loss"].backward(gradient=self._seed_grad(out["loss"], 1.0 / world if seed_scaled else 1.0))
                     if plan is not None:
                         hip.LaunchPlan.settle()
                     if self.post_backward is not None:
@@ -311,6 +320,7 @@ class GraphedTrainStep:
             # the capture ran the python of one step without executing a kernel: put the host counters back
             self.opt.set_host_counters(counters)
             self.opt.set_device_clock(False)
+        had_pool = self._pool is not None
         if self._pool is None:
             self._pool = g.pool()
         if plan is not None:
@@ -325,6 +335,14 @@ class GraphedTrainStep:
             if why is not None:
                 plan.destroy()
                 plan, self.why_not_plan = None, why
+                if self._sharded:
+                    # the capture above holds no collective (the plan had taken them over): once more, as a plain hipGraph
+                    del g, out
+                    if not had_pool:
+                        self._pool = None
+                    return self._capture(P, force_graph=True)
+            elif self._sharded:
+                pass  # (one stream, no sections; the static inputs are filled by the staging copy)
             else:
                 # the sections run on the very streams the eager path overlaps on (sort-ahead / first-layer weight gradient):
                 # a stream of the plan's own may share the main stream's hardware queue (csrc/plan.hip)
@@ -361,10 +379,14 @@ class GraphedTrainStep:
         self.outs[P] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
         del out
 
-    def _seed_grad(self, loss):
+    def _seed_grad(self, loss, value: float = 1.0):
         """the persistent 1.0 a captured backward starts from (created in _alloc, outside any capture); None — the default
-        seed, an ATen fill — when the loss is not the float32 scalar every model here returns"""
-        one = self._one
+        seed, an ATen fill — when the loss is not the float32 scalar every model here returns.  value = 1 / world: the seed of
+        a row-sharded step recorded as a launch plan (sharded._SEED_SCALED)"""
+        if value != 1.0:
+            one = self._seed if (self._seed is not None and self._seed_value == value) else None  # (made in front of the capture)
+        else:
+            one = self._one
         if one is not None and one.device == loss.device and one.dtype == loss.dtype and one.shape == loss.shape:
             return one
         return None

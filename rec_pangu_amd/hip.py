@@ -92,6 +92,10 @@ _SIGNATURES = {
     "rp_plan_slowest_call": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "rp_plan_launch_name": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(_i32)]),
     "rp_plan_join_side": (C.c_int, []),
+    "rp_plan_host_mark": (C.c_int, [C.POINTER(_i32)]),
+    "rp_plan_host_marks": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "rp_plan_replay_segment": (C.c_int, [_vp, _i32, _vp]),
+    "rp_fill_words": (C.c_int, [_vp, _i64, C.c_uint32, _vp]),
     "rp_plan_side2_sync": (C.c_int, []),
     "rp_plan_bind_inputs": (C.c_int, [_vp, _vp, _i32, C.POINTER(_i32)]),
     "rp_plan_bind_report": (C.c_int, [_vp, _vp, _vp, _i32, _vp, C.POINTER(_i32)]),
@@ -742,6 +746,18 @@ def embed_grad_ss(sorted_keys, sorted_pos, B: int, D: int, dh, w, gfm, sum_in, a
     return ws
 
 
+def zeros(shape, dtype, device):
+    """torch.zeros through the library's own fill launch (rp_fill_words): inside a recorded step an ATen fill kernel would
+    keep the step from replaying as a launch plan"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    nb = t.numel() * t.element_size()
+    if nb % 4 != 0 or t.data_ptr() % 16 != 0:
+        return t.zero_()
+    if nb:
+        _check(lib().rp_fill_words(t.data_ptr(), nb // 4, 0, _stream()), "rp_fill_words")
+    return t
+
+
 def zero_rows(keys, D: int, grad_arena):
     with _Timed("zero_rows"):
         _check(lib().rp_zero_rows(keys.data_ptr(), keys.numel(), D, grad_arena.data_ptr(), _stream()), "rp_zero_rows")
@@ -978,13 +994,32 @@ class LaunchPlan:
         self._h = None
         self._streams = None
         self.nodes = self.side = self.streams = self.inline = 0
+        self.host_calls = []  # what the caller issues itself between two segments of the replay (host marks)
+
+    _recording = None  # the plan being recorded (host_call appends to it)
 
     def begin(self):
         h = _vp()
         _check(lib().rp_plan_begin(C.byref(h)), "rp_plan_begin")
         self._h = h
+        LaunchPlan._recording = self
+
+    @classmethod
+    def host_call(cls, fn) -> bool:
+        """Inside a recording: `fn` is work the library does not launch (a collective of the row-sharded path) — it is NOT
+        issued now; the plan is cut here (rp_plan_host_mark) and every replay calls fn() between the two segments, on the
+        replay's stream.  -> True when the call was taken over (the caller skips issuing it), False outside a recording."""
+        pl = cls._recording
+        if pl is None or not cls.is_recording():
+            return False
+        k = _i32()
+        _check(lib().rp_plan_host_mark(C.byref(k)), "rp_plan_host_mark")
+        assert k.value == len(pl.host_calls)
+        pl.host_calls.append(fn)
+        return True
 
     def end(self):
+        LaunchPlan._recording = None
         if LaunchPlan._deferred and LaunchPlan.is_recording():
             LaunchPlan.join()  # (nobody joined the inline section after the last deferred launch was queued)
         LaunchPlan._deferred, LaunchPlan._kept, LaunchPlan._ahead_keep = [], [], []
@@ -1077,6 +1112,17 @@ class LaunchPlan:
         return bool(lib().rp_plan_is_recording())
 
     def replay(self):
+        if self.host_calls:  # segments, the caller's own work (collectives) in between — all on the current stream
+            s = _stream()
+            for k, fn in enumerate(self.host_calls):
+                rc = lib().rp_plan_replay_segment(self._h, k, s)
+                if rc != 0:
+                    _check(rc, "rp_plan_replay_segment")
+                fn()
+            rc = lib().rp_plan_replay_segment(self._h, len(self.host_calls), s)
+            if rc != 0:
+                _check(rc, "rp_plan_replay_segment")
+            return
         rc = lib().rp_plan_replay(self._h, _stream())
         if rc != 0:
             _check(rc, "rp_plan_replay")
@@ -1882,7 +1928,7 @@ def route_build(sorted_keys, sorted_pos, world: int, lbits: int):
 def route_pad(sorted_keys, sorted_pos, world: int, lbits: int, capacity: int, counts, slot_sorted, slot_of_pair, err_flag):
     """fixed-capacity form of a route (rp_route_pad): slot_sorted / slot_of_pair are rewritten in place / overwritten;
     -> rows_padded int64 [world * capacity] (local rows to ask each owner for, unused slots 0)."""
-    rows_padded = torch.zeros((world * capacity,), dtype=torch.int64, device=sorted_keys.device)
+    rows_padded = zeros((world * capacity,), torch.int64, sorted_keys.device)
     with _Timed("route_pad"):
         _check(lib().rp_route_pad(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), world, lbits, capacity,
                                   counts.data_ptr(), slot_sorted.data_ptr(), slot_of_pair.data_ptr(),

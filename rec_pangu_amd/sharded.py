@@ -50,23 +50,78 @@ def _host_staged(t, group) -> bool:
     return _STAGED[k]
 
 
+def _recorded(fn, t) -> bool:
+    """While a LAUNCH PLAN is being recorded (graph_step.GraphedTrainStep on a row-sharded model, round 6) a collective is not
+    issued: the plan is cut at this point (rp_plan_host_mark) and every replay issues `fn` itself between the two segments,
+    on the replay's stream, with the very buffers of the recording (they live in the capture's pool; the closure keeps them
+    referenced).  -> True when the plan took the call over."""
+    if not t.is_cuda:
+        return False
+    from . import hip
+    return hip.LaunchPlan.host_call(fn)
+
+
 def all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
-    if _host_staged(inp, group):
-        h_out = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-        out.copy_(h_out)
-        return
-    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    def issue():
+        if _host_staged(inp, group):
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+            out.copy_(h_out)
+            return
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+    if not _recorded(issue, inp):
+        issue()
 
 
 def all_reduce(t, op=None, group=None):
     op = dist.ReduceOp.SUM if op is None else op
-    if _host_staged(t, group):
-        h = t.cpu()
-        dist.all_reduce(h, op=op, group=group)
-        t.copy_(h)
-        return
-    dist.all_reduce(t, op=op, group=group)
+
+    def issue():
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+            return
+        dist.all_reduce(t, op=op, group=group)
+    if not _recorded(issue, t):
+        issue()
+
+
+# A recorded step seeds its backward with 1 / world instead of 1 (graph_step.GraphedTrainStep._seed_grad): every gradient of
+# the step — the row gradients that travel AND the dense ones — then carries the 1 / G of "loss = mean over the GLOBAL
+# batch" from the start, and neither the row gradients nor the all-reduced bucket need a scaling pass of their own (two ATen
+# launches a launch plan must not hold).  [on, world]
+_SEED_SCALED = [False]
+
+
+class seed_scaled:
+    """context: the backward inside is seeded with 1 / world (see _SEED_SCALED)"""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _SEED_SCALED[0] = _SEED_SCALED[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SEED_SCALED[0] = self.prev
+        return False
+
+
+_CONSTS: dict = {}
+
+
+def _const_i64(device, n: int, value: int):
+    """a persistent [n] int64 tensor filled with `value` (kernel-argument tables rebuilt every step otherwise: an ATen fill
+    launch each, which a launch plan must not hold)"""
+    k = (str(device), n, value)
+    t = _CONSTS.get(k)
+    if t is None:
+        if len(_CONSTS) > 64:
+            _CONSTS.clear()
+        t = _CONSTS[k] = torch.full((n,), value, dtype=torch.int64, device=device)
+    return t
 
 
 def _force_a2a() -> bool:
@@ -200,14 +255,18 @@ class _ShardedRows(torch.autograd.Function):
         ctx.scaled, layer._scaled = layer._scaled, None
         ctx.save_for_backward(recv_rows)
         ctx.mark_non_differentiable(route.slot_of_pair, route.slot_sorted, route.pos_sorted)
+        # (autograd materialised a zero "gradient" for each of the three index outputs: three ATen fill launches per step)
+        ctx.set_materialize_grads(False)
         return rows, route.slot_of_pair, route.slot_sorted, route.pos_sorted
 
     @staticmethod
     def backward(ctx, g_rows, *_unused):
         (recv_rows,) = ctx.saved_tensors
         layer, route = ctx.layer, ctx.route
+        if g_rows is None:  # (nothing downstream asked for the rows' gradient)
+            return None, None, None
         # 1/G: the update must equal the 1-GPU update on the global batch (unless the producer already folded it in)
-        prescaled = layer.world == 1 or (ctx.scaled is not None and ctx.scaled[0])
+        prescaled = layer.world == 1 or (ctx.scaled is not None and ctx.scaled[0]) or _SEED_SCALED[0]
         g_rows = g_rows.contiguous() if prescaled else (g_rows * (1.0 / layer.world)).contiguous()
         recv_g = _a2a_rows(g_rows, route.recv, route.send, layer)
         layer._local_scatter_add(recv_rows, recv_g, presorted=ctx.presorted)
@@ -225,8 +284,7 @@ class _RowsToX(torch.autograd.Function):
         from . import hip
         n, D = rows.shape
         dev = rows.device
-        zero = torch.zeros((F,), dtype=torch.int64, device=dev)
-        cnt = torch.full((F,), n, dtype=torch.int64, device=dev)
+        zero, cnt = _const_i64(dev, F, 0), _const_i64(dev, F, n)
         idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
         x, fm, ssum, _ = hip.embed_gather_fwd(rows, zero, cnt, idx, dense, ldx, want_fm, want_fm, False, err_flag)
         ctx.cfg = (b, F, D, want_fm)
@@ -238,8 +296,8 @@ class _RowsToX(torch.autograd.Function):
         from . import hip
         rows, slot_sorted, pos_sorted, ssum = ctx.saved_tensors
         b, F, D, want_fm = ctx.cfg
-        # zero-initialised: runs of equal slots that cross a segment border are added atomically by the kernel
-        g_rows = torch.zeros_like(rows)
+        # zero-initialised: slots no request reads (fixed-capacity padding) carry a zero gradient
+        g_rows = hip.zeros(rows.shape, rows.dtype, rows.device)
         gfm = dfm.contiguous() if (want_fm and dfm is not None) else None
         dx = None if dx is None else Fh._unit_inner(dx)
         hip.embed_grad_reduce(slot_sorted, pos_sorted, b, D, dx, gfm, ssum if gfm is not None else None,
@@ -259,8 +317,7 @@ class _RowsToLinear(torch.autograd.Function):
         from . import hip
         n, D = rows.shape
         dev = rows.device
-        zero = torch.zeros((F,), dtype=torch.int64, device=dev)
-        cnt = torch.full((F,), n, dtype=torch.int64, device=dev)
+        zero, cnt = _const_i64(dev, F, 0), _const_i64(dev, F, n)
         idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
         x, h1, fm, ssum, _ = hip.embed_gather_linear_fwd(rows, zero, cnt, idx, dense, ldx, Fh._rows16(weight), bias, True,
                                                          True, False, err_flag)
@@ -285,13 +342,13 @@ class _RowsToLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = hip.transpose(weight, rows_out=x.shape[1])
             gfm = dfm.contiguous() if dfm is not None else None
-            if scale != 1.0:
+            if scale != 1.0 and not _SEED_SCALED[0]:
                 # the 1/G of the row gradients that travel, folded into the two small operands the rows are linear in
-                # (instead of a pass over [n_unique, D] afterwards)
+                # (instead of a pass over [n_unique, D] afterwards; a recorded step's backward is seeded with it: _SEED_SCALED)
                 dpre = dpre * scale
                 gfm = None if gfm is None else gfm * scale
                 scaled[0] = True
-            g_rows = torch.zeros_like(rows)  # slots no request reads (fixed-capacity padding) carry a zero gradient
+            g_rows = hip.zeros(rows.shape, rows.dtype, rows.device)  # slots no request reads (padding): a zero gradient
             hip.embed_grad_gemm(slot_sorted, pos_sorted, b, D, dpre, wt, None, gfm, ssum if gfm is not None else None,
                                 rows, g_rows, accumulate=False)
         return g_rows, None, None, None, None, None, None, None, dw, db, None, None, None, None
@@ -530,7 +587,7 @@ class ShardedEmbeddingLayer(nn.Module):
             served_sorted = None
             if self._lazy is not None and recv_rows.numel():
                 from . import hip
-                served_sorted = hip.sort_pairs(recv_rows.to(torch.int32), end_bit=self._meta()[3])
+                served_sorted = hip.sort_pairs(self._rows_i32(recv_rows), end_bit=self._meta()[3])
             event = torch.cuda.Event()
             event.record(side)
         self._ahead = (src, ver, route, event, recv_rows, served_sorted)
@@ -546,15 +603,22 @@ class ShardedEmbeddingLayer(nn.Module):
             if self._lazy is not None and self._lazy.t > 0:
                 # exact lazy dense Adam: rows about to be served first replay the steps they skipped
                 sk, sp = served_sorted if served_sorted is not None else \
-                    hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
+                    hip.sort_pairs(self._rows_i32(rows_idx), end_bit=self._meta()[3])
                 self._lazy.replay(self, sk, mark=mark)
                 self._served_sorted = (sk, sp)
-            zero = torch.zeros((1,), dtype=torch.int64, device=rows_idx.device)
-            cnt = torch.full((1,), self.local_arena.shape[0], dtype=torch.int64, device=rows_idx.device)
+            zero, cnt = _const_i64(rows_idx.device, 1, 0), _const_i64(rows_idx.device, 1, self.local_arena.shape[0])
             x, _, _, _ = hip.embed_gather_fwd(self.local_arena.detach(), zero, cnt, [rows_idx], [], self.embedding_dim,
                                               False, False, False, self._err)
             return x
         return self.local_arena.detach()[rows_idx]
+
+    def _rows_i32(self, rows_idx):
+        """the requested local rows (int64, as they travelled) as the int32 keys the row sort takes: rp_embed_keys with one
+        table of local_arena.shape[0] rows at base 0 — the cast as a library launch (`.to(torch.int32)` is an ATen one)"""
+        from . import hip
+        dev = rows_idx.device
+        return hip.embed_keys(_const_i64(dev, 1, 0), _const_i64(dev, 1, self.local_arena.shape[0]), [rows_idx],
+                              self._err_flag(dev))
 
     def _local_scatter_add(self, rows_idx, g, presorted=None):
         p = self.local_arena
@@ -572,7 +636,7 @@ class ShardedEmbeddingLayer(nn.Module):
                 if presorted is not None:
                     sk, sp = presorted
                 else:
-                    sk, sp = hip.sort_pairs(rows_idx.to(torch.int32), end_bit=self._meta()[3])
+                    sk, sp = hip.sort_pairs(self._rows_i32(rows_idx), end_bit=self._meta()[3])
                 hip.embed_grad_reduce(sk, sp, rows_idx.numel(), self.embedding_dim, g, None, None, None,
                                       self._grad_buf, accumulate=not clean)
                 if self._touched is None:
@@ -832,14 +896,34 @@ def allreduce_dense_grads(model: nn.Module, group=None):
     """Average the replicated parameters' gradients over the ranks in one flat bucket."""
     ps = [p for p in dense_parameters(model) if p.grad is not None]
     if ps:
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        lib_copy = False
+        if ps[0].grad.is_cuda and all(p.grad.is_contiguous() and p.grad.dtype is torch.float32 for p in ps):
+            # the bucket is a persistent buffer filled and emptied by ONE library launch each (rp_multi_copy): torch.cat and
+            # the per-tensor copy_ back are ATen launches, which a recorded step (launch plan) must not hold
+            from . import hip
+            total = sum(p.numel() for p in ps)
+            flat = getattr(model, "_rp_flat_grads", None)
+            if flat is None or flat.numel() != total or flat.device != ps[0].grad.device:
+                flat = torch.empty((total,), dtype=torch.float32, device=ps[0].grad.device)
+                object.__setattr__(model, "_rp_flat_grads", flat)
+            views, off = [], 0
+            for p in ps:
+                views.append(flat[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+            lib_copy = hip.multi_copy(views, [p.grad for p in ps])
+        if not lib_copy:
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
         all_reduce(flat, group=group)
-        flat /= dist.get_world_size(group)
-        off = 0
-        for p in ps:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        if not _SEED_SCALED[0] and dist.get_world_size(group) > 1:  # (a recorded step's backward is seeded with 1 / world: the sum IS the mean)
+            flat /= dist.get_world_size(group)
+        if lib_copy:
+            hip.multi_copy([p.grad for p in ps], views)
+        else:
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
     # this step's collectives are all enqueued: the announced next batch may now request its rows (side stream)
     for m in model.modules():
         if isinstance(m, ShardedEmbeddingLayer):

@@ -360,11 +360,13 @@ def test_graphed_step_refuses_what_it_cannot_capture():
 
 
 @pytest.mark.parametrize("force_a2a", [False, True])
-def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, monkeypatch):
-    """The captured step WITH its collectives (round 4): a DeepFM whose tables are row-sharded under a 1-rank RCCL group —
-    route, exchange (the identity, or RCCL self-copies with RP_FORCE_A2A=1: all_to_all_single as a graph node), owner-side
-    gather / reduce, dense all-reduce, deferred lazy Adam with device-resident counters — replayed as a hipGraph, against
-    the eager loop on the same batches: every prediction and the final weights bit-identical."""
+def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, backend, monkeypatch):
+    """The captured step WITH its collectives: a DeepFM whose tables are row-sharded under a 1-rank RCCL group — route,
+    exchange (the identity, or RCCL self-copies with RP_FORCE_A2A=1), owner-side gather / reduce, dense all-reduce, deferred
+    lazy Adam with device-resident counters — against the eager loop on the same batches: every prediction and the final
+    weights bit-identical.  Replayed as a hipGraph (round 4: all_to_all_single as graph nodes) and, round 6, as a LAUNCH PLAN
+    in segments: the plan is cut at every collective (rp_plan_host_mark) and the replay issues them itself in between —
+    which needs the whole sharded step to consist of library launches (no ATen fill / cast / cat / scale left in it)."""
     import copy
     import socket
     import torch.distributed as dist
@@ -407,7 +409,10 @@ def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, monkeypatch
                 preds.append(out["pred"].detach().clone())
             model.embedding_layer.raise_if_bad_index()
             if gstep is not None:
-                assert gstep.replays >= 36 and gstep.backend_used == "hipgraph", (gstep.replays, gstep.backend_used)
+                assert gstep.replays >= 36 and gstep.backend_used == backend, (gstep.replays, gstep.backend_used, gstep.why_not_plan)
+                if backend == "plan":
+                    # the three exchanges (ids, rows, row gradients) and the dense all-reduce are the replay's own calls
+                    assert len(gstep.plans[0].host_calls) == (4 if force_a2a else 1), len(gstep.plans[0].host_calls)
             results[mode] = (preds, {k: v.clone() for k, v in model.state_dict().items()})
             del gstep
         for a, b in zip(results["eager"][0], results["graph"][0]):

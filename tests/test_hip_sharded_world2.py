@@ -242,3 +242,75 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_hip_model(monkeypatch):
         p = step(_global_batch(enc, 60 + i))
         got = torch.cat([r[0]["recovery"][i], r[1]["recovery"][i]])
         torch.testing.assert_close(got, p, rtol=0, atol=5e-6, msg=lambda m: f"recovery step {i}: {m}")
+
+
+def _worker_plan(rank, world, port, ret):
+    """eager loop against the recorded step (launch plan in segments, collectives issued by the replay) on the same batches"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    import copy
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    try:
+        import bench
+        from rec_pangu_amd import hip
+        from rec_pangu_amd.graph_step import GraphedTrainStep
+        from rec_pangu_amd.optim import make_adam
+        from rec_pangu_amd.sharded import build_sharded_model, allreduce_dense_grads
+        hip.lib()
+        enc = bench.criteo_enc_dict(SCALE)
+        base = build_sharded_model(lambda: bench.build_model("deepfm", enc), world, rank, DEV, seed=1)
+        with torch.no_grad():
+            base.embedding_layer.local_arena.mul_(TABLE_SCALE)
+        n_steps, b = 14, 2048
+        batches = [_local(_global_batch(enc, 200 + i, b), rank, b) for i in range(n_steps + 1)]
+        res = {}
+        for mode in ("eager", "plan"):
+            model = copy.deepcopy(base)
+            for m in model.modules():
+                if hasattr(m, "check_indices"):
+                    m.check_indices = "deferred"
+            opt = make_adam(model, 1e-2)
+            gstep = GraphedTrainStep(model, opt, post_backward=lambda: allreduce_dense_grads(model), backend="plan") \
+                if mode == "plan" else None
+            preds = []
+            for i in range(n_steps):
+                if gstep is not None:
+                    out = gstep(batches[i], batches[i + 1])
+                else:
+                    out = model(batches[i])
+                    out["loss"].backward()
+                    allreduce_dense_grads(model)
+                    opt.step()
+                    model.zero_grad()
+                preds.append(out["pred"].detach().cpu().clone())
+            model.embedding_layer.raise_if_bad_index()
+            opt.flush()
+            torch.cuda.synchronize()
+            if gstep is not None:
+                res["backend"] = (gstep.backend_used, gstep.why_not_plan, gstep.replays,
+                                  len(gstep.plans[0].host_calls) if gstep.plans[0] is not None else -1)
+            res[mode] = (preds, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+            del gstep
+        ret[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_recorded_step_equals_the_eager_loop():
+    """Round 6: the row-sharded training step of each of two ranks recorded as a LAUNCH PLAN — cut at its three exchanges and
+    at the dense all-reduce, which every replay issues itself between two segments (here through the host-staged gloo wire) —
+    against the same ranks' eager loop on the same batches.  The recorded backward is seeded with 1 / world (a power of two:
+    exact), so predictions of every step and the final shards and dense weights are BIT-identical."""
+    require_gpu()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _spawn(_worker_plan, (WORLD, _free_port(), ret))
+    assert len(ret) == WORLD
+    for rank in range(WORLD):
+        r = ret[rank]
+        assert r["backend"][0] == "plan" and r["backend"][2] >= 10 and r["backend"][3] == 4, r["backend"]
+        for a, b in zip(r["eager"][0], r["plan"][0]):
+            assert torch.equal(a, b), f"rank {rank}: predictions differ"
+        for k in r["eager"][1]:
+            assert torch.equal(r["eager"][1][k], r["plan"][1][k]), (rank, k)
