@@ -1091,6 +1091,8 @@ def test_embed_grad_seg_vs_fp64_and_grad_gemm(hip, rows, B, with_fm, accumulate,
     ([300, 40, 1000, 5000, 27, 90], 2048, True, True, [0, 2, 3], True),        # EVERY pair of the launch's fields a duplicate
     ([50000, 7, 2000000, 300000], 65536, True, False, [0, 2, 3], False),       # full batch: 1024 units per field, hot + big
     ([50000, 13, 5, 700, 9000000, 90], 16384 + 77, True, False, [0, 4], True),  # keys beyond 2^23 rows, ragged
+    ([40, 2000000, 10, 5000], 4099, True, False, [0, 1], False),               # runs of ~100 duplicates: summed by a whole workgroup
+    ([1, 300000, 77], 2048 + 5, True, True, [0, 1], False),                    # ONE run over the whole batch + a few pairs
 ])
 def test_embed_grad_smp_vs_fp64_and_seg(hip, rows, B, with_fm, accumulate, smp, with_tiny):
     """rp_embed_grad_smp_mark + rp_embed_grad_smp (round 6: the big tables' share of the first layer's backward, SAMPLE-major:
