@@ -427,6 +427,10 @@ def main():
                     help="un-timed training steps on distinct batches before the warm-up, so that the lazy optimizer's "
                          "per-row step stamps are in their long-run state (default: 1000 for --mode train with "
                          "--optimizer lazy, else 0)")
+    ap.add_argument("--window-events", action="store_true",
+                    help="diagnostic: one timing event per step of the timed window (per-step device durations on stderr)")
+    ap.add_argument("--pre-window", type=int, default=-1,
+                    help="replays issued right in front of the timed window, on batches of their own (default: 3 + --warmup)")
     ap.add_argument("--long-steps", type=int, default=2000,
                     help="after the timed region: this many more steps over 512 distinct resident batches with an event after "
                          "every step -> `long_run` (mean / p50 / p99 / max step); 0 = skip")
@@ -655,13 +659,20 @@ def main():
         # region (the eager warm-up above was the per-kernel profiling pass; without these the first timed steps run on a
         # device that has just sat idle — the 20-step window then reads 1.5-4 % above the long-run mean of the same replays)
         # (on batches of their own — never the timed ones; the last one announces the first timed batch)
-        n_pre = 3 + args.warmup
-        pw = [gen(n_seen + 500000 + i) for i in range(n_pre)] + [batches[0]]
+        # (round 6: 256 of them.  Per-step timing events inside the window — bench.py --window-events, profiles/r06_window_ramp.txt
+        #  — show the device speeding up over the first ~40 steps after any idle stretch of a few ms: 8 replays in front of the
+        #  window gave 0.80 -> 0.785 ms falling through the 20 timed steps, 200 replays 0.765 flat, the 2000-step run 0.75.  The
+        #  batch generation just above IS such an idle stretch; these replays bring the device back to the state the pre-roll
+        #  left it in.  They are untimed, on batches of their own, and their count is on the line: pre_window_replays.)
+        n_pre = args.pre_window if args.pre_window >= 0 else max(3 + args.warmup, 256)
+        n_pw = min(n_pre, 64)  # distinct batches (1.3 GB), cycled: none of them is a timed batch
+        pw = [gen(n_seen + 500000 + i) for i in range(n_pw)]
         for i in range(n_pre):
-            step(pw[i], pw[i + 1], graphed=True)
+            step(pw[i % n_pw], pw[(i + 1) % n_pw] if i + 1 < n_pre else batches[0], graphed=True)
         del pw
         barrier()
         t0 = time.perf_counter()
+    n_pre_done = n_pre if gstep is not None else 0
     replays0 = gstep.replays if gstep is not None else 0
     hc0 = (gstep.host_call_s, gstep.host_wait_s) if gstep is not None else None
     if gstep is not None:
@@ -682,16 +693,25 @@ def main():
 
     gc.callbacks.append(_gc_cb)
     host_each = []
+    wev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.window_events else None
+    if wev is not None:
+        wev[0].record()
     for i in range(args.steps):
         hip.pause_timing(i % ev_stride != 0)
         th = time.perf_counter()
         step(batches[i % n_batches], batches[(i + 1) % n_batches] if ahead else None, graphed=True)
         host_each.append(time.perf_counter() - th)  # time the host needs to ENQUEUE a step (it runs ahead of the device)
+        if wev is not None:
+            wev[i + 1].record()
     host_s = sum(host_each)
     hip.pause_timing(False)
     barrier()
     dt = time.perf_counter() - t0
     gc.callbacks.remove(_gc_cb)
+    if wev is not None:
+        print("window events (ms per step):", [round(wev[i].elapsed_time(wev[i + 1]), 4) for i in range(args.steps)],
+              "span", round(wev[0].elapsed_time(wev[-1]), 4), "wall", round(dt * 1e3, 4),
+              "host enqueue", [round(h * 1e3, 3) for h in host_each], file=sys.stderr)
     # the lazy optimizer's owed work at the END of the timed window, read before anything else runs (read
     # after the probes' ~125 further steps over the window's own 20 batches it said something else)
     backlog1 = lazy_backlog() if lazy else None
@@ -1230,6 +1250,7 @@ def main():
                        "parallelism": "single GPU" if not sharded else
                        f"tables row-sharded x{world}, all-to-all lookup ({args.wire} rows on the wire)"},
             "pre_roll_steps": pre_roll, "cold": cold,
+            "pre_window_replays": n_pre_done,
             "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 4),
             "host_call_ms_per_step_unblocked": None if host_call_ms is None else round(host_call_ms, 4),
             "host_wait_ms_per_step": None if host_wait_ms is None else round(host_wait_ms, 4),

@@ -770,6 +770,15 @@ int rp_route_build(void *workspace, size_t workspace_bytes, const int32_t *sorte
 int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_pos, int64_t n, int world, int lbits,
                  int64_t capacity, const int64_t *counts, int32_t *slot_sorted, int64_t *slot_of_pair,
                  int64_t *rows_padded, int32_t *err_flag, rp_stream_t stream);
+/* FIELD-MAJOR copy of a route's sorted request list (round 6).  Sorted by composite key the list is ordered (owner, field,
+ * row); the first layer's backward launches (rp_embed_grad_seg / _ss / _smp) want field f's B requests at [f B, (f + 1) B)
+ * with equal keys adjacent.  slot_fm / pos_fm [n] int32: the (slot, position) pairs of slot_sorted / sorted_pos moved
+ * segment by segment — inside a field the order is (owner, row) = ascending slot, positions of a run keep their order.
+ * n = F * B requests, world * F <= 1024 segments; delta: int64 scratch [world * F].  world == 1: the list is field-major
+ * already (callers skip the call).  No reference counterpart (the reference is single-device: trainer.py:75). */
+int rp_route_field_major(const int32_t *sorted_keys, const int32_t *sorted_pos, const int32_t *slot_sorted, int64_t n,
+                         int64_t B, int world, int lbits, int32_t *slot_fm, int32_t *pos_fm, int64_t *delta,
+                         rp_stream_t stream);
 
 /* ---- LAUNCH PLANS: record a sequence of this library's kernel launches once, re-issue it with one call (csrc/plan.hip).
  * No reference counterpart (the reference's step loop is Python: model_pipeline.py:47-61); this is the host-side

@@ -77,6 +77,19 @@ def shard_file(ckpt_dir: str, rank: int, world: int) -> str:
     return os.path.join(ckpt_dir, f"shard_{rank:03d}_of_{world:03d}.pth")
 
 
+def _save_atomic(obj, path: str) -> None:
+    """torch.save into a temporary file of the same directory, then os.replace: a reader (another rank that did not wait for
+    the writer — save_checkpoint(collective=None) of a replicated model has no barrier) sees the old file or the
+    complete new one, never a partial one"""
+    tmp = f"{path}.tmp.{os.getpid()}"
+    try:
+        torch.save(obj, tmp)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, optimizer=None, group=None,
                     merge: bool = True, filename: str = "model.pth", keep_shards: bool = False,
                     collective: Optional[bool] = None) -> None:
@@ -136,7 +149,7 @@ def save_checkpoint(model: nn.Module, enc_dict: Optional[dict], ckpt_dir: str, o
                 if ts is not None:
                     opt["dense"][k] = ts
         payload["optimizer"] = opt
-    torch.save(payload, shard_file(ckpt_dir, rank, world))
+    _save_atomic(payload, shard_file(ckpt_dir, rank, world))
     if world > 1:
         dist.barrier(group=group)
     if merge and rank == 0:
@@ -197,9 +210,9 @@ def merge_shards(ckpt_dir: str, world: int, enc_dict: Optional[dict], filename: 
     ckpt = {"model": model_sd}
     if enc_dict is not None:
         ckpt["enc_dict"] = enc_dict
-    torch.save(ckpt, os.path.join(ckpt_dir, filename))
+    _save_atomic(ckpt, os.path.join(ckpt_dir, filename))
     if has_opt:
-        torch.save({"step": head["optimizer"]["step"], "param_groups": head["optimizer"]["param_groups"],
+        _save_atomic({"step": head["optimizer"]["step"], "param_groups": head["optimizer"]["param_groups"],
                     "state": opt_state}, os.path.join(ckpt_dir, "optimizer.pth"))
 
 

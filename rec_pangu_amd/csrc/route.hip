@@ -259,6 +259,78 @@ extern "C" int rp_route_pad(const int32_t *sorted_keys, const int32_t *sorted_po
     return RP_OK;
 }
 
+// FIELD-MAJOR copy of a route's sorted request list (round 6).  The list sorted by composite key is ordered (owner, field,
+// row): with more than one owner a field's requests are no longer one contiguous run, which the first layer's backward
+// launches (rp_embed_grad_seg / _ss / _smp: field f's B pairs at [f B, (f + 1) B) of the list, equal keys adjacent) count on.
+// Every (owner, field) segment is contiguous in both orders, so the re-ordering is a move of at most world * F segments:
+//     dest(j) = f B + (requests of field f with a smaller owner) + (j - start of j's segment)
+// — the order inside a field is (owner, row) = ascending slot, equal slots stay adjacent, positions inside a run keep their
+// ascending order (the list came from a stable sort).  Two launches: one workgroup finds the segment starts by binary search
+// over (owner, field) of the sorted entries and turns them into per-segment offsets, then one thread per entry moves it.
+__global__ __launch_bounds__(1024) void route_fm_starts_kernel(const int32_t *__restrict__ sk, const int32_t *__restrict__ sp,
+                                                               int64_t n, int64_t B, int F, int world, int lbits,
+                                                               int64_t *__restrict__ delta) {
+    __shared__ int64_t start[RP_MAX_FIELDS * RP_MAX_FIELDS / 4 + 1];  // world * F + 1 <= 1025 entries
+    const int S = world * F;
+    for (int s = threadIdx.x; s <= S; s += blockDim.x) {
+        // first j with (owner(j), field(j)) >= (s / F, s % F); s == S: n
+        int64_t lo = 0, hi = n;
+        if (s < S) {
+            const int o = s / F, f = s % F;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const int om = sk[mid] >> lbits;
+                const int fm = (int)(sp[mid] / B);
+                if (om < o || (om == o && fm < f)) lo = mid + 1;
+                else hi = mid;
+            }
+        } else {
+            lo = n;
+        }
+        start[s] = lo;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < S; s += blockDim.x) {
+        const int o = s / F, f = s % F;
+        int64_t before = 0;
+        for (int q = 0; q < o; ++q) before += start[q * F + f + 1] - start[q * F + f];
+        delta[s] = (int64_t)f * B + before - start[s];
+    }
+}
+
+__global__ __launch_bounds__(256) void route_fm_move_kernel(const int32_t *__restrict__ sk, const int32_t *__restrict__ sp,
+                                                            const int32_t *__restrict__ slot_sorted, int64_t n, int64_t B, int F,
+                                                            int lbits, const int64_t *__restrict__ delta,
+                                                            int32_t *__restrict__ slot_fm, int32_t *__restrict__ pos_fm) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t p = sp[j];
+    const int o = sk[j] >> lbits, f = (int)(p / B);
+    const int64_t d = j + delta[o * F + f];
+    slot_fm[d] = slot_sorted[j];
+    pos_fm[d] = p;
+}
+
+extern "C" int rp_route_field_major(const int32_t *sorted_keys, const int32_t *sorted_pos, const int32_t *slot_sorted, int64_t n,
+                                    int64_t B, int world, int lbits, int32_t *slot_fm, int32_t *pos_fm, int64_t *delta,
+                                    rp_stream_t stream) {
+    RP_REQUIRE(sorted_keys && sorted_pos && slot_sorted && slot_fm && pos_fm && delta, "route_field_major: null pointer");
+    RP_REQUIRE(n >= 1 && n < INT32_MAX && B >= 1 && n % B == 0 && n / B <= RP_MAX_FIELDS, "route_field_major: needs n = F * B pairs, F <= %d", RP_MAX_FIELDS);
+    RP_REQUIRE(world >= 1 && lbits >= 1 && lbits <= 30, "route_field_major: bad world/lbits");
+    const int F = (int)(n / B);
+    RP_REQUIRE((int64_t)world * F <= RP_MAX_FIELDS * RP_MAX_FIELDS / 4, "route_field_major: world * F = %d segments (at most %d)", world * F,
+               RP_MAX_FIELDS * RP_MAX_FIELDS / 4);
+    RP_REQUIRE(slot_fm != slot_sorted && pos_fm != sorted_pos, "route_field_major: the outputs must not alias the inputs");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(route_fm_starts_kernel, dim3(1), dim3(1024), 0, s, sorted_keys, sorted_pos, n, B, F, world, lbits, delta);
+    RP_LAUNCH_CHECK("route_field_major (segment starts)");
+    hipLaunchKernelGGL(route_fm_move_kernel, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, s, sorted_keys, sorted_pos, slot_sorted,
+                       n, B, F, lbits, delta, slot_fm, pos_fm);
+    RP_LAUNCH_CHECK("route_field_major (move)");
+    rp_count_launch();
+    return RP_OK;
+}
+
 // dst[0 .. n_words) = value (32-bit words) — the zero fill of a buffer inside a recorded step (an ATen fill kernel or a memset
 // node there would keep the step from replaying as a launch plan): the padded request list of rp_route_pad, the
 // requester's per-slot gradient rows

@@ -1088,7 +1088,7 @@ class _EmbedGatherLinear(torch.autograd.Function):
             # a 2^-9-relative inconsistency inside the mode's stated tolerance, and closer to the fp32 reference);
             # RP_GRAD_SEG=0: the stored bf16 activation + rp_linear_wgrad_xbf16 (round 4)
             seg16 = (need_grad and need_w and K > Kg and len(idx) <= 64 and os.environ.get("RP_GRAD_SEG", "1") != "0"
-                     and weight.shape[0] == 64)
+                     and weight.shape[0] == 64 and store.embedding_dim == 64)  # (what rp_embed_grad_seg_fits asks for: ADVICE r5)
             x, h1, fm, ssum, keys = hip.embed_gather_linear_fwd_bf16(shadow, store.row_base, store.row_count, idx, dense, w16, bias,
                                                                      store.err_flag, train_ldx=ldx, want_keys=want_keys,
                                                                      dense_only=seg16)

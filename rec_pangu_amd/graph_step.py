@@ -202,6 +202,7 @@ class GraphedTrainStep:
         self._keys = list(batch.keys())
         self._copy_lists = [None, None]  # per static batch: the destination side of its staging copy, converted once
         self._x_valid, self._bind_sites, self._held = [False, False], [0, 0], []
+        self._pins = None  # (sharded: the static batches' prepared lookups in persistent buffers, made once the capacity is known)
         if self._sharded:
             return
         for x in self.X:  # both static batches get their persistent sort buffers before anything is captured
@@ -231,7 +232,26 @@ class GraphedTrainStep:
         self._x_valid[self.P] = True
         if not self._sharded:
             self.model.embedding_layer.pin_sort(self.X[self.P])
+        elif self._sharded_pins():
+            # the route, id exchange and owner-side sort of the batch, eagerly (no replay prepared them beside the step before)
+            self.model.embedding_layer.route_into(self.X[self.P], self._pins[self.P])
         self._staged = batch
+
+    def _sharded_pins(self) -> bool:
+        """round 6: a row-sharded step reads the part of its lookup that does not depend on the weights (route, requested rows,
+        owner-side sort) from persistent buffers, filled by the replay of the step BEFORE it on the ahead stream
+        (ShardedEmbeddingLayer.route_into inside the recording) — RP_SHARD_AHEAD=0: built inside the step itself (rounds 4-5)"""
+        if os.environ.get("RP_SHARD_AHEAD", "1") == "0" or self.backend != "plan":
+            return False
+        emb = self.model.embedding_layer
+        if self._pins is not None and self._pins[0].capacity != emb._capacity:
+            torch.cuda.synchronize()  # (the exchange capacity was re-measured: the recorded steps hold the old buffers)
+            self._drop_captures()
+            self._pins = None
+        if self._pins is None:
+            pins = [emb.pinned_route(x) for x in self.X]
+            self._pins = pins if all(p is not None for p in pins) else None
+        return self._pins is not None
 
     def _capture(self, P, force_graph: bool = False):
         if self.graphs[1 - P] is None:
@@ -276,6 +296,18 @@ class GraphedTrainStep:
                         # (A/B switch: the next batch's sort beside the catch-up and the gather instead.  Catch-up ahead: the
                         #  step itself consumes the sort at its end and starts at the lookup — the sort gets the whole step)
                         plan.fork_here()
+                    pins = self._pins if (self._sharded and self._pins is not None) else None
+                    if pins is not None:
+                        # the NEXT batch's route, id exchange and owner-side sort into its persistent buffers: segments of the
+                        # ahead stream (LaunchPlan.cut), forked at the start of a replay and joined at its end.  Recorded FIRST,
+                        # every temporary held until the recording ends: they run BESIDE the step, whose temporaries must not
+                        # land in memory the capture's allocator got back from them (hip.holding)
+                        hip.LaunchPlan.cut(1)
+                        with hip.holding() as held_ahead:
+                            emb.route_into(self.X[1 - P], pins[1 - P])
+                        held.append(held_ahead)
+                        hip.LaunchPlan.cut(0)
+                        emb.use_pinned(pins[P])
                     out = self.model(self.X[P])  # (finds X[P]'s pinned sort; nothing is announced inside the capture)
                     if plan is not None and not fork_start:
                         # the side section (the next batch's sort, recorded last) is forked here: beside the backward,
@@ -292,7 +324,7 @@ class GraphedTrainStep:
                     if ahead:
                         # the dense step runs on the side section until the end of the replay: the capture's one-stream
                         # allocator must not hand the gradients' memory to the launches recorded behind it
-                        held = [p.grad for g_ in self.opt.param_groups for p in g_["params"] if p.grad is not None]
+                        held += [p.grad for g_ in self.opt.param_groups for p in g_["params"] if p.grad is not None]
                     self.model.zero_grad()
                     # the next batch (already staged in X[1-P] when the step is launched): keys + sort into its pinned
                     # tensors.  It depends on nothing the step computes and touches persistent buffers only: a plan
@@ -342,7 +374,11 @@ class GraphedTrainStep:
                         self._pool = None
                     return self._capture(P, force_graph=True)
             elif self._sharded:
-                pass  # (one stream, no sections; the static inputs are filled by the staging copy)
+                # (no sections; the static inputs are filled by the staging copy.  Segments tagged for the ahead stream — the
+                #  next batch's prepared lookup — run on the sharded path's own plain stream)
+                if any(plan.seg_tags):
+                    from .sharded import route_stream
+                    plan.ahead_stream = route_stream(next(iter(self.X[0].values())).device)
             else:
                 # the sections run on the very streams the eager path overlaps on (sort-ahead / first-layer weight gradient):
                 # a stream of the plan's own may share the main stream's hardware queue (csrc/plan.hip)

@@ -185,6 +185,7 @@ _SIGNATURES = {
     "rp_route_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_route_build": (C.c_int, [_vp, _sz, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rp_route_pad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rp_route_field_major": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rp_adam_step_scalars": (C.c_int, [_f64, _f64, _f64, _f64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rp_adam_step_scalars_range": (C.c_int, [_f64, _f64, _f64, _f64, _i64, _i64, _vp]),
     "rp_lazy_adam_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f64, _f64, _f64,
@@ -507,6 +508,7 @@ def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None, workspace=None):
         ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
     ko, po = out if out is not None else (torch.empty_like(keys), torch.empty_like(keys))
     assert ko.shape == keys.shape and po.shape == keys.shape and ko.dtype == po.dtype == torch.int32
+    _held(keys, ws, ko, po)
     with _Timed("sort_pairs_i32"):
         _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
                                    end_bit, _stream()), "rp_sort_pairs_i32")
@@ -994,7 +996,11 @@ class LaunchPlan:
         self._h = None
         self._streams = None
         self.nodes = self.side = self.streams = self.inline = 0
-        self.host_calls = []  # what the caller issues itself between two segments of the replay (host marks)
+        self.host_calls = []  # what the caller issues itself between two segments of the replay (host marks); None = a cut
+        self.seg_tags = [0]   # per segment: 0 = the replay's stream, 1 = the ahead stream (cut)
+        self._tag = 0
+        self.ahead_stream = None  # torch stream of the tag-1 segments (set by the owner of the plan)
+        self._ev_fork = self._ev_join = None
 
     _recording = None  # the plan being recorded (host_call appends to it)
 
@@ -1008,7 +1014,8 @@ class LaunchPlan:
     def host_call(cls, fn) -> bool:
         """Inside a recording: `fn` is work the library does not launch (a collective of the row-sharded path) — it is NOT
         issued now; the plan is cut here (rp_plan_host_mark) and every replay calls fn() between the two segments, on the
-        replay's stream.  -> True when the call was taken over (the caller skips issuing it), False outside a recording."""
+        stream of the segments around it.  -> True when the call was taken over (the caller skips issuing it), False outside
+        a recording.  fn None: a plain cut (see cut)."""
         pl = cls._recording
         if pl is None or not cls.is_recording():
             return False
@@ -1016,7 +1023,20 @@ class LaunchPlan:
         _check(lib().rp_plan_host_mark(C.byref(k)), "rp_plan_host_mark")
         assert k.value == len(pl.host_calls)
         pl.host_calls.append(fn)
+        pl.seg_tags.append(pl._tag)
         return True
+
+    @classmethod
+    def cut(cls, tag: int) -> bool:
+        """Inside a recording of a plan that replays in segments (a row-sharded step): the segments recorded from here on —
+        and the host calls between them — belong to stream `tag`: 0 = the replay's stream, 1 = the AHEAD stream (the next
+        batch's route, id exchange and owner-side sort: work that depends on nothing the step computes; the replay forks it
+        at its start and joins it at its end, LaunchPlan.replay)."""
+        pl = cls._recording
+        if pl is None or not cls.is_recording():
+            return False
+        pl._tag = int(tag)
+        return cls.host_call(None)
 
     def end(self):
         LaunchPlan._recording = None
@@ -1112,16 +1132,50 @@ class LaunchPlan:
         return bool(lib().rp_plan_is_recording())
 
     def replay(self):
-        if self.host_calls:  # segments, the caller's own work (collectives) in between — all on the current stream
+        if self.host_calls:  # segments, the caller's own work (collectives) in between
             s = _stream()
-            for k, fn in enumerate(self.host_calls):
-                rc = lib().rp_plan_replay_segment(self._h, k, s)
+            tags, calls, nseg = self.seg_tags, self.host_calls, len(self.host_calls) + 1
+            side = self.ahead_stream if any(tags) else None
+            if any(tags) and side is None:
+                tags = [0] * nseg  # (no ahead stream given: everything in recorded order on the replay's stream)
+            if side is not None:
+                # fork: the ahead segments depend on what was enqueued BEFORE this replay only (the next batch's staged ids,
+                # the previous replay's reads of the buffers they rewrite)
+                main = torch.cuda.current_stream()
+                if self._ev_fork is None:
+                    self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
+                self._ev_fork.record(main)
+                side.wait_event(self._ev_fork)
+                s1 = _vp(side.cuda_stream)
+                # the ahead segments in front of their first host call (the route: launches only) are issued first — beside
+                # the step from its start; their collectives follow the step's own (RCCL runs collectives in issue order: an
+                # id exchange waiting for the route must not sit in front of the row / gradient exchanges of the step)
+                first_side = next(k for k in range(nseg) if tags[k] == 1)
+                rc = lib().rp_plan_replay_segment(self._h, first_side, s1)
                 if rc != 0:
                     _check(rc, "rp_plan_replay_segment")
-                fn()
-            rc = lib().rp_plan_replay_segment(self._h, len(self.host_calls), s)
-            if rc != 0:
-                _check(rc, "rp_plan_replay_segment")
+            else:
+                first_side = -1
+            for k in range(nseg):  # the replay's own stream: segments and the host calls between two of them
+                if tags[k] == 0:
+                    rc = lib().rp_plan_replay_segment(self._h, k, s)
+                    if rc != 0:
+                        _check(rc, "rp_plan_replay_segment")
+                    if k < nseg - 1 and tags[k + 1] == 0 and calls[k] is not None:
+                        calls[k]()
+            if side is not None:
+                with torch.cuda.stream(side):
+                    for k in range(first_side, nseg):
+                        if tags[k] != 1:
+                            continue
+                        if k > first_side:
+                            if calls[k - 1] is not None and tags[k - 1] == 1:
+                                calls[k - 1]()
+                            rc = lib().rp_plan_replay_segment(self._h, k, s1)
+                            if rc != 0:
+                                _check(rc, "rp_plan_replay_segment")
+                self._ev_join.record(side)
+                main.wait_event(self._ev_join)
             return
         rc = lib().rp_plan_replay(self._h, _stream())
         if rc != 0:
@@ -1191,6 +1245,32 @@ class LaunchPlan:
 
 
 _COPY_PLANS: dict = {}
+
+
+# Tensors the wrappers below allocate while a `holding()` block is open stay referenced by its list.  Why: inside a stream
+# capture the allocator hands a freed block to the NEXT allocation of the same capture — fine for launches that replay in
+# recorded order on one stream, wrong for a group of launches the replay runs on another stream BESIDE the rest (the
+# row-sharded step's look-ahead: graph_step).  Their temporaries — also the ones a wrapper allocates and drops internally —
+# must outlive the recording of everything they run beside.
+_HOLDING = None
+
+
+class holding:
+    def __enter__(self):
+        global _HOLDING
+        self.prev, self.items = _HOLDING, []
+        _HOLDING = self.items
+        return self.items
+
+    def __exit__(self, *exc):
+        global _HOLDING
+        _HOLDING = self.prev
+        return False
+
+
+def _held(*tensors):
+    if _HOLDING is not None:
+        _HOLDING.extend(t for t in tensors if t is not None)
 
 
 def make_side_stream(device, role: str = "sort") -> "torch.cuda.Stream":
@@ -1890,6 +1970,7 @@ def embed_keys(row_base, row_count, idx: List[torch.Tensor], err_flag, out=None)
     F, B = len(idx), idx[0].shape[0]
     keys = out if out is not None else torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
     assert keys.numel() == F * B and keys.dtype == torch.int32
+    _held(keys)
     with _Timed("embed_keys"):
         _check(lib().rp_embed_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, keys.data_ptr(),
                                    err_flag.data_ptr(), _stream()), "rp_embed_keys")
@@ -1900,24 +1981,32 @@ def shard_keys(row_base, row_count, idx: List[torch.Tensor], world: int, lbits: 
     """composite (owner << lbits | local row) int32 keys of a batch's row requests, p = f*B + b (rp_shard_keys)."""
     F, B = len(idx), idx[0].shape[0]
     keys = torch.empty((F * B,), dtype=torch.int32, device=idx[0].device)
+    _held(keys)
     with _Timed("shard_keys"):
         _check(lib().rp_shard_keys(row_base.data_ptr(), row_count.data_ptr(), _ptr_array(idx), F, B, world, lbits,
                                    keys.data_ptr(), err_flag.data_ptr(), _stream()), "rp_shard_keys")
     return keys
 
 
-def route_build(sorted_keys, sorted_pos, world: int, lbits: int):
+def route_build(sorted_keys, sorted_pos, world: int, lbits: int, out=None):
     """-> (slot_sorted int32 [n], slot_of_pair int64 [n], uniq_rows int64 [n] (first counts[world] valid),
-    counts int64 [world+1]) from the sorted composite keys (rp_route_build)."""
+    counts int64 [world+1]) from the sorted composite keys (rp_route_build).  out = (slot_sorted, slot_of_pair): persistent
+    buffers to write into (the prepared lookup of a recorded step's static batch)"""
     n = sorted_keys.numel()
     dev = sorted_keys.device
-    slot_sorted = torch.empty((n,), dtype=torch.int32, device=dev)
-    slot_of_pair = torch.empty((n,), dtype=torch.int64, device=dev)
+    if out is not None:
+        slot_sorted, slot_of_pair = out
+        assert slot_sorted.shape == (n,) and slot_sorted.dtype == torch.int32 and slot_of_pair.shape == (n,) \
+            and slot_of_pair.dtype == torch.int64
+    else:
+        slot_sorted = torch.empty((n,), dtype=torch.int32, device=dev)
+        slot_of_pair = torch.empty((n,), dtype=torch.int64, device=dev)
     uniq_rows = torch.empty((n,), dtype=torch.int64, device=dev)
     counts = torch.empty((world + 1,), dtype=torch.int64, device=dev)
     nbytes = _sz(0)
     _check(lib().rp_route_workspace_bytes(n, world, C.byref(nbytes)), "rp_route_workspace_bytes")
     ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+    _held(slot_sorted, slot_of_pair, uniq_rows, counts, ws)
     with _Timed("route_build"):
         _check(lib().rp_route_build(ws.data_ptr(), nbytes.value, sorted_keys.data_ptr(), sorted_pos.data_ptr(), n, world,
                                     lbits, slot_sorted.data_ptr(), slot_of_pair.data_ptr(), uniq_rows.data_ptr(),
@@ -1925,15 +2014,42 @@ def route_build(sorted_keys, sorted_pos, world: int, lbits: int):
     return slot_sorted, slot_of_pair, uniq_rows, counts
 
 
-def route_pad(sorted_keys, sorted_pos, world: int, lbits: int, capacity: int, counts, slot_sorted, slot_of_pair, err_flag):
+def route_pad(sorted_keys, sorted_pos, world: int, lbits: int, capacity: int, counts, slot_sorted, slot_of_pair, err_flag,
+              out=None):
     """fixed-capacity form of a route (rp_route_pad): slot_sorted / slot_of_pair are rewritten in place / overwritten;
-    -> rows_padded int64 [world * capacity] (local rows to ask each owner for, unused slots 0)."""
-    rows_padded = zeros((world * capacity,), torch.int64, sorted_keys.device)
+    -> rows_padded int64 [world * capacity] (local rows to ask each owner for, unused slots 0); out: a persistent buffer for it"""
+    if out is not None:
+        assert out.shape == (world * capacity,) and out.dtype == torch.int64
+        rows_padded = out
+        _check(lib().rp_fill_words(rows_padded.data_ptr(), rows_padded.numel() * 2, 0, _stream()), "rp_fill_words")
+    else:
+        rows_padded = zeros((world * capacity,), torch.int64, sorted_keys.device)
+    _held(rows_padded)
     with _Timed("route_pad"):
         _check(lib().rp_route_pad(sorted_keys.data_ptr(), sorted_pos.data_ptr(), sorted_keys.numel(), world, lbits, capacity,
                                   counts.data_ptr(), slot_sorted.data_ptr(), slot_of_pair.data_ptr(),
                                   rows_padded.data_ptr(), err_flag.data_ptr(), _stream()), "rp_route_pad")
     return rows_padded
+
+
+def route_field_major(sorted_keys, sorted_pos, slot_sorted, B: int, world: int, lbits: int, out=None):
+    """-> (slot_fm, pos_fm): the route's sorted (slot, position) list moved into FIELD-major order (rp_route_field_major) —
+    what rp_embed_grad_seg takes as its sorted pair list when the rows came from more than one owner"""
+    n = sorted_keys.numel()
+    dev = sorted_keys.device
+    if out is not None:
+        slot_fm, pos_fm = out
+        assert slot_fm.shape == (n,) and pos_fm.shape == (n,) and slot_fm.dtype == pos_fm.dtype == torch.int32
+    else:
+        slot_fm = torch.empty((n,), dtype=torch.int32, device=dev)
+        pos_fm = torch.empty((n,), dtype=torch.int32, device=dev)
+    delta = torch.empty((world * (n // B),), dtype=torch.int64, device=dev)
+    _held(slot_fm, pos_fm, delta)
+    with _Timed("route_field_major"):
+        _check(lib().rp_route_field_major(sorted_keys.data_ptr(), sorted_pos.data_ptr(), slot_sorted.data_ptr(), n, B, world, lbits,
+                                          slot_fm.data_ptr(), pos_fm.data_ptr(), delta.data_ptr(), _stream()),
+               "rp_route_field_major")
+    return slot_fm, pos_fm
 
 
 def batchnorm_update_running(mean, var, bn, M: int):

@@ -95,16 +95,40 @@ class StepTables:
         self._upload(self.ns_d[t_new:hi + 1], torch.stack([ns, d], 1))
         self.lr, self.lr_from, self.filled_to = lr, t_new, hi
 
-    @staticmethod
-    def _upload(dst, src):
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_pins":  # (staging buffers + their events: per instance, made on demand)
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k != "_pins"}
+
+    def _upload(self, dst, src):
         """host rows -> device rows in stream order WITHOUT blocking the host: a copy from pageable memory waits for the
         stream to drain first — every 1024th step the host lost the 6 replayed steps it was ahead (5.4 ms inside one call,
-        bench.py host_stall, round 5) and the device then idled until the next step was enqueued.  The pinned staging tensor
-        goes back to torch's host allocator, which holds it until the copy has run."""
+        bench.py host_stall, round 5) and the device then idled until the next step was enqueued.  The pinned staging
+        buffers are this table's own (round 6: a pinned allocation inside the call is a hipHostMalloc the first time — 5.5 ms
+        where it fell on the first call of a timed window, profiles/r06_window_ramp.txt); a buffer is reused only once the
+        copy that last read it has run (refills are a chunk of steps apart: the wait never blocks in practice)."""
         if dst.is_cuda:
-            pin = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            key = (src.dtype, tuple(src.shape))
+            pins = self.__dict__.setdefault("_pins", {})
+            slot = pins.get(key)
+            if slot is None:
+                if len(pins) > 8:
+                    pins.clear()
+                slot = pins[key] = [torch.empty(src.shape, dtype=src.dtype, pin_memory=True), None]
+            pin, ev = slot
+            if ev is not None:
+                ev.synchronize()
             pin.copy_(src)
             dst.copy_(pin, non_blocking=True)
+            ev = slot[1] = ev if ev is not None else torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dst.device))
         else:
             dst.copy_(src)
 

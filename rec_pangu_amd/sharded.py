@@ -110,6 +110,33 @@ class seed_scaled:
 
 
 _CONSTS: dict = {}
+# the stream the look-ahead of a sharded lookup runs on (route, id exchange, owner-side sort): a PLAIN torch stream of this
+# module's own — RCCL's collectives are issued on it, and the lowest-priority ExternalStream the single-device path keeps in
+# embedding._SIDE_STREAMS has not run under a process group with more than one rank (sharing that dict made the
+# choice depend on which layer created the entry first)
+_ROUTE_STREAMS: dict = {}
+
+
+def route_stream(dev):
+    """The lowest-priority stream of hip.make_side_stream, an instance of this module's own (RP_ROUTE_STREAM=plain: a torch
+    stream of the normal priority, rounds 3-5).  HIP multiplexes the streams of one priority onto a handful of hardware
+    queues, and a plain stream that lands on the main stream's queue runs IN FRONT of or BEHIND the step instead of beside it
+    (measured on one MI355X: the recorded sharded step with its look-ahead on a plain stream took exactly the serial time,
+    DESIGN.md §8).  Collectives are issued with this stream current (torch's process group orders its own communication
+    stream against the CURRENT stream with events, whatever kind of stream that is): covered by the 1-rank RCCL test with
+    RP_FORCE_A2A=1 and the two-rank host-staged test; RCCL with N > 1 has not executed on any stream yet."""
+    side = _ROUTE_STREAMS.get(dev)
+    if side is None:
+        kind = os.environ.get("RP_ROUTE_STREAM", "low")
+        if kind == "low":
+            from . import hip
+            side = hip.make_side_stream(dev, "route")
+        elif kind == "high":
+            side = torch.cuda.Stream(device=dev, priority=-1)
+        else:
+            side = torch.cuda.Stream(device=dev)
+        _ROUTE_STREAMS[dev] = side
+    return side
 
 
 def _const_i64(device, n: int, value: int):
@@ -171,9 +198,10 @@ class _Route:
       slot_of_pair[p]: the slot request p reads its row from
     """
 
-    def __init__(self, keys, layer):
+    def __init__(self, keys, layer, pin=None):
         """keys: int64 arena rows [n] (p = f*b + i) — or, on a HIP device, the list of per-field id tensors (the
-        range check, the composite keys and everything after the sort then run in rp_shard_keys / rp_route_build)."""
+        range check, the composite keys and everything after the sort then run in rp_shard_keys / rp_route_build).
+        pin (HIP, fixed-capacity exchange only): a _PinnedRoute whose persistent buffers the lists are written into."""
         world, lbits = layer.world, layer.lbits
         nbits = lbits + max(1, (world - 1).bit_length())
         if isinstance(keys, (list, tuple)):
@@ -182,8 +210,13 @@ class _Route:
             n = len(idx) * idx[0].numel()
             err = layer._err_flag(idx[0].device)
             comp = hip.shard_keys(layer._row_base, layer._row_count, idx, world, lbits, err)
-            sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # stable radix sort (csrc/sort.hip), (key, position) pairs
-            self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(sk, sp, world, lbits)
+            if pin is not None:
+                sk, sp = hip.sort_pairs(comp, end_bit=nbits, out=(torch.empty_like(comp), pin.pos_sorted))
+                hip._held(sk)
+            else:
+                sk, sp = hip.sort_pairs(comp, end_bit=nbits)  # stable radix sort (csrc/sort.hip), (key, position) pairs
+            self.slot_sorted, self.slot_of_pair, uniq_rows, counts = hip.route_build(
+                sk, sp, world, lbits, out=None if pin is None else (pin.slot_sorted, pin.slot_of_pair))
             self.pos_sorted = sp
             self.n_requests = n
             # fixed-capacity exchange (check_indices == "deferred"): every owner gets `cap` slots, the split sizes are
@@ -194,10 +227,14 @@ class _Route:
             # flag, which raise_if_bad_index() — all-reduced over the ranks — turns into an exception on EVERY rank.
             cap = layer._capacity if (layer.check_indices == "deferred" and n <= layer._capacity_n) else None
             if cap is not None:
-                self.local_rows = hip.route_pad(sk, sp, world, lbits, cap, counts, self.slot_sorted, self.slot_of_pair, err)
+                self.local_rows = hip.route_pad(sk, sp, world, lbits, cap, counts, self.slot_sorted, self.slot_of_pair, err,
+                                                out=None if pin is None else pin.local_rows)
                 self.send = self.recv = [cap] * world
                 self.n_unique = self.n_recv = cap * world
+                self._field_major(sk, sp, n // len(idx), world, lbits, pin)
                 return
+            if pin is not None:
+                raise RuntimeError("_Route: persistent buffers need the fixed-capacity exchange")
             send_counts = counts[:world]
             recv_counts = torch.empty_like(send_counts)
             all_to_all(recv_counts, send_counts, group=layer.group)
@@ -205,6 +242,7 @@ class _Route:
             self.send, self.recv = torch.stack([send_counts, recv_counts]).tolist()
             self.n_unique, self.n_recv = sum(self.send), sum(self.recv)
             self.local_rows = uniq_rows[:self.n_unique]
+            self._field_major(sk, sp, n // len(idx), world, lbits)
             if layer.check_indices == "deferred":
                 # from the next step on: fixed capacity, 25 % above the largest per-owner count any rank saw now (never
                 # below what an earlier measurement gave)
@@ -229,6 +267,42 @@ class _Route:
         self.slot_of_pair = torch.empty((keys.numel(),), dtype=torch.int64, device=keys.device)
         self.slot_of_pair[sp.long()] = inverse.long()
         self.n_requests = keys.numel()
+
+
+def _route_field_major(self, sk, sp, b, world, lbits, pin=None):
+    """slot_fm / pos_fm: the sorted (slot, position) list in FIELD-major order — what the segment-sum-first backward of the
+    fused first layer takes (rp_embed_grad_seg).  One owner: the composite-key order is field-major already."""
+    if world == 1:
+        self.slot_fm, self.pos_fm = self.slot_sorted, self.pos_sorted
+        return
+    from . import hip
+    self.slot_fm, self.pos_fm = hip.route_field_major(sk, sp, self.slot_sorted, b, world, lbits,
+                                                      out=None if pin is None else (pin.slot_fm, pin.pos_fm))
+
+
+_Route._field_major = _route_field_major
+_Route.slot_fm = _Route.pos_fm = None  # (routes built with torch ops — CPU — have no field-major list)
+
+
+class _PinnedRoute:
+    """The prepared lookup of ONE static batch of a recorded step (graph_step.GraphedTrainStep, round 6) in PERSISTENT
+    buffers: its route, the rows this rank is asked for and their owner-side sort.  A replayed step reads them; the replay
+    of the step BEFORE it (or, for the first replay / a restaged batch, an eager pass) fills them — on the ahead stream,
+    beside the step (ShardedEmbeddingLayer.route_into).  Looks like a _Route to _ShardedRows / _RowsToLinear."""
+
+    def __init__(self, layer, n: int, b: int):
+        dev = layer.local_arena.device
+        world, cap = layer.world, layer._capacity
+        i32 = lambda m: torch.zeros((m,), dtype=torch.int32, device=dev)
+        i64 = lambda m: torch.zeros((m,), dtype=torch.int64, device=dev)
+        self.slot_sorted, self.pos_sorted, self.slot_of_pair = i32(n), i32(n), i64(n)
+        self.slot_fm, self.pos_fm = (self.slot_sorted, self.pos_sorted) if world == 1 else (i32(n), i32(n))
+        self.local_rows = i64(world * cap)
+        self.recv_rows = self.local_rows if (world == 1 and not _force_a2a()) else i64(world * cap)
+        self.served = (i32(world * cap), i32(world * cap))
+        self.send = self.recv = [cap] * world
+        self.n_unique = self.n_recv = cap * world
+        self.n_requests, self.capacity, self.b = n, cap, b
 
 
 class _ShardedRows(torch.autograd.Function):
@@ -257,6 +331,7 @@ class _ShardedRows(torch.autograd.Function):
         ctx.mark_non_differentiable(route.slot_of_pair, route.slot_sorted, route.pos_sorted)
         # (autograd materialised a zero "gradient" for each of the three index outputs: three ATen fill launches per step)
         ctx.set_materialize_grads(False)
+        layer._route_fm = (route.slot_fm, route.pos_fm)  # (read by gather_linear right after this call: not autograd outputs)
         return rows, route.slot_of_pair, route.slot_sorted, route.pos_sorted
 
     @staticmethod
@@ -313,15 +388,24 @@ class _RowsToLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, slot_of_pair, dense: List[torch.Tensor], slot_sorted, pos_sorted, b: int, F: int, ldx: int,
-                weight, bias, out_link, err_flag, scale: float, scaled):
+                weight, bias, out_link, err_flag, scale: float, scaled, fm_lists=None):
         from . import hip
         n, D = rows.shape
         dev = rows.device
         zero, cnt = _const_i64(dev, F, 0), _const_i64(dev, F, n)
         idx = [slot_of_pair[f * b:(f + 1) * b] for f in range(F)]
+        K = weight.shape[1]
+        # round 6, as on the single-device path (functional._EmbedGatherLinear "seg"): NO activation is stored — the embedding
+        # columns of the layer's weight gradient come out of the gather backward (rp_embed_grad_seg over the received rows, the
+        # route's FIELD-major pair list), the dense columns from a small weight gradient over xd [b, 64].  RP_GRAD_SEG=0: the
+        # stored x + rp_linear_wgrad + rp_embed_grad_gemm of rounds 3-5.
+        seg = (fm_lists is not None and fm_lists[0] is not None and K > F * D and F <= 64 and D == 64 and weight.shape[0] == 64
+               and (ctx.needs_input_grad[8] or ctx.needs_input_grad[0]) and os.environ.get("RP_GRAD_SEG", "1") != "0")
         x, h1, fm, ssum, _ = hip.embed_gather_linear_fwd(rows, zero, cnt, idx, dense, ldx, Fh._rows16(weight), bias, True,
-                                                         True, False, err_flag)
-        ctx.cfg = (b, D, weight.shape[1], bias is not None, out_link, scale, scaled)
+                                                         True, False, err_flag, x_mode="dense" if seg else "full")
+        ctx.cfg = (b, D, K, bias is not None, out_link, scale, scaled, seg, F)
+        if seg:
+            slot_sorted, pos_sorted = fm_lists
         ctx.save_for_backward(rows, slot_sorted, pos_sorted, ssum, x, h1, weight)
         return h1, fm
 
@@ -329,13 +413,36 @@ class _RowsToLinear(torch.autograd.Function):
     def backward(ctx, dh1, dfm):
         from . import hip
         rows, slot_sorted, pos_sorted, ssum, x, h1, weight = ctx.saved_tensors
-        b, D, K, has_bias, lk, scale, scaled = ctx.cfg
+        b, D, K, has_bias, lk, scale, scaled, seg, F = ctx.cfg
         dh1 = Fh._unit_inner(dh1)
         masked = lk is not None and lk.dx is not None and lk.dx.data_ptr() == dh1.data_ptr() and lk.dx.shape == dh1.shape
         if lk is not None:
             lk.dx = None
         dpre = dh1 if masked else hip.relu_bwd(dh1, h1)
         dw = db = None
+        if seg:
+            # x = xd [b, 64] (the dense columns); slot_sorted / pos_sorted = the route's field-major lists.  dw's dense columns
+            # and the bias gradient from the UNSCALED dpre (like every dense gradient: the all-reduce carries their 1/G, or the
+            # recorded step's seed), the embedding columns from rp_embed_grad_seg — scaled with the row gradients when the 1/G
+            # is folded into dpre here, and scaled back below in that (eager, world > 1) case
+            Kg = F * D
+            dw = torch.empty((64, K), dtype=torch.float32, device=dpre.device)
+            _, db = hip.linear_wgrad(dpre, x, K - Kg, dw=dw[:, Kg:], want_bias=has_bias)
+            gfm = dfm.contiguous() if dfm is not None else None
+            fold = scale != 1.0 and not _SEED_SCALED[0]
+            dpre_r, gfm_r = dpre, gfm
+            if fold:
+                dpre_r = dpre * scale
+                gfm_r = None if gfm is None else gfm * scale
+                scaled[0] = True
+            g_rows = hip.zeros(rows.shape, rows.dtype, rows.device)  # slots no request reads (padding): a zero gradient
+            hip.embed_grad_seg(slot_sorted, pos_sorted, b, D, dpre_r, weight, gfm_r, ssum if gfm_r is not None else None, rows,
+                               g_rows, accumulate=False, dw=dw)
+            if fold:
+                dw[:, :Kg].mul_(1.0 / scale)
+            if not ctx.needs_input_grad[0]:
+                g_rows = None
+            return g_rows, None, None, None, None, None, None, None, dw, db, None, None, None, None, None
         if ctx.needs_input_grad[8] or (has_bias and ctx.needs_input_grad[9]):
             dw, db = hip.linear_wgrad(dpre, x, K, want_bias=has_bias)
         g_rows = None
@@ -351,7 +458,7 @@ class _RowsToLinear(torch.autograd.Function):
             g_rows = hip.zeros(rows.shape, rows.dtype, rows.device)  # slots no request reads (padding): a zero gradient
             hip.embed_grad_gemm(slot_sorted, pos_sorted, b, D, dpre, wt, None, gfm, ssum if gfm is not None else None,
                                 rows, g_rows, accumulate=False)
-        return g_rows, None, None, None, None, None, None, None, dw, db, None, None, None, None
+        return g_rows, None, None, None, None, None, None, None, dw, db, None, None, None, None, None
 
 
 class ShardedEmbeddingLayer(nn.Module):
@@ -416,6 +523,10 @@ class ShardedEmbeddingLayer(nn.Module):
         self._capacity = None  # per-owner slots of the fixed-capacity exchange (check_indices == "deferred", HIP)
         self._capacity_n = 0   # requests of the (largest) batch the capacity was measured on
         self._prepared = None  # (route, requested rows, their sort) of the batch about to be looked up, as far as prepared ahead
+        # the owner-side gradient launch (rp_embed_grad_reduce over the sorted rows this rank was asked for) writes EVERY row of
+        # its key list — the list the catch-up launch in front of the lookup stamped: that launch may leave the gradient rows it
+        # applied uncleared (1 of its 8 row transfers; LazyAdamRows.replay, as on the single-device path)
+        self._noclear_ok = True
         self._scaled = None     # per-lookup flag shared by _ShardedRows and _RowsToLinear (who applies the 1/G)
         self._announced = None  # the batch of the next step (prefetch_sort), until its route is started
         self._ahead = None      # (id tensors, versions, route, event[, requested rows, their sort]) prepared on the side stream
@@ -467,6 +578,11 @@ class ShardedEmbeddingLayer(nn.Module):
 
     def grads_were_zeroed(self):
         self._touched, self._touched_unsorted = None, False
+
+    @property
+    def _grad_clean(self) -> bool:
+        """the next owner-side gradient launch overwrites (no backward has written since the last zero_grad / fused step)"""
+        return self._grad_buf is not None and self._touched is None
 
     def flush_lazy(self):
         if self._lazy is not None:
@@ -535,13 +651,8 @@ class ShardedEmbeddingLayer(nn.Module):
                 or self.lbits + max(1, (self.world - 1).bit_length()) > 31 \
                 or len(self.emb_feature) * X[self.emb_feature[0]].numel() > self._capacity_n:
             return  # (a batch larger than the one the capacity was measured on takes the exact exchange, in its own step)
-        from .models.layers.embedding import _SIDE_STREAMS
         dev = self.local_arena.device
-        side = _SIDE_STREAMS.get(dev)
-        if side is None:
-            # (a plain torch stream: RCCL's collectives are issued on it — the lowest-priority ExternalStream of the
-            #  single-device path has not run under a process group with more than one rank)
-            side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        side = route_stream(dev)
         src = tuple(X[c] for c in self.emb_feature)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -555,6 +666,10 @@ class ShardedEmbeddingLayer(nn.Module):
     def _take_prepared(self, X) -> None:
         """the forward of batch X begins: use what _route_ahead prepared for exactly these tensors, if anything"""
         a, self._ahead, self._prepared = self._ahead, None, None
+        pin, self._pinned_next = getattr(self, "_pinned_next", None), None
+        if pin is not None:
+            self._prepared = (pin, pin.recv_rows, pin.served if self._lazy is not None else None)
+            return
         if a is None:
             return
         src, ver, prepared, event = a[:4]
@@ -571,6 +686,38 @@ class ShardedEmbeddingLayer(nn.Module):
                 t.record_stream(stream)
         self._prepared = (prepared, recv_rows, served_sorted)
 
+    # ---- the prepared lookup of a recorded step's static batch, in persistent buffers (graph_step, round 6) ---------------
+    def pinned_route(self, X):
+        """persistent buffers for the prepared lookup of a batch shaped like X (None: the fixed-capacity exchange is not
+        active, or the batch is larger than the one its capacity was measured on)"""
+        b = X[self.emb_feature[0]].numel()
+        n = len(self.emb_feature) * b
+        if self._capacity is None or self.check_indices != "deferred" or n > self._capacity_n or not self.local_arena.is_cuda \
+                or self.lbits + max(1, (self.world - 1).bit_length()) > 31:
+            return None
+        return _PinnedRoute(self, n, b)
+
+    def route_into(self, X, pin) -> None:
+        """Everything of X's lookup that does not depend on the weights — route, id exchange, owner-side sort of the rows
+        asked for — into `pin` (library launches + one collective; under a plan recording the collective is a host mark).
+        The results are computed into fresh buffers and moved with ONE launch (rp_multi_copy)."""
+        from . import hip
+        if pin.capacity != self._capacity:
+            raise RuntimeError("route_into: the exchange capacity changed since the buffers were made")
+        n = len(self.emb_feature) * X[self.emb_feature[0]].numel()
+        if n != pin.n_requests or n > self._capacity_n:
+            raise RuntimeError("route_into: the batch does not take the fixed-capacity exchange these buffers were made for")
+        route = _Route(self._requests(X), self, pin=pin)  # (every list straight into its persistent buffer)
+        if pin.recv_rows is not pin.local_rows:
+            all_to_all(pin.recv_rows, route.local_rows, route.recv, route.send, self.group)
+        if self._lazy is not None:
+            hip.sort_pairs(self._rows_i32(pin.recv_rows), end_bit=self._meta()[3], out=pin.served)
+
+    def use_pinned(self, pin) -> None:
+        """the NEXT lookup of this layer reads its prepared part from `pin` (graph_step sets it for the recording of a step and
+        for nothing else: a replay runs no python)"""
+        self._pinned_next = pin
+
     def _request_ahead(self) -> None:
         """Second half of the look-ahead, called once the current step's collectives are enqueued (allreduce_dense_grads):
         the id exchange of the announced batch and the owner-side sort of the rows this rank is asked for, on the side
@@ -579,9 +726,8 @@ class ShardedEmbeddingLayer(nn.Module):
         a = self._ahead
         if a is None or len(a) != 4 or self._capacity is None:
             return
-        from .models.layers.embedding import _SIDE_STREAMS
         src, ver, route, _ = a
-        side = _SIDE_STREAMS[self.local_arena.device]
+        side = route_stream(self.local_arena.device)
         with torch.cuda.stream(side):
             recv_rows = _a2a(route.local_rows, route.recv, route.send, self.group, self.world)
             served_sorted = None
@@ -637,6 +783,10 @@ class ShardedEmbeddingLayer(nn.Module):
                     sk, sp = presorted
                 else:
                     sk, sp = hip.sort_pairs(self._rows_i32(rows_idx), end_bit=self._meta()[3])
+                if self._lazy is not None and self._lazy._noclear is not None:
+                    # the catch-up in front of this step's lookup left its applied gradient rows uncleared, counting on THIS
+                    # launch to overwrite them: kept if it writes that very key list without accumulating
+                    self._lazy.resolve_noclear(self, sk if clean else None)
                 hip.embed_grad_reduce(sk, sp, rows_idx.numel(), self.embedding_dim, g, None, None, None,
                                       self._grad_buf, accumulate=not clean)
                 if self._touched is None:
@@ -687,8 +837,9 @@ class ShardedEmbeddingLayer(nn.Module):
         d = F * D + len(dense)
         ldx = (d + pad_to - 1) // pad_to * pad_to
         dense = [t.float().reshape(-1).contiguous() for t in dense]
+        fm_lists, self._route_fm = getattr(self, "_route_fm", None), None
         out = _RowsToLinear.apply(rows, slot_of_pair, dense, slot_sorted, pos_sorted, b, F, ldx, linear.weight, linear.bias,
-                                  out_link, self._err, 1.0 / self.world, scaled)
+                                  out_link, self._err, 1.0 / self.world, scaled, fm_lists)
         self._route_ahead()
         if self.check_indices == "sync":
             self.raise_if_bad_index()

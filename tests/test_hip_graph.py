@@ -412,7 +412,10 @@ def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, backend, mo
                 assert gstep.replays >= 36 and gstep.backend_used == backend, (gstep.replays, gstep.backend_used, gstep.why_not_plan)
                 if backend == "plan":
                     # the three exchanges (ids, rows, row gradients) and the dense all-reduce are the replay's own calls
-                    assert len(gstep.plans[0].host_calls) == (4 if force_a2a else 1), len(gstep.plans[0].host_calls)
+                    pl = gstep.plans[0]
+                    assert sum(1 for fn in pl.host_calls if fn is not None) == (4 if force_a2a else 1), pl.host_calls
+                    # (round 6) the next batch's route, id exchange and owner-side sort are segments of the ahead stream
+                    assert sum(pl.seg_tags) == (2 if force_a2a else 1) and pl.ahead_stream is not None, pl.seg_tags
             results[mode] = (preds, {k: v.clone() for k, v in model.state_dict().items()})
             del gstep
         for a, b in zip(results["eager"][0], results["graph"][0]):

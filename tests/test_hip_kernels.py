@@ -440,6 +440,15 @@ def test_route_kernels_vs_torch(world, rows, b):
     assert int(counts[world]) == uniq.numel()
     assert torch.equal(counts[:world], torch.bincount(uniq >> lbits, minlength=world))
     assert torch.equal(uniq_rows[:uniq.numel()].cpu(), uniq & ((1 << lbits) - 1))
+    # rp_route_field_major (round 6): the sorted (slot, position) list moved into FIELD-major order = a stable sort of the
+    # list by field: field f's b requests at [f b, (f + 1) b), inside a field ascending slots with the positions of a run in
+    # their sorted order — identical integers
+    if world > 1:
+        slot_fm, pos_fm = hip.route_field_major(sk, sp, slot_sorted, b, world, lbits)
+        field = torch.div(rp_, b, rounding_mode="floor")
+        _, order = torch.sort(field, stable=True)
+        assert torch.equal(pos_fm.cpu().long(), rp_[order]) and torch.equal(slot_fm.cpu().long(), inverse[order])
+        assert torch.equal(torch.div(pos_fm.cpu().long(), b, rounding_mode="floor"), torch.arange(F).repeat_interleave(b))
 
 
 @pytest.mark.parametrize("shape,p", [((4096, 64), 0.1), ((1000, 37), 0.5), ((65536, 256), 0.2), ((3, 5), 0.3)])

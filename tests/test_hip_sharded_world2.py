@@ -288,8 +288,10 @@ def _worker_plan(rank, world, port, ret):
             opt.flush()
             torch.cuda.synchronize()
             if gstep is not None:
+                pl = gstep.plans[0]
                 res["backend"] = (gstep.backend_used, gstep.why_not_plan, gstep.replays,
-                                  len(gstep.plans[0].host_calls) if gstep.plans[0] is not None else -1)
+                                  sum(1 for fn in pl.host_calls if fn is not None) if pl is not None else -1,
+                                  sum(pl.seg_tags) if pl is not None else -1, pl.ahead_stream is not None if pl is not None else False)
             res[mode] = (preds, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
             del gstep
         ret[rank] = res
@@ -310,6 +312,8 @@ def test_two_ranks_on_one_gpu_recorded_step_equals_the_eager_loop():
     for rank in range(WORLD):
         r = ret[rank]
         assert r["backend"][0] == "plan" and r["backend"][2] >= 10 and r["backend"][3] == 4, r["backend"]
+        # (round 6) the next batch's route | id exchange | owner-side sort: two segments of the ahead stream around one exchange
+        assert r["backend"][4] == 2 and r["backend"][5], r["backend"]
         for a, b in zip(r["eager"][0], r["plan"][0]):
             assert torch.equal(a, b), f"rank {rank}: predictions differ"
         for k in r["eager"][1]:
