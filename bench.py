@@ -665,7 +665,11 @@ def main():
         #  batch generation just above IS such an idle stretch; these replays bring the device back to the state the pre-roll
         #  left it in.  They are untimed, on batches of their own, and their count is on the line: pre_window_replays.)
         n_pre = args.pre_window if args.pre_window >= 0 else max(3 + args.warmup, 256)
-        n_pw = min(n_pre, 64)  # distinct batches (1.3 GB), cycled: none of them is a timed batch
+        # DISTINCT batches (5 GB at 256), none of them a timed one: cycling a few through 256 steps leaves every row outside
+        # them 256 steps older than the stream's own age distribution — the first timed steps then replay different gaps
+        # (measured with 64 cycled batches: Zipf ids 0.85 ms in the window against 0.66 over 300 steps, the serial-replay
+        # mode 2.11 against 1.07)
+        n_pw = n_pre
         pw = [gen(n_seen + 500000 + i) for i in range(n_pw)]
         for i in range(n_pre):
             step(pw[i % n_pw], pw[(i + 1) % n_pw] if i + 1 < n_pre else batches[0], graphed=True)
@@ -719,19 +723,67 @@ def main():
     host_slowest = max(range(args.steps), key=lambda i_: host_each[i_])
     host_call_ms = host_wait_ms = host_call_max_ms = host_stall = None
     in_step = None
+    win_host = None
+    if gstep is not None:
+        assert gstep.replays - replays0 == args.steps, "every timed step must have been a graph replay"
+        win_host = (gstep.host_call_s, gstep.host_wait_s, gstep.host_call_max_s, dict(gstep.host_seg_max),
+                    max((pl.slowest_call(reset=True) for pl in gstep.plans if pl is not None), key=lambda t_: t_[2])
+                    if gstep.backend_used == "plan" else None)
+    # ---- (4b) long run: >= 2000 more steps of the same execution form over 512 DISTINCT resident
+    #          batches, a timing event after every step: mean / p50 / p99 / max step.  (The 20-step window above is 20 ms.)
+    #          Round 6: run RIGHT BEHIND the timed window, in front of everything that changes the optimizer's state — it used
+    #          to follow the flush below, which brings every row up to date: the first few hundred steps after it replay short
+    #          gaps only and read 3 % faster with uniform ids (0.748 over 300 steps against 0.777 over 2000), 25 % with Zipf
+    #          ids (0.66 against 0.82) and 55 % in the serial-replay mode (1.07 against 1.65) than the state the window is in
+    long_run = None
+    if args.mode == "train" and args.long_steps > 0 and world == 1:  # (multi-rank runs: the contract's timed region only)
+        n_long = max(64, min(args.long_steps, int(25.0 / max(dt / args.steps, 1e-6))))  # (bounded to ~25 s: slow configs)
+        n_dist = min(512, n_long)
+        hip.pause_timing(True)  # (eager form: the per-kernel events of the timed window stay the window's)
+        lb = [gen(n_seen + 300000 + i) for i in range(n_dist)]
+        for i in range(4):
+            step(lb[i], lb[i + 1] if ahead else None, graphed=True)
+        barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_long + 1)]
+        hcl = (gstep.host_call_s, gstep.host_wait_s) if gstep is not None else None
+        t_l = time.perf_counter()
+        evs[0].record()
+        for i in range(n_long):
+            step(lb[(4 + i) % n_dist], lb[(5 + i) % n_dist] if ahead else None, graphed=True)
+            evs[i + 1].record()
+        barrier()
+        wall = time.perf_counter() - t_l
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_long))
+        med = per[n_long // 2]
+        long_run = {"steps": n_long, "distinct_batches": n_dist, "execution": "replays of the captured step" if gstep is not None else "eager",
+                    "mean_ms": round(wall / n_long * 1e3, 4), "value": round(B * n_long / wall, 1), "unit": "samples/s",
+                    "p50_ms": round(med, 4), "p99_ms": round(per[int(0.99 * (n_long - 1))], 4), "max_ms": round(per[-1], 4),
+                    "min_ms": round(per[0], 4), "steps_over_1p5x_median": int(sum(1 for x_ in per if x_ > 1.5 * med)),
+                    "note": "run right behind the timed window, in front of anything that changes the optimizer's state (the flush "
+                            "measured further down brings every row up to date: steps behind it replay short gaps only); "
+                            "mean = wall clock / steps between two barriers (max over ranks not taken: a secondary figure); "
+                            "percentiles = HIP event pairs around each step on the main stream (one event record per step). "
+                            "The 2 ms step every ~1000 of round 4's trace was the host refilling the per-step scalar table with "
+                            "1025 ctypes calls (optim.StepTables.ensure): one C call now (rp_adam_step_scalars_range)"}
+        if hcl is not None:
+            long_run["host_call_ms_per_step_unblocked"] = round((gstep.host_call_s - hcl[0]) / n_long * 1e3, 4)
+            long_run["host_wait_ms_per_step"] = round((gstep.host_wait_s - hcl[1]) / n_long * 1e3, 4)
+        del lb, evs
+        hip.pause_timing(False)
+
     # everything behind the timed window (per-launch probes, the eager event passes) runs on batches of its OWN, distinct and
     # never the timed ones: 48 of them, cycled
     xb = [gen(n_seen + 600000 + i) for i in range(48)] if gstep is not None else None
     if gstep is not None:
-        assert gstep.replays - replays0 == args.steps, "every timed step must have been a graph replay"
         # the host's own work per replayed step (python + ctypes + the plan's launches) and, apart from it, the time it sat
-        # in the back-pressure wait (MAX_IN_FLIGHT replays queued: the DEVICE's time)
-        host_call_ms = (gstep.host_call_s - hc0[0]) / args.steps * 1e3
-        host_wait_ms = (gstep.host_wait_s - hc0[1]) / args.steps * 1e3
-        host_call_max_ms = gstep.host_call_max_s * 1e3
-        host_stall = {"slowest_part_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in gstep.host_seg_max.items()}}
+        # in the back-pressure wait (MAX_IN_FLIGHT replays queued: the DEVICE's time) — of the timed window (read in front of
+        # the long run above)
+        host_call_ms = (win_host[0] - hc0[0]) / args.steps * 1e3
+        host_wait_ms = (win_host[1] - hc0[1]) / args.steps * 1e3
+        host_call_max_ms = win_host[2] * 1e3
+        host_stall = {"slowest_part_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in win_host[3].items()}}
         if gstep.backend_used == "plan":
-            sc = max((pl.slowest_call(reset=True) for pl in gstep.plans if pl is not None), key=lambda t_: t_[2])
+            sc = win_host[4]
             host_stall["slowest_hip_call_in_replay"] = {"kind": sc[0], "node": sc[1], "ms": round(sc[2], 4)}
         if gstep.backend_used == "plan":
             # ---- per-launch durations INSIDE the replayed step, live: the plan brackets ONE launch per replay with a HIP
@@ -876,40 +928,6 @@ def main():
                          "key names kept from round 3: 'hip_graph' = the captured step, replayed as captured_step_backend)"}
         barrier()
         del gs_small
-
-    # ---- (7) long run: >= 2000 more steps of the same execution form over 512 DISTINCT resident
-    #          batches, a timing event after every step: mean / p50 / p99 / max step.  (The 20-step window above is 20 ms.)
-    long_run = None
-    if args.mode == "train" and args.long_steps > 0 and world == 1:  # (multi-rank runs: the contract's timed region only)
-        n_long = max(64, min(args.long_steps, int(25.0 / max(ms_per_step * 1e-3, 1e-6))))  # (bounded to ~25 s: slow configs)
-        n_dist = min(512, n_long)
-        lb = [gen(n_seen + 300000 + i) for i in range(n_dist)]
-        for i in range(4):
-            step(lb[i], lb[i + 1] if ahead else None, graphed=True)
-        barrier()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_long + 1)]
-        hcl = (gstep.host_call_s, gstep.host_wait_s) if gstep is not None else None
-        t_l = time.perf_counter()
-        evs[0].record()
-        for i in range(n_long):
-            step(lb[(4 + i) % n_dist], lb[(5 + i) % n_dist] if ahead else None, graphed=True)
-            evs[i + 1].record()
-        barrier()
-        wall = time.perf_counter() - t_l
-        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_long))
-        med = per[n_long // 2]
-        long_run = {"steps": n_long, "distinct_batches": n_dist, "execution": "replays of the captured step" if gstep is not None else "eager",
-                    "mean_ms": round(wall / n_long * 1e3, 4), "value": round(B * n_long / wall, 1), "unit": "samples/s",
-                    "p50_ms": round(med, 4), "p99_ms": round(per[int(0.99 * (n_long - 1))], 4), "max_ms": round(per[-1], 4),
-                    "min_ms": round(per[0], 4), "steps_over_1p5x_median": int(sum(1 for x_ in per if x_ > 1.5 * med)),
-                    "note": "mean = wall clock / steps between two barriers (max over ranks not taken: a secondary figure); "
-                            "percentiles = HIP event pairs around each step on the main stream (one event record per step). "
-                            "The 2 ms step every ~1000 of round 4's trace was the host refilling the per-step scalar table with "
-                            "1025 ctypes calls (optim.StepTables.ensure): one C call now (rp_adam_step_scalars_range)"}
-        if hcl is not None:
-            long_run["host_call_ms_per_step_unblocked"] = round((gstep.host_call_s - hcl[0]) / n_long * 1e3, 4)
-            long_run["host_wait_ms_per_step"] = round((gstep.host_wait_s - hcl[1]) / n_long * 1e3, 4)
-        del lb, evs
 
     # ---- per-kernel numbers (algorithmic bytes from SURVEY.md 8d) --------------------------------
     F = sum(1 for v in enc.values() if "vocab_size" in v)

@@ -336,7 +336,10 @@ class EmbeddingLayer(nn.Module):
         if hit is not None and hit[0] is sig and hit[1] == B:
             return hit[2]
         out = None
-        if self.embedding_dim == 64 and os.environ.get("RP_GRAD_SMP", "1") != "0" and len(sig) <= 64:
+        # (batches below RP_SMP_MIN_BATCH keep round 5's single row-sorted launch: the three-form backward is 16 launches more,
+        #  and a b = 8192 step — the per-GPU batch of a strong-scaling run — is bound by launches: 0.50 ms against 0.43)
+        if self.embedding_dim == 64 and os.environ.get("RP_GRAD_SMP", "1") != "0" and len(sig) <= 64 \
+                and B >= int(os.environ.get("RP_SMP_MIN_BATCH", "32768")):
             tiny = {t[0] for t in (self._tiny_tables() or ())}
             need = float(os.environ.get("RP_SMP_MIN", "1.0")) * B
             pick = sorted((f for f in range(len(sig)) if f not in tiny and need <= sig[f] < (1 << 24)),

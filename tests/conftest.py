@@ -9,6 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The sample-major / streaming forms of the first layer's backward (round 6) are the default from batch 32768 on (below it a
+# step is bound by its launches, not their work: EmbeddingLayer._smp_tables).  The model-level tests run batches of a few
+# thousand samples: they take the round-6 forms too, so that bit-identity / parity / capture tests cover them end to end;
+# the C-ABI tests call every form directly, and bench.full_size_parity runs the default choice at B = 65536.
+os.environ.setdefault("RP_SMP_MIN_BATCH", "1")
 
 
 def pytest_configure(config):
