@@ -665,10 +665,8 @@ def main():
         #  batch generation just above IS such an idle stretch; these replays bring the device back to the state the pre-roll
         #  left it in.  They are untimed, on batches of their own, and their count is on the line: pre_window_replays.)
         n_pre = args.pre_window if args.pre_window >= 0 else max(3 + args.warmup, 256)
-        # DISTINCT batches (5 GB at 256), none of them a timed one: cycling a few through 256 steps leaves every row outside
-        # them 256 steps older than the stream's own age distribution — the first timed steps then replay different gaps
-        # (measured with 64 cycled batches: Zipf ids 0.85 ms in the window against 0.66 over 300 steps, the serial-replay
-        # mode 2.11 against 1.07)
+        # DISTINCT batches (5 GB at 256), none of them a timed one: a few batches cycled through 256 steps would leave every
+        # row outside them 256 steps older than the stream's own age distribution
         n_pw = n_pre
         pw = [gen(n_seen + 500000 + i) for i in range(n_pw)]
         for i in range(n_pre):
