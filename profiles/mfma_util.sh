@@ -13,7 +13,7 @@ cd "$(dirname "$0")/.."
 TAG=$1; shift
 OUT=gpurun_out/prof_${TAG}_mfma
 rm -rf $OUT; mkdir -p $OUT gpurun_out/profiles
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex 'linear_|cin_|mlp_tail|embed_gather_linear|embed_grad_seg|embed_grad_tiny' \
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex 'linear_|cin_|mlp_tail|embed_gather_linear|embed_grad_|embed_ss_|embed_segsum' \
     --output-format csv -d $OUT -o m -- python bench.py --no-cpu-baseline --no-small-batch --long-steps 0 --pre-roll 0 --warmup 3 --steps 4 --graph off "$@" > $OUT/log.txt 2>&1
 echo "mfma pass rc=$?"
 python - "$OUT" "$TAG" <<'PY'
