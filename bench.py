@@ -671,7 +671,9 @@ def main():
         pw = [gen(n_seen + 500000 + i) for i in range(n_pw)]
         for i in range(n_pre):
             step(pw[i % n_pw], pw[(i + 1) % n_pw] if i + 1 < n_pre else batches[0], graphed=True)
-        del pw
+        # (pw stays alive through the window: dropping its ~10 k tensors here made ONE launch call of the first timed replay
+        #  block 0.3-1.5 ms inside the runtime — profiles/microbench/probes/probe_first_call.py: first call 0.75-1.97 ms with the
+        #  list dropped in front of the synchronisation, 0.31-0.38 with it kept; profiles/r06_window_ramp.txt)
         barrier()
         t0 = time.perf_counter()
     n_pre_done = n_pre if gstep is not None else 0
@@ -710,6 +712,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.callbacks.remove(_gc_cb)
+    pw = None
     if wev is not None:
         print("window events (ms per step):", [round(wev[i].elapsed_time(wev[i + 1]), 4) for i in range(args.steps)],
               "span", round(wev[0].elapsed_time(wev[-1]), 4), "wall", round(dt * 1e3, 4),
