@@ -136,6 +136,17 @@ int rp_embed_gather_linear_fwd_bf16(const void *arena_bf16, const int64_t *row_b
 int rp_sort_workspace_bytes(int64_t n, size_t *bytes);
 int rp_sort_pairs_i32(void *workspace, size_t workspace_bytes, const int32_t *keys_in, int32_t *keys_out,
                       int32_t *pos_out, int64_t n, int end_bit, rp_stream_t stream);
+/* The same sort for the pair list of ONE lookup over F tables that sit in the arena in field order (round 6; csrc/sort.hip):
+ * keys_in[f * B + b] = arena row of pair (field f, sample b) (rp_embed_keys); field_base / field_rows: host arrays [F], first
+ * arena row and row count of each field's table.  The list is sorted segment by segment — a field's B pairs by the row inside
+ * its table, ceil(log2 rows) key bits instead of the arena's — and comes out as rp_sort_pairs_i32(end_bit = bits of the arena)
+ * gives it, bit for bit (the stable sort by arena row; pos_out = field * B + sample).  9-bit passes over the fields that still
+ * have bits left: 49 field-passes instead of 78 at Criteo shape.  Kernel launches only; workspace from
+ * rp_sort_pairs_fields_workspace_bytes(B, F). */
+int rp_sort_pairs_fields_workspace_bytes(int64_t B, int F, size_t *bytes);
+int rp_sort_pairs_fields_i32(void *workspace, size_t workspace_bytes, const int32_t *keys_in, int32_t *keys_out,
+                             int32_t *pos_out, int64_t B, int F, const int64_t *field_base, const int64_t *field_rows,
+                             rp_stream_t stream);
 /*   grad_arena[key] (+)= sum over pairs p=(f,b) with that key of
  *        dx[b, f*D:(f+1)*D]  +  (gfm ? gfm[b] * (sum_in[b,:] - arena[key,:]) : 0)
  *        (sum_in may be NULL with gfm given: the gfm[b]*sum_in[b,:] part was already added to dx by

@@ -238,6 +238,209 @@ SortPlan sort_plan(int64_t n) {
 
 }  // namespace
 
+// ---- the FIELD-SEGMENTED form (round 6) --------------------------------------------------------------------------------------
+// The pair list of a lookup is field-major (position = field * B + sample) and a field's keys are that field's table rows:
+// sorting the whole list by arena row is F independent sorts, one per segment of B pairs, each by the row INSIDE the table —
+// and a table of r rows needs ceil(log2 r) key bits, not the arena's 26: at Criteo shape 9 of the 26 fields are done after ONE
+// 9-bit pass, 11 more after two, only the 6 tables of more than 2^18 rows take the third: 49 field-passes instead of 78.
+// Same three kernels per pass, over the fields that still have bits left (blockIdx.y = the field's place among them); a
+// field's pass reads and writes its own segment [f B, (f + 1) B) of whichever buffer its remaining pass count makes the
+// source / the destination (the last pass of every field lands in the caller's buffers).  The result is the global stable sort
+// by arena row, bit for bit (tables sit in the arena in field order).
+struct SortSegs {
+    int n;                         // fields in this pass
+    unsigned char field[RP_MAX_FIELDS];
+    unsigned char src[RP_MAX_FIELDS], dst[RP_MAX_FIELDS];  // 0 = the caller's input (values = positions), 1 = workspace, 2 = output
+    int32_t base[RP_MAX_FIELDS];   // first arena row of the field's table
+};
+struct SortBufs {
+    const int32_t *k[3];
+    const int32_t *v[3];
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_seg_hist_kernel(SortBufs bufs, SortSegs sg, int Bi, int tpf, int shift,
+                                                                     int32_t *__restrict__ hist) {
+    __shared__ int32_t cnt[SORT_WAVES][SORT_BINS];
+    const int y = blockIdx.y, f = sg.field[y], w = threadIdx.x / RP_WAVE;
+    for (int d = threadIdx.x; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    const int64_t seg0 = (int64_t)f * Bi, seg1 = seg0 + Bi;
+    const int64_t first = seg0 + (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * SORT_WAVE_SPAN;
+    int32_t k[SORT_ROUNDS], rk[SORT_ROUNDS];
+    sort_load_keys(bufs.k[sg.src[y]], first, seg1, k);
+    const int32_t base = sg.base[y];
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) k[r] -= base;
+    __syncthreads();
+    sort_rank_wave<false>(k, first, seg1, shift, SORT_RB, SORT_BINS - 1, 0u, (lds_counter *)cnt[w], rk);
+    __syncthreads();
+    for (int d = threadIdx.x; d < SORT_BINS; d += SORT_THREADS)
+        hist[((int64_t)y * tpf + blockIdx.x) * SORT_BINS + d] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+}
+
+// grid = (512 / 4, fields of the pass); wave -> one digit of one field
+__global__ __launch_bounds__(SORT_THREADS) void sort_seg_scan_kernel(int32_t *__restrict__ hist, int tpf, int32_t *__restrict__ totals) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int d = blockIdx.x * SORT_WAVES + threadIdx.x / RP_WAVE;
+    int32_t *h = hist + (int64_t)blockIdx.y * tpf * SORT_BINS;
+    int32_t carry = 0;
+    for (int t0 = 0; t0 < tpf; t0 += RP_WAVE) {
+        const int t = t0 + lane;
+        const int32_t v = t < tpf ? h[(int64_t)t * SORT_BINS + d] : 0;
+        int32_t s = v;
+#pragma unroll
+        for (int o = 1; o < RP_WAVE; o <<= 1) {
+            const int32_t up = __shfl_up(s, o, RP_WAVE);
+            if (lane >= o) s += up;
+        }
+        if (t < tpf) h[(int64_t)t * SORT_BINS + d] = carry + s - v;
+        carry += __shfl(s, RP_WAVE - 1, RP_WAVE);
+    }
+    if (lane == 0) totals[(int64_t)blockIdx.y * SORT_BINS + d] = carry;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_seg_scatter_kernel(SortBufs bufs, int32_t *__restrict__ k1, int32_t *__restrict__ v1,
+                                                                        int32_t *__restrict__ k2, int32_t *__restrict__ v2, SortSegs sg,
+                                                                        int Bi, int tpf, int shift, const int32_t *__restrict__ hist,
+                                                                        const int32_t *__restrict__ totals) {
+    __shared__ int32_t cnt[SORT_WAVES][SORT_BINS];
+    __shared__ int32_t dbase[SORT_BINS];
+    __shared__ int32_t wsum[SORT_WAVES];
+    const int tid = threadIdx.x, lane = tid & (RP_WAVE - 1), w = tid / RP_WAVE;
+    const int y = blockIdx.y, f = sg.field[y];
+    for (int d = tid; d < SORT_WAVES * SORT_BINS; d += SORT_THREADS) (&cnt[0][0])[d] = 0;
+    const int64_t seg0 = (int64_t)f * Bi, seg1 = seg0 + Bi;
+    const int64_t first = seg0 + (int64_t)blockIdx.x * SORT_TILE + (int64_t)w * SORT_WAVE_SPAN;
+    const int32_t base = sg.base[y];
+    const int32_t *vin = bufs.v[sg.src[y]];
+    int32_t k[SORT_ROUNDS], v[SORT_ROUNDS], rk[SORT_ROUNDS];
+    sort_load_keys(bufs.k[sg.src[y]], first, seg1, k);
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const int64_t i = first + r * RP_WAVE + lane;
+        v[r] = vin ? (i < seg1 ? vin[i] : 0) : (int32_t)i;
+        k[r] -= base;
+    }
+    {
+        const int32_t *tt = totals + (int64_t)y * SORT_BINS;
+        const int32_t a = tt[2 * tid], b = tt[2 * tid + 1];
+        int32_t s = a + b;
+#pragma unroll
+        for (int o = 1; o < RP_WAVE; o <<= 1) {
+            const int32_t up = __shfl_up(s, o, RP_WAVE);
+            if (lane >= o) s += up;
+        }
+        if (lane == RP_WAVE - 1) wsum[w] = s;
+        __syncthreads();  // also publishes the zeroed counters
+        int32_t before = 0;
+        for (int x = 0; x < w; ++x) before += wsum[x];
+        const int32_t excl = before + s - (a + b);
+        dbase[2 * tid] = excl;
+        dbase[2 * tid + 1] = excl + a;
+    }
+    sort_rank_wave<true>(k, first, seg1, shift, SORT_RB, SORT_BINS - 1, 0u, (lds_counter *)cnt[w], rk);
+    __syncthreads();
+    for (int d = tid; d < SORT_BINS; d += SORT_THREADS) {
+        int32_t run = dbase[d] + hist[((int64_t)y * tpf + blockIdx.x) * SORT_BINS + d];
+#pragma unroll
+        for (int x = 0; x < SORT_WAVES; ++x) {
+            const int32_t c = cnt[x][d];
+            cnt[x][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    int32_t *kout = sg.dst[y] == 2 ? k2 : k1, *vout = sg.dst[y] == 2 ? v2 : v1;
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        if (first + r * RP_WAVE + lane < seg1) {
+            const int64_t dst = seg0 + cnt[w][sort_digit(k[r], shift, SORT_BINS - 1, 0u)] + rk[r];
+            kout[dst] = k[r] + base;
+            vout[dst] = v[r];
+        }
+    }
+}
+
+struct SortSegPlan {
+    int tpf;
+    size_t off_vals, off_hist, off_totals, bytes;
+};
+
+static SortSegPlan sort_seg_plan(int64_t B, int F) {
+    SortSegPlan p;
+    p.tpf = (int)rp_cdiv(B, SORT_TILE);
+    const size_t col = align256((size_t)B * F * sizeof(int32_t));
+    p.off_vals = col;
+    p.off_hist = 2 * col;
+    p.off_totals = p.off_hist + align256((size_t)F * p.tpf * SORT_BINS * sizeof(int32_t));
+    p.bytes = p.off_totals + align256((size_t)F * SORT_BINS * sizeof(int32_t));
+    return p;
+}
+
+extern "C" int rp_sort_pairs_fields_workspace_bytes(int64_t B, int F, size_t *bytes) {
+    RP_REQUIRE(bytes && B >= 1 && F >= 1 && F <= RP_MAX_FIELDS && B * F < INT32_MAX, "sort_pairs_fields_workspace_bytes: bad argument");
+    *bytes = sort_seg_plan(B, F).bytes + 256;
+    return RP_OK;
+}
+
+extern "C" int rp_sort_pairs_fields_i32(void *workspace, size_t workspace_bytes, const int32_t *keys_in, int32_t *keys_out,
+                                        int32_t *pos_out, int64_t B, int F, const int64_t *field_base, const int64_t *field_rows,
+                                        rp_stream_t stream) {
+    RP_REQUIRE(workspace && keys_in && keys_out && pos_out && field_base && field_rows, "sort_pairs_fields: null pointer");
+    RP_REQUIRE(B >= 1 && F >= 1 && F <= RP_MAX_FIELDS && B * F < INT32_MAX, "sort_pairs_fields: bad B / F");
+    RP_REQUIRE(keys_in != keys_out && keys_in != pos_out && keys_out != pos_out, "sort_pairs_fields: buffers alias");
+    size_t need = 0;
+    rp_sort_pairs_fields_workspace_bytes(B, F, &need);
+    RP_REQUIRE(workspace_bytes >= need, "sort_pairs_fields: workspace %zu < %zu bytes", workspace_bytes, need);
+    int npass[RP_MAX_FIELDS], maxp = 1;
+    for (int f = 0; f < F; ++f) {
+        RP_REQUIRE(field_rows[f] >= 1 && field_base[f] >= 0 && field_base[f] + field_rows[f] <= (int64_t)INT32_MAX,
+                   "sort_pairs_fields: table %d (base %lld, %lld rows) does not fit int32 keys", f, (long long)field_base[f],
+                   (long long)field_rows[f]);
+        RP_REQUIRE(f == 0 || field_base[f] >= field_base[f - 1] + field_rows[f - 1],
+                   "sort_pairs_fields: the tables must sit in the arena in field order");
+        int bits = 1;
+        while (((int64_t)1 << bits) < field_rows[f]) ++bits;
+        npass[f] = (bits + SORT_RB - 1) / SORT_RB;
+        if (npass[f] > maxp) maxp = npass[f];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *base = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    const SortSegPlan p = sort_seg_plan(B, F);
+    int32_t *tmp_k = reinterpret_cast<int32_t *>(base);
+    int32_t *tmp_v = reinterpret_cast<int32_t *>(base + p.off_vals);
+    int32_t *hist = reinterpret_cast<int32_t *>(base + p.off_hist);
+    int32_t *totals = reinterpret_cast<int32_t *>(base + p.off_totals);
+    SortBufs bufs;
+    bufs.k[0] = keys_in;
+    bufs.v[0] = nullptr;  // positions are implicit in the first pass
+    bufs.k[1] = tmp_k;
+    bufs.v[1] = tmp_v;
+    bufs.k[2] = keys_out;
+    bufs.v[2] = pos_out;
+    for (int pass = 0; pass < maxp; ++pass) {
+        SortSegs sg;
+        memset(&sg, 0, sizeof(sg));
+        for (int f = 0; f < F; ++f) {
+            if (npass[f] <= pass) continue;
+            const int y = sg.n++;
+            sg.field[y] = (unsigned char)f;
+            sg.base[y] = (int32_t)field_base[f];
+            // the field's last pass lands in the caller's buffers; the passes before it alternate backwards from there
+            const bool to_out = ((npass[f] - 1 - pass) & 1) == 0;
+            sg.dst[y] = to_out ? 2 : 1;
+            sg.src[y] = pass == 0 ? 0 : (to_out ? 1 : 2);
+        }
+        const int shift = pass * SORT_RB;
+        hipLaunchKernelGGL(sort_seg_hist_kernel, dim3((unsigned)p.tpf, (unsigned)sg.n), dim3(SORT_THREADS), 0, s, bufs, sg, (int)B, p.tpf,
+                           shift, hist);
+        hipLaunchKernelGGL(sort_seg_scan_kernel, dim3(SORT_BINS / SORT_WAVES, (unsigned)sg.n), dim3(SORT_THREADS), 0, s, hist, p.tpf, totals);
+        hipLaunchKernelGGL(sort_seg_scatter_kernel, dim3((unsigned)p.tpf, (unsigned)sg.n), dim3(SORT_THREADS), 0, s, bufs, tmp_k, tmp_v,
+                           keys_out, pos_out, sg, (int)B, p.tpf, shift, hist, totals);
+    }
+    RP_LAUNCH_CHECK("sort_pairs_fields");
+    return RP_OK;
+}
+
 extern "C" int rp_sort_workspace_bytes(int64_t n, size_t *bytes) {
     RP_REQUIRE(bytes && n >= 0 && n < INT32_MAX, "sort_workspace_bytes: bad argument");
     const int64_t m = n > 0 ? n : 1;

@@ -36,6 +36,8 @@ _SIGNATURES = {
                                          _vp]),
     "rp_sort_workspace_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "rp_sort_pairs_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "rp_sort_pairs_fields_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
+    "rp_sort_pairs_fields_i32": (C.c_int, [_vp, _sz, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "rp_embed_grad_reduce_workspace_bytes": (C.c_int, [_i64, _i32, C.POINTER(_sz)]),
     "rp_embed_grad_reduce": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
     "rp_embed_grad_gemm_fits": (C.c_int, [_i32, _i32, _i64, _i64]),
@@ -512,6 +514,47 @@ def sort_pairs(keys: torch.Tensor, end_bit: int = 32, out=None, workspace=None):
     with _Timed("sort_pairs_i32"):
         _check(lib().rp_sort_pairs_i32(ws.data_ptr(), nbytes.value, keys.data_ptr(), ko.data_ptr(), po.data_ptr(), n,
                                    end_bit, _stream()), "rp_sort_pairs_i32")
+    return ko, po
+
+
+_SORT_FIELDS: dict = {}
+
+
+def sort_fields_workspace(B: int, F: int, device) -> torch.Tensor:
+    nbytes = _sz(0)
+    _check(lib().rp_sort_pairs_fields_workspace_bytes(B, F, C.byref(nbytes)), "rp_sort_pairs_fields_workspace_bytes")
+    return torch.empty((nbytes.value,), dtype=torch.uint8, device=device)
+
+
+def sort_pairs_fields(keys: torch.Tensor, B: int, field_rows, out=None, workspace=None):
+    """rp_sort_pairs_fields_i32: the pair list of one lookup (keys[f * B + b] = arena row, the tables back to back in field
+    order with `field_rows` rows each) sorted field segment by field segment — the result of sort_pairs(keys, bits of the arena),
+    bit for bit, in 49 instead of 78 field-passes at Criteo shape.  out / workspace as sort_pairs."""
+    _req(keys, torch.int32, "keys")
+    F = len(field_rows)
+    assert keys.numel() == F * B
+    ck = tuple(int(r) for r in field_rows)
+    arrs = _SORT_FIELDS.get(ck)
+    if arrs is None:
+        if len(_SORT_FIELDS) > 64:
+            _SORT_FIELDS.clear()
+        base, acc = [], 0
+        for r in ck:
+            base.append(acc)
+            acc += r
+        arrs = _SORT_FIELDS[ck] = ((C.c_int64 * F)(*base), (C.c_int64 * F)(*ck))
+    nbytes = _sz(0)
+    _check(lib().rp_sort_pairs_fields_workspace_bytes(B, F, C.byref(nbytes)), "rp_sort_pairs_fields_workspace_bytes")
+    if workspace is not None and workspace.numel() >= nbytes.value and workspace.device == keys.device:
+        ws = workspace
+    else:
+        ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=keys.device)
+    ko, po = out if out is not None else (torch.empty_like(keys), torch.empty_like(keys))
+    assert ko.shape == keys.shape and po.shape == keys.shape and ko.dtype == po.dtype == torch.int32
+    _held(keys, ws, ko, po)
+    with _Timed("sort_pairs_i32"):  # (the same row of the per-kernel table as the plain sort: it is that sort)
+        _check(lib().rp_sort_pairs_fields_i32(ws.data_ptr(), ws.numel(), keys.data_ptr(), ko.data_ptr(), po.data_ptr(), B, F,
+                                              arrs[0], arrs[1], _stream()), "rp_sort_pairs_fields_i32")
     return ko, po
 
 

@@ -731,7 +731,7 @@ class EmbeddingLayer(nn.Module):
         if lookup_only:
             return None
         keys = hip.embed_keys(row_base, row_count, idx, self.err_flag)
-        sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+        sk, sp = self._sort_pairs(keys) if row_base is self.row_base else hip.sort_pairs(keys, end_bit=self._meta()[3])
         if row_base is self.row_base and torch.is_grad_enabled():
             self._mark_sorted(sk, sp)
         out = (keys, sk, sp)
@@ -783,7 +783,7 @@ class EmbeddingLayer(nn.Module):
             # 'sync' mode raises at the step that finds a bad id: the keys of the NEXT batch must not set this step's flag
             # (its own gather checks the same ids again when its turn comes) — they get a scratch flag
             keys = hip.embed_keys(self.row_base, self.row_count, idx, self._ahead_flag())
-            sk, sp = hip.sort_pairs(keys, end_bit=self._meta()[3])
+            sk, sp = self._sort_pairs(keys)
             self._mark_sorted(sk, sp)
             event = torch.cuda.Event()
             event.record(side)
@@ -799,13 +799,24 @@ class EmbeddingLayer(nn.Module):
             f = self.__dict__["_scratch_flag"] = torch.zeros((1,), dtype=torch.int32, device=self._arena.device)
         return f
 
+    def _sort_pairs(self, keys, out=None, workspace=None):
+        """the (arena row, position) sort of a pair list that covers ALL fields of this layer in order, B pairs each: field
+        segment by field segment (rp_sort_pairs_fields_i32: a table of r rows needs log2 r key bits, not the arena's — the same
+        result in 49 instead of 78 field-passes at Criteo shape); RP_SORT_FIELDS=0 / RP_SORT=rocprim: the plain sort"""
+        from ... import hip
+        F = len(self.emb_feature)
+        n = keys.numel()
+        if n > 0 and n % F == 0 and os.environ.get("RP_SORT_FIELDS", "1") != "0" and os.environ.get("RP_SORT") != "rocprim":
+            return hip.sort_pairs_fields(keys, n // F, self._rows_sig(), out=out, workspace=workspace)
+        return hip.sort_pairs(keys, end_bit=self._meta()[3], out=out, workspace=workspace)
+
     def _sort_into(self, X, out, on_side_stream: bool) -> None:
         from ... import hip
         keys, sk, sp = out
         dev = self._arena.device
         if not on_side_stream:
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
-            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp), workspace=_PINNED_WS.get(id(keys)))
+            self._sort_pairs(keys, out=(sk, sp), workspace=_PINNED_WS.get(id(keys)))
             self._mark_sorted(sk, sp)
             return
         side = _SIDE_STREAMS.get(dev)
@@ -814,7 +825,7 @@ class EmbeddingLayer(nn.Module):
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
-            hip.sort_pairs(keys, end_bit=self._meta()[3], out=(sk, sp))
+            self._sort_pairs(keys, out=(sk, sp))
             self._mark_sorted(sk, sp)
 
     def pin_sort(self, X) -> None:
@@ -829,7 +840,11 @@ class EmbeddingLayer(nn.Module):
                 return
         n = sum(t.numel() for t in src)
         out = tuple(torch.empty((n,), dtype=torch.int32, device=self._arena.device) for _ in range(3))
-        _PINNED_WS[id(out[0])] = hip.sort_workspace(n, self._arena.device)
+        ws = hip.sort_workspace(n, self._arena.device)
+        if n % len(src) == 0 and n > 0:  # (the field-segmented sort's histograms are per field: a few KB more)
+            ws2 = hip.sort_fields_workspace(n // len(src), len(src), self._arena.device)
+            ws = ws2 if ws2.numel() > ws.numel() else ws
+        _PINNED_WS[id(out[0])] = ws
         self._sort_into(X, out, on_side_stream=False)
         _SORT_PINNED.append((src, sig, out))
 

@@ -144,6 +144,38 @@ def test_sort_pairs_field_ordered_keys_and_full_width(hip):
         assert torch.equal(out[0].cpu(), ref_k) and torch.equal(out[1].cpu(), ref_p.to(torch.int32))
 
 
+@pytest.mark.parametrize("rows,B", [
+    ([r // 16 + 1 for r in CRITEO], 8192),                 # the Criteo field structure: 1, 2 and 3 passes per field
+    (list(CRITEO), 65536),                                 # the headline shape: 1.7 M pairs, full cardinalities
+    ([1, 2, 513, 262145, 7, 300000], 4096 + 77),           # ragged tiles; tables right at the 9- and 18-bit borders; one row
+    ([40, 150_000_000, 9, 600], 5000),                     # a table of more than 2^27 rows: FOUR passes
+    ([5], 3), ([1000], 1), ([3, 3], 70001),
+])
+def test_sort_pairs_fields_equals_the_plain_sort(hip, rows, B):
+    """rp_sort_pairs_fields_i32 (round 6): the pair list of one lookup sorted field segment by field segment, every field by
+    the bits of ITS table — identical integers to the stable sort of the whole list by arena row (torch.sort, and
+    rp_sort_pairs_i32), into fresh buffers and into persistent ones twice (nothing is carried between calls)."""
+    g = torch.Generator().manual_seed(B + len(rows))
+    base, parts = 0, []
+    for r in rows:
+        p = base + torch.randint(0, r, (B,), generator=g)
+        p[0], p[-1] = base + r - 1, base  # the last and the first row of every table are there
+        parts.append(p)
+        base += r
+    keys = torch.cat(parts).to(torch.int32)
+    ref_k, ref_p = torch.sort(keys, stable=True)
+    ko, po = hip.sort_pairs_fields(keys.to(DEV), B, rows)
+    assert torch.equal(ko.cpu(), ref_k) and torch.equal(po.cpu(), ref_p.to(torch.int32))
+    k2, p2 = hip.sort_pairs(keys.to(DEV), end_bit=max(1, (base - 1).bit_length()))
+    assert torch.equal(ko, k2) and torch.equal(po, p2)
+    out = (torch.empty_like(ko), torch.empty_like(po))
+    ws = hip.sort_fields_workspace(B, len(rows), DEV)
+    kd = keys.to(DEV)
+    for _ in range(2):
+        hip.sort_pairs_fields(kd, B, rows, out=out, workspace=ws)
+        assert torch.equal(out[0].cpu(), ref_k) and torch.equal(out[1].cpu(), ref_p.to(torch.int32))
+
+
 def test_sort_pairs_rocprim_path():
     """RP_SORT=rocprim (read once per process) keeps rocPRIM's radix sort selectable: same results"""
     import subprocess, sys, os
