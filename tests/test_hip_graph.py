@@ -359,8 +359,8 @@ def test_graphed_step_refuses_what_it_cannot_capture():
         torch.cuda.is_current_stream_capturing = real
 
 
-@pytest.mark.parametrize("force_a2a", [False, True])
-def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, backend, monkeypatch):
+@pytest.mark.parametrize("force_a2a,ahead", [(False, True), (True, True), (True, False)])
+def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, ahead, backend, monkeypatch):
     """The captured step WITH its collectives: a DeepFM whose tables are row-sharded under a 1-rank RCCL group — route,
     exchange (the identity, or RCCL self-copies with RP_FORCE_A2A=1), owner-side gather / reduce, dense all-reduce, deferred
     lazy Adam with device-resident counters — against the eager loop on the same batches: every prediction and the final
@@ -376,6 +376,8 @@ def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, backend, mo
     from rec_pangu_amd.sharded import ShardedEmbeddingLayer, allreduce_dense_grads, shard_model_tables
     if force_a2a:
         monkeypatch.setenv("RP_FORCE_A2A", "1")
+    if not ahead:  # (rounds 4-5: the route of a batch is built inside its own step — the path a step takes when the
+        monkeypatch.setenv("RP_SHARD_AHEAD", "0")  # fixed-capacity buffers cannot be made)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -415,7 +417,10 @@ def test_graphed_step_with_row_sharded_tables_single_rank(force_a2a, backend, mo
                     pl = gstep.plans[0]
                     assert sum(1 for fn in pl.host_calls if fn is not None) == (4 if force_a2a else 1), pl.host_calls
                     # (round 6) the next batch's route, id exchange and owner-side sort are segments of the ahead stream
-                    assert sum(pl.seg_tags) == (2 if force_a2a else 1) and pl.ahead_stream is not None, pl.seg_tags
+                    if ahead:
+                        assert sum(pl.seg_tags) == (2 if force_a2a else 1) and pl.ahead_stream is not None, pl.seg_tags
+                    else:
+                        assert sum(pl.seg_tags) == 0 and pl.ahead_stream is None, pl.seg_tags
             results[mode] = (preds, {k: v.clone() for k, v in model.state_dict().items()})
             del gstep
         for a, b in zip(results["eager"][0], results["graph"][0]):
