@@ -33,7 +33,9 @@ struct SsFields {
     unsigned char rank[64];   // field -> its ordinal among the kept fields in ascending order (record / mark index base)
     unsigned char kept[64];   // ordinal -> field (ascending)
 };
-#define SS_RB 128    // unique rows per workgroup of the second pass
+#ifndef SS_RB
+#define SS_RB 128    // unique rows per workgroup of the second pass (64: -DSS_RB=64, an A/B build)
+#endif
 #define SS_LONG 16   // a row of more pieces than this is summed by the whole workgroup
 struct SsTiles {
     int base[65];  // first tile of sched[o]; base[n] = the tile count (static bound: cdiv(min(B, table rows), SS_RB) per field)
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
     const float *__restrict__ rh, const float *__restrict__ ru, const float *__restrict__ rs, const int32_t *__restrict__ ustart,
     const int32_t *__restrict__ ukey, const int32_t *__restrict__ offs, int nbk, int Bi, const float *__restrict__ w, int64_t ldw,
     const float *__restrict__ arena, float *__restrict__ G, int accumulate, float *__restrict__ dwpart, SsFields sf, SsTiles st) {
-    constexpr int D = 64, RB = SS_RB, MB = 2;
+    constexpr int D = 64, RB = SS_RB, MB = RB / 64, NU = RB / 16;  // (RB = 128 or 64)
     __shared__ __attribute__((aligned(16))) float HsT[RB][SS_HT];  // the rows' dH sums; after the matrix passes: the C tile
     __shared__ __attribute__((aligned(16))) float VT[RB][D];       // the rows' table rows (zero rows behind them)
     __shared__ __attribute__((aligned(16))) float red[16][2 * D + 4];  // a long row's partial sums per group
@@ -215,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
     const bool want_dw = dwpart != nullptr;
     const int nb = wv & 1, mh = wv >> 1;
     // the rows of this group: m = grp + 16 u — their position ranges and keys first (everything else depends on them)
-    int xs[8], xe[8], npc[8];
-    int32_t rk[8];
+    int xs[NU], xe[NU], npc[NU];
+    int32_t rk[NU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int m = grp + 16 * u;
         const bool ok = m < Mb;
         const int64_t at = ob + j0 + (ok ? m : 0);
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
     __syncthreads();
     // ---- (a) the rows' sums: piece e of each of this group's (up to 8) rows in flight together, e = 0, 1, ... in position
     //      order; a row of more than SS_LONG pieces is left to the whole workgroup (b) --------------------------------------
-    f32x4 aH[8], aU[8], vv[8];
-    float aS[8];
+    f32x4 aH[NU], aU[NU], vv[NU];
+    float aS[NU];
     int maxnp = 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NU; ++u) {
         aH[u] = aU[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         aS[u] = 0.f;
         vv[u] = *reinterpret_cast<const f32x4 *>(arena + (int64_t)((npc[u] > 0) ? rk[u] : 0) * D + c);
@@ -248,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
         maxnp = npc[u] > maxnp ? npc[u] : maxnp;
     }
     for (int e = 0; e < maxnp; ++e) {
-        f32x4 vh[8], vu[8];
-        float s1[8];
+        f32x4 vh[NU], vu[NU];
+        float s1[NU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NU; ++u)
             if (e < npc[u]) {
                 const int pe = (xs[u] | (SS_CH - 1)) + SS_CH * e;
                 const int64_t at = ob + (pe < xe[u] ? pe : xe[u]);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
                 }
             }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NU; ++u)
             if (e < npc[u]) {
                 aH[u] += vh[u];
                 if (HAS_FM) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
                 sS += red[g2][2 * D];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < NU; ++u)
                 if (u == ou) {
                     aH[u] = sH;
                     aU[u] = sU;
@@ -344,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
         }
         __syncthreads();
     }
-    f32x4 E[8];
+    f32x4 E[NU];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int m = grp + 16 * u;
         if (m < Mb) {  // (LDS stores only)
             *reinterpret_cast<f32x4 *>(&HsT[m][c]) = aH[u];
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void embed_ss_urows_kernel(
     SS_BARRIER();  // (C)
     // ---- the rows' gradient: C + u - s v, one writer per row ---------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int m = grp + 16 * u;
         if (m < Mb) {
             const f32x4 val = *reinterpret_cast<const f32x4 *>(&HsT[m][c]) + E[u];
