@@ -514,7 +514,7 @@ def main():
     # batch size; a step that must fall back to a hipGraph (dcn: ATen launches inside) only where the host is the limit.
     plan_ok = args.graph_backend != "hipgraph" and os.environ.get("RP_GRAPH_BACKEND", "plan") == "plan"
     use_graph = args.mode == "train" and not args.no_sort_ahead and (
-        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn", "mmoe", "autoint")
+        args.graph == "on" or (args.graph == "auto" and args.model in ("deepfm", "dcn", "mmoe", "autoint", "xdeepfm")
                                and (local_B <= 16384 or plan_ok)))  # (dcn, mmoe: plans since round 5 — their weight-space
     #                              arithmetic, BatchNorm statistics and loss sum are library launches; a step that still
     #                              falls back to a hipGraph is timed eagerly)

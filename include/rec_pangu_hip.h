@@ -470,6 +470,26 @@ int rp_cin_last_bwd_x(const float *x0, int64_t ld0, const float *xp, int64_t ldp
 int rp_cin_last_bwd_v_workspace_bytes(int64_t B, int H, int M, size_t *bytes);
 int rp_cin_last_bwd_v(const float *x0, int64_t ld0, const float *xp, int64_t ldp, const float *g, int H, int M, int D,
                       float *dV, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);
+/* The weight-space arithmetic around the pair kernels and the collapsed last layer (round 6, csrc/cin_head.hip) — what the host
+ * side did with ~50 elementwise / index / matmul launches per step (interaction.py:157-171 has no counterpart: the reference
+ * runs every layer at full width):
+ *   rp_cin_pair_pieces      W [O, H, H] -> the symmetric pair weights Ws[o, (h <= m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the
+ *                           diagonal) as three bf16 pieces (round to nearest even, piece k of what the pieces before it left):
+ *                           wsp [3][128][KP] (rp_cin_pair_fwd / _bwd_w; KP = pairs rounded up to 32) and / or wst [3][KPT][128]
+ *                           (rp_cin_pair_bwd_x; KPT = pairs rounded up to 128); either may be NULL; zero padded.
+ *   rp_cin_head_params_fwd  vt [M, 32] = V^T zero padded, V[h, m] = sum_o c[o] WL[o, h M + m];  vb[0] = sum_o c[o] bL[o]
+ *                           (bL may be NULL: 0) — c = the slice of fc.weight that multiplies the last layer's pooling.
+ *   rp_cin_head_params_bwd  dWL[o, j] = c[o] dV[j];  dbL[o] = Dscale sg[0] c[o];  dc[o] = sum_j WL[o, j] dV[j] + Dscale sg[0] bL[o]
+ *                           (dV [H, M] from rp_cin_last_bwd_v, sg[0] = sum_b g[b], Dscale = the embedding width D).
+ *   rp_add_scalars          out[i] += scale a[0] + (b0 ? b0[0] : 0) for i < n (the head's D vb + fc.bias onto the [B] logit).
+ *   rp_sum_all              out[0] = sum_i x[i], fixed order (one workgroup). */
+int rp_cin_pair_pieces(const float *W, int O, int H, void *wsp, void *wst, rp_stream_t stream);
+int rp_cin_head_params_fwd(const float *WL, const float *bL, const float *c, int O, int H, int M, float *vt, float *vb,
+                           rp_stream_t stream);
+int rp_cin_head_params_bwd(const float *WL, const float *bL, const float *c, const float *dV, const float *sg, float Dscale,
+                           int O, int H, int M, float *dWL, float *dbL, float *dc, rp_stream_t stream);
+int rp_add_scalars(float *out, int64_t n, const float *a, float scale, const float *b0, rp_stream_t stream);
+int rp_sum_all(const float *x, int64_t n, float *out, rp_stream_t stream);
 
 /* ---- K7 (split form): the T x T core of the field self-attention; projections are rp_linear_fwd GEMMs ------
  * replaces attention.py:20-33,73-94 for one AutoInt layer once QKVR = X . [Wq|Wk|Wv|Wres]^T has been computed for

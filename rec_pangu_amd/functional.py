@@ -411,9 +411,19 @@ def crossnet(x0, layer_w, layer_b, wfc=None, bfc=None):
 # ----------------------------------------------------------------------------------------------
 # K6  xDeepFM CIN layer   — layers/interaction.py:164-168
 # ----------------------------------------------------------------------------------------------
+class CINLink:
+    """Hand-off between the CIN's first layer and its collapsed last layer (both read X_0): the last layer's backward — which
+    runs first — parks its gradient of X_0 here and the first layer's backward adds it into its own with one library launch
+    (rp_add_rows), instead of autograd's ATen sum of the two [B, H D] gradients (a recorded step must hold none)."""
+    __slots__ = ("dx0",)
+
+    def __init__(self):
+        self.dx0 = None
+
+
 class _CINLayer(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, xp, W, bias, H: int, M: int, D: int, want_out: bool):
+    def forward(ctx, x0, xp, W, bias, H: int, M: int, D: int, want_out: bool, link=None):
         x0 = _unit_inner(x0)
         same = xp is None
         xp_t = x0 if same else _unit_inner(xp)
@@ -421,34 +431,45 @@ class _CINLayer(torch.autograd.Function):
         O = W.shape[0]
         # first layers (X_{k-1} = X_0, <= 32 fields) run on the bf16 matrix core (rp_cin_bs_*)
         bs = same and hip.get_matmul_precision() != "fp32" and hip.cin_bs_fits(H, M, D)
+        wst = None
         if bs and hip.cin_pair_fits(H, O, D):  # one GEMM over the H(H+1)/2 pair products
-            out, pooled = hip.cin_pair_fwd(x0, hip.cin_pair_pieces(W.view(O, H, M)), bias, H, O, D, want_out, True)
+            # (both layouts of the pair weights' bf16 pieces from one launch: the backward's is kept — the weights do not
+            #  change between this forward and its backward)
+            wsp, wst = hip.cin_pair_pieces(W.view(O, H, M), both=True)
+            out, pooled = hip.cin_pair_fwd(x0, wsp, bias, H, O, D, want_out, True)
         elif bs:
             out, pooled = hip.cin_bs_fwd(x0, xp_t, hip.bf16_pieces(W.view(O, H, M)), bias, H, M, O, D, want_out, True)
         else:
             out, pooled = hip.cin_layer_fwd(x0, xp_t, W, bias, H, M, D, want_out, True)
         ctx.cfg = (H, M, D, same, bias is not None, want_out, bs)
-        ctx.save_for_backward(x0, None if same else xp_t, W)
+        ctx.link = link
+        ctx.save_for_backward(x0, None if same else xp_t, W, wst)
         if want_out:
             return out, pooled
         return pooled
 
     @staticmethod
     def backward(ctx, *grads):
-        x0, xp, W = ctx.saved_tensors
+        x0, xp, W, wst = ctx.saved_tensors
         H, M, D, same, has_bias, want_out, bs = ctx.cfg
         g_out, g_pool = (grads if want_out else (None, grads[0]))
         g_out = None if g_out is None else g_out.contiguous()
         g_pool = None if g_pool is None else _unit_inner(g_pool)
+        extra = None
+        if ctx.link is not None and ctx.link.dx0 is not None:
+            extra, ctx.link.dx0 = ctx.link.dx0, None
         if bs:
             O = W.shape[0]
             W3 = W.view(O, H, M)
             # X_0 enters in both roles: one pass with W[o,h,m] + W[o,m,h] gives its whole gradient
             gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
             if hip.cin_pair_fits(H, O, D) and (g_out is None or g_out.data_ptr() % 16 == 0):
-                dx0 = hip.cin_pair_bwd_x(x0, hip.cin_pair_pieces(W3, transposed=True), g_out, gp, H, O, D, like=x0)
+                dx0 = hip.cin_pair_bwd_x(x0, wst if wst is not None else hip.cin_pair_pieces(W3, transposed=True), g_out, gp,
+                                         H, O, D, like=x0)
             else:
                 dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
+            if extra is not None:
+                hip.add_rows_to(extra, dx0[:, :extra.shape[1]])
             if x0.stride(0) % 4 == 0 and x0.data_ptr() % 16 == 0:
                 if O <= 128:  # symmetric pair form: products formed once, 2.9x fewer matrix-core passes
                     dW, db = hip.cin_pair_bwd_w(x0, g_out, gp, H, O, D, has_bias)
@@ -457,9 +478,11 @@ class _CINLayer(torch.autograd.Function):
                 dW = dW.view_as(W)
             else:
                 dW, db = hip.cin_layer_bwd_w(x0, x0, W, H, M, D, g_out, g_pool, has_bias)
-            return dx0, None, dW, db, None, None, None, None
+            return dx0, None, dW, db, None, None, None, None, None
         dx0, dxp, dW, db = hip.cin_layer_bwd(x0, x0 if same else xp, W, H, M, D, g_out, g_pool, has_bias)
-        return dx0, dxp, dW, db, None, None, None, None
+        if extra is not None:
+            hip.add_rows_to(extra, dx0[:, :extra.shape[1]])
+        return dx0, dxp, dW, db, None, None, None, None, None
 
 
 class _CINLast(torch.autograd.Function):
@@ -555,10 +578,98 @@ def cin_middle(x0, xp, W, bias, H: int, M: int, D: int):
     return _CINChunked.apply(x0, xp, W, bias, H, M, D)
 
 
-def cin_layer(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool = True):
-    """One CIN layer on [B, >=H*D] / [B, M*D] row buffers (xp=None: first layer, X_{k-1} = X_0).
-    -> (X_k [B,O,D], pooled [B,O]) or pooled alone when want_out is False."""
-    return _CINLayer.apply(x0, xp, W, bias, H, M, D, want_out)
+def cin_layer(x0, xp, W, bias, H: int, M: int, D: int, want_out: bool = True, link=None):
+    """(X_k [B, O, D], pooled [B, O]) or pooled alone; link: a CINLink shared with cin_head (the collapsed last layer's
+    gradient of X_0 is added into this layer's inside its backward)"""
+    return _CINLayer.apply(x0, xp, W, bias, H, M, D, want_out, link)
+
+
+class _CINHead(torch.autograd.Function):
+    """The CIN's collapsed LAST layer with its weight-space arithmetic inside (round 6; models/layers/interaction.py has the
+    algebra):  logit[b] = sum_d sum_{h,m} V[h,m] X_0[b,h,d] X_{L-1}[b,m,d] + D (c . b_L) + fc.bias,  V = c . W_L.
+    One launch for (V^T, c . b_L), rp_cin_last_fwd, one launch for the two scalars; the backward's dW_L / db_L / dc from one
+    launch.  What this replaces were two matmuls, four elementwise launches and their autograd counterparts per step."""
+
+    @staticmethod
+    def forward(ctx, x0, xp, WL, bL, c, fcb, H: int, M: int, D: int, link):
+        x0 = _unit_inner(x0)
+        xp = _unit_inner(xp)
+        WL = WL.contiguous()
+        c = c.reshape(-1).contiguous()
+        vt, vb = hip.cin_head_params_fwd(WL, bL, c, H, M)
+        out = hip.cin_last_fwd(x0, xp, vt, H, M, D)
+        hip.add_scalars(out, vb, float(D), fcb)
+        ctx.cfg, ctx.link = (H, M, D, bL is not None, fcb is not None, c.shape), link
+        ctx.save_for_backward(x0, xp, vt, WL, bL, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, xp, vt, WL, bL, c = ctx.saved_tensors
+        H, M, D, has_b, has_fcb, cshape = ctx.cfg
+        g = g.reshape(-1).contiguous()
+        dx0, dxp, dV = hip.cin_last_bwd(x0, xp, vt, g, H, M, D)
+        sg = hip.sum_all(g)
+        dWL, dbL, dc = hip.cin_head_params_bwd(WL, bL, c, dV, sg, D, H, M)
+        if ctx.link is not None:
+            ctx.link.dx0, dx0 = dx0, None  # (added into the first layer's gradient of X_0 by its backward: CINLink)
+        return dx0, dxp, dWL, dbL, dc.view(1, -1), (sg if has_fcb else None), None, None, None, None
+
+
+def cin_head(x0, xp, WL, bL, c, fcb, H: int, M: int, D: int, link=None):
+    """x0 [B, >= H D], xp = X_{L-1} [B, M D], WL [O, H M], bL [O] or None, c [1, O] (fc.weight's slice for the last layer's
+    pooling), fcb [1] or None -> [B, 1]"""
+    return _CINHead.apply(x0, xp, WL, bL, c, fcb, H, M, D, link)
+
+
+class _RowSplit(torch.autograd.Function):
+    """w [1, n] -> (w[:, :k], w[:, k:]) as tensors of their own that alias w's memory (no launch); the backward writes the two
+    gradients into the halves of one [1, n] buffer with one library launch.  (Slicing a parameter leaves autograd a slice node
+    per half: a zero fill and a copy each in the backward — ATen launches a recorded step must not hold.)"""
+
+    @staticmethod
+    def forward(ctx, w, k: int):
+        ctx.k, ctx.n = k, w.shape[1]
+        d = w.detach()
+        return d[:, :k], d[:, k:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        k, n = ctx.k, ctx.n
+        ref = g1 if g1 is not None else g2
+        g = torch.empty((1, n), dtype=torch.float32, device=ref.device)
+        parts = []
+        for gi, (a, b) in ((g1, (0, k)), (g2, (k, n))):
+            parts.append((g[:, a:b], gi if gi is not None else hip.zeros((1, b - a), torch.float32, ref.device)))
+        if not hip.multi_copy([p[0] for p in parts], [p[1].contiguous() for p in parts]):
+            for dst, src in parts:
+                hip.copy_rows_to(src, dst)
+        return g, None
+
+
+def row_split(w, k: int):
+    return _RowSplit.apply(w, k)
+
+
+class _TokenAlias(torch.autograd.Function):
+    """_TokenView without the copy: the first F*D columns of x as a tensor of its own that aliases x's memory, for consumers that
+    take a row stride (the CIN kernels).  The gradient takes the same road: parked in the gather's link, added into the other
+    consumer's dX by the gather's backward (rp_add_rows)."""
+
+    @staticmethod
+    def forward(ctx, x, n: int, link):
+        ctx.link = link
+        return _unit_inner(x).detach()[:, :n]
+
+    @staticmethod
+    def backward(ctx, d):
+        ctx.link.extra = d if d.is_contiguous() else d.contiguous()
+        return None, None, None
+
+
+def token_alias(x, n: int, link):
+    return _TokenAlias.apply(x, n, link)
+
 
 
 # ----------------------------------------------------------------------------------------------

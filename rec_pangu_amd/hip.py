@@ -140,6 +140,11 @@ _SIGNATURES = {
     "rp_cin_last_bwd_x": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
     "rp_cin_last_bwd_v_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_cin_last_bwd_v": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _sz, _vp]),
+    "rp_cin_pair_pieces": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "rp_cin_head_params_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "rp_cin_head_params_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "rp_add_scalars": (C.c_int, [_vp, _i64, _vp, C.c_float, _vp, _vp]),
+    "rp_sum_all": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rp_attention_core_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_attention_core_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
     "rp_attention_core_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _i64, _vp, _i64, _i64,
@@ -1628,10 +1633,8 @@ def _cin_pair_ws(W3):
     return W3[:, iu[0], iu[1]] + W3[:, iu[1], iu[0]] * (iu[0] != iu[1]).to(W3.dtype)
 
 
-def cin_pair_pieces(W3, transposed: bool = False):
-    """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the diagonal) as bf16
-    pieces: [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32) or, transposed, [3, KPT, 128]
-    (rp_cin_pair_bwd_x's wst, KPT = pairs rounded up to 128)."""
+def cin_pair_pieces_torch(W3, transposed: bool = False):
+    """the torch formulation of cin_pair_pieces (rounds 3-5; kept as the tests' reference for rp_cin_pair_pieces)"""
     O = W3.shape[0]
     ws = _cin_pair_ws(W3)
     npair = ws.shape[1]
@@ -1642,6 +1645,59 @@ def cin_pair_pieces(W3, transposed: bool = False):
         full = torch.zeros((128, (npair + 31) // 32 * 32), dtype=torch.float32, device=W3.device)
         full[:O, :npair] = ws
     return _bf16_split3(full)
+
+
+def cin_pair_pieces(W3, transposed: bool = False, both: bool = False):
+    """W [O, H, H] -> the symmetric pair weights Ws[o, (h<=m)] = W[o,h,m] + W[o,m,h] (W[o,h,h] on the diagonal) as bf16
+    pieces: [3, 128, KP] (rp_cin_pair_fwd's wsp, KP = pairs rounded up to 32) or, transposed, [3, KPT, 128]
+    (rp_cin_pair_bwd_x's wst, KPT = pairs rounded up to 128); both: (wsp, wst) from ONE launch (rp_cin_pair_pieces, round 6:
+    the fold + split were ~18 torch launches per layout and step)."""
+    _req(W3, torch.float32, "W")
+    O, H = W3.shape[0], W3.shape[1]
+    W3 = W3.contiguous()
+    npair = H * (H + 1) // 2
+    dev = W3.device
+    wsp = torch.empty((3, 128, (npair + 31) // 32 * 32), dtype=torch.bfloat16, device=dev) if (both or not transposed) else None
+    wst = torch.empty((3, (npair + 127) // 128 * 128, 128), dtype=torch.bfloat16, device=dev) if (both or transposed) else None
+    _check(lib().rp_cin_pair_pieces(W3.data_ptr(), O, H, _ptr(wsp), _ptr(wst), _stream()), "rp_cin_pair_pieces")
+    return (wsp, wst) if both else (wst if transposed else wsp)
+
+
+def cin_head_params_fwd(WL, bL, c, H: int, M: int):
+    """-> (vt [M, 32], vb [1]): V^T = (c . W_L)^T zero padded and c . b_L of the collapsed last CIN layer (rp_cin_head_params_fwd)"""
+    O = WL.shape[0]
+    vt = torch.empty((M, 32), dtype=torch.float32, device=WL.device)
+    vb = torch.empty((1,), dtype=torch.float32, device=WL.device)
+    _check(lib().rp_cin_head_params_fwd(WL.data_ptr(), _ptr(bL), c.data_ptr(), O, H, M, vt.data_ptr(), vb.data_ptr(), _stream()),
+           "rp_cin_head_params_fwd")
+    return vt, vb
+
+
+def cin_head_params_bwd(WL, bL, c, dV, sg, D: int, H: int, M: int):
+    """-> (dWL [O, H M], dbL [O] or None, dc [O]) of the collapsed last layer's weights from dV [H, M] and sg = sum g
+    (rp_cin_head_params_bwd)"""
+    O = WL.shape[0]
+    dWL = torch.empty((O, H * M), dtype=torch.float32, device=WL.device)
+    dbL = torch.empty((O,), dtype=torch.float32, device=WL.device) if bL is not None else None
+    dc = torch.empty((O,), dtype=torch.float32, device=WL.device)
+    _check(lib().rp_cin_head_params_bwd(WL.data_ptr(), _ptr(bL), c.data_ptr(), dV.data_ptr(), sg.data_ptr(), float(D), O, H, M,
+                                        dWL.data_ptr(), _ptr(dbL), dc.data_ptr(), _stream()), "rp_cin_head_params_bwd")
+    return dWL, dbL, dc
+
+
+def add_scalars(out, a, scale: float, b0=None):
+    """out[i] += scale * a[0] + (b0[0] if b0 is given), in place (rp_add_scalars)"""
+    assert out.is_contiguous() and out.dtype == torch.float32
+    _check(lib().rp_add_scalars(out.data_ptr(), out.numel(), a.data_ptr(), float(scale), _ptr(b0), _stream()), "rp_add_scalars")
+    return out
+
+
+def sum_all(x):
+    """-> [1] = the sum of x's elements in a fixed order (rp_sum_all)"""
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _check(lib().rp_sum_all(x.data_ptr(), x.numel(), out.data_ptr(), _stream()), "rp_sum_all")
+    return out
 
 
 _PAIR_LISTS = {}

@@ -103,18 +103,31 @@ class CompressedInteractionNet(nn.Module):
             self.cin_layer["layer_" + str(i + 1)] = nn.Conv1d(num_fields * prev, unit, kernel_size=1)
             prev = unit
 
-    def _forward_hip(self, feature_emb):
+    def _forward_hip(self, feature_emb, as_list: bool = False):
         """fp32-MFMA CIN kernels (rp_cin_layer_*).  Every layer but the last runs at full width and keeps X_k for
         the next one; the LAST layer only feeds sum-pooling and `fc`, both linear, and the CIN has no activation, so
             sum_o c[o] * sum_d X_L[b,o,d] = sum_d sum_{h,m} V[h,m] X_0[b,h,d] X_{L-1}[b,m,d] + D * (c . bias_L),
             V = sum_o c[o] W_L[o]            (c = the slice of fc.weight that multiplies the last layer's pooling)
         and it is evaluated as a single-output-channel layer with weights V: 1/O_L of the work, same algebra."""
         from ... import functional as Fh
-        B, H, D = feature_emb.shape
-        x0 = feature_emb.reshape(B, H * D)
+        from ... import hip
+        if feature_emb.dim() == 2:  # (already the [B, H D] row buffer: a model that hands over its own view of x)
+            B, H, x0 = feature_emb.shape[0], self.num_fields, feature_emb
+            D = x0.shape[1] // H
+        else:
+            B, H, D = feature_emb.shape
+            x0 = feature_emb.reshape(B, H * D)
         if any(u > 32 for u in self.cin_layer_units[:-2]) and (x0.stride(0) % 4 != 0 or x0.data_ptr() % 16 != 0):
             x0 = x0.contiguous()  # the chunked bf16 middle layers need 16-byte aligned rows (the models' x buffer has them)
         L = len(self.cin_layer_units)
+        if self.fc.weight.shape[0] != 1:
+            raise NotImplementedError("CIN on HIP collapses the last layer into fc: output_dim must be 1")
+        # round 6: with a layer in front of the last one and rp_cin_last covering the last, the whole head is library launches —
+        # fc.weight split without autograd slice nodes, V = c . W_L / c . b_L / the scalars / their gradients in cin_head, the
+        # last layer's gradient of X_0 added into the first layer's inside its backward (CINLink)
+        M_last = self.cin_layer_units[-2] if L >= 2 else H
+        fused_head = L >= 2 and hip.cin_last_fits(H, M_last, D)
+        link = Fh.CINLink() if (fused_head and torch.is_grad_enabled() and x0.requires_grad) else None
         xp, M, pooled, n_prev = None, H, [], 0
         for i in range(L - 1):
             conv = self.cin_layer["layer_" + str(i + 1)]
@@ -123,14 +136,18 @@ class CompressedInteractionNet(nn.Module):
                 # a middle layer (fed by any number of maps) on the bf16 matrix core, 32 maps per launch
                 X_i, p_i = Fh.cin_middle(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D)
             else:
-                X_i, p_i = Fh.cin_layer(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D, want_out=True)
+                X_i, p_i = Fh.cin_layer(x0, xp, conv.weight.view(O, H * M), conv.bias, H, M, D, want_out=True,
+                                        link=link if i == 0 else None)
             pooled.append(p_i)
             xp, M, n_prev = X_i.view(B, O * D), O, n_prev + O
         conv = self.cin_layer["layer_" + str(L)]
         O = conv.weight.shape[0]
+        if fused_head:
+            c_prev, c_last = Fh.row_split(self.fc.weight, n_prev)
+            head = Fh.cin_head(x0, xp, conv.weight.view(O, H * M), conv.bias, c_last, self.fc.bias, H, M, D, link)
+            pool_logit = Fh.linear_act(pooled[0] if len(pooled) == 1 else torch.cat(pooled, dim=-1), c_prev, None)
+            return [head, pool_logit] if as_list else head + pool_logit
         c_last = self.fc.weight[:, n_prev:]                                  # [out_dim, O_L]
-        if self.fc.weight.shape[0] != 1:
-            raise NotImplementedError("CIN on HIP collapses the last layer into fc: output_dim must be 1")
         V = c_last @ conv.weight.view(O, H * M)                              # [1, H*M]   (weight-space, tiny)
         vb = (c_last @ conv.bias.view(O, 1)).view(1)                         # c . bias_L
         from ... import hip
@@ -141,7 +158,8 @@ class CompressedInteractionNet(nn.Module):
             logit = Fh.cin_layer(x0, xp, V, vb, H, M, D, want_out=False)     # [B,1] = sum_o c[o] pooled_L[b,o]
         if pooled:
             logit = logit + Fh.linear_act(torch.cat(pooled, dim=-1), self.fc.weight[:, :n_prev].contiguous(), None)
-        return logit + self.fc.bias
+        logit = logit + self.fc.bias
+        return [logit] if as_list else logit
 
     def hip_supported(self, H, D=None) -> bool:
         """<= 32 fields and a single output.  Middle layers (not first, not last) fed by more than 32 maps run on the
@@ -155,10 +173,17 @@ class CompressedInteractionNet(nn.Module):
             return True
         return hip.get_matmul_precision() != "fp32" and D in (32, 64)
 
-    def forward(self, feature_emb):
-        B, H, D = feature_emb.shape
+    def forward(self, feature_emb, as_list: bool = False):
+        """as_list (HIP callers that add their logits inside the loss launch): the logit as a list of [B, 1] addends"""
+        if feature_emb.dim() == 2:
+            H, D = self.num_fields, feature_emb.shape[1] // self.num_fields
+            if not (feature_emb.is_cuda and self.hip_supported(H, D)):
+                feature_emb = feature_emb.reshape(feature_emb.shape[0], H, D)
+        B = feature_emb.shape[0]
+        if feature_emb.dim() == 3:
+            _, H, D = feature_emb.shape
         if feature_emb.is_cuda and self.hip_supported(H, D):
-            return self._forward_hip(feature_emb)
+            return self._forward_hip(feature_emb, as_list)
         if feature_emb.is_cuda:
             from ... import hip
             hip.note_torch_path(f"CompressedInteractionNet with {H} fields, D={D}, layers {list(self.cin_layer_units)}, "
@@ -173,4 +198,5 @@ class CompressedInteractionNet(nn.Module):
             t = torch.einsum("ohm,bmd->bohd", W, X_i)
             X_i = (t * X_0.unsqueeze(1)).sum(dim=2) + conv.bias.view(1, -1, 1)
             pooled.append(X_i.sum(dim=-1))
-        return self.fc(torch.cat(pooled, dim=-1))
+        out = self.fc(torch.cat(pooled, dim=-1))
+        return [out] if as_list else out

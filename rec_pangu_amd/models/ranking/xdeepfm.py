@@ -28,8 +28,16 @@ class xDeepFM(BaseModel):
         if self.on_hip:
             x, _ = self.embedding_layer.gather_concat(data, self._dense_list(data), want_fm=False)
             F, D = self.num_sparse, self.embedding_dim
-            feature_emb = x[:, :F * D].unflatten(1, (F, D))  # strided [B,F,D] view of the MLP input buffer
-            logits = [self.lr_layer(data), self.cin(feature_emb)]
+            link = getattr(self.embedding_layer, "_fm_link", None)
+            if self.dnn is not None and link is not None and x.requires_grad and torch.is_grad_enabled():
+                # the embedding block of the MLP input buffer as the CIN's [B, F D] rows (no copy: the kernels take the row
+                # stride); its gradient joins the MLP's dX inside the gather's backward (Fh.token_alias) instead of through
+                # autograd's zero-filled slice gradient and an ATen sum of two 450 MB tensors
+                from ... import functional as Fh
+                feature_emb = Fh.token_alias(x, F * D, link)
+            else:
+                feature_emb = x[:, :F * D].unflatten(1, (F, D))  # strided [B,F,D] view of the MLP input buffer
+            logits = [self.lr_layer(data)] + list(self.cin(feature_emb, as_list=True))
             if self.dnn is not None:
                 logits.append(self.dnn(x))
             return self._finish(logits, data, is_training, self.loss_fun)

@@ -53,6 +53,9 @@ def _build(kind, enc):
     elif kind == "xdeepfm_dropout":  # the reference's default: dropout 0.1 inside the MLP — ACTIVE in the captured step
         from rec_pangu_amd.models.ranking import xDeepFM
         model = xDeepFM(embedding_dim=16, dnn_hidden_units=[32, 16], cin_layer_units=[8, 8], enc_dict=enc)
+    elif kind == "xdeepfm64":  # BASELINE config 3's structure (CIN [128, 128] at D = 64: pair-form first layer + collapsed last
+        from rec_pangu_amd.models.ranking import xDeepFM  # layer) — round 6: library launches only, replays as a launch plan
+        model = xDeepFM(embedding_dim=64, dnn_hidden_units=[64, 64, 64], cin_layer_units=[128, 128], enc_dict=enc)
     elif kind == "mmoe":  # the reference's defaults: BatchNorm1d + Dropout(0.2) towers, two tasks (round 5: a launch plan)
         from rec_pangu_amd.models.multi_task import MMOE
         model = MMOE(enc_dict=enc, embedding_dim=16, device=None)
@@ -74,7 +77,7 @@ def _build(kind, enc):
                                                      ("deepfm16", "closed", 300, False), ("dcn", "closed", 60, False),
                                                      ("deepfm32tail", "closed", 40, True), ("xdeepfm_dropout", "closed", 40, True),
                                                      ("deepfm64", "closed", 300, True), ("mmoe", "closed", 40, True),
-                                                     ("autoint", "closed", 40, True)])
+                                                     ("autoint", "closed", 40, True), ("xdeepfm64", "closed", 40, True)])
 def test_graphed_step_is_bit_identical_to_the_eager_loop(kind, replay, steps, defer, backend):
     """(330 / 300 steps cross step 256, where the closed-form replay takes over, and — with TABLE_CHUNK = 100 — several
     in-place extensions of the step tables; the learning rate changes twice on the way)"""

@@ -483,6 +483,51 @@ def test_route_kernels_vs_torch(world, rows, b):
         assert torch.equal(torch.div(pos_fm.cpu().long(), b, rounding_mode="floor"), torch.arange(F).repeat_interleave(b))
 
 
+@pytest.mark.parametrize("O,H", [(128, 26), (128, 6), (7, 32), (1, 1), (100, 13)])
+def test_cin_pair_pieces_vs_torch(hip, O, H):
+    """rp_cin_pair_pieces (round 6): the pair kernels' weights — triangular fold + three bf16 pieces, both layouts from one
+    launch — against the torch formulation of rounds 3-5, bit for bit (same fp32 adds, round-to-nearest-even conversions)."""
+    g = torch.Generator().manual_seed(O * 100 + H)
+    W = (torch.randn(O, H, H, generator=g) * 0.3).to(DEV)
+    wsp, wst = hip.cin_pair_pieces(W, both=True)
+    ref_p, ref_t = hip.cin_pair_pieces_torch(W), hip.cin_pair_pieces_torch(W, transposed=True)
+    assert wsp.shape == ref_p.shape and wst.shape == ref_t.shape
+    assert torch.equal(wsp.view(torch.int16), ref_p.view(torch.int16)) and torch.equal(wst.view(torch.int16), ref_t.view(torch.int16))
+    assert torch.equal(hip.cin_pair_pieces(W).view(torch.int16), ref_p.view(torch.int16))
+    assert torch.equal(hip.cin_pair_pieces(W, transposed=True).view(torch.int16), ref_t.view(torch.int16))
+
+
+@pytest.mark.parametrize("O,H,M,with_b", [(128, 26, 128, True), (8, 6, 8, True), (16, 32, 5, False), (1, 1, 1, True)])
+def test_cin_head_params_vs_float64(hip, O, H, M, with_b):
+    """rp_cin_head_params_fwd / _bwd, rp_add_scalars, rp_sum_all (round 6: the weight-space arithmetic of the CIN's collapsed last
+    layer, interaction.py:157-171 behind sum-pooling and fc) against float64:  V^T = (c . W_L)^T zero padded to 32 columns,
+    vb = c . b_L;  dW_L = c^T (x) dV,  db_L = D sg c,  dc = W_L . dV + D sg b_L."""
+    g = torch.Generator().manual_seed(O + H + M)
+    WL, bL, c = torch.randn(O, H * M, generator=g), torch.randn(O, generator=g), torch.randn(O, generator=g)
+    dV, gvec, D = torch.randn(H, M, generator=g), torch.randn(5000, generator=g), 64
+    b_dev = bL.to(DEV) if with_b else None
+    vt, vb = hip.cin_head_params_fwd(WL.to(DEV), b_dev, c.to(DEV), H, M)
+    V = (c.double() @ WL.double()).view(H, M)
+    ref_vt = torch.zeros(M, 32, dtype=torch.float64)
+    ref_vt[:, :H] = V.t()
+    torch.testing.assert_close(vt.cpu().double(), ref_vt, rtol=0, atol=1e-5 * max(1.0, float(V.abs().max())))
+    assert abs(float(vb) - (float(c.double() @ bL.double()) if with_b else 0.0)) <= 1e-5 * O
+    sg = hip.sum_all(gvec.to(DEV))
+    assert abs(float(sg) - float(gvec.double().sum())) <= 1e-4 * float(gvec.abs().sum()) / 100
+    out = torch.ones(300, device=DEV)
+    hip.add_scalars(out, vb, 2.0, sg)
+    assert torch.allclose(out.cpu(), torch.full((300,), 1.0) + 2.0 * float(vb) + float(sg), rtol=1e-6, atol=1e-6)
+    dWL, dbL, dc = hip.cin_head_params_bwd(WL.to(DEV), b_dev, c.to(DEV), dV.to(DEV), sg, D, H, M)
+    s = float(sg)
+    torch.testing.assert_close(dWL.cpu().double(), c.double()[:, None] * dV.double().reshape(1, -1), rtol=1e-6, atol=1e-6)
+    ref_dc = WL.double() @ dV.double().reshape(-1) + (D * s * bL.double() if with_b else 0.0)
+    torch.testing.assert_close(dc.cpu().double(), ref_dc, rtol=1e-5, atol=1e-4 * max(1.0, float(ref_dc.abs().max())))
+    if with_b:
+        torch.testing.assert_close(dbL.cpu().double(), D * s * c.double(), rtol=1e-5, atol=1e-5 * abs(D * s))
+    else:
+        assert dbL is None
+
+
 @pytest.mark.parametrize("shape,p", [((4096, 64), 0.1), ((1000, 37), 0.5), ((65536, 256), 0.2), ((3, 5), 0.3)])
 def test_dropout_kernels(shape, p):
     """rp_dropout_fwd/bwd (nn.Dropout of layers/deep.py:66-68 and the towers): y = x * keep / (1 - p) with a saved
