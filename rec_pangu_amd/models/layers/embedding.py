@@ -37,6 +37,7 @@ _SORT_PINNED: list = []
 # id(keys tensor of a pinned entry) -> its persistent sort workspace: a captured step's re-sort must not allocate (its
 # launches may be re-issued on a side stream, where memory of the capture's pool could alias the step's temporaries)
 _PINNED_WS: dict = {}
+_PINNED_MARKS: dict = {}  # id(pinned key buffer) -> the duplicate marks / unique-row lists are made with its sort
 
 # id(sorted-keys tensor) -> [weakref(sorted keys), (B, fields), (dupq, dupkeys)]: the marks rp_embed_grad_smp wants, made
 # right behind the sort that made the keys (EmbeddingLayer._mark_sorted: on the sort's stream, one step ahead when the sort
@@ -349,9 +350,13 @@ class EmbeddingLayer(nn.Module):
         self.__dict__["_smp_cache"] = (sig, B, out)
         return out
 
-    def _mark_sorted(self, sk, sp) -> None:
-        """behind a sort of this layer's pairs (on the stream that sorted them): the duplicate marks of the big tables"""
+    def _mark_sorted(self, sk, sp, force: bool = False) -> None:
+        """behind a sort of this layer's pairs (on the stream that sorted them): the duplicate marks of the big tables.  Only for
+        a layer whose backward has taken the three-form path before (`_marks_wanted`, set by accumulate_grad) — DCN, xDeepFM,
+        AutoInt and MMOE reduce through rp_embed_grad_reduce and made six launches' worth of marks per step for nobody."""
         from ... import hip
+        if not (force or getattr(self, "_marks_wanted", False)):
+            return
         F = len(self.emb_feature)
         if sk.numel() == 0 or sk.numel() % F:
             return
@@ -382,8 +387,9 @@ class EmbeddingLayer(nn.Module):
 
     def _marks_of(self, sk, sp, smp, B: int):
         ent = _SMP_MARKS.get(id(sk))
+        self._marks_wanted = True
         if ent is None or ent[0]() is not sk or ent[1] != (B, tuple(smp)):
-            self._mark_sorted(sk, sp)  # (a sort nobody marked: an eager backward that sorted for itself)
+            self._mark_sorted(sk, sp, force=True)  # (a sort nobody marked: an eager backward that sorted for itself)
             ent = _SMP_MARKS[id(sk)]
         return ent[2]
 
@@ -817,7 +823,10 @@ class EmbeddingLayer(nn.Module):
         if not on_side_stream:
             hip.embed_keys(self.row_base, self.row_count, self._idx_list(X), self.err_flag, out=keys)
             self._sort_pairs(keys, out=(sk, sp), workspace=_PINNED_WS.get(id(keys)))
-            self._mark_sorted(sk, sp)
+            # (a pinned entry keeps the choice made when it was pinned: marks that first appear inside a recorded step's side
+            #  section would be allocated by the capture behind the step's temporaries and run beside them)
+            if _PINNED_MARKS.get(id(keys), True):
+                self._mark_sorted(sk, sp, force=True)
             return
         side = _SIDE_STREAMS.get(dev)
         if side is None:
@@ -845,6 +854,7 @@ class EmbeddingLayer(nn.Module):
             ws2 = hip.sort_fields_workspace(n // len(src), len(src), self._arena.device)
             ws = ws2 if ws2.numel() > ws.numel() else ws
         _PINNED_WS[id(out[0])] = ws
+        _PINNED_MARKS[id(out[0])] = bool(getattr(self, "_marks_wanted", False))
         self._sort_into(X, out, on_side_stream=False)
         _SORT_PINNED.append((src, sig, out))
 
@@ -854,11 +864,13 @@ class EmbeddingLayer(nn.Module):
         if X is None:
             del _SORT_PINNED[:]
             _PINNED_WS.clear()
+            _PINNED_MARKS.clear()
         else:
             ids = {id(t) for t in X.values()}
             for e in _SORT_PINNED:
                 if any(id(t) in ids for t in e[0]):
                     _PINNED_WS.pop(id(e[2][0]), None)
+                    _PINNED_MARKS.pop(id(e[2][0]), None)
             _SORT_PINNED[:] = [e for e in _SORT_PINNED if not any(id(t) in ids for t in e[0])]
 
     def _rows_sig(self):
