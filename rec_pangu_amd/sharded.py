@@ -119,7 +119,8 @@ _ROUTE_STREAMS: dict = {}
 
 def route_stream(dev):
     """The lowest-priority stream of hip.make_side_stream, an instance of this module's own (RP_ROUTE_STREAM=plain: a torch
-    stream of the normal priority, rounds 3-5).  HIP multiplexes the streams of one priority onto a handful of hardware
+    stream of the normal priority, rounds 3-5 — and the default under an RCCL group of more than one rank, RP_ROUTE_STREAM=low
+    overrides).  HIP multiplexes the streams of one priority onto a handful of hardware
     queues, and a plain stream that lands on the main stream's queue runs IN FRONT of or BEHIND the step instead of beside it
     (measured on one MI355X: the recorded sharded step with its look-ahead on a plain stream took exactly the serial time,
     DESIGN.md §8).  Collectives are issued with this stream current (torch's process group orders its own communication
@@ -127,7 +128,10 @@ def route_stream(dev):
     RP_FORCE_A2A=1 and the two-rank host-staged test; RCCL with N > 1 has not executed on any stream yet."""
     side = _ROUTE_STREAMS.get(dev)
     if side is None:
-        kind = os.environ.get("RP_ROUTE_STREAM", "low")
+        # (more than one rank: the plain stream unless asked otherwise — the exchange issued with an ExternalStream current has
+        #  only run under a one-rank RCCL group and the host-staged two-rank harness; correctness does not depend on the choice)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != "gloo"
+        kind = os.environ.get("RP_ROUTE_STREAM", "plain" if multi else "low")
         if kind == "low":
             from . import hip
             side = hip.make_side_stream(dev, "route")
