@@ -448,10 +448,12 @@ int rp_cin_pair_fwd(const float *x0, int64_t ld0, const void *wsp, const float *
  * wst: Ws^T as bf16 pieces [3][KPT][128], KPT = 128*ceil(H(H+1)/2 / 128), zero padded.  gout [B,O*D] / gpool [B,O] (packed)
  * as in rp_cin_bs_bwd_x.  lstart / lent (device int32): for pair tile t, half c (64 pairs) and field h the entries
  * lent[lstart[(2t+c)*H + h] .. lstart[(2t+c)*H + h + 1]) = (local pair row) | (other field) << 8 of that half's pairs
- * containing h, the diagonal pair listed twice.  dx rows [B, lddx]: the first H*D floats of each row are written. */
+ * containing h, the diagonal pair listed twice.  dx rows [B, lddx]: the first H*D floats of each row are written —
+ * accumulate != 0 (round 6): ADDED to what is there (the collapsed last layer's gradient of X_0, rp_cin_last_bwd_x: the sum of
+ * the two without a pass of its own). */
 int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, const float *gout, const float *gpool,
                       const int32_t *lstart, const int32_t *lent, int H, int O, int D, float *dx, int64_t lddx, int64_t B,
-                      rp_stream_t stream);
+                      int accumulate, rp_stream_t stream);
 int rp_cin_pair_bwd_w_workspace_bytes(int64_t B, int H, int O, size_t *bytes);
 int rp_cin_pair_bwd_w(const float *x0, int64_t ld0, const float *gout, const float *gpool, int H, int O, int D, float *dW,
                       float *db, int64_t B, void *workspace, size_t workspace_bytes, rp_stream_t stream);

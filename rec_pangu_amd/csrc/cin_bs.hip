@@ -880,7 +880,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
                                                                 const float *__restrict__ gout,
                                                                 const float *__restrict__ gpool, float *__restrict__ dx,
                                                                 int64_t lddx, int64_t B, const int *__restrict__ lstart,
-                                                                const int *__restrict__ lent) {
+                                                                const int *__restrict__ lent, int accumulate) {
     constexpr int NPC = NPROD == 6 ? 3 : (NPROD == 3 ? 2 : 1);  // bf16 pieces per operand that are used
     __shared__ __attribute__((aligned(16))) char smem[2 * 3 * 128 * CP_LD * 2 + 32 * 132 * 4];
     typedef __bf16(*Tile)[128][CP_LD];
@@ -1024,7 +1024,10 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
 #pragma unroll
         for (int jh = 0; jh < 8; ++jh) {
             const int h = oq + 4 * jh;
-            if (h < H) dx[bcol * lddx + (int64_t)h * D + dcol] = dacc[jh];
+            if (h < H) {
+                float *dst = dx + bcol * lddx + (int64_t)h * D + dcol;
+                *dst = accumulate ? *dst + dacc[jh] : dacc[jh];
+            }
         }
     }
 }
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(512, 4) void cin_pair_bwd_x_kernel(const float *__r
 // dx rows [B, lddx]: the first H*D floats of each row are written.
 extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, const float *gout, const float *gpool,
                                  const int32_t *lstart, const int32_t *lent, int H, int O, int D, float *dx, int64_t lddx,
-                                 int64_t B, rp_stream_t stream) {
+                                 int64_t B, int accumulate, rp_stream_t stream) {
     RP_REQUIRE(x0 && wst && dx && lstart && lent && (gout || gpool) && B >= 0, "cin_pair_bwd_x: bad argument");
     if (!rp_cin_pair_fits(H, O, D))
         return rp_fail(RP_ERR_UNSUPPORTED, "cin_pair_bwd_x: H=%d (<=32) O=%d (<=128) D=%d (32|64) unsupported", H, O, D);
@@ -1048,7 +1051,7 @@ extern "C" int rp_cin_pair_bwd_x(const float *x0, int64_t ld0, const void *wst, 
     const int nprod = rp_matmul_products(2.0 * O * npair * D * (double)B, 4.0 * (double)B * D * (O + 2 * H));
 #define CPX(NP_)                                                                                                            \
     hipLaunchKernelGGL((cin_pair_bwd_x_kernel<NP_>), dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, x0, ld0, H, O, D, \
-                       KPT, reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent)
+                       KPT, reinterpret_cast<const __bf16 *>(wst), gout, gpool, dx, lddx, B, lstart, lent, accumulate)
     if (nprod == 6) CPX(6);
     else if (nprod == 3) CPX(3);
     else CPX(1);

@@ -213,7 +213,8 @@ class _LinearAct(torch.autograd.Function):
                 # (dH, W^T) on the matrix core, inside the segmented reduce.  What flows back through autograd is a
                 # stride-0 zero of the right shape (other consumers of x add their gradients to it as usual).
                 lk.dgrad = (dpre, wt)
-                dx = torch.zeros((1, 1), dtype=x.dtype, device=x.device).expand(x.shape[0], x.shape[1])
+                # (the library's own fill: an ATen one would keep a recorded step from replaying as a launch plan)
+                dx = hip.zeros((1, 1), x.dtype, x.device).expand(x.shape[0], x.shape[1])
                 if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                     dw, db = hip.linear_wgrad(dpre, x, ctx.K, want_bias=ctx.has_bias)
                 return dx, dw, db, None, None, None, None
@@ -464,8 +465,10 @@ class _CINLayer(torch.autograd.Function):
             # X_0 enters in both roles: one pass with W[o,h,m] + W[o,m,h] gives its whole gradient
             gp = None if g_pool is None else g_pool.contiguous()  # [B, O] packed (it arrives as a slice of the cat)
             if hip.cin_pair_fits(H, O, D) and (g_out is None or g_out.data_ptr() % 16 == 0):
+                # (the last layer's gradient of X_0, parked in the link: this launch adds its own into it)
                 dx0 = hip.cin_pair_bwd_x(x0, wst if wst is not None else hip.cin_pair_pieces(W3, transposed=True), g_out, gp,
-                                         H, O, D, like=x0)
+                                         H, O, D, like=x0, into=extra)
+                extra = None
             else:
                 dx0 = hip.cin_bs_bwd_x(x0, hip.bf16_pieces(W3 + W3.transpose(1, 2)), g_out, gp, H, M, O, D, like=x0)
             if extra is not None:
@@ -1144,9 +1147,14 @@ class _EmbedGather(torch.autograd.Function):
             dx = _unit_inner(dx)
         if ctx.link is not None and ctx.link.extra is not None:
             extra, ctx.link.extra = ctx.link.extra, None
-            if dx is None or fused is not None:
+            if fused is not None and dx is None and extra.shape[1] == len(store.emb_feature) * store.embedding_dim:
+                # the first Linear left its dgrad to this backward (rp_embed_grad_gemm forms the dX rows it needs from (dH, W^T)
+                # inside the segmented reduce): the token consumer's gradient IS the dx operand of that launch — no dX, no add
+                dx = extra
+            elif dx is None or fused is not None:
                 raise RuntimeError("token_view: the gathered activation needs a consumer that materialises its gradient")
-            hip.add_rows_to(extra, dx[:, :extra.shape[1]])
+            else:
+                hip.add_rows_to(extra, dx[:, :extra.shape[1]])
         gfm = dfm.contiguous() if (ctx.want_fm and dfm is not None) else None
         if ctx.link is not None and ctx.link.folded:
             ssum = None  # g_fm * S is already inside dx (rp_linear_fwd_rowadd)

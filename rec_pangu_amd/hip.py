@@ -132,7 +132,7 @@ _SIGNATURES = {
     "rp_cin_bs_bwd_w": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_pair_fits": (C.c_int, [_i32, _i32, _i32]),
     "rp_cin_pair_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp]),
-    "rp_cin_pair_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "rp_cin_pair_bwd_x": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _vp]),
     "rp_cin_pair_bwd_w_workspace_bytes": (C.c_int, [_i64, _i32, _i32, C.POINTER(_sz)]),
     "rp_cin_pair_bwd_w": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "rp_cin_last_fits": (C.c_int, [_i32, _i32, _i32]),
@@ -1725,17 +1725,23 @@ def cin_pair_lists(H: int, device):
     return _PAIR_LISTS[key]
 
 
-def cin_pair_bwd_x(x0, wst, g_out, g_pool, H: int, O: int, D: int, like):
-    """-> dX_0 shaped like `like` ([B, >= H*D], zero beyond H*D) in the pair form (rp_cin_pair_bwd_x)."""
+def cin_pair_bwd_x(x0, wst, g_out, g_pool, H: int, O: int, D: int, like, into=None):
+    """-> dX_0 shaped like `like` ([B, >= H*D], zero beyond H*D) in the pair form (rp_cin_pair_bwd_x).  into: a [B, >= H*D]
+    tensor the gradient is ADDED to and that is returned (the collapsed last layer's gradient of X_0: no pass of its own)"""
     B = x0.shape[0]
-    dx = torch.empty_like(like)
-    if like.shape[1] > H * D:
-        dx[:, H * D:].zero_()
+    if into is not None:
+        _req(into, torch.float32, "into")
+        assert into.shape[0] == B and into.shape[1] >= H * D and into.stride(1) == 1
+        dx = into
+    else:
+        dx = torch.empty_like(like)
+        if like.shape[1] > H * D:
+            dx[:, H * D:].zero_()
     lstart, lent = cin_pair_lists(H, x0.device)
     with _Timed("cin_pair_bwd_x"):
         _check(lib().rp_cin_pair_bwd_x(x0.data_ptr(), _rowmajor(x0, "x0"), wst.data_ptr(), _ptr(g_out), _ptr(g_pool),
                                        lstart.data_ptr(), lent.data_ptr(), H, O, D, dx.data_ptr(), _rowmajor(dx, "dx"), B,
-                                       _stream()), "rp_cin_pair_bwd_x")
+                                       1 if into is not None else 0, _stream()), "rp_cin_pair_bwd_x")
     return dx
 
 

@@ -39,7 +39,9 @@ class xDeepFM(BaseModel):
                 feature_emb = x[:, :F * D].unflatten(1, (F, D))  # strided [B,F,D] view of the MLP input buffer
             logits = [self.lr_layer(data)] + list(self.cin(feature_emb, as_list=True))
             if self.dnn is not None:
-                logits.append(self.dnn(x))
+                # (fm_link: the first Linear leaves its dgrad to the gather's backward where it fits — rp_embed_grad_gemm then
+                #  takes the CIN's gradient of the embedding block as its dx operand: dX is never materialised)
+                logits.append(self.dnn(x, fm_link=link if (link is not None and feature_emb.dim() == 2) else None))
             return self._finish(logits, data, is_training, self.loss_fun)
         feature_emb = self.embedding_layer(data)
         logits = [self.lr_layer(data), self.cin(feature_emb)]
