@@ -39,12 +39,14 @@ class AutoInt(BaseModel):
                 # the fields as [B, F, D] tokens: a packed copy by a library launch; its gradient joins the MLP's dX inside the
                 # gather's backward (Fh.token_view) instead of through autograd's zero-filled slice gradient and ATen sum
                 tokens = Fh.token_view(x, F, D, link)
+                mlp_link = link  # (round 6: the first Linear's dgrad inside the gather's backward, the token gradient its dx operand)
             else:
                 tokens = x[:, :F * D].unflatten(1, (F, D))
+                mlp_link = None
             att = self.self_attention(tokens).flatten(start_dim=1)
             logits = [Fh.linear_act(att, self.fc.weight, self.fc.bias, Fh.ACT_NONE)]
             if self.dnn is not None:
-                logits.append(self.dnn(x))
+                logits.append(self.dnn(x, fm_link=mlp_link))
             if self.lr_layer is not None:
                 logits.append(self.lr_layer(data))
             return self._finish(logits, data, is_training, self.loss_fun)
