@@ -68,6 +68,7 @@ int rp_get_matmul_precision(void);
 typedef void *rp_stream_t;
 
 /* ---- library ------------------------------------------------------------------------------ */
+#define RP_ABI_VERSION 106 /* rp_version(): bumped with every change of an entry point's prototype (106 = round 6) */
 int rp_version(void);
 const char *rp_last_error(void);
 /* number of kernel launches issued through this library since load (tests use it to prove the

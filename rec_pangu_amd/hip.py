@@ -12,6 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 106  # csrc/common.hip: rp_version() — bumped with every change of the entry points' prototypes
 LIB_PATH = os.environ.get("RP_LIB_PATH") or os.path.join(_HERE, "lib", "librecpangu_hip.so")  # (override: A/B builds)
 MAX_FIELDS = 64
 
@@ -223,6 +224,10 @@ def lib():
                 f"{LIB_PATH} not found: build it with `make -C rec_pangu_amd/csrc` "
                 "(or __graft_entry__.build()). The HIP path has no fallback.")
         handle = C.CDLL(LIB_PATH)
+        handle.rp_version.restype = C.c_int
+        if handle.rp_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is version {handle.rp_version()} of the C ABI, these bindings are for {ABI_VERSION}: "
+                               "rebuild it (`make -C rec_pangu_amd/csrc`, or __graft_entry__.build())")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
